@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the ITD hot path from the reference itself.
+
+TEST INFRASTRUCTURE.  Runs ONLY in the build container, where the read-only
+reference checkout lives at /root/reference.  It imports the reference's own
+kernels (`ITD.py:23-121`: isin, detect_peaks, itd_baseline_extract) and the
+only runnable driver (`PyITD.ipynb cell 1`, = `ITD.py:351-432` minus the
+undefined `S/T` check) under a no-op `numba` stand-in (numba is not installed
+here; the bodies are plain numpy, and numba's njit does not enable fast-math
+or contraction, so interpreted numpy executes the same IEEE fp64 operations in
+the same order).  Outputs are *data only* (inputs + expected outputs) written
+to tests/golden/*.npz; no reference source text is stored.
+
+Usage:  python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import contextlib
+import hashlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# numba stand-in: decorators return the function unchanged
+# --------------------------------------------------------------------------
+def _install_numba_shim():
+    class _Ty:
+        """Subscriptable / callable dummy type: float64[:], Tuple((..))(..)"""
+
+        def __init__(self, np_dtype=None):
+            self.dtype = np_dtype
+
+        def __getitem__(self, _):
+            return self
+
+        def __call__(self, *a, **k):
+            return self
+
+    def _decorator(*dargs, **dkw):
+        # used both as @njit and @njit(signature, parallel=True)
+        if len(dargs) == 1 and callable(dargs[0]) and not isinstance(dargs[0], _Ty) and not dkw:
+            return dargs[0]
+        return lambda f: f
+
+    nb = types.ModuleType("numba")
+    nb.njit = _decorator
+    nb.jit = _decorator
+    nb.prange = range
+    # `numba.boolean[:](...)` appears in a decorator argument (evaluated at import) and
+    # `numpy.empty(n, dtype=numba.boolean)` inside isin(): numpy accepts any object
+    # carrying a `.dtype` attribute, so one subscriptable dummy serves both uses
+    nb.boolean = _Ty(np.dtype(np.bool_))
+    nb.int64 = _Ty(np.dtype(np.int64))
+    nb.int32 = _Ty(np.dtype(np.int32))
+    nb.float64 = _Ty(np.dtype(np.float64))
+    nb.float32 = _Ty(np.dtype(np.float32))
+    nb.objmode = lambda **k: contextlib.nullcontext()
+    nbt = types.ModuleType("numba.types")
+    nbt.Tuple = _Ty()
+    nbt.float64 = nb.float64
+    nbt.int32 = nb.int32
+    nbt.int64 = nb.int64
+    nb.types = nbt
+    sys.modules["numba"] = nb
+    sys.modules["numba.types"] = nbt
+
+
+def load_reference(ref_dir):
+    """Return (module ITD.py, class ITD from PyITD.ipynb cell 1, inputarray)."""
+    _install_numba_shim()
+    sys.path.insert(0, ref_dir)
+    try:
+        import ITD as ref_itd  # noqa: N811
+    finally:
+        sys.path.pop(0)
+
+    with open(os.path.join(ref_dir, "PyITD.ipynb")) as f:
+        nb_json = json.load(f)
+    cell1 = "".join(nb_json["cells"][1]["source"])
+    cell2 = "".join(nb_json["cells"][2]["source"])
+    ns1 = {}
+    exec(compile(cell1, "PyITD.ipynb:cell1", "exec"), ns1)
+    ns2 = {}
+    exec(compile(cell2, "PyITD.ipynb:cell2", "exec"), ns2)
+    return ref_itd, ns1, np.asarray(ns2["inputarray"], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+def canon_bytes(a):
+    """Bytes of a float array with every NaN replaced by one canonical NaN."""
+    a = np.ascontiguousarray(a)
+    if a.dtype.kind == "f":
+        a = a.copy()
+        a[np.isnan(a)] = np.float64("nan")
+        a.view(np.uint64)[np.isnan(a)] = np.uint64(0x7FF8000000000000)
+    return a.tobytes()
+
+
+def sha(a):
+    return hashlib.sha256(canon_bytes(a)).hexdigest()
+
+
+def run_driver(ns1, x, max_iteration):
+    """Run the notebook driver; returns rows, baselines, stop ('natural'|'timeout')."""
+    itd = ns1["ITD"]()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
+        rows = itd.itd(x, max_iteration=max_iteration)
+    out = buf.getvalue()
+    if "No more decompositions possible" in out:
+        stop = "natural"
+    elif "Out of time!" in out:
+        stop = "timeout"
+    else:
+        raise RuntimeError("driver produced no stop message: %r" % out)
+    return np.array(rows), np.array(itd.get_baselines()), stop
+
+
+def knots_of(ns1, x64):
+    """Reference knot set of a float64 array (ITD.py:87-98), on private copies."""
+    dp = ns1["detect_peaks"]
+    with np.errstate(all="ignore"):
+        a = np.asarray(dp(x64.copy()))
+        b = np.asarray(dp(-x64))
+    return np.sort(np.unique(np.hstack((a, b)))).astype(np.int64)
+
+
+def make_case(ns1, ref_mod, name, x, max_iteration, out_dir, full_limit=1 << 13):
+    x = np.asarray(x)
+    x_in = x.copy()
+    # the driver may write NaN->inf into a float64 caller array (ITD.py:41,50,389);
+    # hand it a private copy so the stored input stays pristine
+    rows, baselines, stop = run_driver(ns1, x.copy(), max_iteration)
+    n = x.shape[0]
+    rec = {
+        "x": x_in,
+        "max_iteration": np.int64(max_iteration),
+        "n_rows": np.int64(rows.shape[0]),
+        "stop": np.array(stop),
+        "rows_sha256": np.array(sha(rows)),
+        "baselines_shape": np.array(baselines.shape, dtype=np.int64),
+        "baselines_sha256": np.array(sha(baselines)),
+    }
+    finite = bool(np.isfinite(rows).all() and np.isfinite(baselines).all())
+    rec["finite"] = np.bool_(finite)
+    if n <= full_limit:
+        rec["rows"] = rows
+        rec["baselines"] = baselines
+    else:
+        idx = np.unique(np.concatenate([np.arange(0, n, 257), np.arange(64), np.arange(n - 64, n)]))
+        rec["sample_idx"] = idx.astype(np.int64)
+        rec["rows_sample"] = rows[:, idx]
+        rec["baselines_sample"] = baselines[:, idx]
+    # per-level knots: level 0 = the input, level j>=1 = stored baseline j-1.
+    # Also the reference's module-level single-level operator on the input.
+    if finite:
+        levels = [np.asarray(x_in, dtype=np.float64)] + [baselines[j] for j in range(baselines.shape[0])]
+        counts = []
+        for j, xl in enumerate(levels):
+            k = knots_of(ns1, xl)
+            counts.append(len(k))
+            rec["knots_L%d" % j] = k
+        rec["knot_counts"] = np.array(counts, dtype=np.int64)
+        with np.errstate(all="ignore"):
+            r1, b1 = ref_mod.itd_baseline_extract(np.asarray(x_in, dtype=np.float64).copy())
+        rec["extract_rot_sha256"] = np.array(sha(r1))
+        rec["extract_base_sha256"] = np.array(sha(b1))
+        if n <= full_limit:
+            rec["extract_rot"] = np.array(r1)
+            rec["extract_base"] = np.array(b1)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print("%-28s N=%-7d dtype=%-8s m=%-2d rows=%-2d stop=%-8s finite=%s knots=%s" % (
+        name, n, x_in.dtype, max_iteration, rows.shape[0], stop, finite,
+        list(rec.get("knot_counts", []))))
+
+
+def chirp(n, dtype=np.float32):
+    t = np.arange(n, dtype=np.float64) / n
+    return np.sin(2 * np.pi * (50 * t + 0.5 * (8000 - 50) * t * t)).astype(dtype)
+
+
+def sines_noise(n, seed=0, fscale=1.0, dtype=np.float32, fs=48000.0):
+    """BASELINE config 2/3 recipe."""
+    t = np.arange(n, dtype=np.float64) / fs
+    x = np.zeros(n, dtype=np.float64)
+    for a, f, p in ((1, 110, 0.1), (0.5, 440, 1.3), (0.25, 1760, 2.1), (0.125, 7040, 0.7)):
+        x += a * np.sin(2 * np.pi * (f * fscale) * t + p)
+    x += 0.05 * np.random.default_rng(seed).standard_normal(n)
+    return x.astype(dtype)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    ref_mod, ns1, radio = load_reference(args.ref)
+
+    def case(name, x, m, **kw):
+        make_case(ns1, ref_mod, name, x, m, args.out, **kw)
+
+    # (1) the reference's only recorded known-answer: PyITD.ipynb cell 2/3
+    np.savez_compressed(os.path.join(args.out, "radio8000_input.npz"), x=radio)
+    for m in (0, 1, 3, 7, 11):
+        case("radio8000_m%d" % m, radio, m, **({} if m in (3, 11) else {"full_limit": 0}))
+    # (2) ITD.py:491-496 demo signal
+    T = np.linspace(0, 2 * np.pi, 400, dtype=np.float64)
+    case("demo400_m11", np.sin(20 * T * (1 + 0.2 * T)) + T ** 2 + np.sin(13 * T), 11)
+    # class docstring example ITD.py:146-152 (the docstring's shape is wrong; record the truth)
+    T = np.linspace(0, 1, 100)
+    case("doc100_m11", np.sin(2 * 2 * np.pi * T), 11)
+    # (3) chirps (BASELINE config 1 = 2^16, m=3)
+    case("chirp4096_f32_m3", chirp(1 << 12), 3)
+    case("chirp65536_f32_m3", chirp(1 << 16), 3)
+    # (4) sines+noise
+    case("sines16384_f32_m7", sines_noise(1 << 14), 7)
+    case("sines16384_f64_m7", sines_noise(1 << 14, dtype=np.float64), 7)
+    case("sines131072_f32_m7", sines_noise(1 << 17), 7)
+    # (5) quantised + tiled radio clip: plateaus (config-5 substitute, small)
+    q12 = np.round(radio * 2048.0) / 2048.0
+    case("radio_q12_tiled8_m9", np.resize(q12, 8000 * 8), 9)
+    q8 = np.round(radio * 64.0) / 64.0
+    case("radio_q8_tiled2_m9", np.resize(q8, 16000), 9)
+    case("radio_tiled_32768_f32_m9", np.resize(radio, 1 << 15).astype(np.float32), 9)
+    # (6) edge cases
+    rng = np.random.default_rng(1234)
+    case("edge_n3", np.array([0.0, 1.0, 0.5]), 5)
+    case("edge_n4", np.array([0.0, 1.0, -1.0, 0.5]), 5)
+    case("edge_n5_zigzag", np.array([0.0, 1.0, -1.0, 2.0, 0.0]), 5)
+    case("edge_monotone", np.linspace(-1.0, 3.0, 257) ** 3, 5)
+    case("edge_constant", np.full(64, 2.5), 5)
+    case("edge_zigzag1024", np.where(np.arange(1024) % 2 == 0, -1.0, 1.0) * (1 + 0.001 * np.arange(1024)), 20)
+    case("edge_staircase", np.repeat(np.arange(40.0), 7), 5)
+    case("edge_plateau_peaks", np.repeat(rng.standard_normal(300), 5), 9)
+    case("edge_lead_plateau_nan", np.concatenate([np.ones(5), rng.standard_normal(200)]), 6)
+    case("edge_lead_plateau2_nan", np.concatenate([np.zeros(3), np.repeat(rng.standard_normal(100), 3)]), 4)
+    case("edge_trail_plateau", np.concatenate([rng.standard_normal(200), np.ones(6)]), 6)
+    case("edge_one_extremum", -(np.linspace(-1, 1, 101) ** 2), 5)
+    case("edge_two_extrema", np.sin(np.linspace(0, 2 * np.pi, 200)), 5)
+    case("edge_noise_m20", rng.standard_normal(5000), 20)
+    case("edge_noise_m0", rng.standard_normal(777), 0)
+    case("edge_noise_f32_odd", rng.standard_normal(2049).astype(np.float32), 7)
+    case("edge_denormal", rng.standard_normal(512) * 1e-310, 5)
+    case("edge_large", rng.standard_normal(512) * 1e300, 5)
+    case("edge_int_valued", rng.integers(-3, 4, 4000).astype(np.float64), 9)
+
+
+if __name__ == "__main__":
+    main()
