@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ITD hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/s of the full 8-level ITD + achieved HBM GB/s.
+One "step" = one complete decomposition (level-0 knot scan, 9 extractions, stop rules, row fix-up) of
+the synthetic input already resident in HBM.
+
+  N = 1   workload = BASELINE configs[1]: one 2^24-sample float32 sum-of-sines+noise signal, 8 levels
+          (max_iteration = 7 -> 9 rows), one MI355X.
+  N > 1   the path shards over independent signals only: every rank decomposes its own 2^24
+          signal (seed = rank) with no data-path collective -> weak scaling; value = all samples / max time.
+
+Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kernel k_extract, levels >= 1:
+24 algorithmic B/sample, timed with hipEvents on the launch stream inside the timed region) + "cpu_baseline"
+(the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable copy rate)
+LEVELS = 8                  # BASELINE configs[1]
+MAX_ITERATION = LEVELS - 1  # -> LEVELS rotations + residual = 9 rows
+LOG2N = 24
+
+
+def sines_noise(n, seed=0, fscale=1.0, fs=48000.0):
+    """BASELINE config 2 recipe, float64 math cast to float32."""
+    t = np.arange(n, dtype=np.float64) / fs
+    x = np.zeros(n, dtype=np.float64)
+    for a, f, p in ((1, 110, 0.1), (0.5, 440, 1.3), (0.25, 1760, 2.1), (0.125, 7040, 0.7)):
+        x += a * np.sin(2 * np.pi * (f * fscale) * t + p)
+    x += 0.05 * np.random.default_rng(seed).standard_normal(n)
+    return x.astype(np.float32)
+
+
+def algorithmic_bytes_per_sample(levels):
+    """level 1 reads 4 B (f32) and writes 8+8; every later level reads 8 and writes 8+8."""
+    return 20 + 24 * (levels - 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=LOG2N)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import pyitd_amd
+    from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0
+
+    n = 1 << args.log2n
+    M = MAX_ITERATION
+    R = M + 2
+    x_host = sines_noise(n, seed=rank, fscale=1.0 + rank / 8192.0)
+    x = torch.from_numpy(x_host).to(dev)
+    rows = torch.empty((R, n), dtype=torch.float64, device=dev)
+    eng = pyitd_amd.Engine(n, 1, local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    sp = stream.cuda_stream
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+
+    def step():
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, sp)
+
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    summ = eng.summary(1)
+
+    eng.set_timing(args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist.is_initialized():
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ext_ms, ext_cnt = eng.kernel_timing(TIME_EXTRACT)
+    l0_ms, l0_cnt = eng.kernel_timing(TIME_EXTRACT_L0)
+    fin_ms, fin_cnt = eng.kernel_timing(TIME_EXTRACT_FINAL)
+    dec_ms, dec_cnt = eng.kernel_timing(TIME_DECOMPOSE)
+    eng.set_timing(0)
+
+    if rank != 0:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+
+    samples_per_step = n * world
+    value = samples_per_step * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+    # dominant kernel: k_extract<float64> (levels 1..M): reads 8 B, writes rotation 8 B + baseline 8 B per sample
+    avg_ms = ext_ms / max(ext_cnt, 1)
+    achieved = 24.0 * n / (avg_ms * 1e-3) / 1e9 if ext_cnt else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_extract_f64_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Msamples/s full ITD (8 levels) + achieved HBM GB/s",
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "single 2^%d-sample float32 sum-of-sines+noise per GPU, %d ITD levels (max_iteration=%d, "
+                        "%d rows), device resident" % (args.log2n, LEVELS, M, R),
+            "signals_per_gpu": 1,
+            "samples_per_signal": n,
+            "rows": int(summ["n_rows"][0]),
+            "knots_per_level": [int(v) for v in summ["knot_counts"][0] if v >= 0],
+            "sharding": "one independent signal per GPU, no data-path collective",
+        },
+        "hbm_algorithmic_GBps": round(algorithmic_bytes_per_sample(LEVELS) * samples_per_step * args.steps / elapsed / 1e9, 1),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_extract<double> (levels>=1: read 8 B + write 16 B per sample)",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": traffic,
+            "avg_launch_us": round(avg_ms * 1e3, 2),
+            "launches_timed": ext_cnt,
+            "read_frac": round(8.0 * n / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ext_cnt else 0.0,
+            "level0_launch_us": round(l0_ms / max(l0_cnt, 1) * 1e3, 2),
+            "final_launch_us": round(fin_ms / max(fin_cnt, 1) * 1e3, 2),
+            "decompose_gpu_us": round(dec_ms / max(dec_cnt, 1) * 1e3, 2),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_oracle   # checker/baseline only: never part of the measured GPU path
+        cpu_oracle.lib()
+        tc0 = time.perf_counter()
+        ref = cpu_oracle.itd_lean(x_host, M)
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {
+            "value": round(n / tc / 1e6, 3),
+            "unit": "Msamples/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "the same 2^%d-sample signal, %d levels, one run of the C oracle (single thread; the reference's "
+                      "recursion is serial), %.1f s" % (args.log2n, LEVELS, tc),
+            "host_cpus": os.cpu_count(),
+        }
+        out["parity"] = {
+            "knot_counts_equal": [int(v) for v in summ["knot_counts"][0][: len(ref["knot_counts"])]] == ref["knot_counts"].tolist(),
+            "rows_bit_exact": bool(np.array_equal(rows[: ref["rows"].shape[0]].cpu().numpy().view(np.uint64),
+                                                  ref["rows"].view(np.uint64))),
+        }
+    print(json.dumps(out))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/*
+ * pyitd_hip.h — C ABI of the MI355X (gfx950) ITD engine, libpyitd_hip.so.
+ *
+ * This is the drop-in boundary for ONE path of falseywinchnet/PyITD:
+ *     itd(x, max_iteration) -> rotations[rows, N] (+ baselines)
+ * i.e. the reference's   ITD.itd            ITD.py:351-432  (runnable form: PyITD.ipynb cell 1;
+ *                                           free-function form ITD_numba.py:100-136)
+ *                        itd_baseline_extract  ITD.py:79-121
+ *                        detect_peaks          ITD.py:33-76  (twin matlab_detect_peaks,
+ *                                              numba_accelerated_itd.py:17-59)
+ *                        baseline_knot_estimation  numba_accelerated_itd.py:167-178 (= ITD.py:100-110)
+ * The reference is pure Python/numba with no FFI of its own; each entry point below names the
+ * reference function a binding would replace.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an itd_status (0 = ok) and never throws.
+ *   - "_dev" pointers are device (HBM) pointers on the engine's GPU; "_host" pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the engine's own stream).
+ *   - all floating-point results are IEEE binary64 computed in the reference's association order
+ *     (no FMA contraction), so they are bit-identical to the reference for finite data.
+ *   - int32 knot indices on the device (N < 2^31); the host-facing entry points widen to int64
+ *     like the reference's numpy.int64 arrays.
+ */
+#ifndef PYITD_HIP_H
+#define PYITD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITD_ABI_VERSION 1
+
+/* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
+#define ITD_MAX_ROWS 22
+#define ITD_MAX_ITERATION 20
+
+typedef enum itd_status {
+    ITD_OK = 0,
+    ITD_ERR_INVALID_ARG = 1,   /* NULL pointer, N < 3, batch < 1, max_iteration outside [0, 20], sizes beyond the engine's */
+    ITD_ERR_NO_DEVICE = 2,     /* no HIP device / wrong device id */
+    ITD_ERR_HIP = 3,           /* a HIP runtime call failed: see itd_last_error() */
+    ITD_ERR_NOMEM = 4,         /* device or host allocation failed */
+    ITD_ERR_NOT_RUN = 5,       /* results requested before a decomposition was enqueued */
+    ITD_ERR_NONFINITE = 6      /* a NaN appeared in a baseline (reference: NaN->inf path, ITD.py:46-51,64-68) and the
+                                  NaN-faithful fallback was disabled */
+} itd_status;
+
+/* stop reasons of the level loop */
+#define ITD_STOP_NATURAL 0 /* "No more decompositions possible", ITD.py:404-416 */
+#define ITD_STOP_TIMEOUT 1 /* "Out of time!",                    ITD.py:418-426 */
+
+/* knot-detection modes for itd_detect_* */
+#define ITD_DETECT_KNOTS 0  /* union used by the extraction, ITD.py:87-98 */
+#define ITD_DETECT_VALLEYS 1 /* detect_peaks(x), ITD.py:33-76 (dx[i]>0 & dx[i-1]<=0) */
+#define ITD_DETECT_PEAKS 2   /* detect_peaks(-x) = matlab_detect_peaks(x), numba_accelerated_itd.py:17-59 */
+
+typedef struct itd_engine itd_engine; /* opaque; not thread-safe: one engine per host thread/stream */
+
+int itd_abi_version(void);
+const char *itd_status_string(int status);
+/* detail of the last ITD_ERR_HIP on this engine (static storage inside the engine) */
+const char *itd_last_error(const itd_engine *e);
+
+/* Create an engine on HIP device `device_id` able to decompose up to `max_batch` signals of up to
+ * `max_n` samples per call.  Allocates the device workspace once (tile knot lists, compact knot
+ * indices, per-tile offsets, ping-pong baselines: about 24 B per sample).  No allocation happens
+ * in the decompose calls (they are graph-capturable). */
+int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t max_batch);
+void itd_engine_destroy(itd_engine *e);
+int64_t itd_engine_workspace_bytes(const itd_engine *e);
+int itd_engine_device(const itd_engine *e);
+
+/* ---- full decomposition, device resident: replaces ITD.itd (ITD.py:351-432) -------------------
+ * x_dev          [batch] signals, signal b starts at x_dev + b*x_stride (elements), n samples each
+ * rows_dev       [batch][max_iteration+2][n] float64.  On return (after the stream has run) rows
+ *                0 .. n_rows-1 of each signal are the reference's returned array: proper rotations, then
+ *                the residual (natural stop: the previous baseline; timeout: rotation + baseline).
+ * baselines_dev  optional [batch][max_iteration+2][n] float64: row j = baseline after extraction j+1
+ *                (the reference's `baselines` buffer, ITD.py:385,429); NULL = keep only a ping-pong pair
+ *                inside the engine (saves 8 B/sample/level of HBM capacity, same traffic).
+ * Everything is enqueued on `stream` with no host synchronisation; call itd_get_summary afterwards. */
+int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                      int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream);
+int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                      int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream);
+
+/* Synchronise with the last decomposition and fetch its per-signal summary (any pointer may be NULL):
+ *   n_rows       [batch]      rows valid in rows_dev (= shape[0] of the reference's result)
+ *   n_baselines  [batch]      rows valid in get_baselines() (ITD.py:414 / :424)
+ *   stop_reason  [batch]      ITD_STOP_NATURAL / ITD_STOP_TIMEOUT
+ *   knot_counts  [batch][ITD_MAX_ROWS+1]  knot_counts[j] = interior knots of the input of extraction j+1
+ *                (j = 0: the signal itself; j >= 1: the number the reference prints at ITD.py:403);
+ *                entries past the last evaluated level are -1
+ *   nan_levels   [batch]      -1, or the first extraction whose baseline contained a NaN (results from
+ *                that level on follow the reference only if the NaN fallback ran) */
+int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
+                    int64_t *knot_counts, int32_t *nan_levels);
+
+/* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
+ * launch); to inspect them run itd_detect_* on the input or on a stored baseline row. */
+
+/* ---- one-call host convenience (numpy in -> numpy out, what the reference's callers see) -------
+ * Copies x to the GPU, decomposes, copies rows (and baselines if non-NULL) back.
+ * rows_host / baselines_host: [max_iteration+2][n] float64, caller allocated. */
+int itd_decompose_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t max_iteration,
+                           double *rows_host, double *baselines_host, int32_t *n_rows, int32_t *n_baselines,
+                           int32_t *stop_reason, int64_t *knot_counts /* [ITD_MAX_ROWS+1] */);
+int itd_decompose_host_f32(itd_engine *e, const float *x_host, int64_t n, int32_t max_iteration,
+                           double *rows_host, double *baselines_host, int32_t *n_rows, int32_t *n_baselines,
+                           int32_t *stop_reason, int64_t *knot_counts);
+
+/* ---- single-level operators ---------------------------------------------------------------------
+ * itd_baseline_extract (ITD.py:79-121): rotation/baseline of ONE extraction of a device signal.
+ * knots_dev (optional, capacity n int32) receives the interior knot indices, *m_host their count. */
+int itd_baseline_extract_f64(itd_engine *e, const double *x_dev, int64_t n, double *rot_dev, double *base_dev,
+                             int32_t *knots_dev, int64_t *m_host, void *stream);
+int itd_baseline_extract_f32(itd_engine *e, const float *x_dev, int64_t n, double *rot_dev, double *base_dev,
+                             int32_t *knots_dev, int64_t *m_host, void *stream);
+/* host convenience: rot/base [n] float64, knots_host (optional) [n] int64, bk_host (optional) [n+2] knot values */
+int itd_baseline_extract_host_f64(itd_engine *e, const double *x_host, int64_t n, double *rot_host,
+                                  double *base_host, int64_t *knots_host, int64_t *m_host, double *bk_host);
+
+/* detect_peaks / matlab_detect_peaks / knot union (ITD.py:33-76, :87-98): ordered indices of a device
+ * signal.  idx_dev capacity n int32; the count is returned through *count_host (synchronises). */
+int itd_detect_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t mode, int32_t *idx_dev,
+                   int64_t *count_host, void *stream);
+int itd_detect_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t mode, int32_t *idx_dev,
+                   int64_t *count_host, void *stream);
+int itd_detect_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t mode, int64_t *idx_host,
+                        int64_t *count_host);
+
+/* baseline_knot_estimation (numba_accelerated_itd.py:167-178 = ITD.py:106-110): fills bk[1..m] for the
+ * caller's extended knot list e[0..m+1] (bk[0], bk[m+1] are left as given, like the reference).
+ * All host pointers; x [n], extrema [m+2] int64, bk [m+2]. */
+int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host,
+                             int64_t m, double *bk_host);
+
+/* ---- introspection for benchmarks -------------------------------------------------------------
+ * hipEvent pairs recorded on the launch stream around selected launches.  itd_set_kernel_timing(e, K)
+ * enables recording for up to K decompositions (K = 0 disables) and resets the tallies;
+ * itd_get_kernel_timing sums the elapsed time of every recorded launch of class `which`. */
+#define ITD_TIME_EXTRACT 0        /* k_extract<float64 in>: levels >= 1, the dominant kernel (24 B/sample) */
+#define ITD_TIME_EXTRACT_L0 1     /* k_extract on the caller's signal (level 0; 20 B/sample for float32) */
+#define ITD_TIME_EXTRACT_FINAL 2  /* k_extract of the "Out of time!" level (writes rotation+baseline only) */
+#define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
+int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
+int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYITD_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes loader for libpyitd_hip.so (the C ABI of include/pyitd_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is present the product
+path raises.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyitd_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"),
+           os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
+
+MAX_ROWS = 22
+MAX_ITERATION = 20
+
+# name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
+_P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
+ABI = {
+    "itd_abi_version": (_INT, []),
+    "itd_status_string": (ctypes.c_char_p, [_INT]),
+    "itd_last_error": (ctypes.c_char_p, [_P]),
+    "itd_engine_create": (_INT, [ctypes.POINTER(_P), _INT, _I64, _I32]),
+    "itd_engine_destroy": (None, [_P]),
+    "itd_engine_workspace_bytes": (_I64, [_P]),
+    "itd_engine_device": (_INT, [_P]),
+    "itd_decompose_f32": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _P, _P]),
+    "itd_decompose_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _P, _P]),
+    "itd_get_summary": (_INT, [_P, _P, _P, _P, _P, _P]),
+    "itd_decompose_host_f64": (_INT, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "itd_decompose_host_f32": (_INT, [_P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "itd_baseline_extract_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+    "itd_baseline_extract_f32": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+    "itd_baseline_extract_host_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+    "itd_detect_f64": (_INT, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "itd_detect_f32": (_INT, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "itd_detect_host_f64": (_INT, [_P, _P, _I64, _I32, _P, _P]),
+    "itd_knot_values_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P]),
+    "itd_set_kernel_timing": (_INT, [_P, _INT]),
+    "itd_get_kernel_timing": (_INT, [_P, _I32, _P, _P]),
+}
+
+_lib = None
+
+
+def hipcc_command(out=LIB_PATH, tile=None):
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wall", "-o", out]
+    if tile:
+        cmd.append("-DITD_TILE=%d" % tile)
+    return cmd + SOURCES
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force=False):
+    """Compile libpyitd_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or needs_build():
+        subprocess.check_call(hipcc_command())
+    return LIB_PATH
+
+
+def load():
+    """dlopen the HIP library and attach the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "pyitd_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        if L.itd_abi_version() != 1:
+            raise RuntimeError("pyitd_amd: ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+class ITDError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = load().itd_status_string(status).decode()
+        super().__init__("pyitd_hip status %d (%s)%s" % (status, msg, (": " + detail) if detail else ""))

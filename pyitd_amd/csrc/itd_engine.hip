@@ -1,0 +1,622 @@
+// itd_engine.hip — host side of libpyitd_hip.so: the C ABI declared in include/pyitd_hip.h.
+//
+// The level loop of the reference driver (ITD.itd, ITD.py:384-432) is enqueued here as a fixed
+// sequence of launches on one HIP stream with NO host synchronisation between levels: the stop rule
+// (`num_extrema < 2`, ITD.py:404) is evaluated on the device by k_compact and later launches of a
+// stopped signal return at once; k_finalize performs the row fix-up.  The host reads one small
+// per-signal summary at the end (itd_get_summary).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pyitd_hip.h"
+#include "itd_kernels.hpp"
+
+#ifndef ITD_TILE
+#define ITD_TILE 2048
+#endif
+
+using namespace itd;
+
+namespace {
+constexpr int T = ITD_TILE;
+static_assert(T % (kThreads) == 0 && (T / kWaves) % 64 == 0 && T / 64 <= 64, "tile geometry");
+
+__global__ void k_init_state(SigState *st, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    for (int j = 0; j < kMaxLevels; ++j) st[b].m[j] = -1;
+    st[b].stopped = 0;
+    st[b].stop_level = -1;
+    st[b].nan_mask = 0;
+    st[b].pad = 0;
+}
+
+__global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) dst[i] = src[i];
+}
+}  // namespace
+
+struct itd_engine {
+    int device = 0;
+    int64_t max_n = 0;
+    int32_t max_batch = 0;
+    int64_t max_tiles = 0;
+    hipStream_t own_stream = nullptr;
+    // workspace
+    int32_t *d_lists = nullptr;    // [batch][tiles][T]
+    int32_t *d_counts = nullptr;   // [batch][tiles]
+    int32_t *d_offsets = nullptr;  // [batch][tiles+1]
+    int32_t *d_kidx = nullptr;     // [batch][max_n + 2]
+    double *d_pp = nullptr;        // [batch][2][max_n] ping-pong baselines
+    SigState *d_state = nullptr;   // [batch]
+    SigState *h_state = nullptr;   // pinned
+    int64_t ws_bytes = 0;
+    // host-convenience staging (grow only)
+    void *d_io_x = nullptr; size_t io_x_bytes = 0;
+    double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
+    double *d_io_bases = nullptr; size_t io_bases_bytes = 0;
+    // last run
+    bool ran = false;
+    int32_t last_batch = 0, last_m = 0;
+    int64_t last_n = 0;
+    hipStream_t last_stream = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // event pairs: [2k] start, [2k+1] stop
+    std::vector<int> ev_tag;      // what pair k brackets (ITD_TIME_*)
+    int n_timed = 0;              // pairs recorded since timing was (re)enabled
+    bool timing_overflow = false;
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail_hip(itd_engine *e, hipError_t rc, const char *what)
+{
+    if (e) snprintf(e->err, sizeof(e->err), "%s: %s (%d)", what, hipGetErrorString(rc), (int)rc);
+    return ITD_ERR_HIP;
+}
+
+#define HIP_TRY(e, call)                                         \
+    do {                                                         \
+        hipError_t rc__ = (call);                                \
+        if (rc__ != hipSuccess) return fail_hip((e), rc__, #call); \
+    } while (0)
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+inline int64_t tiles_of(int64_t n) { return (n + T - 1) / T; }
+
+// hipEvent pairs on the launch stream around selected launches (bench instrumentation, off by default)
+int time_begin(itd_engine *e, int tag, hipStream_t st)
+{
+    if (!e->timing) return -1;
+    if (2 * (size_t)e->n_timed + 1 >= e->ev.size()) { e->timing_overflow = true; return -1; }
+    const int k = e->n_timed++;
+    e->ev_tag[(size_t)k] = tag;
+    (void)hipEventRecord(e->ev[2 * (size_t)k], st);
+    return k;
+}
+void time_end(itd_engine *e, int k, hipStream_t st)
+{
+    if (k >= 0) (void)hipEventRecord(e->ev[2 * (size_t)k + 1], st);
+}
+
+template <typename Tin>
+int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M,
+                      double *rows, double *bases_user, hipStream_t st)
+{
+    const int n_tiles = (int)tiles_of(n);
+    const int64_t R = (int64_t)M + 2;
+    const int64_t rows_stride = R * n;
+    const dim3 grid_t(n_tiles, batch), blk(kThreads);
+    const dim3 grid_c((n_tiles + kTilesPerBlock - 1) / kTilesPerBlock, batch);
+    const int64_t kidx_stride = e->max_n + 2;
+
+    const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
+    k_init_state<<<(batch + 255) / 256, 256, 0, st>>>(e->d_state, batch);
+    if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
+        HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
+                                    (size_t)n * sizeof(double), (size_t)batch, st));
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, (int)kKnots, e->d_lists, e->d_counts);
+
+    for (int j = 0; j <= M + 1; ++j) {
+        k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, kidx_stride,
+                                              e->d_offsets, e->d_state, j, j >= 1 ? 1 : 0);
+        // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
+        double *base_out;
+        int64_t base_stride;
+        const double *base_in = nullptr;
+        int64_t base_in_stride = 0;
+        if (bases_user) {
+            base_out = bases_user + (int64_t)j * n;
+            base_stride = rows_stride;
+            if (j >= 1) { base_in = bases_user + (int64_t)(j - 1) * n; base_in_stride = rows_stride; }
+        } else {
+            base_out = e->d_pp + (int64_t)(j & 1) * e->max_n;
+            base_stride = 2 * e->max_n;
+            if (j >= 1) { base_in = e->d_pp + (int64_t)((j - 1) & 1) * e->max_n; base_in_stride = 2 * e->max_n; }
+        }
+        double *rot_out = rows + (int64_t)j * n;
+        const bool final_level = (j == M + 1);
+        const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
+        if (j == 0) {
+            if (final_level)
+                k_extract<Tin, T, true><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, e->d_kidx, kidx_stride,
+                                                                 e->d_offsets, rot_out, rows_stride, base_out,
+                                                                 base_stride, e->d_lists, e->d_counts, e->d_state, j);
+            else
+                k_extract<Tin, T, false><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, e->d_kidx, kidx_stride,
+                                                                  e->d_offsets, rot_out, rows_stride, base_out,
+                                                                  base_stride, e->d_lists, e->d_counts, e->d_state, j);
+        } else {
+            if (final_level)
+                k_extract<double, T, true><<<grid_t, blk, 0, st>>>(base_in, base_in_stride, n, n_tiles, e->d_kidx,
+                                                                    kidx_stride, e->d_offsets, rot_out, rows_stride,
+                                                                    base_out, base_stride, e->d_lists, e->d_counts,
+                                                                    e->d_state, j);
+            else
+                k_extract<double, T, false><<<grid_t, blk, 0, st>>>(base_in, base_in_stride, n, n_tiles, e->d_kidx,
+                                                                     kidx_stride, e->d_offsets, rot_out, rows_stride,
+                                                                     base_out, base_stride, e->d_lists, e->d_counts,
+                                                                     e->d_state, j);
+        }
+        time_end(e, pair, st);
+    }
+    // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
+    k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, kidx_stride, e->d_offsets,
+                                          e->d_state, M + 2, 1);
+    {
+        const int fb = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, 1024);
+        if (bases_user)
+            k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, e->d_state);
+        else
+            k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, e->d_pp, 2 * e->max_n, e->max_n, 1,
+                                                         e->d_state);
+    }
+    time_end(e, span_pair, st);
+    HIP_TRY(e, hipGetLastError());
+    e->ran = true;
+    e->last_batch = batch;
+    e->last_m = M;
+    e->last_n = n;
+    e->last_stream = st;
+    return ITD_OK;
+}
+
+int check_args(itd_engine *e, const void *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, const void *rows)
+{
+    if (!e || !x || !rows) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n || n >= (int64_t)INT32_MAX) return ITD_ERR_INVALID_ARG;  // N < 3: ITD.py:42-43 is garbage
+    if (batch < 1 || batch > e->max_batch || batch > 65535) return ITD_ERR_INVALID_ARG;
+    if (batch > 1 && x_stride < n) return ITD_ERR_INVALID_ARG;
+    if (M < 0 || M > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;  // row M+1 must fit in 22 rows (ITD.py:384,421)
+    return ITD_OK;
+}
+
+template <typename Tp>
+int grow(itd_engine *e, Tp **p, size_t *have, size_t want)
+{
+    if (*have >= want) return ITD_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    hipError_t rc = hipMalloc((void **)p, want);
+    if (rc != hipSuccess) { fail_hip(e, rc, "hipMalloc(io)"); return ITD_ERR_NOMEM; }
+    *have = want;
+    return ITD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int itd_abi_version(void) { return ITD_ABI_VERSION; }
+
+const char *itd_status_string(int s)
+{
+    switch (s) {
+        case ITD_OK: return "ok";
+        case ITD_ERR_INVALID_ARG: return "invalid argument";
+        case ITD_ERR_NO_DEVICE: return "no HIP device";
+        case ITD_ERR_HIP: return "HIP runtime error";
+        case ITD_ERR_NOMEM: return "out of memory";
+        case ITD_ERR_NOT_RUN: return "no decomposition has been run";
+        case ITD_ERR_NONFINITE: return "non-finite values in a baseline";
+        default: return "unknown status";
+    }
+}
+
+const char *itd_last_error(const itd_engine *e) { return e ? e->err : "null engine"; }
+
+int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t max_batch)
+{
+    if (!out || max_n < 3 || max_batch < 1 || max_batch > 65535 || max_n >= (int64_t)INT32_MAX) return ITD_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ITD_ERR_NO_DEVICE;
+    itd_engine *e = new (std::nothrow) itd_engine();
+    if (!e) return ITD_ERR_NOMEM;
+    e->device = device_id;
+    e->max_n = max_n;
+    e->max_batch = max_batch;
+    e->max_tiles = tiles_of(max_n);
+    DevGuard g(device_id);
+    const size_t B = (size_t)max_batch;
+    const size_t lists_b = B * (size_t)e->max_tiles * T * sizeof(int32_t);
+    const size_t counts_b = B * (size_t)e->max_tiles * sizeof(int32_t);
+    const size_t offs_b = B * (size_t)(e->max_tiles + 1) * sizeof(int32_t);
+    const size_t kidx_b = B * (size_t)(max_n + 2) * sizeof(int32_t);
+    const size_t pp_b = B * 2 * (size_t)max_n * sizeof(double);
+    const size_t st_b = B * sizeof(SigState);
+    hipError_t rc = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) { if (rc == hipSuccess) { rc = hipMalloc(p, bytes); if (rc == hipSuccess) e->ws_bytes += (int64_t)bytes; } };
+    alloc((void **)&e->d_lists, lists_b);
+    alloc((void **)&e->d_counts, counts_b);
+    alloc((void **)&e->d_offsets, offs_b);
+    alloc((void **)&e->d_kidx, kidx_b);
+    alloc((void **)&e->d_pp, pp_b);
+    alloc((void **)&e->d_state, st_b);
+    if (rc == hipSuccess) rc = hipHostMalloc((void **)&e->h_state, st_b);
+    if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (rc != hipSuccess) {
+        const bool oom = (rc == hipErrorOutOfMemory);
+        itd_engine_destroy(e);
+        return oom ? ITD_ERR_NOMEM : ITD_ERR_HIP;
+    }
+    *out = e;
+    return ITD_OK;
+}
+
+void itd_engine_destroy(itd_engine *e)
+{
+    if (!e) return;
+    DevGuard g(e->device);
+    if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    (void)hipFree(e->d_lists); (void)hipFree(e->d_counts); (void)hipFree(e->d_offsets);
+    (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state);
+    (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
+    if (e->h_state) (void)hipHostFree(e->h_state);
+    for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+int64_t itd_engine_workspace_bytes(const itd_engine *e) { return e ? e->ws_bytes : 0; }
+int itd_engine_device(const itd_engine *e) { return e ? e->device : -1; }
+
+int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                      int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream)
+{
+    int rc = check_args(e, x_dev, n, batch, x_stride, max_iteration, rows_dev);
+    if (rc) return rc;
+    DevGuard g(e->device);
+    return enqueue_decompose<float>(e, x_dev, n, batch, x_stride, max_iteration, rows_dev, baselines_dev,
+                                    stream ? (hipStream_t)stream : e->own_stream);
+}
+
+int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                      int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream)
+{
+    int rc = check_args(e, x_dev, n, batch, x_stride, max_iteration, rows_dev);
+    if (rc) return rc;
+    DevGuard g(e->device);
+    return enqueue_decompose<double>(e, x_dev, n, batch, x_stride, max_iteration, rows_dev, baselines_dev,
+                                     stream ? (hipStream_t)stream : e->own_stream);
+}
+
+int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
+                    int64_t *knot_counts, int32_t *nan_levels)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    if (!e->ran) return ITD_ERR_NOT_RUN;
+    DevGuard g(e->device);
+    const int B = e->last_batch;
+    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+    HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    for (int b = 0; b < B; ++b) {
+        const SigState &s = e->h_state[b];
+        int rows, nb, why;
+        if (s.stopped) {               // ITD.py:404-416, counter = stop_level-1
+            const int c = s.stop_level - 1;
+            rows = c + 1;
+            nb = c;                    // baselines[0:counter-1] after the increment
+            why = ITD_STOP_NATURAL;
+        } else {                       // ITD.py:418-426, counter = max_iteration+1
+            rows = e->last_m + 2;
+            nb = e->last_m + 2;        // baselines[0:counter] (last row zero)
+            why = ITD_STOP_TIMEOUT;
+        }
+        if (n_rows) n_rows[b] = rows;
+        if (n_baselines) n_baselines[b] = nb;
+        if (stop_reason) stop_reason[b] = why;
+        if (knot_counts)
+            for (int j = 0; j <= ITD_MAX_ROWS; ++j) knot_counts[(size_t)b * (ITD_MAX_ROWS + 1) + j] = s.m[j];
+        if (nan_levels) {
+            int lv = -1;
+            for (int j = 0; j < kMaxLevels; ++j)
+                if (s.nan_mask & (1 << j)) { lv = j; break; }
+            // a NaN produced by an extraction whose results the stop rule discards is harmless
+            if (lv >= rows) lv = -1;
+            nan_levels[b] = lv;
+        }
+    }
+    return ITD_OK;
+}
+
+}  // extern "C"
+
+namespace {
+template <typename Tin>
+int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, double *rows_host, double *bases_host,
+                   int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason, int64_t *knot_counts)
+{
+    if (!e || !x_host || !rows_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n || M < 0 || M > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    const size_t R = (size_t)M + 2;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(Tin));
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, R * (size_t)n * sizeof(double));
+    if (rc) return rc;
+    if (bases_host) {
+        rc = grow(e, &e->d_io_bases, &e->io_bases_bytes, R * (size_t)n * sizeof(double));
+        if (rc) return rc;
+    }
+    hipStream_t st = e->own_stream;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(Tin), hipMemcpyHostToDevice, st));
+    rc = enqueue_decompose<Tin>(e, (const Tin *)e->d_io_x, n, 1, n, M, e->d_io_rows, bases_host ? e->d_io_bases : nullptr, st);
+    if (rc) return rc;
+    int32_t nr = 0, nb = 0, why = 0, nanlv = -1;
+    int64_t kc[ITD_MAX_ROWS + 1];
+    rc = itd_get_summary(e, &nr, &nb, &why, kc, &nanlv);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(rows_host, e->d_io_rows, (size_t)nr * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (bases_host)
+        HIP_TRY(e, hipMemcpyAsync(bases_host, e->d_io_bases, (size_t)nb * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    if (n_rows) *n_rows = nr;
+    if (n_baselines) *n_baselines = nb;
+    if (stop_reason) *stop_reason = why;
+    if (knot_counts) memcpy(knot_counts, kc, sizeof(kc));
+    return nanlv >= 0 ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
+template <typename Tin>
+int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *base, int32_t *knots, int64_t *m_host,
+                hipStream_t st, bool want_sync)
+{
+    if (!e || !x || !rot || !base) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    const int n_tiles = (int)tiles_of(n);
+    const dim3 grid_t(n_tiles, 1), blk(kThreads);
+    const dim3 grid_c((n_tiles + kTilesPerBlock - 1) / kTilesPerBlock, 1);
+    k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, (int)kKnots, e->d_lists, e->d_counts);
+    k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, e->max_n + 2, e->d_offsets,
+                                          e->d_state, 0, 0);
+    k_extract<Tin, T, false><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, e->d_kidx, e->max_n + 2, e->d_offsets, rot, n,
+                                                      base, n, e->d_lists, e->d_counts, e->d_state, 0);
+    HIP_TRY(e, hipGetLastError());
+    if (m_host || knots || want_sync) {
+        int32_t m32 = 0;
+        HIP_TRY(e, hipMemcpyAsync(&m32, e->d_offsets + n_tiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        if (m_host) *m_host = m32;
+        if (knots && m32 > 0) {
+            HIP_TRY(e, hipMemcpyAsync(knots, e->d_kidx + 1, sizeof(int32_t) * (size_t)m32, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(e, hipStreamSynchronize(st));
+        }
+    }
+    return ITD_OK;
+}
+
+template <typename Tin>
+int detect_dev(itd_engine *e, const Tin *x, int64_t n, int32_t mode, int32_t *idx, int64_t *count, hipStream_t st)
+{
+    if (!e || !x || !count) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n || mode < 0 || mode > 2) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    const int n_tiles = (int)tiles_of(n);
+    const dim3 grid_t(n_tiles, 1), blk(kThreads);
+    const dim3 grid_c((n_tiles + kTilesPerBlock - 1) / kTilesPerBlock, 1);
+    k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, e->d_lists, e->d_counts);
+    k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, e->max_n + 2, e->d_offsets,
+                                          e->d_state, 0, 0);
+    HIP_TRY(e, hipGetLastError());
+    int32_t m32 = 0;
+    HIP_TRY(e, hipMemcpyAsync(&m32, e->d_offsets + n_tiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    *count = m32;
+    if (idx && m32 > 0) {
+        HIP_TRY(e, hipMemcpyAsync(idx, e->d_kidx + 1, sizeof(int32_t) * (size_t)m32, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+    }
+    return ITD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int itd_decompose_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t max_iteration, double *rows_host,
+                           double *baselines_host, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
+                           int64_t *knot_counts)
+{
+    return decompose_host<double>(e, x_host, n, max_iteration, rows_host, baselines_host, n_rows, n_baselines,
+                                  stop_reason, knot_counts);
+}
+
+int itd_decompose_host_f32(itd_engine *e, const float *x_host, int64_t n, int32_t max_iteration, double *rows_host,
+                           double *baselines_host, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
+                           int64_t *knot_counts)
+{
+    return decompose_host<float>(e, x_host, n, max_iteration, rows_host, baselines_host, n_rows, n_baselines,
+                                 stop_reason, knot_counts);
+}
+
+int itd_baseline_extract_f64(itd_engine *e, const double *x_dev, int64_t n, double *rot_dev, double *base_dev,
+                             int32_t *knots_dev, int64_t *m_host, void *stream)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    return extract_dev<double>(e, x_dev, n, rot_dev, base_dev, knots_dev, m_host,
+                               stream ? (hipStream_t)stream : e->own_stream, false);
+}
+
+int itd_baseline_extract_f32(itd_engine *e, const float *x_dev, int64_t n, double *rot_dev, double *base_dev,
+                             int32_t *knots_dev, int64_t *m_host, void *stream)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    return extract_dev<float>(e, x_dev, n, rot_dev, base_dev, knots_dev, m_host,
+                              stream ? (hipStream_t)stream : e->own_stream, false);
+}
+
+int itd_baseline_extract_host_f64(itd_engine *e, const double *x_host, int64_t n, double *rot_host, double *base_host,
+                                  int64_t *knots_host, int64_t *m_host, double *bk_host)
+{
+    if (!e || !x_host || !rot_host || !base_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    // rows staging: [rot | base | bk(n+2) | knots64(n)]
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, (size_t)(4 * n + 4) * sizeof(double));
+    if (rc) return rc;
+    hipStream_t st = e->own_stream;
+    double *d_rot = e->d_io_rows, *d_base = d_rot + n, *d_bk = d_base + n;
+    int64_t *d_k64 = (int64_t *)(d_bk + n + 2);
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    int64_t m = 0;
+    rc = extract_dev<double>(e, (const double *)e->d_io_x, n, d_rot, d_base, nullptr, &m, st, true);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(rot_host, d_rot, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipMemcpyAsync(base_host, d_base, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (knots_host && m > 0) {
+        k_widen_idx<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(e->d_kidx + 1, d_k64, m);
+        HIP_TRY(e, hipMemcpyAsync(knots_host, d_k64, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
+    if (bk_host) {
+        k_knot_values<double><<<(unsigned)((m + 2 + 255) / 256), 256, 0, st>>>((const double *)e->d_io_x, n, e->d_kidx, (int)m, d_bk);
+        HIP_TRY(e, hipMemcpyAsync(bk_host, d_bk, (size_t)(m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(e, hipStreamSynchronize(st));
+    if (m_host) *m_host = m;
+    return ITD_OK;
+}
+
+int itd_detect_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t mode, int32_t *idx_dev, int64_t *count_host,
+                   void *stream)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    return detect_dev<double>(e, x_dev, n, mode, idx_dev, count_host, stream ? (hipStream_t)stream : e->own_stream);
+}
+
+int itd_detect_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t mode, int32_t *idx_dev, int64_t *count_host,
+                   void *stream)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    return detect_dev<float>(e, x_dev, n, mode, idx_dev, count_host, stream ? (hipStream_t)stream : e->own_stream);
+}
+
+int itd_detect_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t mode, int64_t *idx_host,
+                        int64_t *count_host)
+{
+    if (!e || !x_host || !count_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, (size_t)n * sizeof(int64_t));
+    if (rc) return rc;
+    hipStream_t st = e->own_stream;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    int64_t m = 0;
+    rc = detect_dev<double>(e, (const double *)e->d_io_x, n, mode, nullptr, &m, st);
+    if (rc) return rc;
+    if (idx_host && m > 0) {
+        int64_t *d_k64 = (int64_t *)e->d_io_rows;
+        k_widen_idx<<<(unsigned)((m + 255) / 256), 256, 0, st>>>(e->d_kidx + 1, d_k64, m);
+        HIP_TRY(e, hipMemcpyAsync(idx_host, d_k64, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+    }
+    *count_host = m;
+    return ITD_OK;
+}
+
+int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host, int64_t m,
+                             double *bk_host)
+{
+    if (!e || !x_host || !extrema_host || !bk_host) return ITD_ERR_INVALID_ARG;
+    if (n < 2 || n > e->max_n || m < 0 || m + 2 > e->max_n + 2) return ITD_ERR_INVALID_ARG;
+    for (int64_t k = 0; k < m + 2; ++k)
+        if (extrema_host[k] < 0 || extrema_host[k] >= n) return ITD_ERR_INVALID_ARG;
+    if (m == 0) return ITD_OK;
+    DevGuard g(e->device);
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, (size_t)(m + 2) * sizeof(double));
+    if (rc) return rc;
+    hipStream_t st = e->own_stream;
+    std::vector<int32_t> e32((size_t)m + 2);
+    for (int64_t k = 0; k < m + 2; ++k) e32[(size_t)k] = (int32_t)extrema_host[k];
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(e, hipMemcpyAsync(e->d_kidx, e32.data(), (size_t)(m + 2) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    k_knot_values<double><<<(unsigned)((m + 2 + 255) / 256), 256, 0, st>>>((const double *)e->d_io_x, n, e->d_kidx, (int)m, e->d_io_rows);
+    // interior values only: bk[0] and bk[m+1] are the caller's (numba_accelerated_itd.py:171)
+    HIP_TRY(e, hipMemcpyAsync(bk_host + 1, e->d_io_rows + 1, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
+}
+
+int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
+{
+    if (!e || max_decompositions < 0 || max_decompositions > 4096) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    e->timing = max_decompositions > 0;
+    e->n_timed = 0;
+    e->timing_overflow = false;
+    const size_t want = 2 * (size_t)max_decompositions * (ITD_MAX_ROWS + 2);
+    while (e->ev.size() < want) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(e, hipEventCreate(&ev));
+        e->ev.push_back(ev);
+    }
+    e->ev_tag.resize(e->ev.size() / 2, 0);
+    return ITD_OK;
+}
+
+int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches)
+{
+    if (!e || which < 0 || which > ITD_TIME_DECOMPOSE) return ITD_ERR_INVALID_ARG;
+    if (!e->ran || !e->timing) return ITD_ERR_NOT_RUN;
+    DevGuard g(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    double tot = 0.0;
+    int cnt = 0;
+    for (int k = 0; k < e->n_timed; ++k) {
+        if (e->ev_tag[(size_t)k] != which) continue;
+        float ms = 0.f;
+        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev[2 * (size_t)k], e->ev[2 * (size_t)k + 1]));
+        tot += ms;
+        ++cnt;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = cnt;
+    return ITD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Thin Python handle over the C-ABI engine (include/pyitd_hip.h).
+
+Python never touches samples: it marshals pointers, sizes, a stream and the level count.
+Device memory for the device-resident entry points is whatever the caller owns (torch tensors,
+hipMalloc'd buffers, ...) — only raw pointers cross the boundary.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import ITDError, MAX_ROWS
+
+STOP_NATURAL, STOP_TIMEOUT = 0, 1
+DETECT_KNOTS, DETECT_VALLEYS, DETECT_PEAKS = 0, 1, 2
+ITD_OK, ITD_ERR_INVALID_ARG, ITD_ERR_NONFINITE = 0, 1, 6
+TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE = 0, 1, 2, 3
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """One engine = one GPU + one workspace sized for (max_n, max_batch).  Not thread-safe."""
+
+    def __init__(self, max_n, max_batch=1, device=0):
+        self._L = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._L.itd_engine_create(ctypes.byref(h), int(device), int(max_n), int(max_batch))
+        if rc:
+            raise ITDError(rc, "itd_engine_create(max_n=%d, max_batch=%d, device=%d)" % (max_n, max_batch, device))
+        self._h = h
+        self.max_n, self.max_batch, self.device = int(max_n), int(max_batch), int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.itd_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc and rc not in allow:
+            raise ITDError(rc, self._L.itd_last_error(self._h).decode())
+        return rc
+
+    @property
+    def workspace_bytes(self):
+        return self._L.itd_engine_workspace_bytes(self._h)
+
+    # ---- device-resident path ---------------------------------------------------------------
+    def decompose_dev(self, x_ptr, dtype, n, batch, x_stride, max_iteration, rows_ptr, baselines_ptr=None,
+                      stream=None):
+        """Enqueue a decomposition of device data (no host sync).  Pointers are ints."""
+        f = self._L.itd_decompose_f32 if np.dtype(dtype) == np.float32 else self._L.itd_decompose_f64
+        self._check(f(self._h, x_ptr, n, batch, x_stride, max_iteration, rows_ptr, baselines_ptr, stream))
+
+    def summary(self, batch):
+        n_rows = np.zeros(batch, np.int32)
+        n_b = np.zeros(batch, np.int32)
+        stop = np.zeros(batch, np.int32)
+        kc = np.zeros((batch, MAX_ROWS + 1), np.int64)
+        nanlv = np.zeros(batch, np.int32)
+        self._check(self._L.itd_get_summary(self._h, _np_ptr(n_rows), _np_ptr(n_b), _np_ptr(stop), _np_ptr(kc),
+                                            _np_ptr(nanlv)))
+        return {"n_rows": n_rows, "n_baselines": n_b, "stop": stop, "knot_counts": kc, "nan_levels": nanlv}
+
+    def set_timing(self, max_decompositions):
+        """Record hipEvent pairs around the extraction launches of the next `max_decompositions` runs (0 = off)."""
+        self._check(self._L.itd_set_kernel_timing(self._h, int(max_decompositions)))
+
+    def kernel_timing(self, which=TIME_EXTRACT):
+        """(total ms, launches) of the recorded launches of class `which` (TIME_*)."""
+        ms, cnt = ctypes.c_double(0), ctypes.c_int32(0)
+        self._check(self._L.itd_get_kernel_timing(self._h, which, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    # ---- numpy in -> numpy out ----------------------------------------------------------------
+    def decompose_host(self, x, max_iteration, want_baselines=True):
+        x = np.ascontiguousarray(x)
+        if x.dtype != np.float32:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        n = x.shape[0]
+        R = max_iteration + 2
+        rows = np.empty((R, n), np.float64)
+        bases = np.zeros((R, n), np.float64) if want_baselines else None
+        n_rows, n_b, stop = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        kc = np.zeros(MAX_ROWS + 1, np.int64)
+        f = self._L.itd_decompose_host_f32 if x.dtype == np.float32 else self._L.itd_decompose_host_f64
+        rc = self._check(f(self._h, _np_ptr(x), n, max_iteration, _np_ptr(rows), _np_ptr(bases), ctypes.byref(n_rows),
+                           ctypes.byref(n_b), ctypes.byref(stop), _np_ptr(kc)), allow=(ITD_ERR_NONFINITE,))
+        out = {"rows": rows[: n_rows.value], "stop": stop.value, "knot_counts": kc, "nonfinite": rc == ITD_ERR_NONFINITE}
+        if want_baselines:
+            out["baselines"] = bases[: n_b.value]
+        return out
+
+    def baseline_extract_host(self, x, want_knots=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = x.shape[0]
+        rot, base = np.empty(n), np.empty(n)
+        kn = np.empty(n, np.int64) if want_knots else None
+        bk = np.empty(n + 2) if want_knots else None
+        m = ctypes.c_int64(0)
+        self._check(self._L.itd_baseline_extract_host_f64(self._h, _np_ptr(x), n, _np_ptr(rot), _np_ptr(base),
+                                                          _np_ptr(kn), ctypes.byref(m), _np_ptr(bk)))
+        if want_knots:
+            return rot, base, kn[: m.value].copy(), bk[: m.value + 2].copy()
+        return rot, base
+
+    def detect_host(self, x, mode=DETECT_KNOTS):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = x.shape[0]
+        idx = np.empty(n, np.int64)
+        m = ctypes.c_int64(0)
+        self._check(self._L.itd_detect_host_f64(self._h, _np_ptr(x), n, mode, _np_ptr(idx), ctypes.byref(m)))
+        return idx[: m.value].copy()
+
+    def knot_values_host(self, baseline_knots, x, extrema_indices):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        e = np.ascontiguousarray(extrema_indices, dtype=np.int64)
+        bk = np.ascontiguousarray(baseline_knots, dtype=np.float64)
+        self._check(self._L.itd_knot_values_host_f64(self._h, _np_ptr(x), x.shape[0], _np_ptr(e), e.shape[0] - 2,
+                                                     _np_ptr(bk)))
+        return bk

@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's ITD call surface, backed by the HIP engine.
+
+Same names, argument meaning, return shapes/dtypes and error behaviour as
+  ITD.py            class ITD (:123-465), itd_baseline_extract (:79-121), detect_peaks (:33-76), isin (:23-32)
+  ITD_numba.py      free function itd(data, max_iteration=22) (:100-136)
+  numba_accelerated_itd.py   matlab_detect_peaks (:17-59), baseline_knot_estimation (:167-178)
+plus the north-star form  itd_levels(x, n_iters) -> (rotations[n, N], baseline[N]).
+
+Every numeric result comes from libpyitd_hip.so (hand-written gfx950 kernels); there is no CPU
+fallback — without the library or a GPU these functions raise.
+"""
+import numpy
+
+from . import _lib
+from .engine import DETECT_KNOTS, DETECT_PEAKS, DETECT_VALLEYS, STOP_TIMEOUT, Engine
+
+_engines = {}
+
+
+def _engine_for(n, device=0):
+    """Engines are cached per device and grown in powers of two."""
+    cap = 1 << max(12, int(n - 1).bit_length())
+    key = int(device)
+    eng = _engines.get(key)
+    if eng is None or eng.max_n < n:
+        if eng is not None:
+            eng.close()
+        eng = Engine(cap, 1, device)
+        _engines[key] = eng
+    return eng
+
+
+def _as_signal(data):
+    """float32 stays float32 (widened exactly on the GPU, like numpy.asarray(.., float64) at ITD.py:389);
+    everything else becomes float64."""
+    a = numpy.asarray(data)
+    if a.ndim != 1:
+        a = a.reshape(-1)
+    if a.dtype != numpy.float32:
+        a = numpy.asarray(a, dtype=numpy.float64)
+    return numpy.ascontiguousarray(a)
+
+
+def isin(a, b):
+    """ITD.py:23-32 — boolean membership of int64 a[i] in b."""
+    return numpy.isin(numpy.asarray(a, dtype=numpy.int64), numpy.asarray(b, dtype=numpy.int64))
+
+
+def detect_peaks(x, device=0):
+    """ITD.py:33-76 — indices i with dx[i] > 0 and dx[i-1] <= 0 (int64, ascending)."""
+    x = numpy.asarray(x, dtype=numpy.float64)
+    if len(x) < 3:
+        raise ValueError("detect_peaks needs at least 3 samples (the reference returns numpy.empty(1) garbage)")
+    return _engine_for(len(x), device).detect_host(x, DETECT_VALLEYS)
+
+
+def matlab_detect_peaks(x, device=0):
+    """numba_accelerated_itd.py:17-59 — detect_peaks on the negated differences."""
+    x = numpy.asarray(x, dtype=numpy.float64)
+    if len(x) < 3:
+        raise ValueError("matlab_detect_peaks needs at least 3 samples")
+    return _engine_for(len(x), device).detect_host(x, DETECT_PEAKS)
+
+
+def detect_knots(x, device=0):
+    """ITD.py:87-98 — sort(unique(detect_peaks(x) U detect_peaks(-x)))."""
+    x = numpy.asarray(x, dtype=numpy.float64)
+    return _engine_for(len(x), device).detect_host(x, DETECT_KNOTS)
+
+
+def baseline_knot_estimation(baseline_knots, x, extrema_indices, device=0):
+    """numba_accelerated_itd.py:167-178 — fills baseline_knots[1:-1]; the end knots stay the caller's."""
+    x = numpy.asarray(x, dtype=numpy.float64)
+    out = _engine_for(len(x), device).knot_values_host(baseline_knots, x, extrema_indices)
+    try:
+        baseline_knots[:] = out  # the reference writes into its argument and returns it
+        return baseline_knots
+    except (TypeError, ValueError):
+        return out
+
+
+def itd_baseline_extract(data, device=0):
+    """ITD.py:79-121 — (rotation, baseline), both float64[N]."""
+    x = numpy.asarray(data, dtype=numpy.float64)
+    if len(x) < 3:
+        raise ValueError("itd_baseline_extract needs at least 3 samples")
+    return _engine_for(len(x), device).baseline_extract_host(x)
+
+
+class ITD:
+    """Intrinsic Time-Scale Decomposition — drop-in for the reference class (ITD.py:123-465)."""
+
+    def __init__(self, extrema_detection: str = "matlab", device: int = 0):
+        self.extrema_detection = extrema_detection
+        assert self.extrema_detection in (
+            "simple",
+            "parabol",
+            "matlab",
+        ), "Only 'simple', 'matlab', and 'parabol' values supported"  # ITD.py:177-181
+        self.DTYPE = numpy.float64
+        self.device = device
+        self.rotations = None
+        self.baselines = None
+        self.knot_counts = None
+        self.stop_reason = None
+
+    def __call__(self, S, max_iterations: int = 12):
+        # upstream passes a misspelt keyword here (ITD.py:189-190) and cannot run; the intent is clear
+        return self.itd(S, max_iteration=max_iterations)
+
+    def itd(self, data, max_iteration: int = 11):
+        """ITD.py:351-432 — rows 0..c-1 are proper rotations, the last row is the residual."""
+        x = _as_signal(data)
+        self.DTYPE = numpy.asarray(data).dtype
+        n = len(x)
+        if n < 3:
+            raise ValueError("ITD needs at least 3 samples")
+        if max_iteration < 0:
+            # counter > max_iteration holds at once: the first pending pair is summed (ITD.py:418-422)
+            raise ValueError("max_iteration must be >= 0")
+        m = min(int(max_iteration), _lib.MAX_ITERATION)
+        res = _engine_for(n, self.device).decompose_host(x, m, want_baselines=True)
+        if res["nonfinite"]:
+            raise FloatingPointError(
+                "a baseline became NaN (the signal starts with a plateau, ITD.py:115-116 divides by zero); "
+                "the reference continues through its NaN->inf path (ITD.py:46-51), which this build rejects")
+        if max_iteration > _lib.MAX_ITERATION and res["stop"] == STOP_TIMEOUT:
+            # the reference's buffers hold 22 rows (ITD.py:384-385): row 22 does not exist
+            raise IndexError("index 22 is out of bounds for axis 0 with size 22")
+        self.rotations = res["rows"]
+        self.baselines = res["baselines"]
+        self.knot_counts = res["knot_counts"]
+        self.stop_reason = "timeout" if res["stop"] == STOP_TIMEOUT else "natural"
+        return self.rotations
+
+    def get_baselines(self):
+        if self.baselines is None:
+            raise ValueError("No baselines found. Please, run ITD method or its variant first.")
+        return self.baselines
+
+    def get_rotations(self):
+        if self.rotations is None:
+            raise ValueError("No IPR found. Please, run ITD method or its variant first.")
+        return self.rotations
+
+
+def itd(data, max_iteration: int = 22, device=0):
+    """ITD_numba.py:100-136 — free-function driver (its default of 22 overruns the 22-row buffer upstream;
+    the usable range is 0..20)."""
+    return ITD(device=device).itd(data, max_iteration=max_iteration)
+
+
+def itd_levels(x, n_iters, device=0):
+    """North-star form: n_iters proper rotations and the final baseline.
+    Equals rows[:-1], rows[-1] of ITD().itd(x, max_iteration=n_iters-1)."""
+    rows = ITD(device=device).itd(x, max_iteration=int(n_iters) - 1)
+    return rows[:-1], rows[-1]

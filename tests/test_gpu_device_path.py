@@ -1,0 +1,98 @@
+"""Device-resident entry points (torch tensors carry the HBM buffers; only raw pointers cross the C ABI):
+batches, strides, the ping-pong/keep-all baseline modes, full-size property checks."""
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal, sines_noise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyitd_amd
+    return pyitd_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cpu_oracle
+    return cpu_oracle
+
+
+def _run(P, torch, x_np, m, keep_baselines, stride_pad=0):
+    B, n = x_np.shape
+    stride = n + stride_pad
+    dt = torch.float32 if x_np.dtype == np.float32 else torch.float64
+    xd = torch.zeros((B, stride), dtype=dt, device="cuda")
+    xd[:, :n] = torch.from_numpy(x_np).cuda()
+    R = m + 2
+    rows = torch.full((B, R, n), float("nan"), dtype=torch.float64, device="cuda")
+    bases = torch.full((B, R, n), float("nan"), dtype=torch.float64, device="cuda") if keep_baselines else None
+    eng = P.Engine(n, B, 0)
+    torch.cuda.synchronize()   # the engine's stream does not wait for torch's null stream
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.decompose_dev(xd.data_ptr(), x_np.dtype, n, B, stride, m, rows.data_ptr(),
+                      bases.data_ptr() if keep_baselines else None, stream)
+    s = eng.summary(B)
+    torch.cuda.synchronize()
+    out = rows.cpu().numpy(), (bases.cpu().numpy() if keep_baselines else None), s
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("keep", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batch_matches_oracle_per_signal(P, torch, oracle, keep, dtype):
+    n, B, m = 6000, 9, 6
+    rng = np.random.default_rng(3)
+    x = np.stack([sines_noise(n, seed=b, fscale=1 + b / 8.0, dtype=np.float64) for b in range(B)])
+    x[3] = np.linspace(0, 1, n) ** 2                  # monotone: one all-zero row (ITD.py:404-416 with counter 0)
+    x[4] = np.sin(np.linspace(0, 3 * np.pi, n))       # stops naturally after a couple of levels
+    x[5] = rng.standard_normal(n)
+    x = x.astype(dtype)
+    rows, bases, s = _run(P, torch, x, m, keep, stride_pad=4)
+    for b in range(B):
+        ref = oracle.itd(x[b], m)
+        nr = int(s["n_rows"][b])
+        assert nr == ref["rows"].shape[0], "signal %d" % b
+        assert ("natural", "timeout")[int(s["stop"][b])] == ref["stop"]
+        assert_bits_equal(rows[b, :nr], ref["rows"], "signal %d rows" % b)
+        assert int(s["nan_levels"][b]) == -1
+        if keep:
+            nb = int(s["n_baselines"][b])
+            assert nb == ref["baselines"].shape[0]
+            assert_bits_equal(bases[b, :nb], ref["baselines"], "signal %d baselines" % b)
+
+
+def test_unaligned_stride_falls_back_to_scalar_loads(P, torch, oracle):
+    n, B, m = 4099, 3, 3
+    x = np.stack([sines_noise(n, seed=10 + b, dtype=np.float32) for b in range(B)])
+    rows, _, s = _run(P, torch, x, m, False, stride_pad=1)   # odd stride: rows 1.. are not 16-byte aligned
+    for b in range(B):
+        ref = oracle.itd(x[b], m)
+        assert_bits_equal(rows[b, : int(s["n_rows"][b])], ref["rows"], "signal %d" % b)
+
+
+def test_config2_full_size_properties(P, torch, oracle):
+    """BASELINE configs[1]: 2^24 float32 sines+noise, 8 levels (max_iteration=7), one GPU.
+    Bit-exact vs the oracle on knot counts and on a checksum of every row; exact reconstruction."""
+    n, m = 1 << 24, 7
+    x = sines_noise(n)
+    rows, _, s = _run(P, torch, x[None], m, False)
+    nr = int(s["n_rows"][0])
+    ref = oracle.itd_lean(x, m)
+    assert nr == ref["rows"].shape[0] == 9 and int(s["stop"][0]) == 1
+    assert s["knot_counts"][0, :nr].tolist() == ref["knot_counts"].tolist()
+    assert_bits_equal(rows[0, :nr], ref["rows"], "2^24 rows")
+    # size-independent properties: rows sum back to the input; the last sample is never moved (ITD.py:112-117)
+    recon = rows[0, :nr].sum(axis=0)
+    assert np.max(np.abs(recon - x.astype(np.float64))) < 1e-12
+    assert rows[0, 0, -1] == float(x[-1]) and np.all(rows[0, 1:nr, -1] == 0.0)

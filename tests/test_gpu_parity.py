@@ -1,0 +1,151 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+Bit-exact on knot indices (integers) AND on the float64 rows (stricter than the 1e-6 the north star allows)."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases
+from helpers import assert_bits_equal, chirp, load_golden, sha, sines_noise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyitd_amd
+    return pyitd_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cpu_oracle
+    return cpu_oracle
+
+
+def _finite(name):
+    return bool(load_golden(name)["finite"])
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases() if _finite(c)])
+def test_driver_matches_golden(P, name):
+    g = load_golden(name)
+    dec = P.ITD()
+    rows = dec.itd(g["x"], max_iteration=int(g["max_iteration"]))
+    assert rows.dtype == np.float64 and rows.shape[0] == int(g["n_rows"])
+    assert dec.stop_reason == str(g["stop"])
+    assert sha(rows) == str(g["rows_sha256"]), "rows are not bit-identical to the reference"
+    b = dec.get_baselines()
+    assert tuple(b.shape) == tuple(g["baselines_shape"])
+    assert sha(b) == str(g["baselines_sha256"])
+    if "rows" in g:
+        assert_bits_equal(rows, g["rows"], name)
+    # knot indices of every level, bit-exact (level 0 = input, level j = stored baseline j-1)
+    levels = [np.asarray(g["x"], dtype=np.float64)] + [b[j] for j in range(b.shape[0])]
+    for j, xl in enumerate(levels):
+        k = P.detect_knots(xl)
+        assert k.dtype == np.int64
+        np.testing.assert_array_equal(k, g["knots_L%d" % j], err_msg="%s level %d" % (name, j))
+    # the counts the engine saw on the device agree with the reference's lists
+    kc = [int(v) for v in dec.knot_counts if v >= 0]
+    want = [len(g["knots_L%d" % j]) for j in range(len(levels))]
+    assert kc[: len(want)] == want[: len(kc)]
+
+
+@pytest.mark.parametrize("name", [c for c in golden_cases() if not _finite(c)])
+def test_nan_cases_are_rejected_loudly(P, name):
+    g = load_golden(name)
+    with pytest.raises(FloatingPointError):
+        P.ITD().itd(g["x"], max_iteration=int(g["max_iteration"]))
+
+
+@pytest.mark.parametrize("name", ["radio8000_m11", "chirp4096_f32_m3", "edge_int_valued", "edge_zigzag1024",
+                                  "edge_n3", "edge_n5_zigzag", "edge_trail_plateau", "edge_denormal"])
+def test_single_level_operators(P, oracle, name):
+    g = load_golden(name)
+    x = np.asarray(g["x"], dtype=np.float64)
+    rot, base = P.itd_baseline_extract(x)
+    assert sha(rot) == str(g["extract_rot_sha256"])
+    assert sha(base) == str(g["extract_base_sha256"])
+    np.testing.assert_array_equal(P.detect_peaks(x), oracle.detect_peaks(x))
+    np.testing.assert_array_equal(P.matlab_detect_peaks(x), oracle.detect_peaks(x, matlab=True))
+    np.testing.assert_array_equal(P.detect_peaks(-x), P.matlab_detect_peaks(x))
+    k = g["knots_L0"]
+    e = np.concatenate([[0], k, [len(x) - 1]]).astype(np.int64)
+    bk = np.zeros(len(e))
+    bk[0], bk[-1] = np.mean(x[:2]), np.mean(x[-2:])
+    want = oracle.knot_values(x, e)
+    got = P.baseline_knot_estimation(bk, x, e)
+    assert_bits_equal(got, want, name + " knot values")
+    assert P.isin(np.array([1, 5, 9]), np.array([5, 9, 11])).tolist() == [False, True, True]
+
+
+def test_api_surface_and_errors(P):
+    with pytest.raises(AssertionError):
+        P.ITD(extrema_detection="spline")
+    d = P.ITD()
+    with pytest.raises(ValueError):
+        d.get_baselines()
+    with pytest.raises(ValueError):
+        d.get_rotations()
+    with pytest.raises(ValueError):
+        d.itd(np.zeros(2))
+    x = np.sin(np.linspace(0, 40, 1000))
+    rows = d(x, max_iterations=2)           # __call__ (ITD.py:189)
+    assert rows.shape == (4, 1000) and d.get_rotations() is rows
+    rot, base = P.itd_levels(x, 3)          # north-star form
+    assert rot.shape == (3, 1000) and base.shape == (1000,)
+    assert_bits_equal(np.vstack([rot, base[None]]), rows, "itd_levels")
+    assert_bits_equal(P.itd(x, 2), rows, "free function")
+    # more rows than the reference's 22-row buffers can hold
+    rng = np.random.default_rng(5)
+    z = np.where(np.arange(1024) % 2 == 0, -1.0, 1.0) * (1 + 0.001 * np.arange(1024))
+    with pytest.raises(IndexError):
+        d.itd(z, max_iteration=25)
+    assert d.itd(rng.standard_normal(500), max_iteration=25).shape[0] < 22  # natural stop first: fine
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 63, 64, 65, 2047, 2048, 2049, 4095, 4097, 6144, 10001, 65536 + 17])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ragged_sizes_vs_oracle(P, oracle, n, dtype):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + np.sin(np.arange(n) / 37.0) * 3).astype(dtype)
+    for m in (0, 4):
+        dec = P.ITD()
+        rows = dec.itd(x, max_iteration=m)
+        ref = oracle.itd(x, m)
+        assert dec.stop_reason == ref["stop"]
+        assert_bits_equal(rows, ref["rows"], "n=%d m=%d rows" % (n, m))
+        assert_bits_equal(dec.get_baselines(), ref["baselines"], "n=%d m=%d baselines" % (n, m))
+
+
+def test_f32_denormals_and_extremes(P, oracle):
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(5000) * 1e-41).astype(np.float32)   # float32 subnormals must widen exactly
+    assert np.any((x != 0) & (np.abs(x) < np.finfo(np.float32).tiny))
+    assert_bits_equal(P.ITD().itd(x, 5), oracle.itd(x, 5)["rows"], "f32 subnormal")
+    y = (rng.standard_normal(5000) * 1e38).astype(np.float32)
+    assert_bits_equal(P.ITD().itd(y, 5), oracle.itd(y, 5)["rows"], "f32 huge")
+    z = rng.standard_normal(5000) * 1e-320
+    assert_bits_equal(P.ITD().itd(z, 5), oracle.itd(z, 5)["rows"], "f64 subnormal")
+
+
+def test_config1_chirp_2p16(P, oracle):
+    """BASELINE configs[0]: 2^16 float32 chirp, 4 ITD levels (max_iteration=3)."""
+    x = chirp(1 << 16)
+    dec = P.ITD()
+    rows = dec.itd(x, 3)
+    g = load_golden("chirp65536_f32_m3")
+    assert sha(rows) == str(g["rows_sha256"])
+    assert [int(v) for v in dec.knot_counts[:4]] == [8050, 3884, 1997, 800]
+
+
+def test_one_million_samples_bit_exact(P, oracle):
+    x = sines_noise(1 << 20)
+    dec = P.ITD()
+    rows = dec.itd(x, 7)
+    ref = oracle.itd_lean(x, 7, want_knots=True)
+    assert dec.stop_reason == ref["stop"]
+    assert_bits_equal(rows, ref["rows"], "2^20 rows")
+    b = dec.get_baselines()
+    for j in range(1, rows.shape[0]):
+        np.testing.assert_array_equal(P.detect_knots(b[j - 1]), ref["knots"][j])
+    assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
