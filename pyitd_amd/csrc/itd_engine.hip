@@ -2,7 +2,7 @@
 //
 // The level loop of the reference driver (ITD.itd, ITD.py:384-432) is enqueued here as a fixed
 // sequence of launches on one HIP stream with NO host synchronisation between levels: the stop rule
-// (`num_extrema < 2`, ITD.py:404) is evaluated on the device by k_compact and later launches of a
+// (`num_extrema < 2`, ITD.py:404) is evaluated on the device by block 0 of k_extract and later launches of a
 // stopped signal return at once; k_finalize performs the row fix-up.  The host reads one small
 // per-signal summary at the end (itd_get_summary).
 #include <hip/hip_runtime.h>
@@ -18,7 +18,7 @@
 #include "itd_kernels.hpp"
 
 #ifndef ITD_TILE
-#define ITD_TILE 2048
+#define ITD_TILE 1024
 #endif
 
 using namespace itd;
@@ -52,11 +52,15 @@ struct itd_engine {
     int64_t max_tiles = 0;
     hipStream_t own_stream = nullptr;
     // workspace
-    int32_t *d_lists = nullptr;    // [batch][tiles][T]
-    int32_t *d_counts = nullptr;   // [batch][tiles]
-    int32_t *d_offsets = nullptr;  // [batch][tiles+1]
-    int32_t *d_kidx = nullptr;     // [batch][max_n + 2]
-    double *d_pp = nullptr;        // [batch][2][max_n] ping-pong baselines
+    int32_t *d_lists = nullptr;    // [batch][tiles][T]  per-tile knot lists (a block reads and rewrites only its own)
+    int32_t *d_counts = nullptr;   // [2][batch][tiles]  knots per tile, double buffered by level parity
+    TileRec *d_recs = nullptr;     // [2][batch][tiles]  head/tail knot records, double buffered by level parity
+    int64_t tiles_half = 0;        // elements per counts/recs buffer
+    int32_t *d_gsum = nullptr;     // [3][batch][groups*pitch]: per-64-tile knot totals, rotating by level % 3
+    int64_t gsum_third = 0;        // elements per buffer
+    int32_t *d_kidx = nullptr;     // [max_n + 2]  ordered knot indices for the API helpers (single signal)
+    int32_t *d_total = nullptr;    // [1] knot total written by k_compact
+    double *d_pp = nullptr;        // [batch][3][max_n] rotating baselines (slot = level % 3)
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
     int64_t ws_bytes = 0;
@@ -123,19 +127,20 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
     const dim3 grid_t(n_tiles, batch), blk(kThreads);
-    const dim3 grid_c((n_tiles + kTilesPerBlock - 1) / kTilesPerBlock, batch);
-    const int64_t kidx_stride = e->max_n + 2;
+    auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
+    auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
+    auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
 
     const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
     k_init_state<<<(batch + 255) / 256, 256, 0, st>>>(e->d_state, batch);
+    HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, (int)kKnots, e->d_lists, e->d_counts);
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, (int)kKnots, e->d_lists, cnt(0), rec(0), gs(0),
+                                              e->d_state);
 
     for (int j = 0; j <= M + 1; ++j) {
-        k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, kidx_stride,
-                                              e->d_offsets, e->d_state, j, j >= 1 ? 1 : 0);
         // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
         double *base_out;
         int64_t base_stride;
@@ -146,45 +151,35 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             base_stride = rows_stride;
             if (j >= 1) { base_in = bases_user + (int64_t)(j - 1) * n; base_in_stride = rows_stride; }
         } else {
-            base_out = e->d_pp + (int64_t)(j & 1) * e->max_n;
-            base_stride = 2 * e->max_n;
-            if (j >= 1) { base_in = e->d_pp + (int64_t)((j - 1) & 1) * e->max_n; base_in_stride = 2 * e->max_n; }
+            base_out = e->d_pp + (int64_t)(j % 3) * e->max_n;
+            base_stride = 3 * e->max_n;
+            if (j >= 1) { base_in = e->d_pp + (int64_t)((j - 1) % 3) * e->max_n; base_in_stride = 3 * e->max_n; }
         }
         double *rot_out = rows + (int64_t)j * n;
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
+    k_extract<TIN, T, FIN><<<grid_t, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, e->d_lists, cnt(j), cnt(j + 1), rec(j),  \
+                                                    rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
+                                                    base_out, base_stride, e->d_state, j)
         if (j == 0) {
-            if (final_level)
-                k_extract<Tin, T, true><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, e->d_kidx, kidx_stride,
-                                                                 e->d_offsets, rot_out, rows_stride, base_out,
-                                                                 base_stride, e->d_lists, e->d_counts, e->d_state, j);
-            else
-                k_extract<Tin, T, false><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, e->d_kidx, kidx_stride,
-                                                                  e->d_offsets, rot_out, rows_stride, base_out,
-                                                                  base_stride, e->d_lists, e->d_counts, e->d_state, j);
+            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride);
+            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride);
         } else {
-            if (final_level)
-                k_extract<double, T, true><<<grid_t, blk, 0, st>>>(base_in, base_in_stride, n, n_tiles, e->d_kidx,
-                                                                    kidx_stride, e->d_offsets, rot_out, rows_stride,
-                                                                    base_out, base_stride, e->d_lists, e->d_counts,
-                                                                    e->d_state, j);
-            else
-                k_extract<double, T, false><<<grid_t, blk, 0, st>>>(base_in, base_in_stride, n, n_tiles, e->d_kidx,
-                                                                     kidx_stride, e->d_offsets, rot_out, rows_stride,
-                                                                     base_out, base_stride, e->d_lists, e->d_counts,
-                                                                     e->d_state, j);
+            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride);
+            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride);
         }
+#undef ITD_LAUNCH_EXTRACT
         time_end(e, pair, st);
     }
     // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
-    k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, kidx_stride, e->d_offsets,
-                                          e->d_state, M + 2, 1);
+    k_last_count<<<batch, 64, 0, st>>>(gs(M + 2), n_tiles, e->d_state, M + 2);
     {
         const int fb = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, 1024);
         if (bases_user)
             k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, e->d_state);
         else
-            k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, e->d_pp, 2 * e->max_n, e->max_n, 1,
+            k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->max_n, e->max_n, 3,
                                                          e->d_state);
     }
     time_end(e, span_pair, st);
@@ -256,20 +251,20 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->max_tiles = tiles_of(max_n);
     DevGuard g(device_id);
     const size_t B = (size_t)max_batch;
-    const size_t lists_b = B * (size_t)e->max_tiles * T * sizeof(int32_t);
-    const size_t counts_b = B * (size_t)e->max_tiles * sizeof(int32_t);
-    const size_t offs_b = B * (size_t)(e->max_tiles + 1) * sizeof(int32_t);
-    const size_t kidx_b = B * (size_t)(max_n + 2) * sizeof(int32_t);
-    const size_t pp_b = B * 2 * (size_t)max_n * sizeof(double);
-    const size_t st_b = B * sizeof(SigState);
+    const int max_groups = groups_of((int)e->max_tiles);
+    e->tiles_half = (int64_t)B * e->max_tiles;
+    e->gsum_third = (int64_t)B * max_groups * kGsumPitch;
     hipError_t rc = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (rc == hipSuccess) { rc = hipMalloc(p, bytes); if (rc == hipSuccess) e->ws_bytes += (int64_t)bytes; } };
-    alloc((void **)&e->d_lists, lists_b);
-    alloc((void **)&e->d_counts, counts_b);
-    alloc((void **)&e->d_offsets, offs_b);
-    alloc((void **)&e->d_kidx, kidx_b);
-    alloc((void **)&e->d_pp, pp_b);
-    alloc((void **)&e->d_state, st_b);
+    alloc((void **)&e->d_lists, B * (size_t)e->max_tiles * T * sizeof(int32_t));
+    alloc((void **)&e->d_counts, 2 * (size_t)e->tiles_half * sizeof(int32_t));
+    alloc((void **)&e->d_recs, 2 * (size_t)e->tiles_half * sizeof(TileRec));
+    alloc((void **)&e->d_gsum, 3 * (size_t)e->gsum_third * sizeof(int32_t));
+    alloc((void **)&e->d_kidx, (size_t)(max_n + 2) * sizeof(int32_t));
+    alloc((void **)&e->d_total, 64);
+    alloc((void **)&e->d_pp, B * 3 * (size_t)max_n * sizeof(double));
+    alloc((void **)&e->d_state, B * sizeof(SigState));
+    const size_t st_b = B * sizeof(SigState);
     if (rc == hipSuccess) rc = hipHostMalloc((void **)&e->h_state, st_b);
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (rc != hipSuccess) {
@@ -286,8 +281,8 @@ void itd_engine_destroy(itd_engine *e)
     if (!e) return;
     DevGuard g(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    (void)hipFree(e->d_lists); (void)hipFree(e->d_counts); (void)hipFree(e->d_offsets);
-    (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state);
+    (void)hipFree(e->d_lists); (void)hipFree(e->d_counts); (void)hipFree(e->d_recs); (void)hipFree(e->d_total);
+    (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -395,6 +390,32 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
     return nanlv >= 0 ? ITD_ERR_NONFINITE : ITD_OK;
 }
 
+// level-0 knot scan of one device signal into the workspace of batch slot 0; optional ordered list in d_kidx
+template <typename Tin>
+int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, hipStream_t st)
+{
+    const int n_tiles = (int)tiles_of(n);
+    const dim3 grid_t(n_tiles, 1), blk(kThreads);
+    k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
+    HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, e->d_lists, e->d_counts, e->d_recs, e->d_gsum,
+                                              e->d_state);
+    if (compact)
+        k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_counts, e->d_gsum, n_tiles, n, e->d_kidx, e->max_n + 2,
+                                              e->d_total);
+    HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
+}
+
+int fetch_total(itd_engine *e, hipStream_t st, int64_t *m_host)
+{
+    int32_t m32 = 0;
+    HIP_TRY(e, hipMemcpyAsync(&m32, e->d_total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    *m_host = m32;
+    return ITD_OK;
+}
+
 template <typename Tin>
 int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *base, int32_t *knots, int64_t *m_host,
                 hipStream_t st, bool want_sync)
@@ -404,21 +425,21 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     DevGuard g(e->device);
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kThreads);
-    const dim3 grid_c((n_tiles + kTilesPerBlock - 1) / kTilesPerBlock, 1);
-    k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, (int)kKnots, e->d_lists, e->d_counts);
-    k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, e->max_n + 2, e->d_offsets,
-                                          e->d_state, 0, 0);
-    k_extract<Tin, T, false><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, e->d_kidx, e->max_n + 2, e->d_offsets, rot, n,
-                                                      base, n, e->d_lists, e->d_counts, e->d_state, 0);
+    const bool want_list = m_host || knots || want_sync;
+    int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
+    if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
+    k_extract<Tin, T, false><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, e->d_lists, e->d_counts,
+                                                      e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
+                                                      e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
+                                                      rot, n, base, n, e->d_state, 0);
     HIP_TRY(e, hipGetLastError());
-    if (m_host || knots || want_sync) {
-        int32_t m32 = 0;
-        HIP_TRY(e, hipMemcpyAsync(&m32, e->d_offsets + n_tiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(e, hipStreamSynchronize(st));
-        if (m_host) *m_host = m32;
-        if (knots && m32 > 0) {
-            HIP_TRY(e, hipMemcpyAsync(knots, e->d_kidx + 1, sizeof(int32_t) * (size_t)m32, hipMemcpyDeviceToDevice, st));
+    if (want_list) {
+        int64_t m = 0;
+        rc = fetch_total(e, st, &m);
+        if (rc) return rc;
+        if (m_host) *m_host = m;
+        if (knots && m > 0) {
+            HIP_TRY(e, hipMemcpyAsync(knots, e->d_kidx + 1, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToDevice, st));
             HIP_TRY(e, hipStreamSynchronize(st));
         }
     }
@@ -431,20 +452,12 @@ int detect_dev(itd_engine *e, const Tin *x, int64_t n, int32_t mode, int32_t *id
     if (!e || !x || !count) return ITD_ERR_INVALID_ARG;
     if (n < 3 || n > e->max_n || mode < 0 || mode > 2) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
-    const int n_tiles = (int)tiles_of(n);
-    const dim3 grid_t(n_tiles, 1), blk(kThreads);
-    const dim3 grid_c((n_tiles + kTilesPerBlock - 1) / kTilesPerBlock, 1);
-    k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, e->d_lists, e->d_counts);
-    k_compact<T><<<grid_c, blk, 0, st>>>(e->d_lists, e->d_counts, n_tiles, n, e->d_kidx, e->max_n + 2, e->d_offsets,
-                                          e->d_state, 0, 0);
-    HIP_TRY(e, hipGetLastError());
-    int32_t m32 = 0;
-    HIP_TRY(e, hipMemcpyAsync(&m32, e->d_offsets + n_tiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(e, hipStreamSynchronize(st));
-    *count = m32;
-    if (idx && m32 > 0) {
-        HIP_TRY(e, hipMemcpyAsync(idx, e->d_kidx + 1, sizeof(int32_t) * (size_t)m32, hipMemcpyDeviceToDevice, st));
+    int rc = scan_level0<Tin>(e, x, n, mode, true, st);
+    if (rc) return rc;
+    rc = fetch_total(e, st, count);
+    if (rc) return rc;
+    if (idx && *count > 0) {
+        HIP_TRY(e, hipMemcpyAsync(idx, e->d_kidx + 1, sizeof(int32_t) * (size_t)*count, hipMemcpyDeviceToDevice, st));
         HIP_TRY(e, hipStreamSynchronize(st));
     }
     return ITD_OK;
