@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyitd_hip.so")
+LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]

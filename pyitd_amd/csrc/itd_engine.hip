@@ -18,14 +18,18 @@
 #include "itd_kernels.hpp"
 
 #ifndef ITD_TILE
-#define ITD_TILE 1024
+#define ITD_TILE 256
 #endif
 
 using namespace itd;
 
 namespace {
 constexpr int T = ITD_TILE;
-static_assert(T % (kThreads) == 0 && (T / kWaves) % 64 == 0 && T / 64 <= 64, "tile geometry");
+#ifndef ITD_PERSIST
+#define ITD_PERSIST 0
+#endif
+constexpr bool kPersist = ITD_PERSIST != 0;  // 1: resident wavefronts loop over tiles with a software pipeline
+static_assert(T % 256 == 0 && T / 64 <= 64, "tile geometry: whole float4/double2 loads per lane, <= 64 flag words");
 
 __global__ void k_init_state(SigState *st, int batch)
 {
@@ -52,7 +56,7 @@ struct itd_engine {
     int64_t max_tiles = 0;
     hipStream_t own_stream = nullptr;
     // workspace
-    int32_t *d_lists = nullptr;    // [batch][tiles][T]  per-tile knot lists (a block reads and rewrites only its own)
+    int32_t *d_lists = nullptr;    // [tiles][T]  per-tile knot lists, written only for the API helpers (k_compact)
     int32_t *d_counts = nullptr;   // [2][batch][tiles]  knots per tile, double buffered by level parity
     TileRec *d_recs = nullptr;     // [2][batch][tiles]  head/tail knot records, double buffered by level parity
     int64_t tiles_half = 0;        // elements per counts/recs buffer
@@ -64,6 +68,7 @@ struct itd_engine {
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
     int64_t ws_bytes = 0;
+    int64_t persistent_waves = 0;  // resident wavefronts of k_extract: CUs x (LDS-limited workgroups per CU)
     // host-convenience staging (grow only)
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
@@ -126,7 +131,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int n_tiles = (int)tiles_of(n);
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
-    const dim3 grid_t(n_tiles, batch), blk(kThreads);
+    const dim3 grid_t(n_tiles, batch), blk(kWave);
+    const dim3 grid_p((unsigned)std::min<int64_t>((int64_t)n_tiles * batch, e->persistent_waves));
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
@@ -137,7 +143,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, (int)kKnots, e->d_lists, cnt(0), rec(0), gs(0),
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, (int)kKnots, nullptr, cnt(0), rec(0), gs(0),
                                               e->d_state);
 
     for (int j = 0; j <= M + 1; ++j) {
@@ -159,7 +165,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
-    k_extract<TIN, T, FIN><<<grid_t, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, e->d_lists, cnt(j), cnt(j + 1), rec(j),  \
+    k_extract<TIN, T, FIN, kPersist><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
                                                     rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
                                                     base_out, base_stride, e->d_state, j)
         if (j == 0) {
@@ -175,12 +181,13 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
     k_last_count<<<batch, 64, 0, st>>>(gs(M + 2), n_tiles, e->d_state, M + 2);
     {
-        const int fb = (int)std::min<int64_t>((n + kThreads - 1) / kThreads, 1024);
+        const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
         if (bases_user)
-            k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, e->d_state);
+            k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0,
+                                                                      e->d_state);
         else
-            k_finalize<<<dim3(fb, batch), blk, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->max_n, e->max_n, 3,
-                                                         e->d_state);
+            k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->max_n,
+                                                                      e->max_n, 3, e->d_state);
     }
     time_end(e, span_pair, st);
     HIP_TRY(e, hipGetLastError());
@@ -250,13 +257,23 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->max_batch = max_batch;
     e->max_tiles = tiles_of(max_n);
     DevGuard g(device_id);
+    {
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete e; return ITD_ERR_HIP; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extract<double, T, false, kPersist>, kWave, 0) != hipSuccess || per_cu < 1)
+            per_cu = 8;
+        const char *env = getenv("PYITD_WAVES_PER_CU");
+        if (env && atoi(env) > 0) per_cu = atoi(env);
+        e->persistent_waves = kPersist ? (int64_t)prop.multiProcessorCount * per_cu : INT64_MAX / 4;
+    }
     const size_t B = (size_t)max_batch;
     const int max_groups = groups_of((int)e->max_tiles);
     e->tiles_half = (int64_t)B * e->max_tiles;
     e->gsum_third = (int64_t)B * max_groups * kGsumPitch;
     hipError_t rc = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (rc == hipSuccess) { rc = hipMalloc(p, bytes); if (rc == hipSuccess) e->ws_bytes += (int64_t)bytes; } };
-    alloc((void **)&e->d_lists, B * (size_t)e->max_tiles * T * sizeof(int32_t));
+    alloc((void **)&e->d_lists, (size_t)e->max_tiles * T * sizeof(int32_t));   // API helpers only (one signal)
     alloc((void **)&e->d_counts, 2 * (size_t)e->tiles_half * sizeof(int32_t));
     alloc((void **)&e->d_recs, 2 * (size_t)e->tiles_half * sizeof(TileRec));
     alloc((void **)&e->d_gsum, 3 * (size_t)e->gsum_third * sizeof(int32_t));
@@ -395,11 +412,11 @@ template <typename Tin>
 int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, hipStream_t st)
 {
     const int n_tiles = (int)tiles_of(n);
-    const dim3 grid_t(n_tiles, 1), blk(kThreads);
+    const dim3 grid_t(n_tiles, 1), blk(kWave);
     k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
     HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, e->d_lists, e->d_counts, e->d_recs, e->d_gsum,
-                                              e->d_state);
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
+                                              e->d_recs, e->d_gsum, e->d_state);
     if (compact)
         k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_counts, e->d_gsum, n_tiles, n, e->d_kidx, e->max_n + 2,
                                               e->d_total);
@@ -424,11 +441,12 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     const int n_tiles = (int)tiles_of(n);
-    const dim3 grid_t(n_tiles, 1), blk(kThreads);
+    const dim3 grid_t(n_tiles, 1), blk(kWave);
     const bool want_list = m_host || knots || want_sync;
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
-    k_extract<Tin, T, false><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, e->d_lists, e->d_counts,
+    const dim3 grid_p((unsigned)std::min<int64_t>(n_tiles, e->persistent_waves));
+    k_extract<Tin, T, false, kPersist><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0);
@@ -594,6 +612,19 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
     HIP_TRY(e, hipStreamSynchronize(st));
     return ITD_OK;
 }
+
+#ifdef ITD_STAMPS
+// diagnostic builds only (not declared in the public header)
+int itd_debug_stamps(unsigned long long *out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_itd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return ITD_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_itd_stamps), z, sizeof(z)) != hipSuccess) return ITD_ERR_HIP;
+    }
+    return ITD_OK;
+}
+#endif
 
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
 {

@@ -1,19 +1,22 @@
 // itd_kernels.hpp — CDNA4 (gfx950) device code of the ITD engine.
 //
 // One extraction level of the reference (itd_baseline_extract, ITD.py:79-121) is ONE kernel launch that
-// streams the level's input once:
+// streams the level's input once.  The unit of work is a TILE of TW consecutive samples owned by ONE
+// 64-lane wavefront: the wavefront stages the tile in LDS, and everything after that (halo search, knot
+// values, baseline map, rotation, next level's knot scan) is wave-synchronous — no workgroup barrier, no
+// inter-workgroup communication inside a launch.
 //
 //   k_detect   (level 0 only) 3-point knot predicate of detect_peaks(x) U detect_peaks(-x)
-//              (ITD.py:44-59, :87-98) on an LDS-staged tile; wavefront __ballot + popcount ordered
-//              compaction into a per-tile knot list, plus a 64-byte per-tile record (count, first three
-//              and last two knots with their values).
+//              (ITD.py:44-59, :87-98) on the LDS tile; __ballot + popcount ordered compaction into a
+//              per-tile knot list, plus a 64-byte per-tile record (count, first three and last two knots
+//              with their values).
 //   k_extract  finds the two knots in front of and the three knots behind its tile from the neighbouring
 //              tiles' records (no global knot array, no prefix scan over the signal), computes the knot
 //              values B_k (ITD.py:100-110), the per-segment slope, the affine baseline map
 //              (ITD.py:114-117), rotation = x - baseline (ITD.py:119), AND the knot list/record of the
-//              NEXT level from the baseline tile it has just produced.  Block 0 also totals the level's
-//              knot count and evaluates the stop rule `num_extrema < 2` (ITD.py:404) on the device, so
-//              the host never synchronises between levels.
+//              NEXT level from the baseline tile it has just produced.  The wavefront of tile 0 also totals
+//              the level's knot count and evaluates the stop rule `num_extrema < 2` (ITD.py:404) on the
+//              device, so the host never synchronises between levels.
 //   k_compact  (API helpers only) per-tile lists -> one ordered index array e[0..m+1] (ITD.py:95-98).
 //   k_last_count / k_finalize   stop test of the last pending baseline and the row fix-up (ITD.py:404-416).
 //
@@ -28,10 +31,38 @@
 
 #pragma clang fp contract(off)
 
+#ifndef ITD_ABLATE
+#define ITD_ABLATE 0
+#endif
+// ITD_STAMPS: diagnostic build only — per-phase shader-clock totals of k_extract (never in the shipped library)
+#ifdef ITD_STAMPS
+__device__ unsigned long long g_itd_stamps[16];
+#define ITD_STAMP(slot)                                                                       \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        stamp_acc__[slot] += now__ - stamp_prev__;                                            \
+        stamp_prev__ = __builtin_amdgcn_s_memtime();                                          \
+    } while (0)
+#define ITD_STAMP_BEGIN() stamp_prev__ = __builtin_amdgcn_s_memtime()
+#define ITD_STAMP_DECL() unsigned long long stamp_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_prev__ = 0
+#define ITD_STAMP_FLUSH()                                                                     \
+    do {                                                                                      \
+        if (threadIdx.x == 0)                                                                 \
+            for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
+    } while (0)
+#else
+#define ITD_STAMP_DECL() do { } while (0)
+#define ITD_STAMP_FLUSH() do { } while (0)
+#define ITD_STAMP(slot) do { } while (0)
+#define ITD_STAMP_BEGIN() do { } while (0)
+#endif
+
 namespace itd {
 
-constexpr int kThreads = 256;          // 4 wavefronts of 64
-constexpr int kWaves = kThreads / 64;
+constexpr int kWave = 64;              // one wavefront per workgroup
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 
 // Per-signal device state (one per batch element).
@@ -64,58 +95,66 @@ constexpr int kTilesPerGroup = 64;
 constexpr int kGsumPitch = 32;  // int32 elements between consecutive group sums
 __host__ __device__ constexpr int groups_of(int n_tiles) { return (n_tiles + kTilesPerGroup - 1) / kTilesPerGroup; }
 
+// compiler-level ordering point between wave-synchronous LDS phases (LDS executes one wave's accesses in
+// program order; this only stops the compiler from moving accesses across the phase boundary)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------------------------
-// LDS tile: T samples + 1 halo sample each side.  tile[pos + 2] <-> sample s + pos, pos in [-1, T];
+// LDS tile: TW samples + 1 halo sample each side.  tile[pos + 2] <-> sample s + pos, pos in [-1, TW];
 // the body starts 16-byte aligned so the staging stores are ds_write_b128.
 // ---------------------------------------------------------------------------------------------
-template <int T>
+template <int TW>
 struct Tile {
-    static constexpr int kSize = T + 4;
+    static constexpr int kSize = TW + 4;
     double *p;
     __device__ __forceinline__ double &at(int pos) const { return p[pos + 2]; }
 };
 
 // Tile fetch split in two (issue early / commit late) so the HBM latency overlaps the halo search.
-template <typename Tin, int T>
+template <typename Tin, int TW>
 struct TileRegs {
     using V = typename std::conditional<sizeof(Tin) == 8, __attribute__((ext_vector_type(2))) double,
                                         __attribute__((ext_vector_type(4))) float>::type;
     static constexpr int kPer = sizeof(Tin) == 8 ? 2 : 4;
-    static constexpr int kN = T / (kPer * kThreads);
+    static constexpr int kN = TW / (kPer * kWave);
     V q[kN];
     double lo, hi;
     bool vec;
 };
 
-template <typename Tin, int T>
-__device__ __forceinline__ void tile_fetch(TileRegs<Tin, T> &r, const Tin *__restrict__ x, int64_t n, int64_t s)
+template <typename Tin, int TW>
+__device__ __forceinline__ void tile_fetch(TileRegs<Tin, TW> &r, const Tin *__restrict__ x, int64_t n, int64_t s)
 {
-    using R = TileRegs<Tin, T>;
-    const int tid = threadIdx.x;
+    using R = TileRegs<Tin, TW>;
+    const int lane = threadIdx.x;
     const Tin *src = x + s;
-    r.vec = (s + T <= n) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    r.vec = (s + TW <= n) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
     if (r.vec) {
         const typename R::V *v = reinterpret_cast<const typename R::V *>(src);
 #pragma unroll
-        for (int k = 0; k < R::kN; ++k) r.q[k] = v[tid + k * kThreads];
+        for (int k = 0; k < R::kN; ++k) r.q[k] = v[lane + k * kWave];
     }
     r.lo = 0.0;
     r.hi = 0.0;
-    if (tid == 0 && s >= 1) r.lo = (double)x[s - 1];
-    if (tid == 64 && s + T < n) r.hi = (double)x[s + T];
+    if (lane == 0 && s >= 1) r.lo = (double)x[s - 1];
+    if (lane == 1 && s + TW < n) r.hi = (double)x[s + TW];
 }
 
-template <typename Tin, int T>
-__device__ __forceinline__ void tile_commit(const TileRegs<Tin, T> &r, const Tin *__restrict__ x, int64_t n,
-                                            int64_t s, Tile<T> tile)
+template <typename Tin, int TW>
+__device__ __forceinline__ void tile_commit(const TileRegs<Tin, TW> &r, const Tin *__restrict__ x, int64_t n,
+                                            int64_t s, Tile<TW> tile)
 {
-    using R = TileRegs<Tin, T>;
+    using R = TileRegs<Tin, TW>;
     using D2 = __attribute__((ext_vector_type(2))) double;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     if (r.vec) {
 #pragma unroll
         for (int k = 0; k < R::kN; ++k) {
-            const int e = (tid + k * kThreads) * R::kPer;
+            const int e = (lane + k * kWave) * R::kPer;
             if constexpr (sizeof(Tin) == 8) {
                 *reinterpret_cast<D2 *>(&tile.p[2 + e]) = r.q[k];
             } else {
@@ -126,13 +165,13 @@ __device__ __forceinline__ void tile_commit(const TileRegs<Tin, T> &r, const Tin
             }
         }
     } else {
-        for (int k = tid; k < T; k += kThreads) {
+        for (int k = lane; k < TW; k += kWave) {
             const int64_t i = s + k;
             tile.at(k) = (i < n) ? (double)x[i] : 0.0;
         }
     }
-    if (tid == 0) tile.at(-1) = r.lo;
-    if (tid == 64) tile.at(T) = r.hi;
+    if (lane == 0) tile.at(-1) = r.lo;
+    if (lane == 1) tile.at(TW) = r.hi;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -140,24 +179,19 @@ __device__ __forceinline__ void tile_commit(const TileRegs<Tin, T> &r, const Tin
 //   vil = x[i+1]-x[i], vix = x[i]-x[i-1];  valley: vil > 0 & vix <= 0  (detect_peaks(x),  ITD.py:59)
 //                                          peak:   vil < 0 & vix >= 0  (detect_peaks(-x): the same test
 //                                                                       on the exactly negated differences)
-// First and last sample are never knots (ITD.py:70-73).  Each wavefront owns a contiguous quarter of
-// the tile and walks it in 64-sample groups: __ballot gives the group's flag mask, popcounts give the
-// ordered output slot.  Returns the tile's knot count to every thread.
+// First and last sample are never knots (ITD.py:70-73).  The wavefront walks the tile in 64-sample groups:
+// __ballot gives the group's flag mask, popcounts give the ordered output slot.  Returns the knot count.
 // ---------------------------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ int detect_tile(Tile<T> tile, int64_t s, int64_t n, int mode,
-                                           int32_t *__restrict__ list, TileRec *__restrict__ rec,
-                                           int *wave_counts /* LDS[kWaves] */)
+template <int TW>
+__device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, int mode,
+                                          unsigned long long (&masks)[TW / 64])
 {
-    constexpr int CH = T / kWaves;   // samples per wavefront
-    constexpr int G = CH / 64;       // 64-sample groups per wavefront
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    unsigned long long masks[G];
-    int cnt = 0;
+    constexpr int G = TW / 64;
+    const int lane = threadIdx.x;
+    int total = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int pos = w * CH + g * 64 + lane;
+        const int pos = g * 64 + lane;
         const int64_t i = s + pos;
         const double xm = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
         const double vil = xp - x0;
@@ -167,26 +201,30 @@ __device__ __forceinline__ int detect_tile(Tile<T> tile, int64_t s, int64_t n, i
         bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
         f = f && (i >= 1) && (i <= n - 2);
         masks[g] = __ballot(f);
-        cnt += __popcll(masks[g]);
+        total += __popcll(masks[g]);
     }
-    if (lane == 0) wave_counts[w] = cnt;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kWaves; ++k) {
-        const int c = wave_counts[k];
-        if (k < w) base += c;
-        total += c;
-    }
+    return total;
+}
+
+// producer side: the tile's record for its neighbours and (optionally, API helpers) its ordered knot list
+template <int TW>
+__device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, int mode,
+                                           int32_t *__restrict__ list, TileRec *__restrict__ rec)
+{
+    constexpr int G = TW / 64;
+    const int lane = threadIdx.x;
+    unsigned long long masks[G];
+    const int total = scan_flags<TW>(tile, s, n, mode, masks);
     const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const unsigned long long mk = masks[g];
         if ((mk >> lane) & 1ull) {
-            const int pos = w * CH + g * 64 + lane;
+            const int pos = g * 64 + lane;
             const int k = base + __popcll(mk & lt);
             const int32_t idx = (int32_t)(s + pos);
-            list[k] = idx;
+            if (list) list[k] = idx;
             if (k < 3) {
                 rec->hidx[k] = idx;
                 rec->hval[k] = tile.at(pos);
@@ -199,45 +237,44 @@ __device__ __forceinline__ int detect_tile(Tile<T> tile, int64_t s, int64_t n, i
         }
         base += __popcll(mk);
     }
-    if (threadIdx.x == 0) rec->count = total;
+    if (lane == 0) rec->count = total;
     return total;
 }
 
 // the four end samples of the level's input for the NEXT level (ITD.py:101-102), taken from an LDS tile
-template <int T>
-__device__ __forceinline__ void publish_ends(Tile<T> tile, int64_t s, int64_t n, double *ends)
+template <int TW>
+__device__ __forceinline__ void publish_ends(Tile<TW> tile, int64_t s, int64_t n, double *ends)
 {
     const int q = threadIdx.x;
     if (q < 4) {
         const int64_t i = (q == 0) ? 0 : (q == 1 ? 1 : (q == 2 ? n - 2 : n - 1));
-        if (i >= s && i < s + T) ends[q] = tile.at((int)(i - s));
+        if (i >= s && i < s + TW) ends[q] = tile.at((int)(i - s));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_detect: level-0 knot scan of the caller's signal (float32 or float64 input).
-// grid = (n_tiles, batch).  lists: [batch][n_tiles][T] int32; counts: [batch][n_tiles]; recs likewise.
+// grid = (n_tiles, batch), 64 threads.  lists: [batch][n_tiles][TW] int32; counts/recs: [batch][n_tiles].
 // ---------------------------------------------------------------------------------------------
-template <typename Tin, int T>
-__global__ __launch_bounds__(kThreads) void k_detect(const Tin *__restrict__ x, int64_t x_stride, int64_t n,
-                                                     int n_tiles, int mode, int32_t *__restrict__ lists,
-                                                     int32_t *__restrict__ counts, TileRec *__restrict__ recs,
-                                                     int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
+template <typename Tin, int TW>
+__global__ __launch_bounds__(kWave) void k_detect(const Tin *__restrict__ x, int64_t x_stride, int64_t n,
+                                                  int n_tiles, int mode, int32_t *__restrict__ lists,
+                                                  int32_t *__restrict__ counts, TileRec *__restrict__ recs,
+                                                  int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
 {
-    __shared__ __attribute__((aligned(16))) double s_x[Tile<T>::kSize];
-    __shared__ int s_wc[kWaves];
+    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
     const int t = blockIdx.x;
     const int sig = blockIdx.y;
-    const int64_t s = (int64_t)t * T;
+    const int64_t s = (int64_t)t * TW;
     const Tin *xs = x + (int64_t)sig * x_stride;
-    Tile<T> tile{s_x};
-    TileRegs<Tin, T> regs;
-    tile_fetch<Tin, T>(regs, xs, n, s);
-    tile_commit<Tin, T>(regs, xs, n, s, tile);
-    __syncthreads();
-    publish_ends<T>(tile, s, n, state[sig].ends[0]);
+    Tile<TW> tile{s_x};
+    TileRegs<Tin, TW> regs;
+    tile_fetch<Tin, TW>(regs, xs, n, s);
+    tile_commit<Tin, TW>(regs, xs, n, s, tile);
+    wave_sync();
+    publish_ends<TW>(tile, s, n, state[sig].ends[0]);
     const size_t slot = (size_t)sig * n_tiles + t;
-    const int total = detect_tile<T>(tile, s, n, mode, lists + slot * T, recs + slot, s_wc);
+    const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot);
     if (threadIdx.x == 0) {
         counts[slot] = total;
         if (total) atomicAdd(&gsum_out[((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch], total);
@@ -246,39 +283,34 @@ __global__ __launch_bounds__(kThreads) void k_detect(const Tin *__restrict__ x, 
 
 // ---------------------------------------------------------------------------------------------
 // k_compact (API helpers: detect_peaks / knot lists handed back to the caller):
-// per-tile lists -> ordered knot array e[0..m+1], one block per tile.  The block sums the group totals in
+// per-tile lists -> ordered knot array e[0..m+1], one wavefront per tile.  It sums the group totals in
 // front of its group and the tile counts in front of it inside the group, then copies its list.
 // ---------------------------------------------------------------------------------------------
-template <int T>
-__global__ __launch_bounds__(kThreads) void k_compact(const int32_t *__restrict__ lists,
-                                                      const int32_t *__restrict__ counts,
-                                                      const int32_t *__restrict__ gsum_in, int n_tiles, int64_t n,
-                                                      int32_t *__restrict__ kidx, int64_t kidx_stride,
-                                                      int32_t *__restrict__ total_out)
+template <int TW>
+__global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ lists,
+                                                   const int32_t *__restrict__ counts,
+                                                   const int32_t *__restrict__ gsum_in, int n_tiles, int64_t n,
+                                                   int32_t *__restrict__ kidx, int64_t kidx_stride,
+                                                   int32_t *__restrict__ total_out)
 {
-    __shared__ int s_red[kWaves];
     const int sig = blockIdx.y;
     const int t = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lane = threadIdx.x;
     const int n_groups = groups_of(n_tiles);
     const int32_t *cnt = counts + (size_t)sig * n_tiles;
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
     const int g = t / kTilesPerGroup;
     int acc = 0;
-    for (int k = tid; k < g; k += kThreads) acc += gs[(size_t)k * kGsumPitch];
-    if (tid < t - g * kTilesPerGroup) acc += cnt[g * kTilesPerGroup + tid];
+    for (int k = lane; k < g; k += kWave) acc += gs[(size_t)k * kGsumPitch];
+    if (lane < t - g * kTilesPerGroup) acc += cnt[g * kTilesPerGroup + lane];
     const int c = cnt[t];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) s_red[w] = acc;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int k = 0; k < kWaves; ++k) base += s_red[k];
+    const int base = acc;
     int32_t *e = kidx + (size_t)sig * kidx_stride;
-    const int32_t *src = lists + ((size_t)sig * n_tiles + t) * T;
-    for (int j = tid; j < c; j += kThreads) e[1 + base + j] = src[j];
-    if (tid == 0 && t == n_tiles - 1) {
+    const int32_t *src = lists + ((size_t)sig * n_tiles + t) * TW;
+    for (int j = lane; j < c; j += kWave) e[1 + base + j] = src[j];
+    if (lane == 0 && t == n_tiles - 1) {
         const int m = base + c;
         e[0] = 0;                    // ITD.py:96
         e[m + 1] = (int32_t)(n - 1); // ITD.py:98
@@ -295,7 +327,7 @@ template <int DIR>
 __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__restrict__ gs, int n_tiles,
                             int start, int *count_out)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const int n_groups = groups_of(n_tiles);
     while (start >= 0 && start < n_tiles) {
         const int g = start / kTilesPerGroup;
@@ -327,284 +359,370 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_extract: one extraction on one tile.
+// k_extract: one extraction level.  PERSISTENT wavefronts: wavefront w (one per workgroup) handles the
+// tiles w, w + NW, w + 2 NW, ... of the flattened (signal, tile) index space in a three-stage software
+// pipeline, so every global load has a whole tile's worth of compute to land:
+//     stage A (two tiles ahead)  the neighbouring tiles' knot counts (64 in front, 64 behind)
+//     stage B (one tile ahead)   the tile itself (registers) and the records of the neighbours that hold
+//                                the two knots in front of / three knots behind the tile
+//     stage C (this tile)        registers -> LDS, knot predicate on the tile (the consumer re-derives its own
+//                                knots: no knot list is read or written), knot values B_k (ITD.py:100-110),
+//                                slopes, baseline map + rotation (ITD.py:114-119), and the next level's
+//                                counts/records from the baseline tile it has just produced.
 //   xin           level input (float32/float64 caller signal at level 0, float64 baseline afterwards)
-//   lists/counts/recs/gsum_in   this level's per-tile knot lists, counts, records, group sums
+//   counts/recs   per-tile counts and records, double buffered by level parity (neighbours read them)
+//   gsum_in/out/clear   group sums, rotating by level % 3
 //   rot_out       rotation row   (FINAL: rotation + baseline, the "Out of time!" row, ITD.py:420)
 //   base_out      baseline row   (FINAL: not written)
-//   the same lists/counts/recs arrays receive the NEXT level's data for this tile (a block reads only its
-//   own list, and neighbours' records are double buffered by level parity); gsum_out / gsum_clear rotate.
-// grid = (n_tiles, batch).
+// grid = (NW), 64 threads.
 // ---------------------------------------------------------------------------------------------
-template <typename Tin, int T, bool FINAL>
-__global__ __launch_bounds__(kThreads) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
-                                                      int n_tiles, int32_t *__restrict__ lists,
-                                                      const int32_t *__restrict__ counts_in,
-                                                      int32_t *__restrict__ counts_out,
-                                                      const TileRec *__restrict__ recs_in,
-                                                      TileRec *__restrict__ recs_out,
-                                                      const int32_t *__restrict__ gsum_in,
-                                                      int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
-                                                      double *__restrict__ rot_out, int64_t rot_stride,
-                                                      double *__restrict__ base_out, int64_t base_stride,
-                                                      SigState *__restrict__ state, int level)
+struct HaloRegs {          // raw record fields of the candidate neighbour tiles (wave-uniform)
+    int ub0, ub1, cb0;     // nearest / second nearest non-empty tile in front (-1: none in the window), count of ub0
+    int uf0, uf1, uf2, cf0, cf1;
+    int32_t b0i1, b0i0, b1i1;
+    double b0v1, b0v0, b1v1;
+    int32_t f0i0, f0i1, f0i2, f1i0, f1i1, f2i0;
+    double f0v0, f0v1, f0v2, f1v0, f1v1, f2v0;
+};
+
+template <typename Tin, int TW, bool FINAL, bool PERSIST>
+__global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
+                                                   int n_tiles, int batch,
+                                                   const int32_t *__restrict__ counts_in,
+                                                   int32_t *__restrict__ counts_out,
+                                                   const TileRec *__restrict__ recs_in,
+                                                   TileRec *__restrict__ recs_out,
+                                                   const int32_t *__restrict__ gsum_in,
+                                                   int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
+                                                   double *__restrict__ rot_out, int64_t rot_stride,
+                                                   double *__restrict__ base_out, int64_t base_stride,
+                                                   SigState *__restrict__ state, int level)
 {
-    constexpr int CH = T / kWaves;
-    constexpr int G = CH / 64;
-    constexpr int W = T / 64;   // 64-bit flag words per tile
-    constexpr int LPT = T / kThreads;  // list entries per thread
-    __shared__ __attribute__((aligned(16))) double s_x[Tile<T>::kSize];
-    __shared__ __attribute__((aligned(16))) double s_b[Tile<T>::kSize];
-    __shared__ double s_B[T];       // knot value  B_k   at the knot's position in the tile
-    __shared__ double s_S[T];       // slope of the segment that STARTS at that knot
-    __shared__ int32_t s_kk[T + 8]; // knot indices: [0],[1] two knots in front, [2..c+1] the tile's, [c+2..c+4] behind
-    __shared__ unsigned long long s_bm[W];
-    __shared__ double s_hx[5], s_hB[5], s_hS[5]; // out-of-tile knots: [0],[1] in front; [2],[3],[4] behind
-    __shared__ int32_t s_hidx[5];
-    __shared__ int s_nb, s_nf;                   // real knots found in front (0..2) / behind (0..3)
-    __shared__ int s_wc[kWaves];
-    __shared__ int s_lastpos[kWaves];
+    constexpr int G = TW / 64;    // 64-sample groups = 64-bit flag words per tile
+    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];  // the tile: input, then baseline in place
+    __shared__ double s_B[TW];        // knot value  B_k   at the knot's position in the tile
+    __shared__ double s_S[TW];        // slope of the segment that STARTS at that knot
+    __shared__ int32_t s_kk[TW + 8];  // knot indices: [0],[1] in front, [2..c+1] the tile's, [c+2..c+4] behind
+    __shared__ double s_hB[5], s_hS[5];   // values / slopes of the out-of-tile knots
 
-    const int t = blockIdx.x;
-    const int sig = blockIdx.y;
-    SigState *st = state + sig;
-    if (st->stopped) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t s = (int64_t)t * T;
-    const Tin *x = xin + (int64_t)sig * x_stride;
-    const size_t slot0 = (size_t)sig * n_tiles;
-    const int32_t *cnts = counts_in + slot0;
-    const TileRec *recs = recs_in + slot0;
+    const int lane = threadIdx.x;
+    const int NW = gridDim.x;
+    const int64_t total_tiles = (int64_t)n_tiles * batch;
     const int n_groups = groups_of(n_tiles);
-    const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
-    Tile<T> xt{s_x}, bt{s_b};
+    Tile<TW> xt{s_x};
 
-    // ---- issue every independent load first: the tile, this tile's knot list, the neighbours' counts -------
-    TileRegs<Tin, T> regs;
-    tile_fetch<Tin, T>(regs, x, n, s);
-    const int c = cnts[t];   // knots inside the tile
-    int32_t lr[LPT];
-    {
-        const int32_t *mylist = lists + (slot0 + t) * T;
-#pragma unroll
-        for (int k = 0; k < LPT; ++k) {
-            const int j = tid + k * kThreads;
-            lr[k] = (j < c) ? mylist[j] : 0;
-        }
-    }
-    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
-    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
-
-    if (w == 0) {
-        // ---- halo search: two knots in front of the tile, three behind, from the neighbours' records ----
+    // ---- stage A: knot counts of the 64 tiles in front of / behind tile k -----------------------------------
+    auto stage_a = [&](int64_t k, int &cb, int &cf) {
+        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        const int32_t *cnts = counts_in + (size_t)sig * n_tiles;
         const int tb = t - 1 - lane, tf = t + 1 + lane;
-        const int cb = (tb >= 0) ? cnts[tb] : 0;
-        const int cf = (tf < n_tiles) ? cnts[tf] : 0;
-        {   // in front (nearest first): slot 1 = the knot that starts the segment entering the tile, slot 0 before it
-            unsigned long long mk = __ballot(cb != 0);
-            int found = 0, far = t - 65;
-            while (found < 2) {
-                int u, cu;
-                if (mk) {
-                    const int l = __ffsll((long long)mk) - 1;
-                    mk &= mk - 1;
-                    u = t - 1 - l;
-                    cu = __shfl(cb, l);
-                } else {
-                    u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
+        cb = (tb >= 0) ? cnts[tb] : 0;
+        cf = (tf < n_tiles) ? cnts[tf] : 0;
+    };
+    // ---- stage B: the tile and the candidate neighbours' records ---------------------------------------------
+    auto stage_b = [&](int64_t k, int cb, int cf, TileRegs<Tin, TW> &regs, HaloRegs &h) {
+        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        tile_fetch<Tin, TW>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
+        const TileRec *recs = recs_in + (size_t)sig * n_tiles;
+        unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
+        h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
+        h.cb0 = h.cf0 = h.cf1 = 0;
+        if (mb) {
+            const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+            h.ub0 = t - 1 - l; h.cb0 = __shfl(cb, l);
+            if (h.cb0 < 2 && mb) h.ub1 = t - 1 - (__ffsll((long long)mb) - 1);
+        }
+        if (mf) {
+            const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
+            h.uf0 = t + 1 + l; h.cf0 = __shfl(cf, l);
+            if (h.cf0 < 3 && mf) {
+                const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
+                h.uf1 = t + 1 + l1; h.cf1 = __shfl(cf, l1);
+                if (h.cf0 + h.cf1 < 3 && mf) h.uf2 = t + 1 + (__ffsll((long long)mf) - 1);
+            }
+        }
+        // uniform addresses: these become scalar loads
+        const TileRec *rb0 = recs + __builtin_amdgcn_readfirstlane(max(h.ub0, 0));
+        const TileRec *rb1 = recs + __builtin_amdgcn_readfirstlane(max(h.ub1, 0));
+        const TileRec *rf0 = recs + __builtin_amdgcn_readfirstlane(max(h.uf0, 0));
+        const TileRec *rf1 = recs + __builtin_amdgcn_readfirstlane(max(h.uf1, 0));
+        const TileRec *rf2 = recs + __builtin_amdgcn_readfirstlane(max(h.uf2, 0));
+        h.b0i1 = rb0->tidx[1]; h.b0i0 = rb0->tidx[0]; h.b0v1 = rb0->tval[1]; h.b0v0 = rb0->tval[0];
+        h.b1i1 = rb1->tidx[1]; h.b1v1 = rb1->tval[1];
+        h.f0i0 = rf0->hidx[0]; h.f0i1 = rf0->hidx[1]; h.f0i2 = rf0->hidx[2];
+        h.f0v0 = rf0->hval[0]; h.f0v1 = rf0->hval[1]; h.f0v2 = rf0->hval[2];
+        h.f1i0 = rf1->hidx[0]; h.f1i1 = rf1->hidx[1]; h.f1v0 = rf1->hval[0]; h.f1v1 = rf1->hval[1];
+        h.f2i0 = rf2->hidx[0]; h.f2v0 = rf2->hval[0];
+    };
+
+    int64_t k = blockIdx.x;
+    if (k >= total_tiles) return;
+    int cbA = 0, cfA = 0;
+    TileRegs<Tin, TW> regs;
+    HaloRegs hr;
+    stage_a(k, cbA, cfA);
+    stage_b(k, cbA, cfA, regs, hr);
+    if constexpr (PERSIST)
+        if (k + NW < total_tiles) stage_a(k + NW, cbA, cfA);
+
+    ITD_STAMP_DECL();
+    for (; k < total_tiles; k += NW) {
+        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        SigState *st = state + sig;
+        const int64_t s = (int64_t)t * TW;
+        const Tin *x = xin + (int64_t)sig * x_stride;
+        const size_t slot0 = (size_t)sig * n_tiles;
+        const int32_t *cnts = counts_in + slot0;
+        const TileRec *recs = recs_in + slot0;
+        const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
+        const bool stopped = st->stopped != 0;
+        const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
+        const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
+
+        ITD_STAMP_BEGIN();
+        // ---- stage C, part 1: finish the halo, stage the tile in LDS ------------------------------------------
+        // slots: [0],[1] in front (slot 1 starts the segment that enters the tile), [2],[3],[4] behind; missing
+        // ones are the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98)
+        int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
+        double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
+        int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
+        if (!stopped) {
+            if (hr.ub0 >= 0) {
+                hi1 = hr.b0i1; hx1 = hr.b0v1; nb = 1;
+                if (hr.cb0 >= 2) { hi0 = hr.b0i0; hx0 = hr.b0v0; nb = 2; }
+                else if (hr.ub1 >= 0) { hi0 = hr.b1i1; hx0 = hr.b1v1; nb = 2; }
+            }
+            if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further (rare)
+                int far = t - 65;
+                while (nb < 2) {
+                    int cu;
+                    const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
                     if (u < 0) break;
                     far = u - 1;
-                }
-                const TileRec *r = recs + u;
-                if (lane == 0) { s_hidx[1 - found] = r->tidx[1]; s_hx[1 - found] = r->tval[1]; }
-                ++found;
-                if (found < 2 && cu >= 2) {
-                    if (lane == 0) { s_hidx[1 - found] = r->tidx[0]; s_hx[1 - found] = r->tval[0]; }
-                    ++found;
+                    const TileRec *r = recs + u;
+                    const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
+                    const double v1 = r->tval[1], v0 = r->tval[0];
+                    if (nb == 0) { hi1 = i1; hx1 = v1; } else { hi0 = i1; hx0 = v1; }
+                    ++nb;
+                    if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
                 }
             }
-            if (lane == 0) {
-                s_nb = found;
-                for (int q = found; q < 2; ++q) { s_hidx[1 - q] = 0; s_hx[1 - q] = e0; }  // e[0] = 0, ITD.py:96
+            if (hr.uf0 >= 0) {
+                hi2 = hr.f0i0; hx2 = hr.f0v0; nf = 1;
+                if (hr.cf0 >= 2) { hi3 = hr.f0i1; hx3 = hr.f0v1; nf = 2; }
+                if (hr.cf0 >= 3) { hi4 = hr.f0i2; hx4 = hr.f0v2; nf = 3; }
+                if (nf < 3 && hr.uf1 >= 0) {
+                    if (nf == 1) {
+                        hi3 = hr.f1i0; hx3 = hr.f1v0; nf = 2;
+                        if (hr.cf1 >= 2) { hi4 = hr.f1i1; hx4 = hr.f1v1; nf = 3; }
+                    } else {
+                        hi4 = hr.f1i0; hx4 = hr.f1v0; nf = 3;
+                    }
+                    if (nf < 3 && hr.uf2 >= 0) { hi4 = hr.f2i0; hx4 = hr.f2v0; nf = 3; }
+                }
             }
-        }
-        {   // behind (nearest first): slots 2, 3, 4
-            unsigned long long mk = __ballot(cf != 0);
-            int found = 0, far = t + 65;
-            while (found < 3) {
-                int u, cu;
-                if (mk) {
-                    const int l = __ffsll((long long)mk) - 1;
-                    mk &= mk - 1;
-                    u = t + 1 + l;
-                    cu = __shfl(cf, l);
-                } else {
-                    u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
+            if (nf < 3 && t + 65 < n_tiles) {
+                int far = t + 65;
+                while (nf < 3) {
+                    int cu;
+                    const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
                     if (u < 0) break;
                     far = u + 1;
+                    const TileRec *r = recs + u;
+                    const int32_t i0 = r->hidx[0], i1 = r->hidx[1], i2 = r->hidx[2];
+                    const double v0 = r->hval[0], v1 = r->hval[1], v2 = r->hval[2];
+                    if (nf == 0) {
+                        hi2 = i0; hx2 = v0;
+                        if (cu >= 2) { hi3 = i1; hx3 = v1; }
+                        if (cu >= 3) { hi4 = i2; hx4 = v2; }
+                        nf = min(cu, 3);
+                    } else if (nf == 1) {
+                        hi3 = i0; hx3 = v0;
+                        if (cu >= 2) { hi4 = i1; hx4 = v1; }
+                        nf = 1 + min(cu, 2);
+                    } else {
+                        hi4 = i0; hx4 = v0;
+                        nf = 3;
+                    }
                 }
-                const TileRec *r = recs + u;
-                const int take = min(cu, 3 - found);
-                if (lane == 0)
-                    for (int q = 0; q < take; ++q) { s_hidx[2 + found + q] = r->hidx[q]; s_hx[2 + found + q] = r->hval[q]; }
-                found += take;
             }
+            tile_commit<Tin, TW>(regs, x, n, s, xt);
+        }
+
+        ITD_STAMP(0);
+        // ---- keep the pipeline full: stage B of the next tile, stage A of the one after ----------------------
+        if constexpr (PERSIST) {
+            const int64_t kn = k + NW;
+            if (kn < total_tiles) {
+                stage_b(kn, cbA, cfA, regs, hr);
+                if (kn + NW < total_tiles) stage_a(kn + NW, cbA, cfA);
+            }
+        }
+        if (stopped) { if constexpr (PERSIST) continue; else return; }
+        ITD_STAMP(1);
+
+        if (t == 0) {
+            // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ------------------
+            int acc = 0;
+            for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
             if (lane == 0) {
-                s_nf = found;
-                for (int q = found; q < 3; ++q) { s_hidx[2 + q] = (int32_t)(n - 1); s_hx[2 + q] = e3; }  // e[m+1] = n-1, ITD.py:98
+                st->m[level] = acc;
+                if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
+                    st->stop_level = level;
+                    st->stopped = 1;
+                }
+            }
+            int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
+            for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
+        }
+        wave_sync();
+
+        // ---- this level's knots inside the tile: the predicate the producer ran on the same values ----------
+        unsigned long long mks[G];
+        const int c = (ITD_ABLATE & 16) ? 0 : scan_flags<TW>(xt, s, n, kKnots, mks);
+        if (ITD_ABLATE & 16) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) mks[g] = 0ull;
+        }
+        {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            int base = 2;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long mk = mks[g];
+                if ((mk >> lane) & 1ull) s_kk[base + __popcll(mk & lt)] = (int32_t)(s + g * 64 + lane);
+                base += __popcll(mk);
+            }
+            if (lane < 5) {
+                const int32_t v = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
+                s_kk[lane < 2 ? lane : c + lane] = v;
             }
         }
-    } else if (w == 1 && t == 0) {
-        // ---- block 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
-        int acc = 0;
-        for (int k = lane; k < n_groups; k += 64) acc += gs[(size_t)k * kGsumPitch];
+        wave_sync();
+        ITD_STAMP(2);
+
+        // ---- knot values, ITD.py:100-110.  j indexes s_kk --------------------------------------------------
+        auto in_tile = [&](int j) { return j >= 2 && j <= c + 1; };
+        auto hslot = [&](int j) { return j < 2 ? j : j - c; };
+        auto hx = [&](int q) -> double { return q == 0 ? hx0 : q == 1 ? hx1 : q == 2 ? hx2 : q == 3 ? hx3 : hx4; };
+        auto xval = [&](int j) -> double { return in_tile(j) ? xt.at(s_kk[j] - (int32_t)s) : hx(hslot(j)); };
+        auto is_end0 = [&](int j) { return (j == 1 && nb == 0) || (j == 0 && nb < 2); };   // e[0] = sample 0
+        auto is_endn = [&](int j) { return j >= c + 2 && (j - (c + 2)) >= nf; };           // e[m+1] = sample n-1
+        for (int j = 1 + lane; j <= c + 3 && !(ITD_ABLATE & 4); j += kWave) {
+            double Bv;
+            if (is_end0(j)) {
+                Bv = (e0 + e1) / 2.0;                 // numpy.mean(x[:2]),  ITD.py:101
+            } else if (is_endn(j)) {
+                Bv = (e2 + e3) / 2.0;                 // numpy.mean(x[-2:]), ITD.py:102
+            } else {
+                const int32_t k0 = s_kk[j - 1], k1 = s_kk[j], k2 = s_kk[j + 1];
+                const double x0 = xval(j - 1), x1 = xval(j), x2 = xval(j + 1);
+                const double frac = (double)(k1 - k0) / (double)(k2 - k0);
+                const double tt = frac * (x2 - x0);
+                const double u = x0 + tt;
+                Bv = 0.5 * u + 0.5 * x1;              // ITD.py:107-110
+            }
+            if (in_tile(j)) s_B[s_kk[j] - (int32_t)s] = Bv;
+            else s_hB[hslot(j)] = Bv;
+        }
+        wave_sync();
+        ITD_STAMP(3);
+        // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 -------------------------
+        auto Bof = [&](int j) -> double { return in_tile(j) ? s_B[s_kk[j] - (int32_t)s] : s_hB[hslot(j)]; };
+        for (int j = 1 + lane; j <= c + 2 && !(ITD_ABLATE & 4); j += kWave) {
+            if (is_endn(j)) continue; // sample n-1 starts no segment
+            const double sl = (Bof(j + 1) - Bof(j)) / (xval(j + 1) - xval(j));
+            if (in_tile(j)) s_S[s_kk[j] - (int32_t)s] = sl;
+            else s_hS[hslot(j)] = sl;
+        }
+        wave_sync();
+        ITD_STAMP(4);
+
+        // ---- baseline map + rotation, ITD.py:114-119 -------------------------------------------------------
+        // Segment of sample i = the last knot at or before i.  Inside a 64-sample group that is a bit scan of
+        // the group's flag word; in front of the group's first knot it is the carry (B, slope, x of the last
+        // knot in front of the group).  The baseline overwrites the tile in place, after every read.
+        double *rot = rot_out + (int64_t)sig * rot_stride;
+        double *bas = FINAL ? nullptr : base_out + (int64_t)sig * base_stride;
+        const double hB1 = s_hB[1], hS1 = s_hS[1];
+        const double x_lo = xt.at(-1), x_hi = xt.at(TW);
+        double cBg[G + 1], cSg[G + 1], cXg[G + 1];
+        {
+            int PL = -1;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+            for (int g = 0; g <= G; ++g) {
+                if (PL >= 0) { cBg[g] = s_B[PL]; cSg[g] = s_S[PL]; cXg[g] = xt.at(PL); }
+                else         { cBg[g] = hB1;     cSg[g] = hS1;     cXg[g] = hx1; }
+                if (g < G && mks[g]) PL = g * 64 + 63 - __clzll((long long)mks[g]);
+            }
+        }
+        double bv[G], rv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int gbase = g * 64;
+            const int pos = gbase + lane;
+            const int64_t i = s + pos;
+            const unsigned long long le = mks[g] & ((2ull << lane) - 1ull);
+            const double xi = xt.at(pos);
+            double Bk = cBg[g], Sk = cSg[g], Xk = cXg[g];
+            if (le) {
+                const int P = gbase + 63 - __clzll((long long)le);
+                Bk = s_B[P]; Sk = s_S[P]; Xk = xt.at(P);
+            }
+            double bi = Bk + Sk * (xi - Xk);
+            if (i >= n - 1) bi = 0.0;             // baseline[n-1] is never written, ITD.py:112-117
+            bv[g] = bi;
+            rv[g] = xi - bi;
+        }
+        wave_sync();
+        ITD_STAMP(5);
+        bool has_nan = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int pos = g * 64 + lane;
+            const int64_t i = s + pos;
+            xt.at(pos) = bv[g];
+            if (i < n && (!(ITD_ABLATE & 1) || bv[g] == 1.2345e-300)) {
+                if constexpr (FINAL) {
+                    rot[i] = rv[g] + bv[g];       // ITD.py:420
+                } else {
+                    rot[i] = rv[g];
+                    bas[i] = bv[g];
+                }
+                has_nan = has_nan || (bv[g] != bv[g]);
+            }
+        }
         if (lane == 0) {
-            st->m[level] = acc;
-            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches return at once
-                st->stop_level = level;
-                st->stopped = 1;
+            // halo samples: s-1 lives in the carry-in segment; s+TW is either a knot itself (slot 2) or in the
+            // tile's last segment (= the carry behind the last group)
+            xt.at(-1) = (s >= 1) ? (hB1 + hS1 * (x_lo - hx1)) : 0.0;
+            const int64_t i = s + TW;
+            double v = 0.0;
+            if (i < n - 1) {
+                if (nf >= 1 && hi2 == (int32_t)i) v = s_hB[2] + s_hS[2] * (x_hi - hx2);
+                else v = cBg[G] + cSg[G] * (x_hi - cXg[G]);
             }
+            xt.at(TW) = v;
         }
-    }
-    if (t == 0 && w >= 2) {
-        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
-        for (int k = tid - 128; k < n_groups; k += kThreads - 128) gc[(size_t)k * kGsumPitch] = 0;
-    }
+        if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
+        wave_sync();
+        ITD_STAMP(6);
 
-    tile_commit<Tin, T>(regs, x, n, s, xt);
-#pragma unroll
-    for (int k = 0; k < LPT; ++k) {
-        const int j = tid + k * kThreads;
-        if (j < c) s_kk[2 + j] = lr[k];
-    }
-    if (tid < W) s_bm[tid] = 0ull;
-    __syncthreads();
-    if (tid < 5) s_kk[tid < 2 ? tid : c + tid] = s_hidx[tid];
-    // flag bits of the knots inside the tile
-#pragma unroll
-    for (int k = 0; k < LPT; ++k) {
-        const int j = tid + k * kThreads;
-        if (j < c) {
-            const int pos = lr[k] - (int32_t)s;
-            atomicOr(&s_bm[pos >> 6], 1ull << (pos & 63));
+        // ---- knots of the baseline just produced = the next level's input --------------------------------
+        if constexpr (!FINAL) publish_ends<TW>(xt, s, n, st->ends[(level + 1) & 1]);
+        const size_t slot = slot0 + t;
+        const int total = (ITD_ABLATE & 2) ? 0 : detect_tile<TW>(xt, s, n, kKnots, nullptr, recs_out + slot);
+        if (lane == 0) {
+            counts_out[slot] = total;
+            if (total) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
         }
+        wave_sync();   // the next tile's commit must not overtake this tile's LDS reads
+        ITD_STAMP(7);
+        if constexpr (!PERSIST) break;   // grid = one wavefront per tile
     }
-    __syncthreads();
-    const int nb = s_nb, nf = s_nf;
-
-    // ---- knot values, ITD.py:100-110.  j indexes s_kk ------------------------------------------------------
-    auto in_tile = [&](int j) { return j >= 2 && j <= c + 1; };
-    auto hslot = [&](int j) { return j < 2 ? j : j - c; };
-    auto xval = [&](int j) -> double { return in_tile(j) ? xt.at(s_kk[j] - (int32_t)s) : s_hx[hslot(j)]; };
-    auto is_end0 = [&](int j) { return (j == 1 && nb == 0) || (j == 0 && nb < 2); };   // e[0] = sample 0
-    auto is_endn = [&](int j) { return j >= c + 2 && (j - (c + 2)) >= nf; };           // e[m+1] = sample n-1
-    for (int j = 1 + tid; j <= c + 3; j += kThreads) {
-        double Bv;
-        if (is_end0(j)) {
-            Bv = (e0 + e1) / 2.0;                 // numpy.mean(x[:2]),  ITD.py:101
-        } else if (is_endn(j)) {
-            Bv = (e2 + e3) / 2.0;                 // numpy.mean(x[-2:]), ITD.py:102
-        } else {
-            const int32_t k0 = s_kk[j - 1], k1 = s_kk[j], k2 = s_kk[j + 1];
-            const double x0 = xval(j - 1), x1 = xval(j), x2 = xval(j + 1);
-            const double frac = (double)(k1 - k0) / (double)(k2 - k0);
-            const double tt = frac * (x2 - x0);
-            const double u = x0 + tt;
-            Bv = 0.5 * u + 0.5 * x1;              // ITD.py:107-110
-        }
-        if (in_tile(j)) s_B[s_kk[j] - (int32_t)s] = Bv;
-        else s_hB[hslot(j)] = Bv;
-    }
-    __syncthreads();
-    // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 -----------------------------
-    auto Bof = [&](int j) -> double { return in_tile(j) ? s_B[s_kk[j] - (int32_t)s] : s_hB[hslot(j)]; };
-    for (int j = 1 + tid; j <= c + 2; j += kThreads) {
-        if (is_endn(j)) continue; // sample n-1 starts no segment
-        const double sl = (Bof(j + 1) - Bof(j)) / (xval(j + 1) - xval(j));
-        if (in_tile(j)) s_S[s_kk[j] - (int32_t)s] = sl;
-        else s_hS[hslot(j)] = sl;
-    }
-    __syncthreads();
-
-    // ---- baseline map + rotation, ITD.py:114-119 -----------------------------------------------------------
-    // Segment of sample i = the last knot at or before i: inside the tile that is a max-scan of the flag
-    // words; before the tile's first knot it is the carry-in knot (slot 1).
-    double *rot = rot_out + (int64_t)sig * rot_stride;
-    double *bas = FINAL ? nullptr : base_out + (int64_t)sig * base_stride;
-    int carry = -1;
-    {
-        const int nw = w * (CH / 64);   // flag words in front of this wavefront's chunk
-        int v = -1;
-        if (lane < nw) {
-            const unsigned long long q = s_bm[lane];
-            if (q) v = lane * 64 + 63 - __clzll((long long)q);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-        carry = v;
-    }
-    const double cB = s_hB[1], cS = s_hS[1], cX = s_hx[1];
-    bool has_nan = false;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int gbase = w * CH + g * 64;
-        const int pos = gbase + lane;
-        const int64_t i = s + pos;
-        const unsigned long long mk = s_bm[gbase >> 6];
-        const unsigned long long le = mk & ((2ull << lane) - 1ull);
-        const int P = le ? (gbase + 63 - __clzll((long long)le)) : carry;
-        const double xi = xt.at(pos);
-        double Bk, Sk, Xk;
-        if (P >= 0) { Bk = s_B[P]; Sk = s_S[P]; Xk = xt.at(P); }
-        else        { Bk = cB;     Sk = cS;     Xk = cX; }
-        double bi = Bk + Sk * (xi - Xk);
-        if (i >= n - 1) bi = 0.0;             // baseline[n-1] is never written, ITD.py:112-117
-        const double ri = xi - bi;
-        bt.at(pos) = bi;
-        if (i < n) {
-            if constexpr (FINAL) {
-                rot[i] = ri + bi;             // ITD.py:420
-            } else {
-                rot[i] = ri;
-                bas[i] = bi;
-            }
-            has_nan = has_nan || (bi != bi);
-        }
-        if (mk) carry = gbase + 63 - __clzll((long long)mk);
-    }
-    if (lane == 0) s_lastpos[w] = carry;
-    // halo sample s-1 lives in the carry-in segment
-    if (tid == 0) bt.at(-1) = (s >= 1) ? (cB + cS * (xt.at(-1) - cX)) : 0.0;
-    __syncthreads();
-    if (tid == 0) {
-        // halo sample s+T: either a knot itself (slot 2) or in the tile's last segment
-        const int64_t i = s + T;
-        double v = 0.0;
-        if (i < n - 1) {
-            const double xi = xt.at(T);
-            if (nf >= 1 && s_hidx[2] == (int32_t)i) {
-                v = s_hB[2] + s_hS[2] * (xi - s_hx[2]);
-            } else {
-                const int P = s_lastpos[kWaves - 1];
-                if (P >= 0) v = s_B[P] + s_S[P] * (xi - xt.at(P));
-                else v = cB + cS * (xi - cX);
-            }
-        }
-        bt.at(T) = v;
-    }
-    if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
-    __syncthreads();
-
-    // ---- knots of the baseline just produced = the next level's input ------------------------------------
-    if constexpr (!FINAL) publish_ends<T>(bt, s, n, st->ends[(level + 1) & 1]);
-    const size_t slot = slot0 + t;
-    const int total = detect_tile<T>(bt, s, n, kKnots, lists + slot * T, recs_out + slot, s_wc);
-    if (tid == 0) {
-        counts_out[slot] = total;
-        if (total) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
-    }
+    ITD_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -636,12 +754,13 @@ __global__ void k_last_count(const int32_t *__restrict__ gsum_in, int n_tiles, S
 // k_finalize: the stop rule's row fix-up on the device (ITD.py:404-416).
 // Natural stop detected at level j (input of extraction j+1 has < 2 knots) means the reference's
 // counter is c = j-1: row c of the result is baselines[c-1] (= the input of extraction j, B_c), or the
-// untouched all-zero last row when c = 0.  grid = (blocks, batch).
+// untouched all-zero last row when c = 0.  grid = (blocks, batch), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_finalize(double *__restrict__ rows, int64_t rows_stride, int64_t n,
-                                                       const double *__restrict__ bases, int64_t bases_stride,
-                                                       int64_t bases_row_pitch, int bases_rotate,
-                                                       const SigState *__restrict__ state)
+constexpr int kFinalizeThreads = 256;
+__global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restrict__ rows, int64_t rows_stride,
+                                                               int64_t n, const double *__restrict__ bases,
+                                                               int64_t bases_stride, int64_t bases_row_pitch,
+                                                               int bases_rotate, const SigState *__restrict__ state)
 {
     const int sig = blockIdx.y;
     const SigState *st = state + sig;
@@ -654,7 +773,8 @@ __global__ __launch_bounds__(kThreads) void k_finalize(double *__restrict__ rows
         const int row = bases_rotate ? ((c - 1) % bases_rotate) : (c - 1);
         src = bases + (int64_t)sig * bases_stride + (int64_t)row * bases_row_pitch;
     }
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+    for (int64_t i = (int64_t)blockIdx.x * kFinalizeThreads + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kFinalizeThreads)
         dst[i] = src ? src[i] : 0.0;
 }
 
