@@ -43,8 +43,7 @@ typedef enum itd_status {
     ITD_ERR_HIP = 3,           /* a HIP runtime call failed: see itd_last_error() */
     ITD_ERR_NOMEM = 4,         /* device or host allocation failed */
     ITD_ERR_NOT_RUN = 5,       /* results requested before a decomposition was enqueued */
-    ITD_ERR_NONFINITE = 6      /* a NaN appeared in a baseline (reference: NaN->inf path, ITD.py:46-51,64-68) and the
-                                  NaN-faithful fallback was disabled */
+    ITD_ERR_NONFINITE = 6      /* the input signal contains a NaN, or a baseline went NaN while the NaN fallback was off */
 } itd_status;
 
 /* stop reasons of the level loop */
@@ -93,10 +92,17 @@ int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t bat
  *   knot_counts  [batch][ITD_MAX_ROWS+1]  knot_counts[j] = interior knots of the input of extraction j+1
  *                (j = 0: the signal itself; j >= 1: the number the reference prints at ITD.py:403);
  *                entries past the last evaluated level are -1
- *   nan_levels   [batch]      -1, or the first extraction whose baseline contained a NaN (results from
- *                that level on follow the reference only if the NaN fallback ran) */
+ *   nan_levels   [batch]      -1 = results follow the reference; -2 = the input signal itself contains a NaN
+ *                (rejected, rows undefined); j >= 0 (only with the fallback disabled) = first extraction
+ *                whose baseline contained a NaN
+ * NaN fallback: a baseline acquires NaNs when the signal starts with a plateau (ITD.py:115-116 divides by
+ * x[e_1]-x[0] = 0).  The reference then counts knots under detect_peaks' NaN rules (ITD.py:46-51,64-68) and
+ * overwrites NaN with +inf in place.  itd_get_summary re-runs exactly those signals through the NaN-faithful
+ * launch sequence before it returns, so x_dev / rows_dev / baselines_dev must stay valid until then. */
 int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
                     int64_t *knot_counts, int32_t *nan_levels);
+/* enable (default) / disable the NaN-faithful re-run inside itd_get_summary */
+int itd_set_nan_fallback(itd_engine *e, int enable);
 
 /* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
  * launch); to inspect them run itd_detect_* on the input or on a stored baseline row. */

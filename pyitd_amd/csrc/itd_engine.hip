@@ -39,7 +39,9 @@ __global__ void k_init_state(SigState *st, int batch)
     st[b].stopped = 0;
     st[b].stop_level = -1;
     st[b].nan_mask = 0;
-    st[b].pad = 0;
+    st[b].in_nan = 0;
+    st[b].c_nan = 0;
+    st[b].c_has_nan = 0;
 }
 
 __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
@@ -78,6 +80,11 @@ struct itd_engine {
     int32_t last_batch = 0, last_m = 0;
     int64_t last_n = 0;
     hipStream_t last_stream = nullptr;
+    const void *last_x = nullptr;      // the caller's device signal of the last decomposition (careful re-runs)
+    bool last_x_f32 = false;
+    int64_t last_x_stride = 0;
+    double *last_rows = nullptr, *last_bases = nullptr;
+    bool nan_fallback = true;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // event pairs: [2k] start, [2k+1] stop
@@ -167,7 +174,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
     k_extract<TIN, T, FIN, kPersist><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
                                                     rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
-                                                    base_out, base_stride, e->d_state, j)
+                                                    base_out, base_stride, e->d_state, j, 0)
         if (j == 0) {
             if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride);
             else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride);
@@ -179,7 +186,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         time_end(e, pair, st);
     }
     // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
-    k_last_count<<<batch, 64, 0, st>>>(gs(M + 2), n_tiles, e->d_state, M + 2);
+    k_last_count<<<batch, 64, 0, st>>>(gs(M + 2), n_tiles, e->d_state, M + 2, 0);
     {
         const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
         if (bases_user)
@@ -196,6 +203,78 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_m = M;
     e->last_n = n;
     e->last_stream = st;
+    e->last_x = x;
+    e->last_x_f32 = sizeof(Tin) == 4;
+    e->last_x_stride = x_stride;
+    e->last_rows = rows;
+    e->last_bases = bases_user;
+    return ITD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The NaN-faithful path for ONE signal (batch slot b), used after the fast path reported a NaN in one of that
+// signal's baselines.  Same launches as the fast path, except that the next level's knot scan is not fused into
+// the extraction: between two extractions the reference's stop test counts knots under its NaN rules and turns
+// NaN into +inf in place (k_careful_count / k_careful_apply).  Enqueued asynchronously on `st`.
+// ---------------------------------------------------------------------------------------------
+template <typename Tin>
+int enqueue_careful(itd_engine *e, int b, hipStream_t st)
+{
+    const int64_t n = e->last_n;
+    const int32_t M = e->last_m;
+    const int n_tiles = (int)tiles_of(n);
+    const int n_groups = groups_of(n_tiles);
+    const int64_t R = (int64_t)M + 2;
+    const int64_t rows_stride = R * n;
+    const dim3 grid_t(n_tiles, 1), blk(kWave);
+    const dim3 grid_p((unsigned)std::min<int64_t>((int64_t)n_tiles, e->persistent_waves));
+    const Tin *x = (const Tin *)e->last_x + (int64_t)b * e->last_x_stride;
+    double *rows = e->last_rows + (int64_t)b * rows_stride;
+    double *bases_user = e->last_bases ? e->last_bases + (int64_t)b * rows_stride : nullptr;
+    double *pp = e->d_pp + (int64_t)b * 3 * e->max_n;
+    SigState *state = e->d_state + b;
+    const int B = e->last_batch;
+    auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b * n_groups * kGsumPitch; };
+    auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b * n_tiles; };
+    auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b * n_tiles; };
+    (void)B;
+    k_init_state<<<1, 64, 0, st>>>(state, 1);
+    for (int q = 0; q < 3; ++q)
+        HIP_TRY(e, hipMemsetAsync(gs(q), 0, sizeof(int32_t) * (size_t)n_groups * kGsumPitch, st));
+    if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, (int)kKnots, nullptr, cnt(0), rec(0), gs(0), state);
+    for (int j = 0; j <= M + 1; ++j) {
+        double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->max_n;
+        const double *base_in = nullptr;
+        if (j >= 1) base_in = bases_user ? bases_user + (int64_t)(j - 1) * n : pp + (int64_t)((j - 1) % 3) * e->max_n;
+        // the "Out of time!" level keeps its pending baseline too: the stop test and the mutation come first.
+        // With the caller's baselines buffer that row (index M+1) must end up zero (ITD.py:424), so the pending
+        // baseline of the last level goes to the engine's rotating slot instead.
+        const bool final_level = (j == M + 1);
+        if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
+        double *rot_out = rows + (int64_t)j * n;
+        if (j == 0)
+            k_extract<Tin, T, false, kPersist><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+                                                                        rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
+                                                                        n, base_out, n, state, j, 1);
+        else
+            k_extract<double, T, false, kPersist><<<grid_p, blk, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+                                                                           rec(j), rec(j + 1), gs(j), gs(j + 1),
+                                                                           gs(j + 2), rot_out, n, base_out, n, state, j, 1);
+        k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
+        k_careful_apply<T><<<grid_t, blk, 0, st>>>(base_out, n, n_tiles, cnt(j + 1), rec(j + 1), gs(j + 1), state, j + 1);
+        if (final_level)   // ITD.py:420: rotation_ + baseline_ (baseline_ already mutated by the stop test)
+            k_add_rows<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, st>>>(rot_out, base_out, n);
+    }
+    k_last_count<<<1, 64, 0, st>>>(gs(M + 2), n_tiles, state, M + 2, 1);
+    {
+        const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
+        if (bases_user)
+            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, state);
+        else
+            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, pp, 3 * e->max_n, e->max_n, 3, state);
+    }
+    HIP_TRY(e, hipGetLastError());
     return ITD_OK;
 }
 
@@ -339,6 +418,29 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     const int B = e->last_batch;
     HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    auto rows_of = [&](const SigState &s) { return s.stopped ? s.stop_level : e->last_m + 2; };
+    auto first_nan = [&](const SigState &s) {
+        // a NaN in a baseline whose knots no decision looked at (extraction >= rows) is harmless
+        for (int j = 0; j < rows_of(s) && j < kMaxLevels; ++j)
+            if (s.nan_mask & (1 << j)) return j;
+        return -1;
+    };
+    // ---- NaN-faithful re-run of the signals whose baselines went NaN (the reference's NaN -> inf path) ----
+    if (e->nan_fallback) {
+        bool any = false;
+        for (int b = 0; b < B; ++b) {
+            const SigState &s = e->h_state[b];
+            if (s.in_nan || first_nan(s) < 0) continue;
+            const int rc = e->last_x_f32 ? enqueue_careful<float>(e, b, e->last_stream)
+                                         : enqueue_careful<double>(e, b, e->last_stream);
+            if (rc) return rc;
+            any = true;
+        }
+        if (any) {
+            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+            HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+        }
+    }
     for (int b = 0; b < B; ++b) {
         const SigState &s = e->h_state[b];
         int rows, nb, why;
@@ -357,15 +459,15 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         if (stop_reason) stop_reason[b] = why;
         if (knot_counts)
             for (int j = 0; j <= ITD_MAX_ROWS; ++j) knot_counts[(size_t)b * (ITD_MAX_ROWS + 1) + j] = s.m[j];
-        if (nan_levels) {
-            int lv = -1;
-            for (int j = 0; j < kMaxLevels; ++j)
-                if (s.nan_mask & (1 << j)) { lv = j; break; }
-            // a NaN produced by an extraction whose results the stop rule discards is harmless
-            if (lv >= rows) lv = -1;
-            nan_levels[b] = lv;
-        }
+        if (nan_levels) nan_levels[b] = s.in_nan ? -2 : (e->nan_fallback ? -1 : first_nan(s));
     }
+    return ITD_OK;
+}
+
+int itd_set_nan_fallback(itd_engine *e, int enable)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    e->nan_fallback = enable != 0;
     return ITD_OK;
 }
 
@@ -404,7 +506,7 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
     if (n_baselines) *n_baselines = nb;
     if (stop_reason) *stop_reason = why;
     if (knot_counts) memcpy(knot_counts, kc, sizeof(kc));
-    return nanlv >= 0 ? ITD_ERR_NONFINITE : ITD_OK;
+    return nanlv != -1 ? ITD_ERR_NONFINITE : ITD_OK;
 }
 
 // level-0 knot scan of one device signal into the workspace of batch slot 0; optional ordered list in d_kidx
@@ -449,7 +551,7 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     k_extract<Tin, T, false, kPersist><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
-                                                      rot, n, base, n, e->d_state, 0);
+                                                      rot, n, base, n, e->d_state, 0, 0);
     HIP_TRY(e, hipGetLastError());
     if (want_list) {
         int64_t m = 0;

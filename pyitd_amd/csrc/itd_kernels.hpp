@@ -71,7 +71,9 @@ struct SigState {
     int32_t stopped;         // 1 once the natural stop rule fired (later kernels return at once)
     int32_t stop_level;      // level j (>= 1) whose input had < 2 knots: the reference stops at counter j-1
     int32_t nan_mask;        // bit j set: the baseline written by extraction j+1 contains a NaN
-    int32_t pad;
+    int32_t in_nan;          // the caller's signal contains a NaN (rejected: ITD_ERR_NONFINITE)
+    int32_t c_nan;           // careful mode: knot count of the pending baseline under the reference's NaN rules
+    int32_t c_has_nan;       // careful mode: the pending baseline contained a NaN (c_nan applies)
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
@@ -273,6 +275,15 @@ __global__ __launch_bounds__(kWave) void k_detect(const Tin *__restrict__ x, int
     tile_commit<Tin, TW>(regs, xs, n, s, tile);
     wave_sync();
     publish_ends<TW>(tile, s, n, state[sig].ends[0]);
+    {
+        bool nan_in = false;
+#pragma unroll
+        for (int g = 0; g < TW / 64; ++g) {
+            const double v = tile.at(g * 64 + threadIdx.x);
+            nan_in = nan_in || (v != v);
+        }
+        if (__any(nan_in) && threadIdx.x == 0) state[sig].in_nan = 1;
+    }
     const size_t slot = (size_t)sig * n_tiles + t;
     const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot);
     if (threadIdx.x == 0) {
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                                                    int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
                                                    double *__restrict__ rot_out, int64_t rot_stride,
                                                    double *__restrict__ base_out, int64_t base_stride,
-                                                   SigState *__restrict__ state, int level)
+                                                   SigState *__restrict__ state, int level, int careful)
 {
     constexpr int G = TW / 64;    // 64-sample groups = 64-bit flag words per tile
     __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];  // the tile: input, then baseline in place
@@ -568,6 +579,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
             if (lane == 0) {
+                if (careful) {   // the reference counted this level's knots under its NaN rules (k_detect_careful)
+                    if (st->c_has_nan) acc = st->c_nan;
+                    st->c_nan = 0;
+                    st->c_has_nan = 0;
+                }
                 st->m[level] = acc;
                 if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
                     st->stop_level = level;
@@ -711,12 +727,15 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         ITD_STAMP(6);
 
         // ---- knots of the baseline just produced = the next level's input --------------------------------
-        if constexpr (!FINAL) publish_ends<TW>(xt, s, n, st->ends[(level + 1) & 1]);
-        const size_t slot = slot0 + t;
-        const int total = (ITD_ABLATE & 2) ? 0 : detect_tile<TW>(xt, s, n, kKnots, nullptr, recs_out + slot);
-        if (lane == 0) {
-            counts_out[slot] = total;
-            if (total) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
+        // (careful mode: k_detect_careful does this after the reference's NaN -> inf mutation)
+        if (!careful) {
+            if constexpr (!FINAL) publish_ends<TW>(xt, s, n, st->ends[(level + 1) & 1]);
+            const size_t slot = slot0 + t;
+            const int total = (ITD_ABLATE & 2) ? 0 : detect_tile<TW>(xt, s, n, kKnots, nullptr, recs_out + slot);
+            if (lane == 0) {
+                counts_out[slot] = total;
+                if (total) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
+            }
         }
         wave_sync();   // the next tile's commit must not overtake this tile's LDS reads
         ITD_STAMP(7);
@@ -729,7 +748,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 // k_last_count: knot count of the last pending baseline and its stop test (ITD.py:400-404), which takes
 // priority over the "Out of time!" branch.  grid = (batch), one wavefront each.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_last_count(const int32_t *__restrict__ gsum_in, int n_tiles, SigState *__restrict__ state, int level)
+__global__ void k_last_count(const int32_t *__restrict__ gsum_in, int n_tiles, SigState *__restrict__ state, int level,
+                             int careful)
 {
     const int sig = blockIdx.x;
     SigState *st = state + sig;
@@ -742,12 +762,110 @@ __global__ void k_last_count(const int32_t *__restrict__ gsum_in, int n_tiles, S
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if (lane == 0) {
+        if (careful && st->c_has_nan) acc = st->c_nan;
         st->m[level] = acc;
         if (acc < 2) {
             st->stop_level = level;
             st->stopped = 1;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_careful_count + k_careful_apply: the reference's stop test on a pending baseline that may contain NaNs, then the
+// knot scan the next extraction will see.  Restates, per tile of the float64 row `xio`:
+//   (1) num_extrema = len(detect_peaks(b)) + len(detect_peaks(-b))  (ITD.py:400-402) with detect_peaks' NaN
+//       rules (ITD.py:46-51, 64-68): differences that are NaN become +inf, NaN samples and their neighbours
+//       cannot be peaks — these rules apply only if the array holds a NaN at all (`indl.size != 0`), so the
+//       count is accumulated separately and used only when some tile reports a NaN;
+//   (2) the in-place mutation NaN -> +inf of the array (ITD.py:50; no copy is made at ITD.py:41);
+//   (3) the plain predicate on the mutated array = what itd_baseline_extract(baseline_) evaluates next
+//       (ITD.py:87-88 see no NaN any more), feeding the usual counts / records / group sums / end samples.
+// grid = (n_tiles, 1), 64 threads; pointers are already offset to the signal.
+// ---------------------------------------------------------------------------------------------
+template <int TW>
+__global__ __launch_bounds__(kWave) void k_careful_count(const double *__restrict__ xin, int64_t n,
+                                                         SigState *__restrict__ st)
+{
+    // step (1): read-only, so no tile can observe a neighbour's mutation
+    constexpr int G = TW / 64;
+    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
+    if (st->stopped) return;
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t s = (int64_t)t * TW;
+    Tile<TW> tile{s_x};
+    TileRegs<double, TW> regs;
+    tile_fetch<double, TW>(regs, xin, n, s);
+    tile_commit<double, TW>(regs, xin, n, s, tile);
+    wave_sync();
+    const double inf = __builtin_huge_val();
+    int cnt_nan = 0;
+    bool any_nan = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int pos = g * 64 + lane;
+        const int64_t i = s + pos;
+        const double xm = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
+        const bool nm = xm != xm, n0 = x0 != x0, np = xp != xp;
+        // detect_peaks(b): dx from the original values, NaN differences -> +inf (ITD.py:44,51)
+        double d1 = xp - x0, d0 = x0 - xm;
+        if (d1 != d1) d1 = inf;
+        if (d0 != d0) d0 = inf;
+        const bool in = (i >= 1) && (i <= n - 2);
+        const bool fa = in && (d1 > 0.0) && (d0 <= 0.0) && !(nm || n0 || np);   // ITD.py:59, 64-68
+        // detect_peaks(-b) on the mutated array (ITD.py:401): plain rules, raw differences
+        const double ym = nm ? inf : xm, y0 = n0 ? inf : x0, yp = np ? inf : xp;
+        const double e1 = yp - y0, e0 = y0 - ym;
+        const bool fb = in && (e1 < 0.0) && (e0 >= 0.0);
+        cnt_nan += __popcll(__ballot(fa)) + __popcll(__ballot(fb));
+        any_nan = any_nan || (n0 && i < n);
+    }
+    if (lane == 0 && cnt_nan) atomicAdd(&st->c_nan, cnt_nan);
+    if (__any(any_nan) && lane == 0) atomicOr(&st->c_has_nan, 1);
+}
+
+template <int TW>
+__global__ __launch_bounds__(kWave) void k_careful_apply(double *__restrict__ xio, int64_t n, int n_tiles,
+                                                         int32_t *__restrict__ counts, TileRec *__restrict__ recs,
+                                                         int32_t *__restrict__ gsum_out, SigState *__restrict__ st,
+                                                         int level)
+{
+    // steps (2) and (3).  Every NaN the tile sees (its own samples or a neighbour's halo sample, mutated yet or
+    // not) is read as +inf, so the result does not depend on the order in which tiles run.
+    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
+    if (st->stopped) return;
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t s = (int64_t)t * TW;
+    Tile<TW> tile{s_x};
+    TileRegs<double, TW> regs;
+    tile_fetch<double, TW>(regs, xio, n, s);
+    tile_commit<double, TW>(regs, xio, n, s, tile);
+    wave_sync();
+    const double inf = __builtin_huge_val();
+    for (int pos = lane - 1; pos <= TW; pos += kWave) {
+        const double v = tile.at(pos);
+        if (v != v) {
+            tile.at(pos) = inf;
+            const int64_t i = s + pos;
+            if (pos >= 0 && pos < TW && i < n) xio[i] = inf;   // ITD.py:50
+        }
+    }
+    wave_sync();
+    publish_ends<TW>(tile, s, n, st->ends[level & 1]);
+    const int total = detect_tile<TW>(tile, s, n, kKnots, nullptr, recs + t);
+    if (lane == 0) {
+        counts[t] = total;
+        if (total) atomicAdd(&gsum_out[(size_t)(t / kTilesPerGroup) * kGsumPitch], total);
+    }
+}
+
+// rows[i] += add[i]: the "Out of time!" row of the careful path (ITD.py:420 with the mutated baseline)
+__global__ void k_add_rows(double *__restrict__ row, const double *__restrict__ add, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        row[i] = row[i] + add[i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -121,9 +121,9 @@ class ITD:
         m = min(int(max_iteration), _lib.MAX_ITERATION)
         res = _engine_for(n, self.device).decompose_host(x, m, want_baselines=True)
         if res["nonfinite"]:
-            raise FloatingPointError(
-                "a baseline became NaN (the signal starts with a plateau, ITD.py:115-116 divides by zero); "
-                "the reference continues through its NaN->inf path (ITD.py:46-51), which this build rejects")
+            # the reference would run detect_peaks' NaN branch on the INPUT and write +inf into the caller's array
+            # (ITD.py:46-51); this build only follows NaNs that arise inside the decomposition
+            raise ValueError("the input signal contains NaN")
         if max_iteration > _lib.MAX_ITERATION and res["stop"] == STOP_TIMEOUT:
             # the reference's buffers hold 22 rows (ITD.py:384-385): row 22 does not exist
             raise IndexError("index 22 is out of bounds for axis 0 with size 22")
