@@ -94,7 +94,9 @@ def main():
     torch.cuda.synchronize()
     summ = eng.summary(1)
 
-    eng.set_timing(args.steps)
+    # hipEvent pairs around the extraction launches of every 4th step of the timed region (an event record
+    # costs ~5 us of stream time, so instrumenting every step would slow the region it measures by ~7 %)
+    eng.set_timing(args.steps, stride=4)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -108,6 +110,12 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal)
+    table = None
+    if dist.is_initialized():
+        from pyitd_amd.distributed import gather_summaries
+        table = gather_summaries(eng.summary(1), world, device=dev)
 
     ext_ms, ext_cnt = eng.kernel_timing(TIME_EXTRACT)
     l0_ms, l0_cnt = eng.kernel_timing(TIME_EXTRACT_L0)
@@ -154,6 +162,7 @@ def main():
             "rows": int(summ["n_rows"][0]),
             "knots_per_level": [int(v) for v in summ["knot_counts"][0] if v >= 0],
             "sharding": "one independent signal per GPU, no data-path collective",
+            "rows_all_ranks": None if table is None else [int(v) for v in table["n_rows"]],
         },
         "hbm_algorithmic_GBps": round(algorithmic_bytes_per_sample(LEVELS) * samples_per_step * args.steps / elapsed / 1e9, 1),
         "roofline": {

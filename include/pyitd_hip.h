@@ -152,6 +152,8 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
 #define ITD_TIME_EXTRACT_FINAL 2  /* k_extract of the "Out of time!" level (writes rotation+baseline only) */
 #define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
+/* instrument only every stride-th decomposition (an event record costs ~5 us of stream time) */
+int itd_set_kernel_timing_stride(itd_engine *e, int stride);
 int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches);
 
 #ifdef __cplusplus

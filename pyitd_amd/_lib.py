@@ -40,6 +40,7 @@ ABI = {
     "itd_knot_values_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P]),
     "itd_set_nan_fallback": (_INT, [_P, _INT]),
     "itd_set_kernel_timing": (_INT, [_P, _INT]),
+    "itd_set_kernel_timing_stride": (_INT, [_P, _INT]),
     "itd_get_kernel_timing": (_INT, [_P, _I32, _P, _P]),
 }
 

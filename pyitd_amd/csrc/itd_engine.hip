@@ -91,6 +91,9 @@ struct itd_engine {
     std::vector<int> ev_tag;      // what pair k brackets (ITD_TIME_*)
     int n_timed = 0;              // pairs recorded since timing was (re)enabled
     bool timing_overflow = false;
+    int timing_stride = 1;        // instrument every stride-th decomposition only (event records cost ~5 us each)
+    int timing_seq = 0;
+    bool timing_now = false;
     char err[512] = {0};
 };
 
@@ -119,7 +122,7 @@ inline int64_t tiles_of(int64_t n) { return (n + T - 1) / T; }
 // hipEvent pairs on the launch stream around selected launches (bench instrumentation, off by default)
 int time_begin(itd_engine *e, int tag, hipStream_t st)
 {
-    if (!e->timing) return -1;
+    if (!e->timing || !e->timing_now) return -1;
     if (2 * (size_t)e->n_timed + 1 >= e->ev.size()) { e->timing_overflow = true; return -1; }
     const int k = e->n_timed++;
     e->ev_tag[(size_t)k] = tag;
@@ -144,6 +147,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
 
+    e->timing_now = e->timing && (e->timing_seq++ % e->timing_stride == 0);
     const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
     k_init_state<<<(batch + 255) / 256, 256, 0, st>>>(e->d_state, batch);
     HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
@@ -733,6 +737,7 @@ int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
     if (!e || max_decompositions < 0 || max_decompositions > 4096) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     e->timing = max_decompositions > 0;
+    e->timing_seq = 0;
     e->n_timed = 0;
     e->timing_overflow = false;
     const size_t want = 2 * (size_t)max_decompositions * (ITD_MAX_ROWS + 2);
@@ -742,6 +747,13 @@ int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
         e->ev.push_back(ev);
     }
     e->ev_tag.resize(e->ev.size() / 2, 0);
+    return ITD_OK;
+}
+
+int itd_set_kernel_timing_stride(itd_engine *e, int stride)
+{
+    if (!e || stride < 1) return ITD_ERR_INVALID_ARG;
+    e->timing_stride = stride;
     return ITD_OK;
 }
 

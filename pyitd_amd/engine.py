@@ -70,9 +70,14 @@ class Engine:
                                             _np_ptr(nanlv)))
         return {"n_rows": n_rows, "n_baselines": n_b, "stop": stop, "knot_counts": kc, "nan_levels": nanlv}
 
-    def set_timing(self, max_decompositions):
-        """Record hipEvent pairs around the extraction launches of the next `max_decompositions` runs (0 = off)."""
+    def set_timing(self, max_decompositions, stride=1):
+        """Record hipEvent pairs around the extraction launches of the next `max_decompositions` runs (0 = off);
+        only every `stride`-th run is instrumented."""
+        self._check(self._L.itd_set_kernel_timing_stride(self._h, int(stride)))
         self._check(self._L.itd_set_kernel_timing(self._h, int(max_decompositions)))
+
+    def set_nan_fallback(self, on):
+        self._check(self._L.itd_set_nan_fallback(self._h, 1 if on else 0))
 
     def kernel_timing(self, which=TIME_EXTRACT):
         """(total ms, launches) of the recorded launches of class `which` (TIME_*)."""
