@@ -25,10 +25,6 @@ using namespace itd;
 
 namespace {
 constexpr int T = ITD_TILE;
-#ifndef ITD_PERSIST
-#define ITD_PERSIST 0
-#endif
-constexpr bool kPersist = ITD_PERSIST != 0;  // 1: resident wavefronts loop over tiles with a software pipeline
 static_assert(T % 256 == 0 && T / 64 <= 64, "tile geometry: whole float4/double2 loads per lane, <= 64 flag words");
 
 __global__ void k_init_state(SigState *st, int batch)
@@ -70,7 +66,6 @@ struct itd_engine {
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
     int64_t ws_bytes = 0;
-    int64_t persistent_waves = 0;  // resident wavefronts of k_extract: CUs x (LDS-limited workgroups per CU)
     // host-convenience staging (grow only)
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
@@ -141,8 +136,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int n_tiles = (int)tiles_of(n);
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
-    const dim3 grid_t(n_tiles, batch), blk(kWave);
-    const dim3 grid_p((unsigned)std::min<int64_t>((int64_t)n_tiles * batch, e->persistent_waves));
+    const dim3 blk(kBlock);
+    const dim3 grid_t((n_tiles + kWPB - 1) / kWPB, batch);                      // k_detect: kWPB tiles per workgroup
+    const dim3 grid_p((unsigned)(((int64_t)n_tiles * batch + kWPB - 1) / kWPB)); // k_extract: flattened (signal, tile)
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
@@ -176,7 +172,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
-    k_extract<TIN, T, FIN, kPersist><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
+    k_extract<TIN, T, FIN><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
                                                     rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
                                                     base_out, base_stride, e->d_state, j, 0)
         if (j == 0) {
@@ -230,8 +226,9 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
-    const dim3 grid_t(n_tiles, 1), blk(kWave);
-    const dim3 grid_p((unsigned)std::min<int64_t>((int64_t)n_tiles, e->persistent_waves));
+    const dim3 grid_t(n_tiles, 1), blk(kWave);                       // one-wavefront workgroups (k_careful_*)
+    const dim3 grid_d((n_tiles + kWPB - 1) / kWPB, 1), blk_d(kBlock);  // k_detect / k_extract
+    const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
     const Tin *x = (const Tin *)e->last_x + (int64_t)b * e->last_x_stride;
     double *rows = e->last_rows + (int64_t)b * rows_stride;
     double *bases_user = e->last_bases ? e->last_bases + (int64_t)b * rows_stride : nullptr;
@@ -246,7 +243,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     for (int q = 0; q < 3; ++q)
         HIP_TRY(e, hipMemsetAsync(gs(q), 0, sizeof(int32_t) * (size_t)n_groups * kGsumPitch, st));
     if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, (int)kKnots, nullptr, cnt(0), rec(0), gs(0), state);
+    k_detect<Tin, T><<<grid_d, blk_d, 0, st>>>(x, n, n, n_tiles, (int)kKnots, nullptr, cnt(0), rec(0), gs(0), state);
     for (int j = 0; j <= M + 1; ++j) {
         double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->max_n;
         const double *base_in = nullptr;
@@ -258,11 +255,11 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
         if (j == 0)
-            k_extract<Tin, T, false, kPersist><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+            k_extract<Tin, T, false><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
                                                                         n, base_out, n, state, j, 1);
         else
-            k_extract<double, T, false, kPersist><<<grid_p, blk, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+            k_extract<double, T, false><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
                                                                            rec(j), rec(j + 1), gs(j), gs(j + 1),
                                                                            gs(j + 2), rot_out, n, base_out, n, state, j, 1);
         k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
@@ -340,16 +337,6 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->max_batch = max_batch;
     e->max_tiles = tiles_of(max_n);
     DevGuard g(device_id);
-    {
-        hipDeviceProp_t prop;
-        int per_cu = 0;
-        if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete e; return ITD_ERR_HIP; }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extract<double, T, false, kPersist>, kWave, 0) != hipSuccess || per_cu < 1)
-            per_cu = 8;
-        const char *env = getenv("PYITD_WAVES_PER_CU");
-        if (env && atoi(env) > 0) per_cu = atoi(env);
-        e->persistent_waves = kPersist ? (int64_t)prop.multiProcessorCount * per_cu : INT64_MAX / 4;
-    }
     const size_t B = (size_t)max_batch;
     const int max_groups = groups_of((int)e->max_tiles);
     e->tiles_half = (int64_t)B * e->max_tiles;
@@ -519,9 +506,10 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
 {
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kWave);
+    const dim3 grid_d((n_tiles + kWPB - 1) / kWPB, 1), blk_d(kBlock);
     k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
     HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
+    k_detect<Tin, T><<<grid_d, blk_d, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
                                               e->d_recs, e->d_gsum, e->d_state);
     if (compact)
         k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_counts, e->d_gsum, n_tiles, n, e->d_kidx, e->max_n + 2,
@@ -547,12 +535,12 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     const int n_tiles = (int)tiles_of(n);
-    const dim3 grid_t(n_tiles, 1), blk(kWave);
+    const dim3 blk(kBlock);
     const bool want_list = m_host || knots || want_sync;
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
-    const dim3 grid_p((unsigned)std::min<int64_t>(n_tiles, e->persistent_waves));
-    k_extract<Tin, T, false, kPersist><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+    const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
+    k_extract<Tin, T, false><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);

@@ -50,7 +50,7 @@ __device__ unsigned long long g_itd_stamps[16];
 #define ITD_STAMP_DECL() unsigned long long stamp_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_prev__ = 0
 #define ITD_STAMP_FLUSH()                                                                     \
     do {                                                                                      \
-        if (threadIdx.x == 0)                                                                 \
+        if ((threadIdx.x & 63) == 0)                                                          \
             for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
     } while (0)
 #else
@@ -62,7 +62,15 @@ __device__ unsigned long long g_itd_stamps[16];
 
 namespace itd {
 
-constexpr int kWave = 64;              // one wavefront per workgroup
+constexpr int kWave = 64;              // one wavefront per tile
+#ifndef ITD_WPB
+#define ITD_WPB 1
+#endif
+constexpr int kWPB = ITD_WPB;          // independent wavefronts per workgroup (they share nothing but the launch slot)
+constexpr int kBlock = kWave * kWPB;
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// wave-uniform by construction: tell the compiler so (keeps tile indices, pointers and the halo search on the scalar unit)
+__device__ __forceinline__ int wave_in_block() { return kWPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 
 // Per-signal device state (one per batch element).
@@ -111,7 +119,9 @@ __device__ __forceinline__ void wave_sync()
 // ---------------------------------------------------------------------------------------------
 template <int TW>
 struct Tile {
-    static constexpr int kSize = TW + 4;
+    // pos -1 .. TW are samples; TW+1 .. TW+5 are five extra slots (k_extract keeps the values of the knots
+    // around the tile there, so a knot's value is one indexed read whether the knot is inside or outside)
+    static constexpr int kSize = TW + 8;
     double *p;
     __device__ __forceinline__ double &at(int pos) const { return p[pos + 2]; }
 };
@@ -132,7 +142,7 @@ template <typename Tin, int TW>
 __device__ __forceinline__ void tile_fetch(TileRegs<Tin, TW> &r, const Tin *__restrict__ x, int64_t n, int64_t s)
 {
     using R = TileRegs<Tin, TW>;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     const Tin *src = x + s;
     r.vec = (s + TW <= n) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
     if (r.vec) {
@@ -152,7 +162,7 @@ __device__ __forceinline__ void tile_commit(const TileRegs<Tin, TW> &r, const Ti
 {
     using R = TileRegs<Tin, TW>;
     using D2 = __attribute__((ext_vector_type(2))) double;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     if (r.vec) {
 #pragma unroll
         for (int k = 0; k < R::kN; ++k) {
@@ -184,62 +194,109 @@ __device__ __forceinline__ void tile_commit(const TileRegs<Tin, TW> &r, const Ti
 // First and last sample are never knots (ITD.py:70-73).  The wavefront walks the tile in 64-sample groups:
 // __ballot gives the group's flag mask, popcounts give the ordered output slot.  Returns the knot count.
 // ---------------------------------------------------------------------------------------------
+// bits lo..hi (inclusive) of a 64-bit word, empty when hi < lo
+__device__ __forceinline__ unsigned long long bit_range(int lo, int hi)
+{
+    if (hi < lo || hi < 0 || lo > 63) return 0ull;
+    lo = lo < 0 ? 0 : lo;
+    const unsigned long long upto = hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull);
+    return upto & ~((1ull << lo) - 1ull);
+}
+
 template <int TW>
 __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, int mode,
                                           unsigned long long (&masks)[TW / 64])
 {
     constexpr int G = TW / 64;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     int total = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int pos = g * 64 + lane;
-        const int64_t i = s + pos;
         const double xm = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
         const double vil = xp - x0;
         const double vix = x0 - xm;
         const bool valley = (vil > 0.0) && (vix <= 0.0);
         const bool peak = (vil < 0.0) && (vix >= 0.0);
-        bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
-        f = f && (i >= 1) && (i <= n - 2);
-        masks[g] = __ballot(f);
-        total += __popcll(masks[g]);
+        const bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
+        unsigned long long mk = __ballot(f);
+        if (s == 0 || s + TW >= n - 1) {
+            // first and last sample are never knots (ITD.py:70-73): wave-uniform range mask, edge tiles only
+            const int64_t g0 = s + g * 64;
+            const int64_t hi64 = (n - 2) - g0;
+            mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
+        }
+        masks[g] = mk;
+        total += __popcll(mk);
     }
     return total;
 }
 
-// producer side: the tile's record for its neighbours and (optionally, API helpers) its ordered knot list
+// producer side: the tile's record for its neighbours and (optionally, API helpers) its ordered knot list.
+// The first three / last two knots are found with scalar bit scans of the wave-uniform flag words.
 template <int TW>
 __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, int mode,
-                                           int32_t *__restrict__ list, TileRec *__restrict__ rec)
+                                           int32_t *__restrict__ list, TileRec *__restrict__ rec,
+                                           int32_t *rec_lds /* 16 ints of wave-private LDS, 16-byte aligned */)
 {
     constexpr int G = TW / 64;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     unsigned long long masks[G];
     const int total = scan_flags<TW>(tile, s, n, mode, masks);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int base = 0;
+    int h0 = 0, h1 = 0, h2 = 0, t0 = 0, t1 = 0;
+    {
+        int k = 0;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const unsigned long long mk = masks[g];
-        if ((mk >> lane) & 1ull) {
-            const int pos = g * 64 + lane;
-            const int k = base + __popcll(mk & lt);
-            const int32_t idx = (int32_t)(s + pos);
-            if (list) list[k] = idx;
-            if (k < 3) {
-                rec->hidx[k] = idx;
-                rec->hval[k] = tile.at(pos);
-            }
-            if (k >= total - 2) {
-                const int q = 1 - (total - 1 - k);
-                rec->tidx[q] = idx;
-                rec->tval[q] = tile.at(pos);
+        for (int g = 0; g < G; ++g) {
+            unsigned long long m = masks[g];
+            while (m && k < 3) {
+                const int pos = g * 64 + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (k == 0) h0 = pos; else if (k == 1) h1 = pos; else h2 = pos;
+                ++k;
             }
         }
-        base += __popcll(mk);
+        k = 0;
+#pragma unroll
+        for (int g = G - 1; g >= 0; --g) {
+            unsigned long long m = masks[g];
+            while (m && k < 2) {
+                const int b = 63 - __clzll((long long)m);
+                m &= ~(1ull << b);
+                if (k == 0) t1 = g * 64 + b; else t0 = g * 64 + b;
+                ++k;
+            }
+        }
     }
-    if (lane == 0) rec->count = total;
+    if (total == 0) {   // nothing to tell the neighbours but the count (most tiles of the deep levels)
+        if (lane == 0 && !(ITD_ABLATE & 64)) rec->count = 0;
+        return 0;
+    }
+    // assemble the 64-byte record in LDS, then hand it to HBM with ONE 4-lane x 16-byte store
+    TileRec *lrec = reinterpret_cast<TileRec *>(rec_lds);
+    if (lane < 5) {
+        const int pos = lane == 0 ? h0 : lane == 1 ? h1 : lane == 2 ? h2 : lane == 3 ? t0 : t1;
+        const int32_t idx = (int32_t)(s + pos);
+        const double v = tile.at(pos);
+        if (lane < 3) { lrec->hidx[lane] = idx; lrec->hval[lane] = v; }
+        else          { lrec->tidx[lane - 3] = idx; lrec->tval[lane - 3] = v; }
+    }
+    if (lane == 5) lrec->count = total;
+    wave_sync();
+    if (lane < 4 && !(ITD_ABLATE & 64)) {
+        using I4 = __attribute__((ext_vector_type(4))) int;
+        reinterpret_cast<I4 *>(rec)[lane] = reinterpret_cast<const I4 *>(rec_lds)[lane];
+    }
+    if (list) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int base = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long mk = masks[g];
+            if ((mk >> lane) & 1ull) list[base + __popcll(mk & lt)] = (int32_t)(s + g * 64 + lane);
+            base += __popcll(mk);
+        }
+    }
     return total;
 }
 
@@ -247,7 +304,7 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
 template <int TW>
 __device__ __forceinline__ void publish_ends(Tile<TW> tile, int64_t s, int64_t n, double *ends)
 {
-    const int q = threadIdx.x;
+    const int q = lane_id();
     if (q < 4) {
         const int64_t i = (q == 0) ? 0 : (q == 1 ? 1 : (q == 2 ? n - 2 : n - 1));
         if (i >= s && i < s + TW) ends[q] = tile.at((int)(i - s));
@@ -259,34 +316,36 @@ __device__ __forceinline__ void publish_ends(Tile<TW> tile, int64_t s, int64_t n
 // grid = (n_tiles, batch), 64 threads.  lists: [batch][n_tiles][TW] int32; counts/recs: [batch][n_tiles].
 // ---------------------------------------------------------------------------------------------
 template <typename Tin, int TW>
-__global__ __launch_bounds__(kWave) void k_detect(const Tin *__restrict__ x, int64_t x_stride, int64_t n,
+__global__ __launch_bounds__(kBlock) void k_detect(const Tin *__restrict__ x, int64_t x_stride, int64_t n,
                                                   int n_tiles, int mode, int32_t *__restrict__ lists,
                                                   int32_t *__restrict__ counts, TileRec *__restrict__ recs,
                                                   int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
 {
-    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
-    const int t = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) double s_x[kWPB][Tile<TW>::kSize];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[kWPB][16];
+    const int t = blockIdx.x * kWPB + wave_in_block();
+    if (t >= n_tiles) return;
     const int sig = blockIdx.y;
     const int64_t s = (int64_t)t * TW;
     const Tin *xs = x + (int64_t)sig * x_stride;
-    Tile<TW> tile{s_x};
+    Tile<TW> tile{s_x[wave_in_block()]};
     TileRegs<Tin, TW> regs;
     tile_fetch<Tin, TW>(regs, xs, n, s);
     tile_commit<Tin, TW>(regs, xs, n, s, tile);
     wave_sync();
-    publish_ends<TW>(tile, s, n, state[sig].ends[0]);
+    if (s == 0 || s + TW >= n - 2) publish_ends<TW>(tile, s, n, state[sig].ends[0]);
     {
         bool nan_in = false;
 #pragma unroll
         for (int g = 0; g < TW / 64; ++g) {
-            const double v = tile.at(g * 64 + threadIdx.x);
+            const double v = tile.at(g * 64 + lane_id());
             nan_in = nan_in || (v != v);
         }
-        if (__any(nan_in) && threadIdx.x == 0) state[sig].in_nan = 1;
+        if (__any(nan_in) && lane_id() == 0) state[sig].in_nan = 1;
     }
     const size_t slot = (size_t)sig * n_tiles + t;
-    const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot);
-    if (threadIdx.x == 0) {
+    const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot, s_rec[wave_in_block()]);
+    if (lane_id() == 0) {
         counts[slot] = total;
         if (total) atomicAdd(&gsum_out[((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch], total);
     }
@@ -306,7 +365,7 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
 {
     const int sig = blockIdx.y;
     const int t = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     const int n_groups = groups_of(n_tiles);
     const int32_t *cnt = counts + (size_t)sig * n_tiles;
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
@@ -338,7 +397,7 @@ template <int DIR>
 __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__restrict__ gs, int n_tiles,
                             int start, int *count_out)
 {
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     const int n_groups = groups_of(n_tiles);
     while (start >= 0 && start < n_tiles) {
         const int g = start / kTilesPerGroup;
@@ -369,378 +428,376 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
     return -1;
 }
 
+// popcount of the bits of m below this lane, plus init (v_mbcnt_lo/hi: two VALU instructions)
+__device__ __forceinline__ int mbcnt64(unsigned long long m, int init)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)init));
+}
+
 // ---------------------------------------------------------------------------------------------
-// k_extract: one extraction level.  PERSISTENT wavefronts: wavefront w (one per workgroup) handles the
-// tiles w, w + NW, w + 2 NW, ... of the flattened (signal, tile) index space in a three-stage software
-// pipeline, so every global load has a whole tile's worth of compute to land:
-//     stage A (two tiles ahead)  the neighbouring tiles' knot counts (64 in front, 64 behind)
-//     stage B (one tile ahead)   the tile itself (registers) and the records of the neighbours that hold
-//                                the two knots in front of / three knots behind the tile
-//     stage C (this tile)        registers -> LDS, knot predicate on the tile (the consumer re-derives its own
-//                                knots: no knot list is read or written), knot values B_k (ITD.py:100-110),
-//                                slopes, baseline map + rotation (ITD.py:114-119), and the next level's
-//                                counts/records from the baseline tile it has just produced.
+// k_extract: one extraction on one tile, one wavefront; grid = (n_tiles * batch / kWPB), kBlock threads.
 //   xin           level input (float32/float64 caller signal at level 0, float64 baseline afterwards)
 //   counts/recs   per-tile counts and records, double buffered by level parity (neighbours read them)
 //   gsum_in/out/clear   group sums, rotating by level % 3
 //   rot_out       rotation row   (FINAL: rotation + baseline, the "Out of time!" row, ITD.py:420)
 //   base_out      baseline row   (FINAL: not written)
-// grid = (NW), 64 threads.
+//   careful       NaN-faithful launch sequence: do not emit the next level's scan (k_careful_* does)
+// After the tile is staged everything is wave-synchronous.  Knot data lives in LDS BY RANK j:
+//   j = 0, 1          the two knots in front of the tile (rank 1 starts the segment that enters the tile)
+//   j = 2 .. c+1      the tile's own c knots, ascending
+//   j = c+2 .. c+4    the three knots behind the tile
+// with their sample index gi[j], value Xr[j], knot value Br[j] (ITD.py:100-110) and the slope Sr[j] of the segment
+// that starts there (ITD.py:115-116).  A sample's segment is rank 1 + (knots at or before it) — one v_mbcnt pair
+// on the group's flag word — so the baseline map is three indexed LDS reads and three flops per sample.
 // ---------------------------------------------------------------------------------------------
-struct HaloRegs {          // raw record fields of the candidate neighbour tiles (wave-uniform)
-    int ub0, ub1, cb0;     // nearest / second nearest non-empty tile in front (-1: none in the window), count of ub0
-    int uf0, uf1, uf2, cf0, cf1;
-    int32_t b0i1, b0i0, b1i1;
-    double b0v1, b0v0, b1v1;
-    int32_t f0i0, f0i1, f0i2, f1i0, f1i1, f2i0;
-    double f0v0, f0v1, f0v2, f1v0, f1v1, f2v0;
-};
-
-template <typename Tin, int TW, bool FINAL, bool PERSIST>
-__global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
-                                                   int n_tiles, int batch,
-                                                   const int32_t *__restrict__ counts_in,
-                                                   int32_t *__restrict__ counts_out,
-                                                   const TileRec *__restrict__ recs_in,
-                                                   TileRec *__restrict__ recs_out,
-                                                   const int32_t *__restrict__ gsum_in,
-                                                   int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
-                                                   double *__restrict__ rot_out, int64_t rot_stride,
-                                                   double *__restrict__ base_out, int64_t base_stride,
-                                                   SigState *__restrict__ state, int level, int careful)
+template <typename Tin, int TW, bool FINAL>
+__global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
+                                                    int n_tiles, int batch,
+                                                    const int32_t *__restrict__ counts_in,
+                                                    int32_t *__restrict__ counts_out,
+                                                    const TileRec *__restrict__ recs_in,
+                                                    TileRec *__restrict__ recs_out,
+                                                    const int32_t *__restrict__ gsum_in,
+                                                    int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
+                                                    double *__restrict__ rot_out, int64_t rot_stride,
+                                                    double *__restrict__ base_out, int64_t base_stride,
+                                                    SigState *__restrict__ state, int level, int careful)
 {
     constexpr int G = TW / 64;    // 64-sample groups = 64-bit flag words per tile
-    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];  // the tile: input, then baseline in place
-    __shared__ double s_B[TW];        // knot value  B_k   at the knot's position in the tile
-    __shared__ double s_S[TW];        // slope of the segment that STARTS at that knot
-    __shared__ int32_t s_kk[TW + 8];  // knot indices: [0],[1] in front, [2..c+1] the tile's, [c+2..c+4] behind
-    __shared__ double s_hB[5], s_hS[5];   // values / slopes of the out-of-tile knots
+    constexpr int RK = TW + 8;    // rank capacity (c + 5 <= TW + 5)
+    // one private LDS slice per wavefront of the workgroup
+    __shared__ __attribute__((aligned(16))) double sx_all[kWPB][Tile<TW>::kSize];  // the tile: input, then baseline in place
+    __shared__ double sX_all[kWPB][RK];      // value of the level's input at knot j
+    __shared__ double sB_all[kWPB][RK];      // knot value B_j
+    __shared__ double sS_all[kWPB][RK];      // slope of the segment that starts at knot j; before the slopes exist the same
+                                             // bytes hold the knots' sample indices gi[j] (dead once the B_j are known)
+    __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][16];   // staging of the tile's 64-byte record
+    double *s_x = sx_all[wave_in_block()];
+    double *s_X = sX_all[wave_in_block()], *s_B = sB_all[wave_in_block()], *s_S = sS_all[wave_in_block()];
+    int32_t *s_gi = reinterpret_cast<int32_t *>(sS_all[wave_in_block()]);
 
-    const int lane = threadIdx.x;
-    const int NW = gridDim.x;
-    const int64_t total_tiles = (int64_t)n_tiles * batch;
+    const int lane = lane_id();
+    const int64_t kflat = (int64_t)blockIdx.x * kWPB + wave_in_block();
+    if (kflat >= (int64_t)n_tiles * batch) return;
+    const int sig = (int)(kflat / n_tiles), t = (int)(kflat - (int64_t)sig * n_tiles);
+    SigState *st = state + sig;
+    const int64_t s = (int64_t)t * TW;
+    const Tin *x = xin + (int64_t)sig * x_stride;
+    const size_t slot0 = (size_t)sig * n_tiles;
+    const int32_t *cnts = counts_in + slot0;
+    const TileRec *recs = recs_in + slot0;
     const int n_groups = groups_of(n_tiles);
+    const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
     Tile<TW> xt{s_x};
+    ITD_STAMP_DECL();
+    ITD_STAMP_BEGIN();
 
-    // ---- stage A: knot counts of the 64 tiles in front of / behind tile k -----------------------------------
-    auto stage_a = [&](int64_t k, int &cb, int &cf) {
-        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
-        const int32_t *cnts = counts_in + (size_t)sig * n_tiles;
-        const int tb = t - 1 - lane, tf = t + 1 + lane;
-        cb = (tb >= 0) ? cnts[tb] : 0;
-        cf = (tf < n_tiles) ? cnts[tf] : 0;
-    };
-    // ---- stage B: the tile and the candidate neighbours' records ---------------------------------------------
-    auto stage_b = [&](int64_t k, int cb, int cf, TileRegs<Tin, TW> &regs, HaloRegs &h) {
-        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
-        tile_fetch<Tin, TW>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
-        const TileRec *recs = recs_in + (size_t)sig * n_tiles;
+    // ---- issue every independent load at once: the tile, the neighbours' knot counts, the two adjacent tiles'
+    //      records (they hold all five surrounding knots whenever the knots are dense), the signal's state ------------
+    TileRegs<Tin, TW> regs;
+    tile_fetch<Tin, TW>(regs, x, n, s);
+    const int tb = t - 1 - lane, tf = t + 1 + lane;
+    const int cb = (tb >= 0) ? cnts[tb] : 0;
+    const int cf = (tf < n_tiles) ? cnts[tf] : 0;
+    const TileRec *rp = recs + (t > 0 ? t - 1 : 0), *rn = recs + (t + 1 < n_tiles ? t + 1 : t);
+    const int32_t pi1 = rp->tidx[1], pi0 = rp->tidx[0];
+    const double pv1 = rp->tval[1], pv0 = rp->tval[0];
+    const int32_t ni0 = rn->hidx[0], ni1 = rn->hidx[1], ni2 = rn->hidx[2];
+    const double nv0 = rn->hval[0], nv1 = rn->hval[1], nv2 = rn->hval[2];
+    const int stopped = st->stopped;
+    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
+    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
+    if (stopped) return;
+
+    if (t == 0) {
+        // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
+        int acc = 0;
+        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) {
+            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
+                if (st->c_has_nan) acc = st->c_nan;
+                st->c_nan = 0;
+                st->c_has_nan = 0;
+            }
+            st->m[level] = acc;
+            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
+                st->stop_level = level;
+                st->stopped = 1;
+            }
+        }
+        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
+        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
+    }
+
+    // ---- halo search (scalar): two knots in front of the tile, three behind, from the neighbours' records ---------
+    // slots: [0],[1] in front (slot 1 starts the segment that enters the tile), [2],[3],[4] behind; missing ones are
+    // the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).  The candidate tiles come from the two 64-tile count
+    // windows and ALL their records are requested together (one round trip); only when a window runs dry does the
+    // search walk on through the group sums (far_nonempty: dependent loads, rare).
+    int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
+    double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
+    int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
+    if (!(ITD_ABLATE & 8)) {
         unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
-        h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
-        h.cb0 = h.cf0 = h.cf1 = 0;
+        int ub0 = -1, ub1 = -1, cb0 = 0, uf0 = -1, uf1 = -1, uf2 = -1, cf0 = 0, cf1 = 0;
         if (mb) {
             const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-            h.ub0 = t - 1 - l; h.cb0 = __shfl(cb, l);
-            if (h.cb0 < 2 && mb) h.ub1 = t - 1 - (__ffsll((long long)mb) - 1);
+            ub0 = t - 1 - l; cb0 = __builtin_amdgcn_readlane(cb, l);
+            if (cb0 < 2 && mb) ub1 = t - 1 - (__ffsll((long long)mb) - 1);
         }
         if (mf) {
             const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
-            h.uf0 = t + 1 + l; h.cf0 = __shfl(cf, l);
-            if (h.cf0 < 3 && mf) {
+            uf0 = t + 1 + l; cf0 = __builtin_amdgcn_readlane(cf, l);
+            if (cf0 < 3 && mf) {
                 const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
-                h.uf1 = t + 1 + l1; h.cf1 = __shfl(cf, l1);
-                if (h.cf0 + h.cf1 < 3 && mf) h.uf2 = t + 1 + (__ffsll((long long)mf) - 1);
+                uf1 = t + 1 + l1; cf1 = __builtin_amdgcn_readlane(cf, l1);
+                if (cf0 + cf1 < 3 && mf) uf2 = t + 1 + (__ffsll((long long)mf) - 1);
             }
         }
-        // uniform addresses: these become scalar loads
-        const TileRec *rb0 = recs + __builtin_amdgcn_readfirstlane(max(h.ub0, 0));
-        const TileRec *rb1 = recs + __builtin_amdgcn_readfirstlane(max(h.ub1, 0));
-        const TileRec *rf0 = recs + __builtin_amdgcn_readfirstlane(max(h.uf0, 0));
-        const TileRec *rf1 = recs + __builtin_amdgcn_readfirstlane(max(h.uf1, 0));
-        const TileRec *rf2 = recs + __builtin_amdgcn_readfirstlane(max(h.uf2, 0));
-        h.b0i1 = rb0->tidx[1]; h.b0i0 = rb0->tidx[0]; h.b0v1 = rb0->tval[1]; h.b0v0 = rb0->tval[0];
-        h.b1i1 = rb1->tidx[1]; h.b1v1 = rb1->tval[1];
-        h.f0i0 = rf0->hidx[0]; h.f0i1 = rf0->hidx[1]; h.f0i2 = rf0->hidx[2];
-        h.f0v0 = rf0->hval[0]; h.f0v1 = rf0->hval[1]; h.f0v2 = rf0->hval[2];
-        h.f1i0 = rf1->hidx[0]; h.f1i1 = rf1->hidx[1]; h.f1v0 = rf1->hval[0]; h.f1v1 = rf1->hval[1];
-        h.f2i0 = rf2->hidx[0]; h.f2v0 = rf2->hval[0];
-    };
-
-    int64_t k = blockIdx.x;
-    if (k >= total_tiles) return;
-    int cbA = 0, cfA = 0;
-    TileRegs<Tin, TW> regs;
-    HaloRegs hr;
-    stage_a(k, cbA, cfA);
-    stage_b(k, cbA, cfA, regs, hr);
-    if constexpr (PERSIST)
-        if (k + NW < total_tiles) stage_a(k + NW, cbA, cfA);
-
-    ITD_STAMP_DECL();
-    for (; k < total_tiles; k += NW) {
-        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
-        SigState *st = state + sig;
-        const int64_t s = (int64_t)t * TW;
-        const Tin *x = xin + (int64_t)sig * x_stride;
-        const size_t slot0 = (size_t)sig * n_tiles;
-        const int32_t *cnts = counts_in + slot0;
-        const TileRec *recs = recs_in + slot0;
-        const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
-        const bool stopped = st->stopped != 0;
-        const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
-        const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
-
-        ITD_STAMP_BEGIN();
-        // ---- stage C, part 1: finish the halo, stage the tile in LDS ------------------------------------------
-        // slots: [0],[1] in front (slot 1 starts the segment that enters the tile), [2],[3],[4] behind; missing
-        // ones are the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98)
-        int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
-        double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
-        int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
-        if (!stopped) {
-            if (hr.ub0 >= 0) {
-                hi1 = hr.b0i1; hx1 = hr.b0v1; nb = 1;
-                if (hr.cb0 >= 2) { hi0 = hr.b0i0; hx0 = hr.b0v0; nb = 2; }
-                else if (hr.ub1 >= 0) { hi0 = hr.b1i1; hx0 = hr.b1v1; nb = 2; }
+        // every record that can be needed, requested at once (the adjacent tiles' are already on their way)
+        int32_t b0i1 = pi1, b0i0 = pi0; double b0v1 = pv1, b0v0 = pv0;
+        if (ub0 >= 0 && ub0 != t - 1) { const TileRec *r = recs + ub0; b0i1 = r->tidx[1]; b0i0 = r->tidx[0]; b0v1 = r->tval[1]; b0v0 = r->tval[0]; }
+        int32_t b1i1 = 0; double b1v1 = 0.0;
+        if (ub1 >= 0) { const TileRec *r = recs + ub1; b1i1 = r->tidx[1]; b1v1 = r->tval[1]; }
+        int32_t f0i0 = ni0, f0i1 = ni1, f0i2 = ni2; double f0v0 = nv0, f0v1 = nv1, f0v2 = nv2;
+        if (uf0 >= 0 && uf0 != t + 1) { const TileRec *r = recs + uf0; f0i0 = r->hidx[0]; f0i1 = r->hidx[1]; f0i2 = r->hidx[2]; f0v0 = r->hval[0]; f0v1 = r->hval[1]; f0v2 = r->hval[2]; }
+        int32_t f1i0 = 0, f1i1 = 0, f2i0 = 0; double f1v0 = 0.0, f1v1 = 0.0, f2v0 = 0.0;
+        if (uf1 >= 0) { const TileRec *r = recs + uf1; f1i0 = r->hidx[0]; f1i1 = r->hidx[1]; f1v0 = r->hval[0]; f1v1 = r->hval[1]; }
+        if (uf2 >= 0) { const TileRec *r = recs + uf2; f2i0 = r->hidx[0]; f2v0 = r->hval[0]; }
+        if (ub0 >= 0) {
+            hi1 = b0i1; hx1 = b0v1; nb = 1;
+            if (cb0 >= 2) { hi0 = b0i0; hx0 = b0v0; nb = 2; }
+            else if (ub1 >= 0) { hi0 = b1i1; hx0 = b1v1; nb = 2; }
+        }
+        if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further
+            int far = t - 65;
+            while (nb < 2) {
+                int cu;
+                const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
+                if (u < 0) break;
+                far = u - 1;
+                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+                const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
+                const double v1 = r->tval[1], v0 = r->tval[0];
+                if (nb == 0) { hi1 = i1; hx1 = v1; } else { hi0 = i1; hx0 = v1; }
+                ++nb;
+                if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
             }
-            if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further (rare)
-                int far = t - 65;
-                while (nb < 2) {
-                    int cu;
-                    const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
-                    if (u < 0) break;
-                    far = u - 1;
-                    const TileRec *r = recs + u;
-                    const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
-                    const double v1 = r->tval[1], v0 = r->tval[0];
-                    if (nb == 0) { hi1 = i1; hx1 = v1; } else { hi0 = i1; hx0 = v1; }
-                    ++nb;
-                    if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
+        }
+        if (uf0 >= 0) {
+            hi2 = f0i0; hx2 = f0v0; nf = 1;
+            if (cf0 >= 2) { hi3 = f0i1; hx3 = f0v1; nf = 2; }
+            if (cf0 >= 3) { hi4 = f0i2; hx4 = f0v2; nf = 3; }
+            if (nf < 3 && uf1 >= 0) {
+                if (nf == 1) {
+                    hi3 = f1i0; hx3 = f1v0; nf = 2;
+                    if (cf1 >= 2) { hi4 = f1i1; hx4 = f1v1; nf = 3; }
+                } else {
+                    hi4 = f1i0; hx4 = f1v0; nf = 3;
+                }
+                if (nf < 3 && uf2 >= 0) { hi4 = f2i0; hx4 = f2v0; nf = 3; }
+            }
+        }
+        if (nf < 3 && t + 65 < n_tiles) {
+            int far = t + 65;
+            while (nf < 3) {
+                int cu;
+                const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
+                if (u < 0) break;
+                far = u + 1;
+                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+                const int32_t i0 = r->hidx[0], i1 = r->hidx[1], i2 = r->hidx[2];
+                const double v0 = r->hval[0], v1 = r->hval[1], v2 = r->hval[2];
+                if (nf == 0) {
+                    hi2 = i0; hx2 = v0;
+                    if (cu >= 2) { hi3 = i1; hx3 = v1; }
+                    if (cu >= 3) { hi4 = i2; hx4 = v2; }
+                    nf = min(cu, 3);
+                } else if (nf == 1) {
+                    hi3 = i0; hx3 = v0;
+                    if (cu >= 2) { hi4 = i1; hx4 = v1; }
+                    nf = 1 + min(cu, 2);
+                } else {
+                    hi4 = i0; hx4 = v0;
+                    nf = 3;
                 }
             }
-            if (hr.uf0 >= 0) {
-                hi2 = hr.f0i0; hx2 = hr.f0v0; nf = 1;
-                if (hr.cf0 >= 2) { hi3 = hr.f0i1; hx3 = hr.f0v1; nf = 2; }
-                if (hr.cf0 >= 3) { hi4 = hr.f0i2; hx4 = hr.f0v2; nf = 3; }
-                if (nf < 3 && hr.uf1 >= 0) {
-                    if (nf == 1) {
-                        hi3 = hr.f1i0; hx3 = hr.f1v0; nf = 2;
-                        if (hr.cf1 >= 2) { hi4 = hr.f1i1; hx4 = hr.f1v1; nf = 3; }
-                    } else {
-                        hi4 = hr.f1i0; hx4 = hr.f1v0; nf = 3;
-                    }
-                    if (nf < 3 && hr.uf2 >= 0) { hi4 = hr.f2i0; hx4 = hr.f2v0; nf = 3; }
-                }
-            }
-            if (nf < 3 && t + 65 < n_tiles) {
-                int far = t + 65;
-                while (nf < 3) {
-                    int cu;
-                    const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
-                    if (u < 0) break;
-                    far = u + 1;
-                    const TileRec *r = recs + u;
-                    const int32_t i0 = r->hidx[0], i1 = r->hidx[1], i2 = r->hidx[2];
-                    const double v0 = r->hval[0], v1 = r->hval[1], v2 = r->hval[2];
-                    if (nf == 0) {
-                        hi2 = i0; hx2 = v0;
-                        if (cu >= 2) { hi3 = i1; hx3 = v1; }
-                        if (cu >= 3) { hi4 = i2; hx4 = v2; }
-                        nf = min(cu, 3);
-                    } else if (nf == 1) {
-                        hi3 = i0; hx3 = v0;
-                        if (cu >= 2) { hi4 = i1; hx4 = v1; }
-                        nf = 1 + min(cu, 2);
-                    } else {
-                        hi4 = i0; hx4 = v0;
-                        nf = 3;
-                    }
-                }
-            }
-            tile_commit<Tin, TW>(regs, x, n, s, xt);
         }
+    }
+    ITD_STAMP(0);
 
-        ITD_STAMP(0);
-        // ---- keep the pipeline full: stage B of the next tile, stage A of the one after ----------------------
-        if constexpr (PERSIST) {
-            const int64_t kn = k + NW;
-            if (kn < total_tiles) {
-                stage_b(kn, cbA, cfA, regs, hr);
-                if (kn + NW < total_tiles) stage_a(kn + NW, cbA, cfA);
-            }
-        }
-        if (stopped) { if constexpr (PERSIST) continue; else return; }
-        ITD_STAMP(1);
+    // ---- stage the tile ---------------------------------------------------------------------------------------------
+    tile_commit<Tin, TW>(regs, x, n, s, xt);
+    wave_sync();
+    ITD_STAMP(1);
 
-        if (t == 0) {
-            // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ------------------
-            int acc = 0;
-            for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-            if (lane == 0) {
-                if (careful) {   // the reference counted this level's knots under its NaN rules (k_detect_careful)
-                    if (st->c_has_nan) acc = st->c_nan;
-                    st->c_nan = 0;
-                    st->c_has_nan = 0;
-                }
-                st->m[level] = acc;
-                if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
-                    st->stop_level = level;
-                    st->stopped = 1;
-                }
-            }
-            int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
-            for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
-        }
-        wave_sync();
-
-        // ---- this level's knots inside the tile: the predicate the producer ran on the same values ----------
-        unsigned long long mks[G];
-        const int c = (ITD_ABLATE & 16) ? 0 : scan_flags<TW>(xt, s, n, kKnots, mks);
-        if (ITD_ABLATE & 16) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) mks[g] = 0ull;
-        }
-        {
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            int base = 2;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const unsigned long long mk = mks[g];
-                if ((mk >> lane) & 1ull) s_kk[base + __popcll(mk & lt)] = (int32_t)(s + g * 64 + lane);
-                base += __popcll(mk);
-            }
-            if (lane < 5) {
-                const int32_t v = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
-                s_kk[lane < 2 ? lane : c + lane] = v;
-            }
-        }
-        wave_sync();
-        ITD_STAMP(2);
-
-        // ---- knot values, ITD.py:100-110.  j indexes s_kk --------------------------------------------------
-        auto in_tile = [&](int j) { return j >= 2 && j <= c + 1; };
-        auto hslot = [&](int j) { return j < 2 ? j : j - c; };
-        auto hx = [&](int q) -> double { return q == 0 ? hx0 : q == 1 ? hx1 : q == 2 ? hx2 : q == 3 ? hx3 : hx4; };
-        auto xval = [&](int j) -> double { return in_tile(j) ? xt.at(s_kk[j] - (int32_t)s) : hx(hslot(j)); };
-        auto is_end0 = [&](int j) { return (j == 1 && nb == 0) || (j == 0 && nb < 2); };   // e[0] = sample 0
-        auto is_endn = [&](int j) { return j >= c + 2 && (j - (c + 2)) >= nf; };           // e[m+1] = sample n-1
-        for (int j = 1 + lane; j <= c + 3 && !(ITD_ABLATE & 4); j += kWave) {
-            double Bv;
-            if (is_end0(j)) {
-                Bv = (e0 + e1) / 2.0;                 // numpy.mean(x[:2]),  ITD.py:101
-            } else if (is_endn(j)) {
-                Bv = (e2 + e3) / 2.0;                 // numpy.mean(x[-2:]), ITD.py:102
-            } else {
-                const int32_t k0 = s_kk[j - 1], k1 = s_kk[j], k2 = s_kk[j + 1];
-                const double x0 = xval(j - 1), x1 = xval(j), x2 = xval(j + 1);
-                const double frac = (double)(k1 - k0) / (double)(k2 - k0);
-                const double tt = frac * (x2 - x0);
-                const double u = x0 + tt;
-                Bv = 0.5 * u + 0.5 * x1;              // ITD.py:107-110
-            }
-            if (in_tile(j)) s_B[s_kk[j] - (int32_t)s] = Bv;
-            else s_hB[hslot(j)] = Bv;
-        }
-        wave_sync();
-        ITD_STAMP(3);
-        // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 -------------------------
-        auto Bof = [&](int j) -> double { return in_tile(j) ? s_B[s_kk[j] - (int32_t)s] : s_hB[hslot(j)]; };
-        for (int j = 1 + lane; j <= c + 2 && !(ITD_ABLATE & 4); j += kWave) {
-            if (is_endn(j)) continue; // sample n-1 starts no segment
-            const double sl = (Bof(j + 1) - Bof(j)) / (xval(j + 1) - xval(j));
-            if (in_tile(j)) s_S[s_kk[j] - (int32_t)s] = sl;
-            else s_hS[hslot(j)] = sl;
-        }
-        wave_sync();
-        ITD_STAMP(4);
-
-        // ---- baseline map + rotation, ITD.py:114-119 -------------------------------------------------------
-        // Segment of sample i = the last knot at or before i.  Inside a 64-sample group that is a bit scan of
-        // the group's flag word; in front of the group's first knot it is the carry (B, slope, x of the last
-        // knot in front of the group).  The baseline overwrites the tile in place, after every read.
-        double *rot = rot_out + (int64_t)sig * rot_stride;
-        double *bas = FINAL ? nullptr : base_out + (int64_t)sig * base_stride;
-        const double hB1 = s_hB[1], hS1 = s_hS[1];
-        const double x_lo = xt.at(-1), x_hi = xt.at(TW);
-        double cBg[G + 1], cSg[G + 1], cXg[G + 1];
-        {
-            int PL = -1;
-#pragma unroll
-            for (int g = 0; g <= G; ++g) {
-                if (PL >= 0) { cBg[g] = s_B[PL]; cSg[g] = s_S[PL]; cXg[g] = xt.at(PL); }
-                else         { cBg[g] = hB1;     cSg[g] = hS1;     cXg[g] = hx1; }
-                if (g < G && mks[g]) PL = g * 64 + 63 - __clzll((long long)mks[g]);
-            }
-        }
-        double bv[G], rv[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int gbase = g * 64;
-            const int pos = gbase + lane;
-            const int64_t i = s + pos;
-            const unsigned long long le = mks[g] & ((2ull << lane) - 1ull);
-            const double xi = xt.at(pos);
-            double Bk = cBg[g], Sk = cSg[g], Xk = cXg[g];
-            if (le) {
-                const int P = gbase + 63 - __clzll((long long)le);
-                Bk = s_B[P]; Sk = s_S[P]; Xk = xt.at(P);
-            }
-            double bi = Bk + Sk * (xi - Xk);
-            if (i >= n - 1) bi = 0.0;             // baseline[n-1] is never written, ITD.py:112-117
-            bv[g] = bi;
-            rv[g] = xi - bi;
-        }
-        wave_sync();
-        ITD_STAMP(5);
-        bool has_nan = false;
+    // ---- this level's knots inside the tile: the predicate the producer ran on the same values; ranked into LDS ----
+    const bool edge_tile = (s == 0) || (s + TW >= n - 1);   // holds sample 0 or n-1, which are never knots
+    unsigned long long mks[G];
+    int c = 0;
+    {
+        int base = 2;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int pos = g * 64 + lane;
-            const int64_t i = s + pos;
+            const double xm = xt.at(pos - 1), x0 = xt.at(pos), xp = xt.at(pos + 1);
+            const double vil = xp - x0;
+            const double vix = x0 - xm;
+            bool f = ((vil > 0.0) && (vix <= 0.0)) || ((vil < 0.0) && (vix >= 0.0));   // ITD.py:59 on x and on -x
+            if (ITD_ABLATE & 16) f = false;
+            unsigned long long mk = __ballot(f);
+            if (edge_tile) {   // first and last sample are never knots (ITD.py:70-73)
+                const int64_t g0 = s + g * 64;
+                const int64_t hi64 = (n - 2) - g0;
+                mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
+                f = (mk >> lane) & 1ull;
+            }
+            mks[g] = mk;
+            if (f) {
+                const int j = mbcnt64(mk, base);
+                s_X[j] = x0;
+                s_gi[j] = (int32_t)s + pos;
+            }
+            base += __popcll(mk);
+        }
+        c = base - 2;
+    }
+    if (lane < 5) {   // the five knots around the tile
+        const int j = lane < 2 ? lane : c + lane;
+        s_X[j] = lane == 0 ? hx0 : lane == 1 ? hx1 : lane == 2 ? hx2 : lane == 3 ? hx3 : hx4;
+        s_gi[j] = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
+    }
+    wave_sync();
+    ITD_STAMP(2);
+
+    // ---- knot values, ITD.py:100-110 -----------------------------------------------------------------------------
+    const double m0 = (e0 + e1) / 2.0;   // numpy.mean(x[:2]),  ITD.py:101
+    const double mn = (e2 + e3) / 2.0;   // numpy.mean(x[-2:]), ITD.py:102
+    for (int j = 1 + lane; j <= c + 3 && !(ITD_ABLATE & 4); j += kWave) {
+        const int32_t k0 = s_gi[j - 1], k1 = s_gi[j], k2 = s_gi[j + 1];
+        const double x0 = s_X[j - 1], x1 = s_X[j], x2 = s_X[j + 1];
+        const double frac = (double)(k1 - k0) / (double)(k2 - k0);
+        const double tt = frac * (x2 - x0);
+        const double u = x0 + tt;
+        double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
+        const bool end0 = (j == 1) && (nb == 0);                          // e[0]   = sample 0
+        const bool endn = (j >= c + 2) && (j - (c + 2) >= nf);            // e[m+1] = sample n-1
+        Bv = end0 ? m0 : (endn ? mn : Bv);
+        s_B[j] = Bv;
+    }
+    wave_sync();
+    ITD_STAMP(3);
+    // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 ------------------------------------
+    for (int j = 1 + lane; j <= c + 2 && !(ITD_ABLATE & 4); j += kWave) {
+        const double sl = (s_B[j + 1] - s_B[j]) / (s_X[j + 1] - s_X[j]);
+        const bool endn = (j >= c + 2) && (j - (c + 2) >= nf);            // sample n-1 starts no segment
+        if (!endn) s_S[j] = sl;
+    }
+    wave_sync();
+    ITD_STAMP(4);
+
+    // ---- baseline map + rotation, ITD.py:114-119 ------------------------------------------------------------------
+    // The baseline overwrites the tile in place, after every read.
+    double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
+    double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
+    const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
+    double bv[G], rv[G];
+    if (c == 0) {
+        // no knot inside the tile (most tiles of the deep levels): one segment, one affine map
+        const double Bk = s_B[1], Sk = s_S[1], Xk = s_X[1];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int pos = g * 64 + lane;
+            const double xi = xt.at(pos);
+            double bi = Bk + Sk * (xi - Xk);
+            if (tail_tile && s + pos >= n - 1) bi = 0.0;
+            bv[g] = bi;
+            rv[g] = xi - bi;
+        }
+    } else {
+        int jb = 1;   // rank of the knot in front of the group
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int pos = g * 64 + lane;
+            const unsigned long long mk = mks[g];
+            const int j = mbcnt64(mk >> 1, jb + (int)(mk & 1ull));   // 1 + knots at or before this sample
+            const double xi = xt.at(pos);
+            const double Bk = s_B[j], Sk = s_S[j], Xk = s_X[j];
+            double bi = Bk + Sk * (xi - Xk);
+            if (tail_tile && s + pos >= n - 1) bi = 0.0;   // baseline[n-1] is never written, ITD.py:112-117
+            bv[g] = bi;
+            rv[g] = xi - bi;
+            jb += __popcll(mk);
+        }
+    }
+    // halo samples: s-1 lives in the segment entering the tile; s+TW is either a knot itself (rank c+2) or in the
+    // tile's last segment (rank 1+c)
+    double b_lo = 0.0, b_hi = 0.0;
+    if (lane == 0) {
+        if (s >= 1) b_lo = s_B[1] + s_S[1] * (xt.at(-1) - s_X[1]);
+        const int64_t i = s + TW;
+        if (i < n - 1) {
+            const int j = (nf >= 1 && hi2 == (int32_t)i) ? c + 2 : 1 + c;
+            b_hi = s_B[j] + s_S[j] * (xt.at(TW) - s_X[j]);
+        }
+    }
+    wave_sync();
+    ITD_STAMP(5);
+    bool has_nan = false;
+    if (!tail_tile) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int pos = g * 64 + lane;
             xt.at(pos) = bv[g];
-            if (i < n && (!(ITD_ABLATE & 1) || bv[g] == 1.2345e-300)) {
+            if (!(ITD_ABLATE & 1) || bv[g] == 1.2345e-300) {
                 if constexpr (FINAL) {
-                    rot[i] = rv[g] + bv[g];       // ITD.py:420
+                    rot_t[pos] = rv[g] + bv[g];       // ITD.py:420
                 } else {
-                    rot[i] = rv[g];
-                    bas[i] = bv[g];
+                    rot_t[pos] = rv[g];
+                    bas_t[pos] = bv[g];
+                }
+            }
+            has_nan = has_nan || (bv[g] != bv[g]);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int pos = g * 64 + lane;
+            xt.at(pos) = bv[g];
+            if (s + pos < n) {
+                if constexpr (FINAL) {
+                    rot_t[pos] = rv[g] + bv[g];
+                } else {
+                    rot_t[pos] = rv[g];
+                    bas_t[pos] = bv[g];
                 }
                 has_nan = has_nan || (bv[g] != bv[g]);
             }
         }
-        if (lane == 0) {
-            // halo samples: s-1 lives in the carry-in segment; s+TW is either a knot itself (slot 2) or in the
-            // tile's last segment (= the carry behind the last group)
-            xt.at(-1) = (s >= 1) ? (hB1 + hS1 * (x_lo - hx1)) : 0.0;
-            const int64_t i = s + TW;
-            double v = 0.0;
-            if (i < n - 1) {
-                if (nf >= 1 && hi2 == (int32_t)i) v = s_hB[2] + s_hS[2] * (x_hi - hx2);
-                else v = cBg[G] + cSg[G] * (x_hi - cXg[G]);
-            }
-            xt.at(TW) = v;
-        }
-        if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
-        wave_sync();
-        ITD_STAMP(6);
-
-        // ---- knots of the baseline just produced = the next level's input --------------------------------
-        // (careful mode: k_detect_careful does this after the reference's NaN -> inf mutation)
-        if (!careful) {
-            if constexpr (!FINAL) publish_ends<TW>(xt, s, n, st->ends[(level + 1) & 1]);
-            const size_t slot = slot0 + t;
-            const int total = (ITD_ABLATE & 2) ? 0 : detect_tile<TW>(xt, s, n, kKnots, nullptr, recs_out + slot);
-            if (lane == 0) {
-                counts_out[slot] = total;
-                if (total) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
-            }
-        }
-        wave_sync();   // the next tile's commit must not overtake this tile's LDS reads
-        ITD_STAMP(7);
-        if constexpr (!PERSIST) break;   // grid = one wavefront per tile
     }
+    if (lane == 0) {
+        xt.at(-1) = b_lo;
+        xt.at(TW) = b_hi;
+    }
+    if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
+    wave_sync();
+    ITD_STAMP(6);
+
+    // ---- knots of the baseline just produced = the next level's input ------------------------------------------
+    // (careful mode: k_careful_apply does this after the reference's NaN -> inf mutation)
+    if (!careful) {
+        if constexpr (!FINAL)
+            if (s == 0 || s + TW >= n - 2) publish_ends<TW>(xt, s, n, st->ends[(level + 1) & 1]);
+        const size_t slot = slot0 + t;
+        const int total = (ITD_ABLATE & 2) ? 0 : detect_tile<TW>(xt, s, n, kKnots, nullptr, recs_out + slot, srec_all[wave_in_block()]);
+        if (lane == 0) {
+            if (!(ITD_ABLATE & 128)) counts_out[slot] = total;
+            if (total && !(ITD_ABLATE & 32)) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
+        }
+    }
+    ITD_STAMP(7);
     ITD_STAMP_FLUSH();
 }
 
@@ -754,7 +811,7 @@ __global__ void k_last_count(const int32_t *__restrict__ gsum_in, int n_tiles, S
     const int sig = blockIdx.x;
     SigState *st = state + sig;
     if (st->stopped) return;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     const int n_groups = groups_of(n_tiles);
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
     int acc = 0;
@@ -792,7 +849,7 @@ __global__ __launch_bounds__(kWave) void k_careful_count(const double *__restric
     __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
     if (st->stopped) return;
     const int t = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     const int64_t s = (int64_t)t * TW;
     Tile<TW> tile{s_x};
     TileRegs<double, TW> regs;
@@ -834,9 +891,10 @@ __global__ __launch_bounds__(kWave) void k_careful_apply(double *__restrict__ xi
     // steps (2) and (3).  Every NaN the tile sees (its own samples or a neighbour's halo sample, mutated yet or
     // not) is read as +inf, so the result does not depend on the order in which tiles run.
     __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[16];
     if (st->stopped) return;
     const int t = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = lane_id();
     const int64_t s = (int64_t)t * TW;
     Tile<TW> tile{s_x};
     TileRegs<double, TW> regs;
@@ -854,7 +912,7 @@ __global__ __launch_bounds__(kWave) void k_careful_apply(double *__restrict__ xi
     }
     wave_sync();
     publish_ends<TW>(tile, s, n, st->ends[level & 1]);
-    const int total = detect_tile<TW>(tile, s, n, kKnots, nullptr, recs + t);
+    const int total = detect_tile<TW>(tile, s, n, kKnots, nullptr, recs + t, s_rec);
     if (lane == 0) {
         counts[t] = total;
         if (total) atomicAdd(&gsum_out[(size_t)(t / kTilesPerGroup) * kGsumPitch], total);

@@ -13,7 +13,7 @@ rows = torch.empty((9, n), dtype=torch.float64, device="cuda")
 eng = pyitd_amd.Engine(n, 1, 0)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
-names = ["halo+commit", "next-tile loads issue", "scan+kk (+tile0)", "B phase", "S phase", "apply reads", "write-back+stores", "detect+outputs"]
+names = ["loads+halo search", "commit", "scan+kp", "B phase", "S phase", "apply reads", "write-back+stores", "detect+outputs"]
 for rep in range(2):
     L.itd_debug_stamps(None, 1)
     eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, 7, rows.data_ptr(), None, None)
@@ -23,4 +23,4 @@ v = np.array(list(out)[:8], dtype=np.float64)
 print("per-phase shader clocks per decomposition (9 levels), share of the stamped total")
 for nm, c in zip(names, v):
     print("  %-24s %12.3e  %5.1f %%" % (nm, c, 100 * c / v.sum()))
-print("  total %.3e clocks; per tile (9 x %d tiles): %.0f clocks" % (v.sum(), n // 512, v.sum() / (9 * (n // 512))))
+print("  total %.3e clocks; per tile (9 x %d tiles): %.0f clocks" % (v.sum(), n // 256, v.sum() / (9 * (n // 256))))
