@@ -25,7 +25,11 @@ using namespace itd;
 
 namespace {
 constexpr int T = ITD_TILE;
-static_assert(T % 256 == 0 && T / 64 <= 64, "tile geometry: whole float4/double2 loads per lane, <= 64 flag words");
+#ifndef ITD_PERSIST
+#define ITD_PERSIST 0
+#endif
+constexpr bool kPersist = ITD_PERSIST != 0;  // resident wavefronts loop over tiles with a software pipeline
+static_assert(T % 128 == 0 && T / 64 <= 64, "tile geometry: whole 8/16-byte loads per lane, <= 64 flag words");
 
 __global__ void k_init_state(SigState *st, int batch)
 {
@@ -66,6 +70,7 @@ struct itd_engine {
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
     int64_t ws_bytes = 0;
+    int64_t resident_wg = 0;       // workgroups of k_extract that fit on the GPU at once (persistent mode)
     // host-convenience staging (grow only)
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
@@ -138,7 +143,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int64_t rows_stride = R * n;
     const dim3 blk(kBlock);
     const dim3 grid_t((n_tiles + kWPB - 1) / kWPB, batch);                      // k_detect: kWPB tiles per workgroup
-    const dim3 grid_p((unsigned)(((int64_t)n_tiles * batch + kWPB - 1) / kWPB)); // k_extract: flattened (signal, tile)
+    const int64_t all_wg = ((int64_t)n_tiles * batch + kWPB - 1) / kWPB;          // k_extract: flattened (signal, tile)
+    const dim3 grid_p((unsigned)(kPersist ? std::min<int64_t>(all_wg, e->resident_wg) : all_wg));
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
@@ -172,7 +178,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
-    k_extract<TIN, T, FIN><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
+    k_extract<TIN, T, FIN, kPersist><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
                                                     rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
                                                     base_out, base_stride, e->d_state, j, 0)
         if (j == 0) {
@@ -255,11 +261,11 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
         if (j == 0)
-            k_extract<Tin, T, false><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+            k_extract<Tin, T, false, false><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
                                                                         n, base_out, n, state, j, 1);
         else
-            k_extract<double, T, false><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+            k_extract<double, T, false, false><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
                                                                            rec(j), rec(j + 1), gs(j), gs(j + 1),
                                                                            gs(j + 2), rot_out, n, base_out, n, state, j, 1);
         k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
@@ -337,6 +343,16 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->max_batch = max_batch;
     e->max_tiles = tiles_of(max_n);
     DevGuard g(device_id);
+    {
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete e; return ITD_ERR_HIP; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extract<double, T, false, true>, kBlock, 0) != hipSuccess || per_cu < 1)
+            per_cu = 8;
+        const char *env = getenv("PYITD_WG_PER_CU");
+        if (env && atoi(env) > 0) per_cu = atoi(env);
+        e->resident_wg = (int64_t)prop.multiProcessorCount * per_cu;
+    }
     const size_t B = (size_t)max_batch;
     const int max_groups = groups_of((int)e->max_tiles);
     e->tiles_half = (int64_t)B * e->max_tiles;
@@ -540,7 +556,7 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
     const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
-    k_extract<Tin, T, false><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+    k_extract<Tin, T, false, false><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);

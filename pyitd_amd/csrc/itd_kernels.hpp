@@ -129,10 +129,11 @@ struct Tile {
 // Tile fetch split in two (issue early / commit late) so the HBM latency overlaps the halo search.
 template <typename Tin, int TW>
 struct TileRegs {
-    using V = typename std::conditional<sizeof(Tin) == 8, __attribute__((ext_vector_type(2))) double,
-                                        __attribute__((ext_vector_type(4))) float>::type;
-    static constexpr int kPer = sizeof(Tin) == 8 ? 2 : 4;
+    // per-lane vector of kPer consecutive samples: 16 bytes (double2 / float4) when the tile allows, else 8 bytes
+    static constexpr int kPer = sizeof(Tin) == 8 ? 2 : (TW >= 256 ? 4 : 2);
+    using V = Tin __attribute__((ext_vector_type(kPer)));
     static constexpr int kN = TW / (kPer * kWave);
+    static constexpr uintptr_t kAlignMask = sizeof(Tin) * kPer - 1;
     V q[kN];
     double lo, hi;
     bool vec;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void tile_fetch(TileRegs<Tin, TW> &r, const Tin *__re
     using R = TileRegs<Tin, TW>;
     const int lane = lane_id();
     const Tin *src = x + s;
-    r.vec = (s + TW <= n) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    r.vec = (s + TW <= n) && ((reinterpret_cast<uintptr_t>(src) & R::kAlignMask) == 0);
     if (r.vec) {
         const typename R::V *v = reinterpret_cast<const typename R::V *>(src);
 #pragma unroll
@@ -169,11 +170,14 @@ __device__ __forceinline__ void tile_commit(const TileRegs<Tin, TW> &r, const Ti
             const int e = (lane + k * kWave) * R::kPer;
             if constexpr (sizeof(Tin) == 8) {
                 *reinterpret_cast<D2 *>(&tile.p[2 + e]) = r.q[k];
-            } else {
+            } else if constexpr (R::kPer == 4) {
                 D2 a = {(double)r.q[k].x, (double)r.q[k].y};
                 D2 b = {(double)r.q[k].z, (double)r.q[k].w};
                 *reinterpret_cast<D2 *>(&tile.p[2 + e]) = a;
                 *reinterpret_cast<D2 *>(&tile.p[4 + e]) = b;
+            } else {
+                D2 a = {(double)r.q[k].x, (double)r.q[k].y};
+                *reinterpret_cast<D2 *>(&tile.p[2 + e]) = a;
             }
         }
     } else {
@@ -450,7 +454,29 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m, int init)
 // that starts there (ITD.py:115-116).  A sample's segment is rank 1 + (knots at or before it) — one v_mbcnt pair
 // on the group's flag word — so the baseline map is three indexed LDS reads and three flops per sample.
 // ---------------------------------------------------------------------------------------------
-template <typename Tin, int TW, bool FINAL>
+// Raw record fields of the candidate neighbour tiles of one tile, fetched with per-lane (vector) loads of a
+// wave-uniform address: they are tracked by vmcnt, in order, so LDS traffic in between does not wait for them.
+struct RecRegs {
+    int ub0, ub1, cb0, uf0, uf1, uf2, cf0, cf1;   // candidate tiles (-1: none in the window) and their knot counts
+    int32_t b0i1, b0i0, b1i1, f0i0, f0i1, f0i2, f1i0, f1i1, f2i0;
+    double b0v1, b0v0, b1v1, f0v0, f0v1, f0v2, f1v0, f1v1, f2v0;
+};
+
+__device__ __forceinline__ int as_vgpr(int v)   // hide uniformity from the compiler: forces a vector (vmcnt) load
+{
+    int r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+    return r;
+}
+__device__ __forceinline__ int32_t sgpr(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double sgpr(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <typename Tin, int TW, bool FINAL, bool PERSIST>
 __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                     int n_tiles, int batch,
                                                     const int32_t *__restrict__ counts_in,
@@ -477,8 +503,71 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     int32_t *s_gi = reinterpret_cast<int32_t *>(sS_all[wave_in_block()]);
 
     const int lane = lane_id();
-    const int64_t kflat = (int64_t)blockIdx.x * kWPB + wave_in_block();
-    if (kflat >= (int64_t)n_tiles * batch) return;
+    const int64_t total_tiles = (int64_t)n_tiles * batch;
+    const int64_t NW = PERSIST ? (int64_t)gridDim.x * kWPB : 1;   // resident wavefronts (persistent mode)
+    int64_t kflat = (int64_t)blockIdx.x * kWPB + wave_in_block();
+    if (kflat >= total_tiles) return;
+    const int n_groups = groups_of(n_tiles);
+    Tile<TW> xt{s_x};
+    ITD_STAMP_DECL();
+
+    // ---- software pipeline (PERSIST): stage A = the neighbours' knot counts of the tile two steps ahead; stage B =
+    //      the next tile itself (registers) and its candidate neighbours' records; stage C = this tile.  Without
+    //      PERSIST (one wavefront per tile) the same code runs once, with the tile's loads issued first. -------------
+    auto stage_a = [&](int64_t k, int &cb, int &cf) {
+        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        const int32_t *cnts = counts_in + (size_t)sig * n_tiles;
+        const int tb = t - 1 - lane, tf = t + 1 + lane;
+        cb = (tb >= 0) ? cnts[tb] : 0;
+        cf = (tf < n_tiles) ? cnts[tf] : 0;
+    };
+    auto fetch_tile = [&](int64_t k, TileRegs<Tin, TW> &regs) {
+        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        tile_fetch<Tin, TW>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
+    };
+    auto fetch_recs = [&](int64_t k, int cb, int cf, RecRegs &h) {
+        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        const TileRec *recs = recs_in + (size_t)sig * n_tiles;
+        unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
+        h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
+        h.cb0 = h.cf0 = h.cf1 = 0;
+        if (mb) {
+            const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+            h.ub0 = t - 1 - l; h.cb0 = __builtin_amdgcn_readlane(cb, l);
+            if (h.cb0 < 2 && mb) h.ub1 = t - 1 - (__ffsll((long long)mb) - 1);
+        }
+        if (mf) {
+            const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
+            h.uf0 = t + 1 + l; h.cf0 = __builtin_amdgcn_readlane(cf, l);
+            if (h.cf0 < 3 && mf) {
+                const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
+                h.uf1 = t + 1 + l1; h.cf1 = __builtin_amdgcn_readlane(cf, l1);
+                if (h.cf0 + h.cf1 < 3 && mf) h.uf2 = t + 1 + (__ffsll((long long)mf) - 1);
+            }
+        }
+        const TileRec *rb0 = recs + as_vgpr(max(h.ub0, 0)), *rb1 = recs + as_vgpr(max(h.ub1, 0));
+        const TileRec *rf0 = recs + as_vgpr(max(h.uf0, 0)), *rf1 = recs + as_vgpr(max(h.uf1, 0));
+        const TileRec *rf2 = recs + as_vgpr(max(h.uf2, 0));
+        h.b0i1 = rb0->tidx[1]; h.b0i0 = rb0->tidx[0]; h.b0v1 = rb0->tval[1]; h.b0v0 = rb0->tval[0];
+        h.b1i1 = rb1->tidx[1]; h.b1v1 = rb1->tval[1];
+        h.f0i0 = rf0->hidx[0]; h.f0i1 = rf0->hidx[1]; h.f0i2 = rf0->hidx[2];
+        h.f0v0 = rf0->hval[0]; h.f0v1 = rf0->hval[1]; h.f0v2 = rf0->hval[2];
+        h.f1i0 = rf1->hidx[0]; h.f1i1 = rf1->hidx[1]; h.f1v0 = rf1->hval[0]; h.f1v1 = rf1->hval[1];
+        h.f2i0 = rf2->hidx[0]; h.f2v0 = rf2->hval[0];
+    };
+
+    TileRegs<Tin, TW> regs;
+    RecRegs rr;
+    int cbA = 0, cfA = 0;
+    fetch_tile(kflat, regs);
+    stage_a(kflat, cbA, cfA);
+    fetch_recs(kflat, cbA, cfA, rr);
+    if constexpr (PERSIST)
+        if (kflat + NW < total_tiles) stage_a(kflat + NW, cbA, cfA);
+
+    int sig_cur = -1, stopped = 0;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+  for (;;) {   // one iteration per tile (exactly one without PERSIST)
     const int sig = (int)(kflat / n_tiles), t = (int)(kflat - (int64_t)sig * n_tiles);
     SigState *st = state + sig;
     const int64_t s = (int64_t)t * TW;
@@ -486,30 +575,16 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     const size_t slot0 = (size_t)sig * n_tiles;
     const int32_t *cnts = counts_in + slot0;
     const TileRec *recs = recs_in + slot0;
-    const int n_groups = groups_of(n_tiles);
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
-    Tile<TW> xt{s_x};
-    ITD_STAMP_DECL();
     ITD_STAMP_BEGIN();
+    if (sig != sig_cur) {   // the signal's state: once per signal and wavefront
+        sig_cur = sig;
+        stopped = st->stopped;
+        e0 = st->ends[level & 1][0]; e1 = st->ends[level & 1][1];
+        e2 = st->ends[level & 1][2]; e3 = st->ends[level & 1][3];
+    }
 
-    // ---- issue every independent load at once: the tile, the neighbours' knot counts, the two adjacent tiles'
-    //      records (they hold all five surrounding knots whenever the knots are dense), the signal's state ------------
-    TileRegs<Tin, TW> regs;
-    tile_fetch<Tin, TW>(regs, x, n, s);
-    const int tb = t - 1 - lane, tf = t + 1 + lane;
-    const int cb = (tb >= 0) ? cnts[tb] : 0;
-    const int cf = (tf < n_tiles) ? cnts[tf] : 0;
-    const TileRec *rp = recs + (t > 0 ? t - 1 : 0), *rn = recs + (t + 1 < n_tiles ? t + 1 : t);
-    const int32_t pi1 = rp->tidx[1], pi0 = rp->tidx[0];
-    const double pv1 = rp->tval[1], pv0 = rp->tval[0];
-    const int32_t ni0 = rn->hidx[0], ni1 = rn->hidx[1], ni2 = rn->hidx[2];
-    const double nv0 = rn->hval[0], nv1 = rn->hval[1], nv2 = rn->hval[2];
-    const int stopped = st->stopped;
-    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
-    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
-    if (stopped) return;
-
-    if (t == 0) {
+    if (t == 0 && !stopped) {
         // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
         int acc = 0;
         for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
@@ -531,45 +606,18 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
         for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
     }
 
-    // ---- halo search (scalar): two knots in front of the tile, three behind, from the neighbours' records ---------
+    // ---- halo knots (scalar): two in front of the tile, three behind, from the candidate records -------------------
     // slots: [0],[1] in front (slot 1 starts the segment that enters the tile), [2],[3],[4] behind; missing ones are
-    // the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).  The candidate tiles come from the two 64-tile count
-    // windows and ALL their records are requested together (one round trip); only when a window runs dry does the
-    // search walk on through the group sums (far_nonempty: dependent loads, rare).
+    // the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).  Only when a 64-tile window ran dry does the search walk
+    // on through the group sums (far_nonempty: dependent loads, rare).
     int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
     double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
     int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
-    if (!(ITD_ABLATE & 8)) {
-        unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
-        int ub0 = -1, ub1 = -1, cb0 = 0, uf0 = -1, uf1 = -1, uf2 = -1, cf0 = 0, cf1 = 0;
-        if (mb) {
-            const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-            ub0 = t - 1 - l; cb0 = __builtin_amdgcn_readlane(cb, l);
-            if (cb0 < 2 && mb) ub1 = t - 1 - (__ffsll((long long)mb) - 1);
-        }
-        if (mf) {
-            const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
-            uf0 = t + 1 + l; cf0 = __builtin_amdgcn_readlane(cf, l);
-            if (cf0 < 3 && mf) {
-                const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
-                uf1 = t + 1 + l1; cf1 = __builtin_amdgcn_readlane(cf, l1);
-                if (cf0 + cf1 < 3 && mf) uf2 = t + 1 + (__ffsll((long long)mf) - 1);
-            }
-        }
-        // every record that can be needed, requested at once (the adjacent tiles' are already on their way)
-        int32_t b0i1 = pi1, b0i0 = pi0; double b0v1 = pv1, b0v0 = pv0;
-        if (ub0 >= 0 && ub0 != t - 1) { const TileRec *r = recs + ub0; b0i1 = r->tidx[1]; b0i0 = r->tidx[0]; b0v1 = r->tval[1]; b0v0 = r->tval[0]; }
-        int32_t b1i1 = 0; double b1v1 = 0.0;
-        if (ub1 >= 0) { const TileRec *r = recs + ub1; b1i1 = r->tidx[1]; b1v1 = r->tval[1]; }
-        int32_t f0i0 = ni0, f0i1 = ni1, f0i2 = ni2; double f0v0 = nv0, f0v1 = nv1, f0v2 = nv2;
-        if (uf0 >= 0 && uf0 != t + 1) { const TileRec *r = recs + uf0; f0i0 = r->hidx[0]; f0i1 = r->hidx[1]; f0i2 = r->hidx[2]; f0v0 = r->hval[0]; f0v1 = r->hval[1]; f0v2 = r->hval[2]; }
-        int32_t f1i0 = 0, f1i1 = 0, f2i0 = 0; double f1v0 = 0.0, f1v1 = 0.0, f2v0 = 0.0;
-        if (uf1 >= 0) { const TileRec *r = recs + uf1; f1i0 = r->hidx[0]; f1i1 = r->hidx[1]; f1v0 = r->hval[0]; f1v1 = r->hval[1]; }
-        if (uf2 >= 0) { const TileRec *r = recs + uf2; f2i0 = r->hidx[0]; f2v0 = r->hval[0]; }
-        if (ub0 >= 0) {
-            hi1 = b0i1; hx1 = b0v1; nb = 1;
-            if (cb0 >= 2) { hi0 = b0i0; hx0 = b0v0; nb = 2; }
-            else if (ub1 >= 0) { hi0 = b1i1; hx0 = b1v1; nb = 2; }
+    if (!(ITD_ABLATE & 8) && !stopped) {
+        if (rr.ub0 >= 0) {
+            hi1 = sgpr(rr.b0i1); hx1 = sgpr(rr.b0v1); nb = 1;
+            if (rr.cb0 >= 2) { hi0 = sgpr(rr.b0i0); hx0 = sgpr(rr.b0v0); nb = 2; }
+            else if (rr.ub1 >= 0) { hi0 = sgpr(rr.b1i1); hx0 = sgpr(rr.b1v1); nb = 2; }
         }
         if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further
             int far = t - 65;
@@ -586,18 +634,18 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
                 if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
             }
         }
-        if (uf0 >= 0) {
-            hi2 = f0i0; hx2 = f0v0; nf = 1;
-            if (cf0 >= 2) { hi3 = f0i1; hx3 = f0v1; nf = 2; }
-            if (cf0 >= 3) { hi4 = f0i2; hx4 = f0v2; nf = 3; }
-            if (nf < 3 && uf1 >= 0) {
+        if (rr.uf0 >= 0) {
+            hi2 = sgpr(rr.f0i0); hx2 = sgpr(rr.f0v0); nf = 1;
+            if (rr.cf0 >= 2) { hi3 = sgpr(rr.f0i1); hx3 = sgpr(rr.f0v1); nf = 2; }
+            if (rr.cf0 >= 3) { hi4 = sgpr(rr.f0i2); hx4 = sgpr(rr.f0v2); nf = 3; }
+            if (nf < 3 && rr.uf1 >= 0) {
                 if (nf == 1) {
-                    hi3 = f1i0; hx3 = f1v0; nf = 2;
-                    if (cf1 >= 2) { hi4 = f1i1; hx4 = f1v1; nf = 3; }
+                    hi3 = sgpr(rr.f1i0); hx3 = sgpr(rr.f1v0); nf = 2;
+                    if (rr.cf1 >= 2) { hi4 = sgpr(rr.f1i1); hx4 = sgpr(rr.f1v1); nf = 3; }
                 } else {
-                    hi4 = f1i0; hx4 = f1v0; nf = 3;
+                    hi4 = sgpr(rr.f1i0); hx4 = sgpr(rr.f1v0); nf = 3;
                 }
-                if (nf < 3 && uf2 >= 0) { hi4 = f2i0; hx4 = f2v0; nf = 3; }
+                if (nf < 3 && rr.uf2 >= 0) { hi4 = sgpr(rr.f2i0); hx4 = sgpr(rr.f2v0); nf = 3; }
             }
         }
         if (nf < 3 && t + 65 < n_tiles) {
@@ -628,10 +676,19 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     }
     ITD_STAMP(0);
 
-    // ---- stage the tile ---------------------------------------------------------------------------------------------
-    tile_commit<Tin, TW>(regs, x, n, s, xt);
+    // ---- stage the tile; keep the pipeline full ------------------------------------------------------------------------
+    if (!stopped) tile_commit<Tin, TW>(regs, x, n, s, xt);
+    if constexpr (PERSIST) {
+        const int64_t kn = kflat + NW;
+        if (kn < total_tiles) {
+            fetch_tile(kn, regs);
+            fetch_recs(kn, cbA, cfA, rr);
+            if (kn + NW < total_tiles) stage_a(kn + NW, cbA, cfA);
+        }
+    }
     wave_sync();
     ITD_STAMP(1);
+  if (!stopped) {
 
     // ---- this level's knots inside the tile: the predicate the producer ran on the same values; ranked into LDS ----
     const bool edge_tile = (s == 0) || (s + TW >= n - 1);   // holds sample 0 or n-1, which are never knots
@@ -798,6 +855,12 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
         }
     }
     ITD_STAMP(7);
+  }   // !stopped
+    if constexpr (!PERSIST) break;
+    kflat += NW;
+    if (kflat >= total_tiles) break;
+    wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
+  }
     ITD_STAMP_FLUSH();
 }
 
