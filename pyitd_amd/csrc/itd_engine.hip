@@ -18,7 +18,7 @@
 #include "itd_kernels.hpp"
 
 #ifndef ITD_TILE
-#define ITD_TILE 256
+#define ITD_TILE 512
 #endif
 
 using namespace itd;

@@ -68,6 +68,11 @@ constexpr int kWave = 64;              // one wavefront per tile
 #endif
 constexpr int kWPB = ITD_WPB;          // independent wavefronts per workgroup (they share nothing but the launch slot)
 constexpr int kBlock = kWave * kWPB;
+#ifndef ITD_RANK_CAP
+#define ITD_RANK_CAP 136
+#endif
+constexpr int kRankCap = ITD_RANK_CAP;   // knots one pass of k_extract can hold by rank (>= 64: a 64-sample group always fits)
+static_assert(kRankCap >= 64, "a pass must be able to take one 64-sample group");
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // wave-uniform by construction: tell the compiler so (keeps tile indices, pointers and the halo search on the scalar unit)
 __device__ __forceinline__ int wave_in_block() { return kWPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
                                                     SigState *__restrict__ state, int level, int careful)
 {
     constexpr int G = TW / 64;    // 64-sample groups = 64-bit flag words per tile
-    constexpr int RK = TW + 8;    // rank capacity (c + 5 <= TW + 5)
+    constexpr int RK = kRankCap + 8;   // by-rank slots: kRankCap knots of a pass + 2 in front + 3 behind (+ padding)
     // one private LDS slice per wavefront of the workgroup
     __shared__ __attribute__((aligned(16))) double sx_all[kWPB][Tile<TW>::kSize];  // the tile: input, then baseline in place
     __shared__ double sX_all[kWPB][RK];      // value of the level's input at knot j
@@ -690,150 +695,182 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     ITD_STAMP(1);
   if (!stopped) {
 
-    // ---- this level's knots inside the tile: the predicate the producer ran on the same values; ranked into LDS ----
+    // ---- this level's knots inside the tile: the predicate the producer ran on the same values -------------------
     const bool edge_tile = (s == 0) || (s + TW >= n - 1);   // holds sample 0 or n-1, which are never knots
     unsigned long long mks[G];
     int c = 0;
-    {
-        int base = 2;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int pos = g * 64 + lane;
-            const double xm = xt.at(pos - 1), x0 = xt.at(pos), xp = xt.at(pos + 1);
-            const double vil = xp - x0;
-            const double vix = x0 - xm;
-            bool f = ((vil > 0.0) && (vix <= 0.0)) || ((vil < 0.0) && (vix >= 0.0));   // ITD.py:59 on x and on -x
-            if (ITD_ABLATE & 16) f = false;
-            unsigned long long mk = __ballot(f);
-            if (edge_tile) {   // first and last sample are never knots (ITD.py:70-73)
-                const int64_t g0 = s + g * 64;
-                const int64_t hi64 = (n - 2) - g0;
-                mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
-                f = (mk >> lane) & 1ull;
-            }
-            mks[g] = mk;
-            if (f) {
-                const int j = mbcnt64(mk, base);
-                s_X[j] = x0;
-                s_gi[j] = (int32_t)s + pos;
-            }
-            base += __popcll(mk);
+    for (int g = 0; g < G; ++g) {
+        const int pos = g * 64 + lane;
+        const double xm = xt.at(pos - 1), x0 = xt.at(pos), xp = xt.at(pos + 1);
+        const double vil = xp - x0;
+        const double vix = x0 - xm;
+        bool f = ((vil > 0.0) && (vix <= 0.0)) || ((vil < 0.0) && (vix >= 0.0));   // ITD.py:59 on x and on -x
+        if (ITD_ABLATE & 16) f = false;
+        unsigned long long mk = __ballot(f);
+        if (edge_tile) {   // first and last sample are never knots (ITD.py:70-73)
+            const int64_t g0 = s + g * 64;
+            const int64_t hi64 = (n - 2) - g0;
+            mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
         }
-        c = base - 2;
+        mks[g] = mk;
+        c += __popcll(mk);
     }
-    if (lane < 5) {   // the five knots around the tile
-        const int j = lane < 2 ? lane : c + lane;
-        s_X[j] = lane == 0 ? hx0 : lane == 1 ? hx1 : lane == 2 ? hx2 : lane == 3 ? hx3 : hx4;
-        s_gi[j] = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
-    }
-    wave_sync();
     ITD_STAMP(2);
 
-    // ---- knot values, ITD.py:100-110 -----------------------------------------------------------------------------
-    const double m0 = (e0 + e1) / 2.0;   // numpy.mean(x[:2]),  ITD.py:101
-    const double mn = (e2 + e3) / 2.0;   // numpy.mean(x[-2:]), ITD.py:102
-    for (int j = 1 + lane; j <= c + 3 && !(ITD_ABLATE & 4); j += kWave) {
-        const int32_t k0 = s_gi[j - 1], k1 = s_gi[j], k2 = s_gi[j + 1];
-        const double x0 = s_X[j - 1], x1 = s_X[j], x2 = s_X[j + 1];
-        const double frac = (double)(k1 - k0) / (double)(k2 - k0);
-        const double tt = frac * (x2 - x0);
-        const double u = x0 + tt;
-        double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
-        const bool end0 = (j == 1) && (nb == 0);                          // e[0]   = sample 0
-        const bool endn = (j >= c + 2) && (j - (c + 2) >= nf);            // e[m+1] = sample n-1
-        Bv = end0 ? m0 : (endn ? mn : Bv);
-        s_B[j] = Bv;
-    }
-    wave_sync();
-    ITD_STAMP(3);
-    // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 ------------------------------------
-    for (int j = 1 + lane; j <= c + 2 && !(ITD_ABLATE & 4); j += kWave) {
-        const double sl = (s_B[j + 1] - s_B[j]) / (s_X[j + 1] - s_X[j]);
-        const bool endn = (j >= c + 2) && (j - (c + 2) >= nf);            // sample n-1 starts no segment
-        if (!endn) s_S[j] = sl;
-    }
-    wave_sync();
-    ITD_STAMP(4);
-
-    // ---- baseline map + rotation, ITD.py:114-119 ------------------------------------------------------------------
-    // The baseline overwrites the tile in place, after every read.
+    // ---- passes: a run of consecutive 64-sample groups whose knots fit the by-rank arrays (one pass unless the tile
+    //      is dense).  A pass is a tile within the tile: local ranks L = 0,1 are the two knots in front of the run,
+    //      L = 2..m+1 its own m knots, L = m+2..m+4 the three knots behind it. -----------------------------------------
     double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
     double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
     const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
-    double bv[G], rv[G];
-    if (c == 0) {
-        // no knot inside the tile (most tiles of the deep levels): one segment, one affine map
-        const double Bk = s_B[1], Sk = s_S[1], Xk = s_X[1];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int pos = g * 64 + lane;
-            const double xi = xt.at(pos);
-            double bi = Bk + Sk * (xi - Xk);
-            if (tail_tile && s + pos >= n - 1) bi = 0.0;
-            bv[g] = bi;
-            rv[g] = xi - bi;
-        }
-    } else {
-        int jb = 1;   // rank of the knot in front of the group
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int pos = g * 64 + lane;
-            const unsigned long long mk = mks[g];
-            const int j = mbcnt64(mk >> 1, jb + (int)(mk & 1ull));   // 1 + knots at or before this sample
-            const double xi = xt.at(pos);
-            const double Bk = s_B[j], Sk = s_S[j], Xk = s_X[j];
-            double bi = Bk + Sk * (xi - Xk);
-            if (tail_tile && s + pos >= n - 1) bi = 0.0;   // baseline[n-1] is never written, ITD.py:112-117
-            bv[g] = bi;
-            rv[g] = xi - bi;
-            jb += __popcll(mk);
-        }
-    }
-    // halo samples: s-1 lives in the segment entering the tile; s+TW is either a knot itself (rank c+2) or in the
-    // tile's last segment (rank 1+c)
+    const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
+    const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
+    int32_t fi0 = hi0, fi1 = hi1;           // the two knots in front of the current pass
+    double fx0 = hx0, fx1 = hx1;
+    int nbp = nb;                           // how many of them are real knots (the rest is the end knot e[0])
+    int own_left = c;                       // the tile's knots not yet consumed by a pass
     double b_lo = 0.0, b_hi = 0.0;
-    if (lane == 0) {
-        if (s >= 1) b_lo = s_B[1] + s_S[1] * (xt.at(-1) - s_X[1]);
-        const int64_t i = s + TW;
-        if (i < n - 1) {
-            const int j = (nf >= 1 && hi2 == (int32_t)i) ? c + 2 : 1 + c;
-            b_hi = s_B[j] + s_S[j] * (xt.at(TW) - s_X[j]);
-        }
-    }
-    wave_sync();
-    ITD_STAMP(5);
     bool has_nan = false;
-    if (!tail_tile) {
+    int g0 = 0;
+    while (g0 < G) {
+        // the run [g0, g1) and its knot count m
+        int g1 = g0, m = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int pos = g * 64 + lane;
-            xt.at(pos) = bv[g];
-            if (!(ITD_ABLATE & 1) || bv[g] == 1.2345e-300) {
-                if constexpr (FINAL) {
-                    rot_t[pos] = rv[g] + bv[g];       // ITD.py:420
-                } else {
-                    rot_t[pos] = rv[g];
-                    bas_t[pos] = bv[g];
-                }
-            }
-            has_nan = has_nan || (bv[g] != bv[g]);
+            const int cg = __popcll(mks[g]);
+            if (g == g1 && g >= g0 && m + cg <= kRankCap) { m += cg; g1 = g + 1; }
         }
-    } else {
+        own_left -= m;
+        // the three knots behind the run: the tile's own knots of later groups first, then the tile's halo
+        int32_t qi0 = hi2, qi1 = hi3, qi2 = hi4;
+        double qx0 = hx2, qx1 = hx3, qx2 = hx4;
+        int nfp = nf;
+        if (own_left > 0) {
+            int k = 0;
+            int32_t oi0 = 0, oi1 = 0, oi2 = 0;
+            double ox0 = 0.0, ox1 = 0.0, ox2 = 0.0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int pos = g * 64 + lane;
-            xt.at(pos) = bv[g];
-            if (s + pos < n) {
-                if constexpr (FINAL) {
-                    rot_t[pos] = rv[g] + bv[g];
-                } else {
-                    rot_t[pos] = rv[g];
-                    bas_t[pos] = bv[g];
+            for (int g = 0; g < G; ++g) {
+                unsigned long long mm = (g >= g1) ? mks[g] : 0ull;
+                while (mm && k < 3) {
+                    const int pos = g * 64 + __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const double v = sgpr(xt.at(pos));
+                    if (k == 0) { oi0 = (int32_t)s + pos; ox0 = v; }
+                    else if (k == 1) { oi1 = (int32_t)s + pos; ox1 = v; }
+                    else { oi2 = (int32_t)s + pos; ox2 = v; }
+                    ++k;
                 }
-                has_nan = has_nan || (bv[g] != bv[g]);
+            }
+            // k own knots, then the tile's halo knots in order
+            if (k == 1)      { qi2 = hi3; qx2 = hx3; qi1 = hi2; qx1 = hx2; qi0 = oi0; qx0 = ox0; }
+            else if (k == 2) { qi2 = hi2; qx2 = hx2; qi1 = oi1; qx1 = ox1; qi0 = oi0; qx0 = ox0; }
+            else             { qi2 = oi2; qx2 = ox2; qi1 = oi1; qx1 = ox1; qi0 = oi0; qx0 = ox0; }
+            nfp = min(3, k + nf);
+        }
+        // fill the by-rank arrays of the pass
+        if (lane < 5) {
+            const int L = lane < 2 ? lane : m + lane;
+            s_X[L] = lane == 0 ? fx0 : lane == 1 ? fx1 : lane == 2 ? qx0 : lane == 3 ? qx1 : qx2;
+            s_gi[L] = lane == 0 ? fi0 : lane == 1 ? fi1 : lane == 2 ? qi0 : lane == 3 ? qi1 : qi2;
+        }
+        {
+            int base = 2;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g >= g0 && g < g1) {
+                    const unsigned long long mk = mks[g];
+                    const int pos = g * 64 + lane;
+                    if ((mk >> lane) & 1ull) {
+                        const int L = mbcnt64(mk, base);
+                        s_X[L] = xt.at(pos);
+                        s_gi[L] = (int32_t)s + pos;
+                    }
+                    base += __popcll(mk);
+                }
             }
         }
+        wave_sync();
+        // the two knots in front of the NEXT pass = this pass's ranks m, m+1 (taken now: the slopes reuse gi's bytes)
+        int32_t ni0 = 0, ni1 = 0;
+        double nx0 = 0.0, nx1 = 0.0;
+        if (g1 < G) {
+            ni0 = sgpr(s_gi[m]); ni1 = sgpr(s_gi[m + 1]);
+            nx0 = sgpr(s_X[m]);  nx1 = sgpr(s_X[m + 1]);
+        }
+        // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
+        for (int L = 1 + lane; L <= m + 3 && !(ITD_ABLATE & 4); L += kWave) {
+            const int32_t k0 = s_gi[L - 1], k1 = s_gi[L], k2 = s_gi[L + 1];
+            const double x0 = s_X[L - 1], x1 = s_X[L], x2 = s_X[L + 1];
+            const double frac = (double)(k1 - k0) / (double)(k2 - k0);
+            const double tt = frac * (x2 - x0);
+            const double u = x0 + tt;
+            double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
+            const bool end0 = (L == 1) && (nbp == 0);                         // e[0]   = sample 0
+            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // e[m+1] = sample n-1
+            Bv = end0 ? m0 : (endn ? mn : Bv);
+            s_B[L] = Bv;
+        }
+        wave_sync();
+        // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 --------------------------------
+        for (int L = 1 + lane; L <= m + 2 && !(ITD_ABLATE & 4); L += kWave) {
+            const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
+            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // sample n-1 starts no segment
+            if (!endn) s_S[L] = sl;
+        }
+        wave_sync();
+
+        // ---- baseline map + rotation, ITD.py:114-119 -----------------------------------------------------------------
+        // halo samples first (they read the by-rank arrays and the untouched halo slots): s-1 lives in the segment
+        // entering the tile; s+TW is either a knot itself (rank m+2 of the last pass) or in the tile's last segment
+        if (lane == 0) {
+            if (g0 == 0 && s >= 1) b_lo = s_B[1] + s_S[1] * (xt.at(-1) - s_X[1]);
+            const int64_t i = s + TW;
+            if (g1 == G && i < n - 1) {
+                const int L = (nf >= 1 && hi2 == (int32_t)i) ? m + 2 : 1 + m;
+                b_hi = s_B[L] + s_S[L] * (xt.at(TW) - s_X[L]);
+            }
+        }
+        // A sample needs its own x and its segment's (B, slope, x) by rank, nothing else of the tile: each group
+        // reads, maps, overwrites itself in place and streams both rows out.
+        {
+            const bool one_seg = (m == 0);   // no knot inside the run (most tiles of the deep levels): one affine map
+            int jb = 1;                      // local rank of the knot in front of the group
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g >= g0 && g < g1) {
+                    const int pos = g * 64 + lane;
+                    const unsigned long long mk = mks[g];
+                    const int L = one_seg ? 1 : mbcnt64(mk >> 1, jb + (int)(mk & 1ull));   // 1 + knots of the run at or before the sample
+                    const double xi = xt.at(pos);
+                    const double Bk = s_B[L], Sk = s_S[L], Xk = s_X[L];
+                    double bi = Bk + Sk * (xi - Xk);
+                    if (tail_tile && s + pos >= n - 1) bi = 0.0;   // baseline[n-1] is never written, ITD.py:112-117
+                    const double ri = xi - bi;
+                    xt.at(pos) = bi;
+                    if (!tail_tile || s + pos < n) {
+                        if (!(ITD_ABLATE & 1) || bi == 1.2345e-300) {
+                            if constexpr (FINAL) {
+                                rot_t[pos] = ri + bi;          // ITD.py:420
+                            } else {
+                                rot_t[pos] = ri;
+                                bas_t[pos] = bi;
+                            }
+                        }
+                        has_nan = has_nan || (bi != bi);
+                    }
+                    jb += __popcll(mk);
+                }
+            }
+        }
+        // next pass
+        nbp = min(2, nbp + m);
+        fi0 = ni0; fi1 = ni1; fx0 = nx0; fx1 = nx1;
+        g0 = g1;
+        wave_sync();
     }
+    ITD_STAMP(5);
     if (lane == 0) {
         xt.at(-1) = b_lo;
         xt.at(TW) = b_hi;
