@@ -96,3 +96,36 @@ def test_config2_full_size_properties(P, torch, oracle):
     recon = rows[0, :nr].sum(axis=0)
     assert np.max(np.abs(recon - x.astype(np.float64))) < 1e-12
     assert rows[0, 0, -1] == float(x[-1]) and np.all(rows[0, 1:nr, -1] == 0.0)
+
+
+def test_batch_with_nan_path_signals(P, torch, oracle):
+    """A batch where some signals take the NaN-faithful re-run and others the fast path."""
+    n, B, m = 5000, 6, 5
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((B, n))
+    x[1, :4] = 1.0          # leading plateau -> NaN path
+    x[4, :130] = -2.0       # a long one, crossing a 64-sample group
+    for keep in (False, True):
+        rows, bases, s = _run(P, torch, x, m, keep)
+        for b in range(B):
+            ref = oracle.itd(x[b], m)
+            nr = int(s["n_rows"][b])
+            assert nr == ref["rows"].shape[0]
+            assert int(s["nan_levels"][b]) == -1
+            assert_bits_equal(rows[b, :nr], ref["rows"], "signal %d rows (keep=%s)" % (b, keep))
+            if keep:
+                nb = int(s["n_baselines"][b])
+                assert_bits_equal(bases[b, :nb], ref["baselines"], "signal %d baselines" % b)
+
+
+def test_config3_shape_small_batch(P, torch, oracle):
+    """BASELINE configs[2] shape at a size the oracle finishes in seconds: many 2^16 signals, 8 levels."""
+    n, B, m = 1 << 16, 24, 7
+    x = np.stack([sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0) for b in range(B)])
+    rows, _, s = _run(P, torch, x, m, False)
+    for b in (0, 5, 17, 23):
+        ref = oracle.itd_lean(x[b], m)
+        nr = int(s["n_rows"][b])
+        assert nr == ref["rows"].shape[0]
+        assert s["knot_counts"][b, :nr].tolist() == ref["knot_counts"].tolist()
+        assert_bits_equal(rows[b, :nr], ref["rows"], "signal %d" % b)

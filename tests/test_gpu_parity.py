@@ -159,3 +159,43 @@ def test_one_million_samples_bit_exact(P, oracle):
     for j in range(1, rows.shape[0]):
         np.testing.assert_array_equal(P.detect_knots(b[j - 1]), ref["knots"][j])
     assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_and_plateau_signals_vs_oracle(P, oracle, seed):
+    """Dense knots (every sample a knot) force several passes per tile; quantised data makes plateaus and staircases;
+    all must stay bit-exact, whatever the tile/pass boundaries hit."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(3000, 9000))
+    kind = seed % 3
+    if kind == 0:      # zigzag with slowly varying envelope: knot at every interior sample
+        x = np.where(np.arange(n) % 2 == 0, -1.0, 1.0) * (1 + 0.3 * np.sin(np.arange(n) / 50.0))
+    elif kind == 1:    # coarse quantisation: long plateaus, equal neighbours everywhere
+        x = np.round(rng.standard_normal(n).cumsum() / 3.0) / 4.0
+        x[0] += 0.125  # no leading plateau (that is the NaN path, tested separately)
+    else:              # dense noise followed by a smooth stretch (dense and empty tiles side by side)
+        x = np.concatenate([rng.standard_normal(n // 2), np.sin(np.linspace(0, 3, n - n // 2)) * 5])
+    for m in (2, 9):
+        dec = P.ITD()
+        rows = dec.itd(x, max_iteration=m)
+        ref = oracle.itd(x, m)
+        assert dec.stop_reason == ref["stop"]
+        assert_bits_equal(rows, ref["rows"], "seed %d m=%d rows" % (seed, m))
+        assert_bits_equal(dec.get_baselines(), ref["baselines"], "seed %d m=%d baselines" % (seed, m))
+
+
+@pytest.mark.parametrize("lead", [2, 3, 7, 64, 300, 700])
+def test_leading_plateau_nan_path_vs_oracle(P, oracle, lead):
+    """A signal that starts with a plateau divides by zero on its first segment (ITD.py:115-116); the reference
+    carries on through detect_peaks' NaN rules and its NaN -> +inf mutation.  Same here, bit for bit."""
+    rng = np.random.default_rng(lead)
+    x = np.concatenate([np.full(lead, 0.25), rng.standard_normal(4000 - lead)])
+    for dtype in (np.float64, np.float32):
+        xx = x.astype(dtype)
+        ref = oracle.itd(xx, 6)
+        dec = P.ITD()
+        rows = dec.itd(xx, 6)
+        assert dec.stop_reason == ref["stop"]
+        assert not np.isfinite(ref["rows"]).all()          # the case really is a NaN case
+        assert_bits_equal(rows, ref["rows"], "lead %d rows" % lead)
+        assert_bits_equal(dec.get_baselines(), ref["baselines"], "lead %d baselines" % lead)
