@@ -177,16 +177,16 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *rot_out = rows + (int64_t)j * n;
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
-    k_extract<TIN, T, FIN, kPersist><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
+    k_extract<TIN, T, FIN, kPersist, CAPK><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
                                                     rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
                                                     base_out, base_stride, e->d_state, j, 0)
         if (j == 0) {
-            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride);
-            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride);
+            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride, kRankCap0);
+            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride, kRankCap0);
         } else {
-            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride);
-            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride);
+            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap);
+            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap);
         }
 #undef ITD_LAUNCH_EXTRACT
         time_end(e, pair, st);
@@ -261,11 +261,11 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
         if (j == 0)
-            k_extract<Tin, T, false, false><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+            k_extract<Tin, T, false, false, kRankCap0><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
                                                                         n, base_out, n, state, j, 1);
         else
-            k_extract<double, T, false, false><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+            k_extract<double, T, false, false, kRankCap><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
                                                                            rec(j), rec(j + 1), gs(j), gs(j + 1),
                                                                            gs(j + 2), rot_out, n, base_out, n, state, j, 1);
         k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
@@ -347,7 +347,7 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
         hipDeviceProp_t prop;
         int per_cu = 0;
         if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete e; return ITD_ERR_HIP; }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extract<double, T, false, true>, kBlock, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extract<double, T, false, true, kRankCap>, kBlock, 0) != hipSuccess || per_cu < 1)
             per_cu = 8;
         const char *env = getenv("PYITD_WG_PER_CU");
         if (env && atoi(env) > 0) per_cu = atoi(env);
@@ -556,7 +556,7 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
     const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
-    k_extract<Tin, T, false, false><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+    k_extract<Tin, T, false, false, kRankCap0><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);

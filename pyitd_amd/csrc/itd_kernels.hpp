@@ -68,11 +68,15 @@ constexpr int kWave = 64;              // one wavefront per tile
 #endif
 constexpr int kWPB = ITD_WPB;          // independent wavefronts per workgroup (they share nothing but the launch slot)
 constexpr int kBlock = kWave * kWPB;
-#ifndef ITD_RANK_CAP
-#define ITD_RANK_CAP 136
+// knots one pass of k_extract can hold by rank (>= 64: a 64-sample group always fits).  Smaller = less LDS = more
+// wavefronts per CU but more passes over a dense tile: the level-0 launch (densest knots) gets the larger one.
+#ifndef ITD_RANK_CAP0
+#define ITD_RANK_CAP0 136
 #endif
-constexpr int kRankCap = ITD_RANK_CAP;   // knots one pass of k_extract can hold by rank (>= 64: a 64-sample group always fits)
-static_assert(kRankCap >= 64, "a pass must be able to take one 64-sample group");
+#ifndef ITD_RANK_CAP
+#define ITD_RANK_CAP 72
+#endif
+constexpr int kRankCap0 = ITD_RANK_CAP0, kRankCap = ITD_RANK_CAP;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // wave-uniform by construction: tell the compiler so (keeps tile indices, pointers and the halo search on the scalar unit)
 __device__ __forceinline__ int wave_in_block() { return kWPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -481,7 +485,7 @@ __device__ __forceinline__ double sgpr(double v)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <typename Tin, int TW, bool FINAL, bool PERSIST>
+template <typename Tin, int TW, bool FINAL, bool PERSIST, int CAP>
 __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                     int n_tiles, int batch,
                                                     const int32_t *__restrict__ counts_in,
@@ -495,7 +499,8 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
                                                     SigState *__restrict__ state, int level, int careful)
 {
     constexpr int G = TW / 64;    // 64-sample groups = 64-bit flag words per tile
-    constexpr int RK = kRankCap + 8;   // by-rank slots: kRankCap knots of a pass + 2 in front + 3 behind (+ padding)
+    static_assert(CAP >= 64, "a pass must be able to take one 64-sample group");
+    constexpr int RK = CAP + 8;   // by-rank slots: CAP knots of a pass + 2 in front + 3 behind (+ padding)
     // one private LDS slice per wavefront of the workgroup
     __shared__ __attribute__((aligned(16))) double sx_all[kWPB][Tile<TW>::kSize];  // the tile: input, then baseline in place
     __shared__ double sX_all[kWPB][RK];      // value of the level's input at knot j
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int cg = __popcll(mks[g]);
-            if (g == g1 && g >= g0 && m + cg <= kRankCap) { m += cg; g1 = g + 1; }
+            if (g == g1 && g >= g0 && m + cg <= CAP) { m += cg; g1 = g + 1; }
         }
         own_left -= m;
         // the three knots behind the run: the tile's own knots of later groups first, then the tile's halo
