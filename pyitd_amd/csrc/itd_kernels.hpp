@@ -139,7 +139,8 @@ struct Tile {
 template <typename Tin, int TW>
 struct TileRegs {
     // per-lane vector of kPer consecutive samples: 16 bytes (double2 / float4) when the tile allows, else 8 bytes
-    static constexpr int kPer = sizeof(Tin) == 8 ? 2 : (TW >= 256 ? 4 : 2);
+    static constexpr int kPer = sizeof(Tin) == 8 ? 2 : (TW % 256 == 0 ? 4 : 2);
+    static_assert(TW % (kPer * kWave) == 0, "whole vector loads per lane");
     using V = Tin __attribute__((ext_vector_type(kPer)));
     static constexpr int kN = TW / (kPer * kWave);
     static constexpr uintptr_t kAlignMask = sizeof(Tin) * kPer - 1;
