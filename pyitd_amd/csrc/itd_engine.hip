@@ -29,7 +29,7 @@ constexpr int T = ITD_TILE;
 #define ITD_PERSIST 0
 #endif
 constexpr bool kPersist = ITD_PERSIST != 0;  // resident wavefronts loop over tiles with a software pipeline
-static_assert(T % 128 == 0 && T / 64 <= 64, "tile geometry: whole 8/16-byte loads per lane, <= 64 flag words");
+static_assert(T % 128 == 0 && T / 64 <= kMaxGroups, "tile geometry: whole 8/16-byte loads per lane, <= 8 flag words per record");
 
 __global__ void k_init_state(SigState *st, int batch)
 {

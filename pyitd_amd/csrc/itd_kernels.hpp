@@ -94,15 +94,19 @@ struct SigState {
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
-// What the producer of a tile's knot list leaves for the tile's neighbours (64 bytes, one per tile).
+// What the producer of a tile's knots leaves for the next launch (128 bytes = one line, one per tile): the first 64
+// bytes are for the tile's neighbours, the flag words for the tile itself.
 struct TileRec {
     int32_t count;     // knots in the tile
     int32_t hidx[3];   // its first min(count,3) knots ...
     int32_t tidx[2];   // ... and its last two: tidx[1] = last, tidx[0] = second last (count >= 2)
     double hval[3];    // values of the level's input at those knots
     double tval[2];
+    unsigned long long flags[8];   // the tile's knot flags, one 64-bit word per 64-sample group: the consumer of the tile
+                                   // (next launch, same tile) reads them instead of re-running the predicate
 };
-static_assert(sizeof(TileRec) == 64, "TileRec layout");
+static_assert(sizeof(TileRec) == 128, "TileRec layout");
+constexpr int kMaxGroups = 8;      // flag words per record -> tiles of at most 512 samples
 
 enum DetectMode : int { kKnots = 0, kValleys = 1, kPeaks = 2 };
 
@@ -251,9 +255,10 @@ __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, i
 template <int TW>
 __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, int mode,
                                            int32_t *__restrict__ list, TileRec *__restrict__ rec,
-                                           int32_t *rec_lds /* 16 ints of wave-private LDS, 16-byte aligned */)
+                                           int32_t *rec_lds /* 32 ints of wave-private LDS, 16-byte aligned */)
 {
     constexpr int G = TW / 64;
+    static_assert(G <= kMaxGroups, "tile too wide for the record's flag words");
     const int lane = lane_id();
     unsigned long long masks[G];
     const int total = scan_flags<TW>(tile, s, n, mode, masks);
@@ -286,7 +291,7 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
         if (lane == 0 && !(ITD_ABLATE & 64)) rec->count = 0;
         return 0;
     }
-    // assemble the 64-byte record in LDS, then hand it to HBM with ONE 4-lane x 16-byte store
+    // assemble the 128-byte record in LDS, then hand it to HBM with ONE 8-lane x 16-byte store
     TileRec *lrec = reinterpret_cast<TileRec *>(rec_lds);
     if (lane < 5) {
         const int pos = lane == 0 ? h0 : lane == 1 ? h1 : lane == 2 ? h2 : lane == 3 ? t0 : t1;
@@ -296,8 +301,14 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
         else          { lrec->tidx[lane - 3] = idx; lrec->tval[lane - 3] = v; }
     }
     if (lane == 5) lrec->count = total;
+    if (lane >= 8 && lane < 8 + G) {
+        unsigned long long v = masks[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) v = (lane == 8 + g) ? masks[g] : v;
+        lrec->flags[lane - 8] = v;
+    }
     wave_sync();
-    if (lane < 4 && !(ITD_ABLATE & 64)) {
+    if (lane < 8 && !(ITD_ABLATE & 64)) {   // 8 lanes x 16 bytes = the whole 128-byte record, one store
         using I4 = __attribute__((ext_vector_type(4))) int;
         reinterpret_cast<I4 *>(rec)[lane] = reinterpret_cast<const I4 *>(rec_lds)[lane];
     }
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_detect(const Tin *__restrict__ x, in
                                                   int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
 {
     __shared__ __attribute__((aligned(16))) double s_x[kWPB][Tile<TW>::kSize];
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[kWPB][16];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[kWPB][32];
     const int t = blockIdx.x * kWPB + wave_in_block();
     if (t >= n_tiles) return;
     const int sig = blockIdx.y;
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     __shared__ double sB_all[kWPB][RK];      // knot value B_j
     __shared__ double sS_all[kWPB][RK];      // slope of the segment that starts at knot j; before the slopes exist the same
                                              // bytes hold the knots' sample indices gi[j] (dead once the B_j are known)
-    __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][16];   // staging of the tile's 64-byte record
+    __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][32];   // staging of the tile's 128-byte record
     double *s_x = sx_all[wave_in_block()];
     double *s_X = sX_all[wave_in_block()], *s_B = sB_all[wave_in_block()], *s_S = sS_all[wave_in_block()];
     int32_t *s_gi = reinterpret_cast<int32_t *>(sS_all[wave_in_block()]);
@@ -571,6 +582,16 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     RecRegs rr;
     int cbA = 0, cfA = 0;
     fetch_tile(kflat, regs);
+    // this tile's own knot count and flag words (stored by its producer), requested with everything else
+    int own_c = 0;
+    unsigned long long own_flags[G];
+    auto fetch_own = [&](int64_t k) {
+        const TileRec *ro = recs_in + k;   // recs are [signal][tile] = flattened index
+        own_c = ro->count;
+#pragma unroll
+        for (int g = 0; g < G; ++g) own_flags[g] = ro->flags[g];
+    };
+    fetch_own(kflat);
     stage_a(kflat, cbA, cfA);
     fetch_recs(kflat, cbA, cfA, rr);
     if constexpr (PERSIST)
@@ -701,27 +722,12 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     ITD_STAMP(1);
   if (!stopped) {
 
-    // ---- this level's knots inside the tile: the predicate the producer ran on the same values -------------------
-    const bool edge_tile = (s == 0) || (s + TW >= n - 1);   // holds sample 0 or n-1, which are never knots
+    // ---- this level's knots inside the tile: the flag words the producer of this tile stored with its record (it ran
+    //      the predicate on exactly these values; first/last sample already excluded, ITD.py:70-73) ------------------
     unsigned long long mks[G];
-    int c = 0;
+    const int c = (ITD_ABLATE & 16) ? 0 : own_c;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int pos = g * 64 + lane;
-        const double xm = xt.at(pos - 1), x0 = xt.at(pos), xp = xt.at(pos + 1);
-        const double vil = xp - x0;
-        const double vix = x0 - xm;
-        bool f = ((vil > 0.0) && (vix <= 0.0)) || ((vil < 0.0) && (vix >= 0.0));   // ITD.py:59 on x and on -x
-        if (ITD_ABLATE & 16) f = false;
-        unsigned long long mk = __ballot(f);
-        if (edge_tile) {   // first and last sample are never knots (ITD.py:70-73)
-            const int64_t g0 = s + g * 64;
-            const int64_t hi64 = (n - 2) - g0;
-            mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
-        }
-        mks[g] = mk;
-        c += __popcll(mk);
-    }
+    for (int g = 0; g < G; ++g) mks[g] = (c > 0) ? own_flags[g] : 0ull;
     ITD_STAMP(2);
 
     // ---- passes: a run of consecutive 64-sample groups whose knots fit the by-rank arrays (one pass unless the tile
@@ -902,6 +908,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     if constexpr (!PERSIST) break;
     kflat += NW;
     if (kflat >= total_tiles) break;
+    fetch_own(kflat);
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
   }
     ITD_STAMP_FLUSH();
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(kWave) void k_careful_apply(double *__restrict__ xi
     // steps (2) and (3).  Every NaN the tile sees (its own samples or a neighbour's halo sample, mutated yet or
     // not) is read as +inf, so the result does not depend on the order in which tiles run.
     __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[16];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[32];
     if (st->stopped) return;
     const int t = blockIdx.x;
     const int lane = lane_id();
