@@ -748,12 +748,18 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     while (g0 < G) {
         // the run [g0, g1) and its knot count m
         int g1 = g0, m = 0;
+        if (own_left <= CAP) {   // everything that is left fits (the common case: one pass per tile)
+            g1 = G;
+            m = own_left;
+        } else {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int cg = __popcll(mks[g]);
-            if (g == g1 && g >= g0 && m + cg <= CAP) { m += cg; g1 = g + 1; }
+            for (int g = 0; g < G; ++g) {
+                const int cg = __popcll(mks[g]);
+                if (g == g1 && g >= g0 && m + cg <= CAP) { m += cg; g1 = g + 1; }
+            }
         }
         own_left -= m;
+        const unsigned in_pass = ((1u << g1) - 1u) & ~((1u << g0) - 1u);   // bit g: group g belongs to this pass
         // the three knots behind the run: the tile's own knots of later groups first, then the tile's halo
         int32_t qi0 = hi2, qi1 = hi3, qi2 = hi4;
         double qx0 = hx2, qx1 = hx3, qx2 = hx4;
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             int base = 2;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g >= g0 && g < g1) {
+                if ((in_pass >> g) & 1u) {
                     const unsigned long long mk = mks[g];
                     const int pos = g * 64 + lane;
                     if ((mk >> lane) & 1ull) {
@@ -851,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             int jb = 1;                      // local rank of the knot in front of the group
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g >= g0 && g < g1) {
+                if ((in_pass >> g) & 1u) {
                     const int pos = g * 64 + lane;
                     const unsigned long long mk = mks[g];
                     const int L = one_seg ? 1 : mbcnt64(mk >> 1, jb + (int)(mk & 1ull));   // 1 + knots of the run at or before the sample
