@@ -143,8 +143,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int64_t rows_stride = R * n;
     const dim3 blk(kBlock);
     const dim3 grid_t((n_tiles + kWPB - 1) / kWPB, batch);                      // k_detect: kWPB tiles per workgroup
-    const int64_t all_wg = ((int64_t)n_tiles * batch + kWPB - 1) / kWPB;          // k_extract: flattened (signal, tile)
-    const dim3 grid_p((unsigned)(kPersist ? std::min<int64_t>(all_wg, e->resident_wg) : all_wg));
+    const int64_t all_wg = ((int64_t)n_tiles * batch + kWPB - 1) / kWPB;          // persistent k_extract: flattened (signal, tile)
+    const dim3 grid_p = kPersist ? dim3((unsigned)std::min<int64_t>(all_wg, e->resident_wg)) : grid_t;
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };

@@ -527,8 +527,25 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     const int lane = lane_id();
     const int64_t total_tiles = (int64_t)n_tiles * batch;
     const int64_t NW = PERSIST ? (int64_t)gridDim.x * kWPB : 1;   // resident wavefronts (persistent mode)
-    int64_t kflat = (int64_t)blockIdx.x * kWPB + wave_in_block();
-    if (kflat >= total_tiles) return;
+    // flattened (signal, tile) index.  Without PERSIST the grid is (tiles, batch): no division anywhere.
+    int64_t kflat;
+    if constexpr (PERSIST) {
+        kflat = (int64_t)blockIdx.x * kWPB + wave_in_block();
+        if (kflat >= total_tiles) return;
+    } else {
+        const int t_ = blockIdx.x * kWPB + wave_in_block();
+        if (t_ >= n_tiles) return;
+        kflat = (int64_t)blockIdx.y * n_tiles + t_;
+    }
+    auto split = [&](int64_t k, int &sig_o, int &t_o) {
+        if constexpr (PERSIST) {
+            sig_o = (int)((unsigned long long)k / (unsigned)n_tiles);
+            t_o = (int)(k - (int64_t)sig_o * n_tiles);
+        } else {
+            sig_o = blockIdx.y;
+            t_o = (int)(k - (int64_t)sig_o * n_tiles);
+        }
+    };
     const int n_groups = groups_of(n_tiles);
     Tile<TW> xt{s_x};
     ITD_STAMP_DECL();
@@ -537,18 +554,21 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     //      the next tile itself (registers) and its candidate neighbours' records; stage C = this tile.  Without
     //      PERSIST (one wavefront per tile) the same code runs once, with the tile's loads issued first. -------------
     auto stage_a = [&](int64_t k, int &cb, int &cf) {
-        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        int sig, t;
+        split(k, sig, t);
         const int32_t *cnts = counts_in + (size_t)sig * n_tiles;
         const int tb = t - 1 - lane, tf = t + 1 + lane;
         cb = (tb >= 0) ? cnts[tb] : 0;
         cf = (tf < n_tiles) ? cnts[tf] : 0;
     };
     auto fetch_tile = [&](int64_t k, TileRegs<Tin, TW> &regs) {
-        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        int sig, t;
+        split(k, sig, t);
         tile_fetch<Tin, TW>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
     };
     auto fetch_recs = [&](int64_t k, int cb, int cf, RecRegs &h) {
-        const int sig = (int)(k / n_tiles), t = (int)(k - (int64_t)sig * n_tiles);
+        int sig, t;
+        split(k, sig, t);
         const TileRec *recs = recs_in + (size_t)sig * n_tiles;
         unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
         h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
@@ -600,7 +620,8 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     int sig_cur = -1, stopped = 0;
     double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
   for (;;) {   // one iteration per tile (exactly one without PERSIST)
-    const int sig = (int)(kflat / n_tiles), t = (int)(kflat - (int64_t)sig * n_tiles);
+    int sig, t;
+    split(kflat, sig, t);
     SigState *st = state + sig;
     const int64_t s = (int64_t)t * TW;
     const Tin *x = xin + (int64_t)sig * x_stride;
