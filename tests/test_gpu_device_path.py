@@ -129,3 +129,32 @@ def test_config3_shape_small_batch(P, torch, oracle):
         assert nr == ref["rows"].shape[0]
         assert s["knot_counts"][b, :nr].tolist() == ref["knot_counts"].tolist()
         assert_bits_equal(rows[b, :nr], ref["rows"], "signal %d" % b)
+
+
+def test_decompose_is_graph_capturable(P, torch, oracle):
+    """The decompose entry points allocate nothing and never synchronise: a whole decomposition can be captured in
+    a hipGraph (here through torch's capture API) and replayed on new data."""
+    n, m = 50000, 5
+    x_np = sines_noise(n, seed=3)
+    x = torch.from_numpy(x_np).cuda()
+    rows = torch.zeros((m + 2, n), dtype=torch.float64, device="cuda")
+    eng = P.Engine(n, 1, 0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, side.cuda_stream)  # warm-up
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None,
+                              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for seed in (4, 5):
+        y_np = sines_noise(n, seed=seed)
+        x.copy_(torch.from_numpy(y_np))
+        rows.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = oracle.itd(y_np, m)
+        assert_bits_equal(rows[: ref["rows"].shape[0]].cpu().numpy(), ref["rows"], "graph replay seed %d" % seed)
+    eng.close()
