@@ -520,6 +520,10 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     __shared__ double sS_all[kWPB][RK];      // slope of the segment that starts at knot j; before the slopes exist the same
                                              // bytes hold the knots' sample indices gi[j] (dead once the B_j are known)
     __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][32];   // staging of the tile's 128-byte record
+    __shared__ double shX_all[kWPB][2][8];   // [0]: the five knots around the TILE (value), [1]: around the current pass
+    __shared__ int32_t shI_all[kWPB][2][8];  // ... and their sample indices
+    double *s_hX = shX_all[wave_in_block()][0], *s_pX = shX_all[wave_in_block()][1];
+    int32_t *s_hI = shI_all[wave_in_block()][0], *s_pI = shI_all[wave_in_block()][1];
     double *s_x = sx_all[wave_in_block()];
     double *s_X = sX_all[wave_in_block()], *s_B = sB_all[wave_in_block()], *s_S = sS_all[wave_in_block()];
     int32_t *s_gi = reinterpret_cast<int32_t *>(sS_all[wave_in_block()]);
@@ -727,6 +731,13 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             }
         }
     }
+    // park the five knots in LDS (tile copy + current-pass copy): they are scalars no longer
+    if (lane < 5) {
+        const double hv = lane == 0 ? hx0 : lane == 1 ? hx1 : lane == 2 ? hx2 : lane == 3 ? hx3 : hx4;
+        const int32_t hv_i = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
+        s_hX[lane] = hv; s_pX[lane] = hv;
+        s_hI[lane] = hv_i; s_pI[lane] = hv_i;
+    }
     ITD_STAMP(0);
 
     // ---- stage the tile; keep the pipeline full ------------------------------------------------------------------------
@@ -759,8 +770,6 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
     const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
-    int32_t fi0 = hi0, fi1 = hi1;           // the two knots in front of the current pass
-    double fx0 = hx0, fx1 = hx1;
     int nbp = nb;                           // how many of them are real knots (the rest is the end knot e[0])
     int own_left = c;                       // the tile's knots not yet consumed by a pass
     double b_lo = 0.0, b_hi = 0.0;
@@ -781,38 +790,33 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
         }
         own_left -= m;
         const unsigned in_pass = ((1u << g1) - 1u) & ~((1u << g0) - 1u);   // bit g: group g belongs to this pass
-        // the three knots behind the run: the tile's own knots of later groups first, then the tile's halo
-        int32_t qi0 = hi2, qi1 = hi3, qi2 = hi4;
-        double qx0 = hx2, qx1 = hx3, qx2 = hx4;
+        // the three knots behind the run (s_pX/s_pI[2..4]): the tile's own knots of later groups first, then the tile's
+        // halo knots in order.  One-pass tiles (the common case) keep the tile's halo untouched.
         int nfp = nf;
         if (own_left > 0) {
             int k = 0;
-            int32_t oi0 = 0, oi1 = 0, oi2 = 0;
-            double ox0 = 0.0, ox1 = 0.0, ox2 = 0.0;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 unsigned long long mm = (g >= g1) ? mks[g] : 0ull;
                 while (mm && k < 3) {
                     const int pos = g * 64 + __ffsll((long long)mm) - 1;
                     mm &= mm - 1;
-                    const double v = sgpr(xt.at(pos));
-                    if (k == 0) { oi0 = (int32_t)s + pos; ox0 = v; }
-                    else if (k == 1) { oi1 = (int32_t)s + pos; ox1 = v; }
-                    else { oi2 = (int32_t)s + pos; ox2 = v; }
+                    if (lane == 0) { s_pX[2 + k] = xt.at(pos); s_pI[2 + k] = (int32_t)s + pos; }
                     ++k;
                 }
             }
-            // k own knots, then the tile's halo knots in order
-            if (k == 1)      { qi2 = hi3; qx2 = hx3; qi1 = hi2; qx1 = hx2; qi0 = oi0; qx0 = ox0; }
-            else if (k == 2) { qi2 = hi2; qx2 = hx2; qi1 = oi1; qx1 = ox1; qi0 = oi0; qx0 = ox0; }
-            else             { qi2 = oi2; qx2 = ox2; qi1 = oi1; qx1 = ox1; qi0 = oi0; qx0 = ox0; }
+            if (lane >= k && lane < 3) { s_pX[2 + lane] = s_hX[2 + lane - k]; s_pI[2 + lane] = s_hI[2 + lane - k]; }
             nfp = min(3, k + nf);
+            wave_sync();
+        } else if (g0 > 0) {   // last pass of a dense tile
+            if (lane < 3) { s_pX[2 + lane] = s_hX[2 + lane]; s_pI[2 + lane] = s_hI[2 + lane]; }
+            wave_sync();
         }
         // fill the by-rank arrays of the pass
         if (lane < 5) {
             const int L = lane < 2 ? lane : m + lane;
-            s_X[L] = lane == 0 ? fx0 : lane == 1 ? fx1 : lane == 2 ? qx0 : lane == 3 ? qx1 : qx2;
-            s_gi[L] = lane == 0 ? fi0 : lane == 1 ? fi1 : lane == 2 ? qi0 : lane == 3 ? qi1 : qi2;
+            s_X[L] = s_pX[lane];
+            s_gi[L] = s_pI[lane];
         }
         {
             int base = 2;
@@ -832,12 +836,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
         }
         wave_sync();
         // the two knots in front of the NEXT pass = this pass's ranks m, m+1 (taken now: the slopes reuse gi's bytes)
-        int32_t ni0 = 0, ni1 = 0;
-        double nx0 = 0.0, nx1 = 0.0;
-        if (g1 < G) {
-            ni0 = sgpr(s_gi[m]); ni1 = sgpr(s_gi[m + 1]);
-            nx0 = sgpr(s_X[m]);  nx1 = sgpr(s_X[m + 1]);
-        }
+        if (g1 < G && lane < 2) { s_pX[lane] = s_X[m + lane]; s_pI[lane] = s_gi[m + lane]; }
         // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
         for (int L = 1 + lane; L <= m + 3 && !(ITD_ABLATE & 4); L += kWave) {
             const int32_t k0 = s_gi[L - 1], k1 = s_gi[L], k2 = s_gi[L + 1];
@@ -905,7 +904,6 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
         }
         // next pass
         nbp = min(2, nbp + m);
-        fi0 = ni0; fi1 = ni1; fx0 = nx0; fx1 = nx1;
         g0 = g1;
         wave_sync();
     }
