@@ -94,6 +94,11 @@ struct SigState {
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
+#ifndef ITD_TILE
+#define ITD_TILE 512
+#endif
+constexpr int kMaxGroups = (ITD_TILE / 64 <= 8) ? 8 : 16;   // flag words per record (tiles of up to 512 / 1024 samples)
+
 // What the producer of a tile's knots leaves for the next launch (128 bytes = one line, one per tile): the first 64
 // bytes are for the tile's neighbours, the flag words for the tile itself.
 struct TileRec {
@@ -102,11 +107,11 @@ struct TileRec {
     int32_t tidx[2];   // ... and its last two: tidx[1] = last, tidx[0] = second last (count >= 2)
     double hval[3];    // values of the level's input at those knots
     double tval[2];
-    unsigned long long flags[8];   // the tile's knot flags, one 64-bit word per 64-sample group: the consumer of the tile
-                                   // (next launch, same tile) reads them instead of re-running the predicate
+    unsigned long long flags[kMaxGroups];   // the tile's knot flags, one 64-bit word per 64-sample group: the consumer of
+                                            // the tile (next launch, same tile) reads them instead of re-running the predicate
 };
-static_assert(sizeof(TileRec) == 128, "TileRec layout");
-constexpr int kMaxGroups = 8;      // flag words per record -> tiles of at most 512 samples
+static_assert(sizeof(TileRec) == 64 + 8 * kMaxGroups && sizeof(TileRec) % 16 == 0, "TileRec layout");
+constexpr int kRecLanes = sizeof(TileRec) / 16;   // 16-byte lanes that move one record
 
 enum DetectMode : int { kKnots = 0, kValleys = 1, kPeaks = 2 };
 
@@ -212,6 +217,12 @@ __device__ __forceinline__ void tile_commit(const TileRegs<Tin, TW> &r, const Ti
 // First and last sample are never knots (ITD.py:70-73).  The wavefront walks the tile in 64-sample groups:
 // __ballot gives the group's flag mask, popcounts give the ordered output slot.  Returns the knot count.
 // ---------------------------------------------------------------------------------------------
+// popcount of the bits of m below this lane, plus init (v_mbcnt_lo/hi: two VALU instructions)
+__device__ __forceinline__ int mbcnt64(unsigned long long m, int init)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)init));
+}
+
 // bits lo..hi (inclusive) of a 64-bit word, empty when hi < lo
 __device__ __forceinline__ unsigned long long bit_range(int lo, int hi)
 {
@@ -221,14 +232,32 @@ __device__ __forceinline__ unsigned long long bit_range(int lo, int hi)
     return upto & ~((1ull << lo) - 1ull);
 }
 
+// The tile's flag words live in two VGPRs: lane g holds word g (one 64-bit word per 64-sample group).  Loops over
+// the groups stay rolled (v_readlane with a scalar lane index), so code size and scalar-register
+// pressure do not grow with the tile width.
+struct WaveMasks {
+    unsigned lo = 0, hi = 0;
+    __device__ __forceinline__ unsigned long long get(int g) const
+    {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, g) << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)lo, g);
+    }
+    __device__ __forceinline__ void set(int g, unsigned long long m)
+    {
+        const bool mine = lane_id() == g;
+        lo = mine ? (unsigned)m : lo;
+        hi = mine ? (unsigned)(m >> 32) : hi;
+    }
+};
+
 template <int TW>
-__device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, int mode,
-                                          unsigned long long (&masks)[TW / 64])
+__device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, int mode, WaveMasks &wm)
 {
     constexpr int G = TW / 64;
     const int lane = lane_id();
+    const bool edge = (s == 0) || (s + TW >= n - 1);
     int total = 0;
-#pragma unroll
+#pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const int pos = g * 64 + lane;
         const double xm = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
@@ -238,36 +267,40 @@ __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, i
         const bool peak = (vil < 0.0) && (vix >= 0.0);
         const bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
         unsigned long long mk = __ballot(f);
-        if (s == 0 || s + TW >= n - 1) {
+        if (edge) {
             // first and last sample are never knots (ITD.py:70-73): wave-uniform range mask, edge tiles only
             const int64_t g0 = s + g * 64;
             const int64_t hi64 = (n - 2) - g0;
             mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
         }
-        masks[g] = mk;
+        wm.set(g, mk);
         total += __popcll(mk);
     }
     return total;
 }
 
-// producer side: the tile's record for its neighbours and (optionally, API helpers) its ordered knot list.
+// producer side: the tile's record for the next launch and (optionally, API helpers) its ordered knot list.
 // The first three / last two knots are found with scalar bit scans of the wave-uniform flag words.
 template <int TW>
 __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, int mode,
                                            int32_t *__restrict__ list, TileRec *__restrict__ rec,
-                                           int32_t *rec_lds /* 32 ints of wave-private LDS, 16-byte aligned */)
+                                           int32_t *rec_lds /* sizeof(TileRec) bytes of wave-private LDS, 16-byte aligned */)
 {
     constexpr int G = TW / 64;
     static_assert(G <= kMaxGroups, "tile too wide for the record's flag words");
     const int lane = lane_id();
-    unsigned long long masks[G];
-    const int total = scan_flags<TW>(tile, s, n, mode, masks);
+    WaveMasks wm;
+    const int total = scan_flags<TW>(tile, s, n, mode, wm);
+    if (total == 0) {   // nothing to tell the next launch but the count (most tiles of the deep levels)
+        if (lane == 0 && !(ITD_ABLATE & 64)) rec->count = 0;
+        return 0;
+    }
     int h0 = 0, h1 = 0, h2 = 0, t0 = 0, t1 = 0;
     {
         int k = 0;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            unsigned long long m = masks[g];
+#pragma unroll 1
+        for (int g = 0; g < G && k < 3; ++g) {
+            unsigned long long m = wm.get(g);
             while (m && k < 3) {
                 const int pos = g * 64 + __ffsll((long long)m) - 1;
                 m &= m - 1;
@@ -276,9 +309,9 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
             }
         }
         k = 0;
-#pragma unroll
-        for (int g = G - 1; g >= 0; --g) {
-            unsigned long long m = masks[g];
+#pragma unroll 1
+        for (int g = G - 1; g >= 0 && k < 2; --g) {
+            unsigned long long m = wm.get(g);
             while (m && k < 2) {
                 const int b = 63 - __clzll((long long)m);
                 m &= ~(1ull << b);
@@ -286,10 +319,6 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
                 ++k;
             }
         }
-    }
-    if (total == 0) {   // nothing to tell the neighbours but the count (most tiles of the deep levels)
-        if (lane == 0 && !(ITD_ABLATE & 64)) rec->count = 0;
-        return 0;
     }
     // assemble the 128-byte record in LDS, then hand it to HBM with ONE 8-lane x 16-byte store
     TileRec *lrec = reinterpret_cast<TileRec *>(rec_lds);
@@ -301,24 +330,18 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
         else          { lrec->tidx[lane - 3] = idx; lrec->tval[lane - 3] = v; }
     }
     if (lane == 5) lrec->count = total;
-    if (lane >= 8 && lane < 8 + G) {
-        unsigned long long v = masks[0];
-#pragma unroll
-        for (int g = 1; g < G; ++g) v = (lane == 8 + g) ? masks[g] : v;
-        lrec->flags[lane - 8] = v;
-    }
+    if (lane < G) lrec->flags[lane] = ((unsigned long long)wm.hi << 32) | wm.lo;   // lane g holds word g
     wave_sync();
-    if (lane < 8 && !(ITD_ABLATE & 64)) {   // 8 lanes x 16 bytes = the whole 128-byte record, one store
+    if (lane < kRecLanes && !(ITD_ABLATE & 64)) {   // kRecLanes x 16 bytes = the whole record, one store
         using I4 = __attribute__((ext_vector_type(4))) int;
         reinterpret_cast<I4 *>(rec)[lane] = reinterpret_cast<const I4 *>(rec_lds)[lane];
     }
     if (list) {
-        const unsigned long long lt = (1ull << lane) - 1ull;
         int base = 0;
-#pragma unroll
+#pragma unroll 1
         for (int g = 0; g < G; ++g) {
-            const unsigned long long mk = masks[g];
-            if ((mk >> lane) & 1ull) list[base + __popcll(mk & lt)] = (int32_t)(s + g * 64 + lane);
+            const unsigned long long mk = wm.get(g);
+            if ((mk >> lane) & 1ull) list[mbcnt64(mk, base)] = (int32_t)(s + g * 64 + lane);
             base += __popcll(mk);
         }
     }
@@ -347,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_detect(const Tin *__restrict__ x, in
                                                   int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
 {
     __shared__ __attribute__((aligned(16))) double s_x[kWPB][Tile<TW>::kSize];
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[kWPB][32];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[kWPB][sizeof(TileRec) / 4];
     const int t = blockIdx.x * kWPB + wave_in_block();
     if (t >= n_tiles) return;
     const int sig = blockIdx.y;
@@ -453,12 +476,6 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
     return -1;
 }
 
-// popcount of the bits of m below this lane, plus init (v_mbcnt_lo/hi: two VALU instructions)
-__device__ __forceinline__ int mbcnt64(unsigned long long m, int init)
-{
-    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)init));
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_extract: one extraction on one tile, one wavefront; grid = (n_tiles * batch / kWPB), kBlock threads.
 //   xin           level input (float32/float64 caller signal at level 0, float64 baseline afterwards)
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     __shared__ double sB_all[kWPB][RK];      // knot value B_j
     __shared__ double sS_all[kWPB][RK];      // slope of the segment that starts at knot j; before the slopes exist the same
                                              // bytes hold the knots' sample indices gi[j] (dead once the B_j are known)
-    __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][32];   // staging of the tile's 128-byte record
+    __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][sizeof(TileRec) / 4];   // staging of the tile's record
     __shared__ double shX_all[kWPB][2][8];   // [0]: the five knots around the TILE (value), [1]: around the current pass
     __shared__ int32_t shI_all[kWPB][2][8];  // ... and their sample indices
     double *s_hX = shX_all[wave_in_block()][0], *s_pX = shX_all[wave_in_block()][1];
@@ -608,12 +625,11 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     fetch_tile(kflat, regs);
     // this tile's own knot count and flag words (stored by its producer), requested with everything else
     int own_c = 0;
-    unsigned long long own_flags[G];
+    unsigned long long own_word = 0ull;   // lane g < G: flag word g
     auto fetch_own = [&](int64_t k) {
         const TileRec *ro = recs_in + k;   // recs are [signal][tile] = flattened index
         own_c = ro->count;
-#pragma unroll
-        for (int g = 0; g < G; ++g) own_flags[g] = ro->flags[g];
+        own_word = ro->flags[lane < G ? lane : 0];
     };
     fetch_own(kflat);
     stage_a(kflat, cbA, cfA);
@@ -756,10 +772,9 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
 
     // ---- this level's knots inside the tile: the flag words the producer of this tile stored with its record (it ran
     //      the predicate on exactly these values; first/last sample already excluded, ITD.py:70-73) ------------------
-    unsigned long long mks[G];
     const int c = (ITD_ABLATE & 16) ? 0 : own_c;
-#pragma unroll
-    for (int g = 0; g < G; ++g) mks[g] = (c > 0) ? own_flags[g] : 0ull;
+    WaveMasks wm;
+    if (c > 0 && lane < G) { wm.lo = (unsigned)own_word; wm.hi = (unsigned)(own_word >> 32); }
     ITD_STAMP(2);
 
     // ---- passes: a run of consecutive 64-sample groups whose knots fit the by-rank arrays (one pass unless the tile
@@ -782,22 +797,23 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             g1 = G;
             m = own_left;
         } else {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int cg = __popcll(mks[g]);
-                if (g == g1 && g >= g0 && m + cg <= CAP) { m += cg; g1 = g + 1; }
+#pragma unroll 1
+            for (int g = g0; g < G; ++g) {
+                const int cg = __popcll(wm.get(g));
+                if (m + cg > CAP) break;
+                m += cg;
+                g1 = g + 1;
             }
         }
         own_left -= m;
-        const unsigned in_pass = ((1u << g1) - 1u) & ~((1u << g0) - 1u);   // bit g: group g belongs to this pass
         // the three knots behind the run (s_pX/s_pI[2..4]): the tile's own knots of later groups first, then the tile's
         // halo knots in order.  One-pass tiles (the common case) keep the tile's halo untouched.
         int nfp = nf;
         if (own_left > 0) {
             int k = 0;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                unsigned long long mm = (g >= g1) ? mks[g] : 0ull;
+#pragma unroll 1
+            for (int g = g1; g < G && k < 3; ++g) {
+                unsigned long long mm = wm.get(g);
                 while (mm && k < 3) {
                     const int pos = g * 64 + __ffsll((long long)mm) - 1;
                     mm &= mm - 1;
@@ -818,20 +834,18 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             s_X[L] = s_pX[lane];
             s_gi[L] = s_pI[lane];
         }
-        {
+        if (m > 0) {
             int base = 2;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if ((in_pass >> g) & 1u) {
-                    const unsigned long long mk = mks[g];
-                    const int pos = g * 64 + lane;
-                    if ((mk >> lane) & 1ull) {
-                        const int L = mbcnt64(mk, base);
-                        s_X[L] = xt.at(pos);
-                        s_gi[L] = (int32_t)s + pos;
-                    }
-                    base += __popcll(mk);
+#pragma unroll 1
+            for (int g = g0; g < g1; ++g) {
+                const unsigned long long mk = wm.get(g);
+                const int pos = g * 64 + lane;
+                if ((mk >> lane) & 1ull) {
+                    const int L = mbcnt64(mk, base);
+                    s_X[L] = xt.at(pos);
+                    s_gi[L] = (int32_t)s + pos;
                 }
+                base += __popcll(mk);
             }
         }
         wave_sync();
@@ -875,11 +889,11 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
         {
             const bool one_seg = (m == 0);   // no knot inside the run (most tiles of the deep levels): one affine map
             int jb = 1;                      // local rank of the knot in front of the group
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if ((in_pass >> g) & 1u) {
+#pragma unroll 1
+            for (int g = g0; g < g1; ++g) {
+                {
                     const int pos = g * 64 + lane;
-                    const unsigned long long mk = mks[g];
+                    const unsigned long long mk = one_seg ? 0ull : wm.get(g);
                     const int L = one_seg ? 1 : mbcnt64(mk >> 1, jb + (int)(mk & 1ull));   // 1 + knots of the run at or before the sample
                     const double xi = xt.at(pos);
                     const double Bk = s_B[L], Sk = s_S[L], Xk = s_X[L];
@@ -1029,7 +1043,7 @@ __global__ __launch_bounds__(kWave) void k_careful_apply(double *__restrict__ xi
     // steps (2) and (3).  Every NaN the tile sees (its own samples or a neighbour's halo sample, mutated yet or
     // not) is read as +inf, so the result does not depend on the order in which tiles run.
     __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[32];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
     if (st->stopped) return;
     const int t = blockIdx.x;
     const int lane = lane_id();
