@@ -1,6 +1,6 @@
 #!/bin/bash
-# bench each diagnostic/variant build under abl_build/ (level-0 / levels>=1 / final extraction times)
-for f in abl_build/*.so; do
+# bench each diagnostic/variant build under variants/ (level-0 / levels>=1 / final extraction times)
+for f in variants/*.so; do
   PYITD_HIP_LIB=$PWD/$f python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
