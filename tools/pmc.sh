@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools_pmc.sh <tag> "<counters>" [bench args]
+# usage (GPU box, repo root): bash tools/pmc.sh <tag> "<counters>" [bench args]
 # one PMC pass of bench.py (kernel-trace only, as gpurun requires), prints per-kernel counter means.
 tag=$1; shift
 ctrs=$1; shift

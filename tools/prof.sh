@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_prof.sh <tag> [bench args]
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag> [bench args]
 # kernel-trace + stats of bench.py into gpurun_out/<tag>/, prints a compact per-kernel table.
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
