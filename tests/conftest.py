@@ -21,3 +21,13 @@ def golden_cases():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """The in-tree HIP library and the oracle normally arrive prebuilt (they travel with the snapshot); build them
+    if they are missing or older than their sources (hipcc cross-compiles gfx950 without a GPU)."""
+    from pyitd_amd import _lib
+    _lib.build()
+    from oracle import cpu_oracle
+    cpu_oracle.build()
