@@ -7,16 +7,16 @@
 // inter-workgroup communication inside a launch.
 //
 //   k_detect   (level 0 only) 3-point knot predicate of detect_peaks(x) U detect_peaks(-x)
-//              (ITD.py:44-59, :87-98) on the LDS tile; __ballot + popcount ordered compaction into a
-//              per-tile knot list, plus a 64-byte per-tile record (count, first three and last two knots
-//              with their values).
-//   k_extract  finds the two knots in front of and the three knots behind its tile from the neighbouring
-//              tiles' records (no global knot array, no prefix scan over the signal), computes the knot
-//              values B_k (ITD.py:100-110), the per-segment slope, the affine baseline map
-//              (ITD.py:114-117), rotation = x - baseline (ITD.py:119), AND the knot list/record of the
-//              NEXT level from the baseline tile it has just produced.  The wavefront of tile 0 also totals
-//              the level's knot count and evaluates the stop rule `num_extrema < 2` (ITD.py:404) on the
-//              device, so the host never synchronises between levels.
+//              (ITD.py:44-59, :87-98) on the LDS tile: one __ballot word per 64-sample group.  Leaves a
+//              per-tile count, a group sum, and a 128-byte per-tile record: count, first three and last two
+//              knots with their values (for the neighbours) and the flag words (for the tile itself).
+//   k_extract  takes its own knots from the flag words of its record, finds the two knots in front of and the
+//              three knots behind its tile in the neighbouring tiles' records (no global knot array, no knot
+//              list, no prefix scan over the signal), computes the knot values B_k (ITD.py:100-110), the
+//              per-segment slope, the affine baseline map (ITD.py:114-117), rotation = x - baseline
+//              (ITD.py:119), AND the record of the NEXT level from the baseline tile it has just produced.
+//              The wavefront of tile 0 also totals the level's knot count and evaluates the stop rule
+//              `num_extrema < 2` (ITD.py:404) on the device, so the host never synchronises between levels.
 //   k_compact  (API helpers only) per-tile lists -> one ordered index array e[0..m+1] (ITD.py:95-98).
 //   k_last_count / k_finalize   stop test of the last pending baseline and the row fix-up (ITD.py:404-416).
 //
