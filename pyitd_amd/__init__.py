@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import ITDError, build
 from .engine import Engine
 from .itd import (ITD, baseline_knot_estimation, detect_knots, detect_peaks, isin, itd, itd_baseline_extract,
-                  itd_levels, matlab_detect_peaks)
+                  itd_batch, itd_levels, matlab_detect_peaks)
 
-__all__ = ["ITD", "ITDError", "Engine", "build", "itd", "itd_levels", "itd_baseline_extract", "detect_peaks",
+__all__ = ["ITD", "ITDError", "Engine", "build", "itd", "itd_levels", "itd_batch", "itd_baseline_extract", "detect_peaks",
            "matlab_detect_peaks", "detect_knots", "baseline_knot_estimation", "isin"]

@@ -144,6 +144,63 @@ class ITD:
         return self.rotations
 
 
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def itd_batch(x, max_iteration: int = 11, keep_baselines: bool = False, device=None):
+    """Decompose a batch of independent signals x[B, N] in one call (device resident, one engine launch sequence
+    for the whole batch — the batched form of ITD.itd the reference only has as `numba.prange` over rows,
+    siftED2D.ipynb cell 1).
+
+    x: numpy array (copied to the GPU) or a torch CUDA tensor (used in place), float32 or float64.
+    Returns a dict: rows [B, max_iteration+2, N] float64 (numpy, or a torch CUDA tensor when x is one), n_rows [B],
+    stop [B] (0 natural / 1 timeout), knot_counts [B, 23], and baselines [B, max_iteration+2, N] + n_baselines [B]
+    when keep_baselines.  Row r of signal b is valid for r < n_rows[b].
+    """
+    import torch
+    if max_iteration < 0 or max_iteration > _lib.MAX_ITERATION:
+        raise ValueError("max_iteration must be in 0..20 (the reference's buffers hold 22 rows, ITD.py:384-385)")
+    was_torch = _is_torch(x)
+    if was_torch:
+        if not x.is_cuda or x.dim() != 2:
+            raise ValueError("expected a 2-D CUDA tensor")
+        xt = x if x.dtype in (torch.float32, torch.float64) else x.double()
+        if xt.stride(1) != 1:
+            xt = xt.contiguous()
+        dev = xt.device.index
+    else:
+        a = numpy.asarray(x)
+        if a.ndim != 2:
+            raise ValueError("expected x[B, N]")
+        if a.dtype != numpy.float32:
+            a = numpy.asarray(a, dtype=numpy.float64)
+        dev = 0 if device is None else int(device)
+        xt = torch.from_numpy(numpy.ascontiguousarray(a)).to("cuda:%d" % dev)
+    B, n = xt.shape
+    if n < 3:
+        raise ValueError("ITD needs at least 3 samples")
+    R = max_iteration + 2
+    rows = torch.empty((B, R, n), dtype=torch.float64, device=xt.device)
+    bases = torch.zeros((B, R, n), dtype=torch.float64, device=xt.device) if keep_baselines else None
+    eng = Engine(n, B, dev)
+    try:
+        torch.cuda.synchronize(xt.device)   # the engine runs on its own stream
+        eng.decompose_dev(xt.data_ptr(), numpy.float32 if xt.dtype == torch.float32 else numpy.float64, n, B,
+                          xt.stride(0), max_iteration, rows.data_ptr(), bases.data_ptr() if keep_baselines else None, None)
+        s = eng.summary(B)
+    finally:
+        eng.close()
+    if (s["nan_levels"] == -2).any():
+        raise ValueError("an input signal contains NaN")
+    out = {"n_rows": s["n_rows"], "stop": s["stop"], "knot_counts": s["knot_counts"],
+           "rows": rows if was_torch else rows.cpu().numpy()}
+    if keep_baselines:
+        out["baselines"] = bases if was_torch else bases.cpu().numpy()
+        out["n_baselines"] = s["n_baselines"]
+    return out
+
+
 def itd(data, max_iteration: int = 22, device=0):
     """ITD_numba.py:100-136 — free-function driver (its default of 22 overruns the 22-row buffer upstream;
     the usable range is 0..20)."""

@@ -158,3 +158,25 @@ def test_decompose_is_graph_capturable(P, torch, oracle):
         ref = oracle.itd(y_np, m)
         assert_bits_equal(rows[: ref["rows"].shape[0]].cpu().numpy(), ref["rows"], "graph replay seed %d" % seed)
     eng.close()
+
+
+def test_itd_batch_python_api(P, torch, oracle):
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((5, 3000)).astype(np.float32)
+    x[2] = np.linspace(0, 1, 3000, dtype=np.float32) ** 2          # monotone: a single all-zero row
+    for src in (x, torch.from_numpy(x).cuda()):
+        out = P.itd_batch(src, max_iteration=4, keep_baselines=True)
+        rows = out["rows"].cpu().numpy() if hasattr(out["rows"], "cpu") else out["rows"]
+        bases = out["baselines"].cpu().numpy() if hasattr(out["baselines"], "cpu") else out["baselines"]
+        for b in range(5):
+            ref = oracle.itd(x[b], 4)
+            nr, nb = int(out["n_rows"][b]), int(out["n_baselines"][b])
+            assert nr == ref["rows"].shape[0] and nb == ref["baselines"].shape[0]
+            assert_bits_equal(rows[b, :nr], ref["rows"], "batch api rows %d" % b)
+            assert_bits_equal(bases[b, :nb], ref["baselines"], "batch api baselines %d" % b)
+    with pytest.raises(ValueError):
+        P.itd_batch(np.zeros((2, 2)))
+    bad = x.copy()
+    bad[1, 7] = np.nan
+    with pytest.raises(ValueError):
+        P.itd_batch(bad, 3)
