@@ -539,6 +539,11 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][sizeof(TileRec) / 4];   // staging of the tile's record
     __shared__ double shX_all[kWPB][2][8];   // [0]: the five knots around the TILE (value), [1]: around the current pass
     __shared__ int32_t shI_all[kWPB][2][8];  // ... and their sample indices
+#ifdef ITD_LDS_PAD   // diagnostic: occupy extra LDS to study the sensitivity to wavefronts per CU
+    __shared__ int s_pad[ITD_LDS_PAD / 4];
+    if (n == -12345) s_pad[threadIdx.x] = level;
+    if (n == -12346) rot_out[0] = s_pad[threadIdx.x ^ 1];
+#endif
     double *s_hX = shX_all[wave_in_block()][0], *s_pX = shX_all[wave_in_block()][1];
     int32_t *s_hI = shI_all[wave_in_block()][0], *s_pI = shI_all[wave_in_block()][1];
     double *s_x = sx_all[wave_in_block()];
