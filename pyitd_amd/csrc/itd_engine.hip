@@ -31,8 +31,11 @@ constexpr int T = ITD_TILE;
 constexpr bool kPersist = ITD_PERSIST != 0;  // resident wavefronts loop over tiles with a software pipeline
 static_assert(T % 128 == 0 && T / 64 <= kMaxGroups, "tile geometry: whole 8/16-byte loads per lane, <= 8 flag words per record");
 
-__global__ void k_init_state(SigState *st, int batch)
+// per-signal state + the (padded) group sums of all three rotating buffers, one launch
+__global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsum_elems)
 {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < gsum_elems; i += (int64_t)gridDim.x * blockDim.x)
+        gsum[i] = 0;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     for (int j = 0; j < kMaxLevels; ++j) st[b].m[j] = -1;
@@ -42,6 +45,8 @@ __global__ void k_init_state(SigState *st, int batch)
     st[b].in_nan = 0;
     st[b].c_nan = 0;
     st[b].c_has_nan = 0;
+    st[b].fin_stopped = 0;
+    st[b].fin_stop_level = -1;
 }
 
 __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
@@ -151,8 +156,12 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 
     e->timing_now = e->timing && (e->timing_seq++ % e->timing_stride == 0);
     const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
-    k_init_state<<<(batch + 255) / 256, 256, 0, st>>>(e->d_state, batch);
-    HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
+    {
+        // only the part of each buffer this batch/size uses needs clearing, but the buffers are small: clear all
+        const int64_t ge = 3 * e->gsum_third;
+        const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
+        k_init_state<<<gb, 256, 0, st>>>(e->d_state, batch, e->d_gsum, ge);
+    }
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
@@ -192,15 +201,14 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         time_end(e, pair, st);
     }
     // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
-    k_last_count<<<batch, 64, 0, st>>>(gs(M + 2), n_tiles, e->d_state, M + 2, 0);
     {
         const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
         if (bases_user)
             k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0,
-                                                                      e->d_state);
+                                                                      gs(M + 2), n_tiles, M + 2, 0, e->d_state);
         else
             k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->max_n,
-                                                                      e->max_n, 3, e->d_state);
+                                                                      e->max_n, 3, gs(M + 2), n_tiles, M + 2, 0, e->d_state);
     }
     time_end(e, span_pair, st);
     HIP_TRY(e, hipGetLastError());
@@ -245,7 +253,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b * n_tiles; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b * n_tiles; };
     (void)B;
-    k_init_state<<<1, 64, 0, st>>>(state, 1);
+    k_init_state<<<1, 64, 0, st>>>(state, 1, nullptr, 0);
     for (int q = 0; q < 3; ++q)
         HIP_TRY(e, hipMemsetAsync(gs(q), 0, sizeof(int32_t) * (size_t)n_groups * kGsumPitch, st));
     if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
@@ -273,13 +281,14 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         if (final_level)   // ITD.py:420: rotation_ + baseline_ (baseline_ already mutated by the stop test)
             k_add_rows<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, st>>>(rot_out, base_out, n);
     }
-    k_last_count<<<1, 64, 0, st>>>(gs(M + 2), n_tiles, state, M + 2, 1);
     {
         const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
         if (bases_user)
-            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, state);
+            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, gs(M + 2),
+                                                                  n_tiles, M + 2, 1, state);
         else
-            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, pp, 3 * e->max_n, e->max_n, 3, state);
+            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, pp, 3 * e->max_n, e->max_n, 3, gs(M + 2),
+                                                                  n_tiles, M + 2, 1, state);
     }
     HIP_TRY(e, hipGetLastError());
     return ITD_OK;
@@ -425,7 +434,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     const int B = e->last_batch;
     HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
-    auto rows_of = [&](const SigState &s) { return s.stopped ? s.stop_level : e->last_m + 2; };
+    auto rows_of = [&](const SigState &s) { return s.fin_stopped ? s.fin_stop_level : e->last_m + 2; };
     auto first_nan = [&](const SigState &s) {
         // a NaN in a baseline whose knots no decision looked at (extraction >= rows) is harmless
         for (int j = 0; j < rows_of(s) && j < kMaxLevels; ++j)
@@ -451,8 +460,8 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     for (int b = 0; b < B; ++b) {
         const SigState &s = e->h_state[b];
         int rows, nb, why;
-        if (s.stopped) {               // ITD.py:404-416, counter = stop_level-1
-            const int c = s.stop_level - 1;
+        if (s.fin_stopped) {           // ITD.py:404-416, counter = stop_level-1
+            const int c = s.fin_stop_level - 1;
             rows = c + 1;
             nb = c;                    // baselines[0:counter-1] after the increment
             why = ITD_STOP_NATURAL;
@@ -523,8 +532,8 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kWave);
     const dim3 grid_d((n_tiles + kWPB - 1) / kWPB, 1), blk_d(kBlock);
-    k_init_state<<<1, 64, 0, st>>>(e->d_state, 1);
-    HIP_TRY(e, hipMemsetAsync(e->d_gsum, 0, sizeof(int32_t) * 3 * (size_t)e->gsum_third, st));
+    k_init_state<<<(unsigned)std::min<int64_t>((3 * e->gsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_state, 1, e->d_gsum,
+                                                                                                  3 * e->gsum_third);
     k_detect<Tin, T><<<grid_d, blk_d, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
                                               e->d_recs, e->d_gsum, e->d_state);
     if (compact)

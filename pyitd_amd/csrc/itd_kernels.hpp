@@ -18,7 +18,7 @@
 //              The wavefront of tile 0 also totals the level's knot count and evaluates the stop rule
 //              `num_extrema < 2` (ITD.py:404) on the device, so the host never synchronises between levels.
 //   k_compact  (API helpers only) per-tile lists -> one ordered index array e[0..m+1] (ITD.py:95-98).
-//   k_last_count / k_finalize   stop test of the last pending baseline and the row fix-up (ITD.py:404-416).
+//   k_finalize  stop test of the last pending baseline and the row fix-up (ITD.py:400-416).
 //
 // Arithmetic: binary64, the reference's association order, no contraction (compiled with
 // -ffp-contract=off, and the pragma below), IEEE division.  Differences (x[i+1]-x[i]) are formed exactly
@@ -91,6 +91,8 @@ struct SigState {
     int32_t in_nan;          // the caller's signal contains a NaN (rejected: ITD_ERR_NONFINITE)
     int32_t c_nan;           // careful mode: knot count of the pending baseline under the reference's NaN rules
     int32_t c_has_nan;       // careful mode: the pending baseline contained a NaN (c_nan applies)
+    int32_t fin_stopped;     // written by k_finalize only: the verdict after the last pending baseline's stop test
+    int32_t fin_stop_level;  // (kept apart from stopped/stop_level, which k_finalize's own workgroups still read)
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
@@ -959,33 +961,6 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_last_count: knot count of the last pending baseline and its stop test (ITD.py:400-404), which takes
-// priority over the "Out of time!" branch.  grid = (batch), one wavefront each.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_last_count(const int32_t *__restrict__ gsum_in, int n_tiles, SigState *__restrict__ state, int level,
-                             int careful)
-{
-    const int sig = blockIdx.x;
-    SigState *st = state + sig;
-    if (st->stopped) return;
-    const int lane = lane_id();
-    const int n_groups = groups_of(n_tiles);
-    const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
-    int acc = 0;
-    for (int k = lane; k < n_groups; k += 64) acc += gs[(size_t)k * kGsumPitch];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) {
-        if (careful && st->c_has_nan) acc = st->c_nan;
-        st->m[level] = acc;
-        if (acc < 2) {
-            st->stop_level = level;
-            st->stopped = 1;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_careful_count + k_careful_apply: the reference's stop test on a pending baseline that may contain NaNs, then the
 // knot scan the next extraction will see.  Restates, per tile of the float64 row `xio`:
 //   (1) num_extrema = len(detect_peaks(b)) + len(detect_peaks(-b))  (ITD.py:400-402) with detect_peaks' NaN
@@ -1084,21 +1059,47 @@ __global__ void k_add_rows(double *__restrict__ row, const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_finalize: the stop rule's row fix-up on the device (ITD.py:404-416).
-// Natural stop detected at level j (input of extraction j+1 has < 2 knots) means the reference's
-// counter is c = j-1: row c of the result is baselines[c-1] (= the input of extraction j, B_c), or the
-// untouched all-zero last row when c = 0.  grid = (blocks, batch), 256 threads.
+// k_finalize: the stop test of the LAST pending baseline (ITD.py:400-404, it takes priority over the "Out of time!"
+// branch) and the stop rule's row fix-up (ITD.py:404-416), on the device.
+// Natural stop detected at level j (input of extraction j+1 has < 2 knots) means the reference's counter is
+// c = j-1: row c of the result is baselines[c-1] (= the input of extraction j, B_c), or the untouched all-zero last
+// row when c = 0.  Every workgroup totals the last level's group sums itself (a few KB from L2) so that all of them
+// reach the same verdict without reading what workgroup 0 publishes.  grid = (blocks, batch), 256 threads.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFinalizeThreads = 256;
 __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restrict__ rows, int64_t rows_stride,
                                                                int64_t n, const double *__restrict__ bases,
                                                                int64_t bases_stride, int64_t bases_row_pitch,
-                                                               int bases_rotate, const SigState *__restrict__ state)
+                                                               int bases_rotate, const int32_t *__restrict__ gsum_last,
+                                                               int n_tiles, int level_last, int careful,
+                                                               SigState *__restrict__ state)
 {
+    __shared__ int s_red[kFinalizeThreads / 64];
     const int sig = blockIdx.y;
-    const SigState *st = state + sig;
-    if (!st->stopped) return;
-    const int c = st->stop_level - 1;
+    SigState *st = state + sig;
+    int stopped = st->stopped, stop_level = st->stop_level;
+    if (!stopped) {
+        const int n_groups = groups_of(n_tiles);
+        const int32_t *gs = gsum_last + (size_t)sig * n_groups * kGsumPitch;
+        int acc = 0;
+        for (int k = threadIdx.x; k < n_groups; k += kFinalizeThreads) acc += gs[(size_t)k * kGsumPitch];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        int m_last = 0;
+#pragma unroll
+        for (int k = 0; k < kFinalizeThreads / 64; ++k) m_last += s_red[k];
+        if (careful && st->c_has_nan) m_last = st->c_nan;   // the reference's NaN-rule count (k_careful_count)
+        if (m_last < 2) { stopped = 1; stop_level = level_last; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->m[level_last] = m_last;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->fin_stopped = stopped;
+        st->fin_stop_level = stop_level;
+    }
+    if (!stopped) return;
+    const int c = stop_level - 1;
     double *dst = rows + (int64_t)sig * rows_stride + (int64_t)c * n;
     // B_c was written by extraction c (level c-1) into baselines row c-1 (rotating slots: (c-1) % 3)
     const double *src = nullptr;
