@@ -199,3 +199,23 @@ def test_leading_plateau_nan_path_vs_oracle(P, oracle, lead):
         assert not np.isfinite(ref["rows"]).all()          # the case really is a NaN case
         assert_bits_equal(rows, ref["rows"], "lead %d rows" % lead)
         assert_bits_equal(dec.get_baselines(), ref["baselines"], "lead %d baselines" % lead)
+
+
+def test_config5_real_audio_tiled_2p22(P, oracle):
+    """BASELINE configs[4] substitute (the wav files are missing blobs upstream): the reference's own
+    8000-sample shortwave clip (PyITD.ipynb cell 2) tiled to 2^22 float32 samples, 10 levels (max_iteration = 9);
+    knot indices of every level bit-exact against the oracle, rows too."""
+    radio = load_golden("radio8000_input")["x"]
+    x = np.resize(radio, 1 << 22).astype(np.float32)
+    dec = P.ITD()
+    rows = dec.itd(x, max_iteration=9)
+    ref = oracle.itd_lean(x, 9, want_knots=True)
+    assert dec.stop_reason == ref["stop"] and rows.shape[0] == ref["rows"].shape[0]
+    assert_bits_equal(rows, ref["rows"], "config 5 rows")
+    b = dec.get_baselines()
+    np.testing.assert_array_equal(P.detect_knots(x.astype(np.float64)), ref["knots"][0])
+    for j in range(1, rows.shape[0]):
+        got = P.detect_knots(b[j - 1])
+        assert got.dtype == np.int64
+        np.testing.assert_array_equal(got, ref["knots"][j], err_msg="level %d" % j)
+    assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
