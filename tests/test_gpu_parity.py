@@ -219,3 +219,19 @@ def test_config5_real_audio_tiled_2p22(P, oracle):
         assert got.dtype == np.int64
         np.testing.assert_array_equal(got, ref["knots"][j], err_msg="level %d" % j)
     assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
+
+
+@pytest.mark.parametrize("log2n,cycles", [(18, 3.0), (18, 0.8), (21, 2.5), (21, 40.0)])
+def test_very_sparse_knots_over_many_tiles(P, oracle, log2n, cycles):
+    """A handful of knots spread over hundreds or thousands of tiles: the neighbours' records are far away, so the
+    halo search has to leave its 64-tile windows and walk through the group sums in both directions."""
+    n = 1 << log2n
+    t = np.arange(n, dtype=np.float64) / n
+    x = np.sin(2 * np.pi * cycles * t) + 0.3 * t * t
+    for m in (1, 6):
+        dec = P.ITD()
+        rows = dec.itd(x, max_iteration=m)
+        ref = oracle.itd_lean(x, m, want_knots=True)
+        assert dec.stop_reason == ref["stop"] and rows.shape[0] == ref["rows"].shape[0]
+        assert_bits_equal(rows, ref["rows"], "sparse 2^%d x%g m=%d" % (log2n, cycles, m))
+        assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
