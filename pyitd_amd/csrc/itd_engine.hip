@@ -186,10 +186,17 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *rot_out = rows + (int64_t)j * n;
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
+#if ITD_REGTILE
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
+    k_extract_r<TIN, T, FIN, kRankCapR><<<dim3(n_tiles, batch), kWave, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
+                                                    cnt(j + 1), rec(j), rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,  \
+                                                    rows_stride, base_out, base_stride, e->d_state, j, 0)
+#else
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
     k_extract<TIN, T, FIN, kPersist, CAPK><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
                                                     rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
                                                     base_out, base_stride, e->d_state, j, 0)
+#endif
         if (j == 0) {
             if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride, kRankCap0);
             else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride, kRankCap0);
@@ -268,6 +275,16 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         const bool final_level = (j == M + 1);
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
+#if ITD_REGTILE
+        if (j == 0)
+            k_extract_r<Tin, T, false, kRankCapR><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+                                                                        rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
+                                                                        n, base_out, n, state, j, 1);
+        else
+            k_extract_r<double, T, false, kRankCapR><<<dim3(n_tiles), kWave, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+                                                                           rec(j), rec(j + 1), gs(j), gs(j + 1),
+                                                                           gs(j + 2), rot_out, n, base_out, n, state, j, 1);
+#else
         if (j == 0)
             k_extract<Tin, T, false, false, kRankCap0><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
@@ -276,6 +293,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
             k_extract<double, T, false, false, kRankCap><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
                                                                            rec(j), rec(j + 1), gs(j), gs(j + 1),
                                                                            gs(j + 2), rot_out, n, base_out, n, state, j, 1);
+#endif
         k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
         k_careful_apply<T><<<grid_t, blk, 0, st>>>(base_out, n, n_tiles, cnt(j + 1), rec(j + 1), gs(j + 1), state, j + 1);
         if (final_level)   // ITD.py:420: rotation_ + baseline_ (baseline_ already mutated by the stop test)
@@ -565,10 +583,18 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
     const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
+#if ITD_REGTILE
+    (void)grid_p;
+    k_extract_r<Tin, T, false, kRankCapR><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+                                                      e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
+                                                      e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
+                                                      rot, n, base, n, e->d_state, 0, 0);
+#else
     k_extract<Tin, T, false, false, kRankCap0><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);
+#endif
     HIP_TRY(e, hipGetLastError());
     if (want_list) {
         int64_t m = 0;

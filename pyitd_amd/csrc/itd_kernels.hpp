@@ -34,6 +34,12 @@
 #ifndef ITD_ABLATE
 #define ITD_ABLATE 0
 #endif
+// cache policy of k_extract's streams (bit 0: rotation stores, bit 1: baseline stores, bit 2: tile loads are
+// nontemporal).  Rotation rows are never read again by the engine and a level's input is read exactly once, so both
+// stream past the caches; the baseline is the next launch's input and stays cacheable (Infinity Cache hit).
+#ifndef ITD_NT
+#define ITD_NT 5
+#endif
 // ITD_STAMPS: diagnostic build only — per-phase shader-clock totals of k_extract (never in the shipped library)
 #ifdef ITD_STAMPS
 __device__ unsigned long long g_itd_stamps[16];
@@ -77,6 +83,11 @@ constexpr int kBlock = kWave * kWPB;
 #define ITD_RANK_CAP 72
 #endif
 constexpr int kRankCap0 = ITD_RANK_CAP0, kRankCap = ITD_RANK_CAP;
+// k_extract_r works in 128-sample groups: one pass must hold a whole group's knots
+#ifndef ITD_RANK_CAP_R
+#define ITD_RANK_CAP_R 136
+#endif
+constexpr int kRankCapR = ITD_RANK_CAP_R;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // wave-uniform by construction: tell the compiler so (keeps tile indices, pointers and the halo search on the scalar unit)
 __device__ __forceinline__ int wave_in_block() { return kWPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -99,6 +110,17 @@ struct SigState {
 #ifndef ITD_TILE
 #define ITD_TILE 512
 #endif
+// ITD_REGTILE = 1 (shipped): k_extract_r keeps the tile in registers and the records use the interleaved flag format:
+// word 2g = knot flags of the EVEN positions of 128-sample group g (bit l <-> position 128 g + 2 l), word 2g+1 = the odd
+// ones.  0: the LDS-tile kernel k_extract with one word per 64-sample group (bit l of word g <-> position 64 g + l).
+#ifndef ITD_REGTILE
+#define ITD_REGTILE 1
+#endif
+constexpr bool kInterleaved = ITD_REGTILE != 0;
+__device__ __forceinline__ int flag_pos(int word, int bit)
+{
+    return kInterleaved ? 128 * (word >> 1) + 2 * bit + (word & 1) : 64 * word + bit;
+}
 constexpr int kMaxGroups = (ITD_TILE / 64 <= 8) ? 8 : 16;   // flag words per record (tiles of up to 512 / 1024 samples)
 
 // What the producer of a tile's knots leaves for the next launch (128 bytes = one line, one per tile): the first 64
@@ -160,7 +182,14 @@ struct TileRegs {
     bool vec;
 };
 
-template <typename Tin, int TW>
+template <bool NT>
+__device__ __forceinline__ void stream_store(double *p, double v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <typename Tin, int TW, bool NT = false>
 __device__ __forceinline__ void tile_fetch(TileRegs<Tin, TW> &r, const Tin *__restrict__ x, int64_t n, int64_t s)
 {
     using R = TileRegs<Tin, TW>;
@@ -170,7 +199,7 @@ __device__ __forceinline__ void tile_fetch(TileRegs<Tin, TW> &r, const Tin *__re
     if (r.vec) {
         const typename R::V *v = reinterpret_cast<const typename R::V *>(src);
 #pragma unroll
-        for (int k = 0; k < R::kN; ++k) r.q[k] = v[lane + k * kWave];
+        for (int k = 0; k < R::kN; ++k) r.q[k] = NT ? __builtin_nontemporal_load(&v[lane + k * kWave]) : v[lane + k * kWave];
     }
     r.lo = 0.0;
     r.hi = 0.0;
@@ -261,20 +290,16 @@ __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, i
     int total = 0;
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
-        const int pos = g * 64 + lane;
+        const int pos = flag_pos(g, lane);
         const double xm = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
         const double vil = xp - x0;
         const double vix = x0 - xm;
         const bool valley = (vil > 0.0) && (vix <= 0.0);
         const bool peak = (vil < 0.0) && (vix >= 0.0);
-        const bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
-        unsigned long long mk = __ballot(f);
-        if (edge) {
-            // first and last sample are never knots (ITD.py:70-73): wave-uniform range mask, edge tiles only
-            const int64_t g0 = s + g * 64;
-            const int64_t hi64 = (n - 2) - g0;
-            mk &= bit_range((int)(g0 >= 1 ? 0 : 1 - g0), hi64 > 63 ? 63 : (int)hi64);
-        }
+        bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
+        // first and last sample are never knots (ITD.py:70-73), nothing beyond sample n-2: edge tiles only
+        if (edge) f = f && (s + pos >= 1) && (s + pos <= n - 2);
+        const unsigned long long mk = __ballot(f);
         wm.set(g, mk);
         total += __popcll(mk);
     }
@@ -298,7 +323,35 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
         return 0;
     }
     int h0 = 0, h1 = 0, h2 = 0, t0 = 0, t1 = 0;
-    {
+    if constexpr (kInterleaved) {
+        // positions 128 g + 2 b (even word) and 128 g + 2 b + 1 (odd word): merge the two words of a group in sample order
+        int k = 0;
+#pragma unroll 1
+        for (int g = 0; g < G / 2 && k < 3; ++g) {
+            unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
+            while ((E | O) && k < 3) {
+                const int pe = E ? __ffsll((long long)E) - 1 : 64, po = O ? __ffsll((long long)O) - 1 : 64;
+                int pos;
+                if (pe <= po) { pos = 128 * g + 2 * pe; E &= E - 1; }
+                else { pos = 128 * g + 2 * po + 1; O &= O - 1; }
+                if (k == 0) h0 = pos; else if (k == 1) h1 = pos; else h2 = pos;
+                ++k;
+            }
+        }
+        k = 0;
+#pragma unroll 1
+        for (int g = G / 2 - 1; g >= 0 && k < 2; --g) {
+            unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
+            while ((E | O) && k < 2) {
+                const int pe = E ? 63 - __clzll((long long)E) : -1, po = O ? 63 - __clzll((long long)O) : -1;
+                int pos;
+                if (po >= pe) { pos = 128 * g + 2 * po + 1; O &= ~(1ull << po); }
+                else { pos = 128 * g + 2 * pe; E &= ~(1ull << pe); }
+                if (k == 0) t1 = pos; else t0 = pos;
+                ++k;
+            }
+        }
+    } else {
         int k = 0;
 #pragma unroll 1
         for (int g = 0; g < G && k < 3; ++g) {
@@ -340,11 +393,23 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
     }
     if (list) {
         int base = 0;
+        if constexpr (kInterleaved) {
 #pragma unroll 1
-        for (int g = 0; g < G; ++g) {
-            const unsigned long long mk = wm.get(g);
-            if ((mk >> lane) & 1ull) list[mbcnt64(mk, base)] = (int32_t)(s + g * 64 + lane);
-            base += __popcll(mk);
+            for (int g = 0; g < G / 2; ++g) {
+                const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
+                const int before = mbcnt64(O, mbcnt64(E, base));   // knots in front of the lane's even position
+                const int bE = (int)((E >> lane) & 1ull);
+                if (bE) list[before] = (int32_t)(s + 128 * g + 2 * lane);
+                if ((O >> lane) & 1ull) list[before + bE] = (int32_t)(s + 128 * g + 2 * lane + 1);
+                base += __popcll(E) + __popcll(O);
+            }
+        } else {
+#pragma unroll 1
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long mk = wm.get(g);
+                if ((mk >> lane) & 1ull) list[mbcnt64(mk, base)] = (int32_t)(s + g * 64 + lane);
+                base += __popcll(mk);
+            }
         }
     }
     return total;
@@ -592,7 +657,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     auto fetch_tile = [&](int64_t k, TileRegs<Tin, TW> &regs) {
         int sig, t;
         split(k, sig, t);
-        tile_fetch<Tin, TW>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
+        tile_fetch<Tin, TW, (ITD_NT & 4) != 0>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
     };
     auto fetch_recs = [&](int64_t k, int cb, int cf, RecRegs &h) {
         int sig, t;
@@ -856,6 +921,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             }
         }
         wave_sync();
+        ITD_STAMP(3);
         // the two knots in front of the NEXT pass = this pass's ranks m, m+1 (taken now: the slopes reuse gi's bytes)
         if (g1 < G && lane < 2) { s_pX[lane] = s_X[m + lane]; s_pI[lane] = s_gi[m + lane]; }
         // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
@@ -879,6 +945,7 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
             if (!endn) s_S[L] = sl;
         }
         wave_sync();
+        ITD_STAMP(4);
 
         // ---- baseline map + rotation, ITD.py:114-119 -----------------------------------------------------------------
         // halo samples first (they read the by-rank arrays and the untouched halo slots): s-1 lives in the segment
@@ -911,10 +978,10 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
                     if (!tail_tile || s + pos < n) {
                         if (!(ITD_ABLATE & 1) || bi == 1.2345e-300) {
                             if constexpr (FINAL) {
-                                rot_t[pos] = ri + bi;          // ITD.py:420
+                                stream_store<(ITD_NT & 1) != 0>(&rot_t[pos], ri + bi);   // ITD.py:420
                             } else {
-                                rot_t[pos] = ri;
-                                bas_t[pos] = bi;
+                                stream_store<(ITD_NT & 1) != 0>(&rot_t[pos], ri);
+                                stream_store<(ITD_NT & 2) != 0>(&bas_t[pos], bi);
                             }
                         }
                         has_nan = has_nan || (bi != bi);
@@ -958,6 +1025,483 @@ __global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin,
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
   }
     ITD_STAMP_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_extract_r: the extraction with the tile held in REGISTERS (the shipped main path; k_extract above is the LDS-tile
+// form it replaced, kept while ITD_REGTILE can still be switched off).
+// Lane l owns two consecutive samples of every 128-sample group g: tile positions 128 g + 2 l (even) and + 1 (odd) —
+// exactly what one coalesced 16-byte load/store per lane moves.  Flag word 2g holds the even samples' knot flags of
+// group g, word 2g+1 the odd ones (the "interleaved" record format, kInterleaved).  Consequences:
+//   * no LDS tile: LDS holds only the by-rank knot arrays (3.7 KB per wavefront -> the CU fills all its wave slots);
+//   * a sample's left/right neighbours are its own lane's other sample or the adjacent lane's (DPP wave shifts):
+//     the next level's knot scan runs on registers, sharing every difference between the two samples that use it;
+//   * half as many group iterations, each moving 16 bytes per lane.
+// Knot ranks are tile-relative (ke = knots at or before the lane's even sample), computed once; a pass (a run of groups
+// whose knots fit the by-rank arrays) covers ranks [rb, rb+m): by-rank slot L = rank - rb + 2, slots 0,1 = the two knots
+// in front of the run, m+2..m+4 = the three behind it (own knots of other groups, written by their owner lanes, or the
+// tile's halo knots).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long dbits(double v) { return __builtin_bit_cast(unsigned long long, v); }
+__device__ __forceinline__ double bits_d(unsigned lo, unsigned hi)
+{
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// DPP wavefront shifts (gfx9): CTRL 0x138 wave_shr:1 (lane l <- l-1), 0x130 wave_shl:1 (l <- l+1),
+// 0x13C wave_ror:1 (shr with lane 0 <- lane 63), 0x134 wave_rol:1 (shl with lane 63 <- lane 0).
+// Lanes without a source lane keep `old`.
+template <int CTRL>
+__device__ __forceinline__ double wave_dpp(double old, double v)
+{
+    const unsigned long long o = dbits(old), u = dbits(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return bits_d((unsigned)lo, (unsigned)hi);
+}
+// this lane's bit of a wave-uniform 64-bit mask: one v_cndmask with the mask as the select operand
+__device__ __forceinline__ int lane_bit(unsigned long long mask)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
+    return r;
+}
+
+template <typename Tin, int TW, bool FINAL, int CAP>
+__global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
+                                                     int n_tiles, int batch,
+                                                     const int32_t *__restrict__ counts_in,
+                                                     int32_t *__restrict__ counts_out,
+                                                     const TileRec *__restrict__ recs_in,
+                                                     TileRec *__restrict__ recs_out,
+                                                     const int32_t *__restrict__ gsum_in,
+                                                     int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
+                                                     double *__restrict__ rot_out, int64_t rot_stride,
+                                                     double *__restrict__ base_out, int64_t base_stride,
+                                                     SigState *__restrict__ state, int level, int careful)
+{
+    constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
+    static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
+    static_assert(CAP >= 128, "a pass must be able to take one 128-sample group");
+    constexpr int RK = CAP + 8;
+    using D2 = double __attribute__((ext_vector_type(2)));
+    using In2 = Tin __attribute__((ext_vector_type(2)));
+    __shared__ double s_X[RK];      // value of the level's input at knot slot L
+    __shared__ double s_B[RK];      // knot value B_L
+    __shared__ double s_S[RK];      // slope of the segment that starts at slot L; before the slopes exist: the knots' indices
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
+    int32_t *s_gi = reinterpret_cast<int32_t *>(s_S);
+
+    const int lane = lane_id();
+    const int t = blockIdx.x;
+    const int sig = blockIdx.y;
+    SigState *st = state + sig;
+    const int64_t s = (int64_t)t * TW;
+    const Tin *x = xin + (int64_t)sig * x_stride;
+    const size_t slot0 = (size_t)sig * n_tiles;
+    const int32_t *cnts = counts_in + slot0;
+    const TileRec *recs = recs_in + slot0;
+    const int n_groups = groups_of(n_tiles);
+    const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
+
+    // ---- requests first: the tile, its own record, the neighbours' knot counts -----------------------------------------
+    const bool full = (s + TW <= n);
+    const bool vec_in = full && ((reinterpret_cast<uintptr_t>(x + s) & (2 * sizeof(Tin) - 1)) == 0);
+    double xr[G2][2];
+    if (vec_in) {
+        const In2 *v = reinterpret_cast<const In2 *>(x + s);
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const In2 q = (ITD_NT & 4) ? __builtin_nontemporal_load(&v[g * 64 + lane]) : v[g * 64 + lane];
+            xr[g][0] = (double)q.x;
+            xr[g][1] = (double)q.y;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int64_t i = s + 128 * g + 2 * lane;
+            xr[g][0] = (i < n) ? (double)x[i] : 0.0;
+            xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
+        }
+    }
+    double xlo = 0.0, xhi = 0.0;   // samples s-1 and s+TW (wave-uniform addresses)
+    if (s >= 1) xlo = (double)x[s - 1];
+    if (s + TW < n) xhi = (double)x[s + TW];
+    const TileRec *ro = recs + t;
+    const int own_c = ro->count;
+    const unsigned long long own_word = ro->flags[lane < 2 * G2 ? lane : 0];   // lane j < 2*G2: flag word j
+    const int tb = t - 1 - lane, tf = t + 1 + lane;
+    const int cb = (tb >= 0) ? cnts[tb] : 0;
+    const int cf = (tf < n_tiles) ? cnts[tf] : 0;
+
+    // ---- candidate neighbour records (all requested at once) -----------------------------------------------------------
+    RecRegs h;
+    {
+        unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
+        h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
+        h.cb0 = h.cf0 = h.cf1 = 0;
+        if (mb) {
+            const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+            h.ub0 = t - 1 - l; h.cb0 = __builtin_amdgcn_readlane(cb, l);
+            if (h.cb0 < 2 && mb) h.ub1 = t - 1 - (__ffsll((long long)mb) - 1);
+        }
+        if (mf) {
+            const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
+            h.uf0 = t + 1 + l; h.cf0 = __builtin_amdgcn_readlane(cf, l);
+            if (h.cf0 < 3 && mf) {
+                const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
+                h.uf1 = t + 1 + l1; h.cf1 = __builtin_amdgcn_readlane(cf, l1);
+                if (h.cf0 + h.cf1 < 3 && mf) h.uf2 = t + 1 + (__ffsll((long long)mf) - 1);
+            }
+        }
+        const TileRec *rb0 = recs + as_vgpr(max(h.ub0, 0)), *rb1 = recs + as_vgpr(max(h.ub1, 0));
+        const TileRec *rf0 = recs + as_vgpr(max(h.uf0, 0)), *rf1 = recs + as_vgpr(max(h.uf1, 0));
+        const TileRec *rf2 = recs + as_vgpr(max(h.uf2, 0));
+        h.b0i1 = rb0->tidx[1]; h.b0i0 = rb0->tidx[0]; h.b0v1 = rb0->tval[1]; h.b0v0 = rb0->tval[0];
+        h.b1i1 = rb1->tidx[1]; h.b1v1 = rb1->tval[1];
+        h.f0i0 = rf0->hidx[0]; h.f0i1 = rf0->hidx[1]; h.f0i2 = rf0->hidx[2];
+        h.f0v0 = rf0->hval[0]; h.f0v1 = rf0->hval[1]; h.f0v2 = rf0->hval[2];
+        h.f1i0 = rf1->hidx[0]; h.f1i1 = rf1->hidx[1]; h.f1v0 = rf1->hval[0]; h.f1v1 = rf1->hval[1];
+        h.f2i0 = rf2->hidx[0]; h.f2v0 = rf2->hval[0];
+    }
+
+    const int stopped = st->stopped;
+    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
+    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
+
+    if (t == 0 && !stopped) {
+        // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
+        int acc = 0;
+        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) {
+            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
+                if (st->c_has_nan) acc = st->c_nan;
+                st->c_nan = 0;
+                st->c_has_nan = 0;
+            }
+            st->m[level] = acc;
+            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
+                st->stop_level = level;
+                st->stopped = 1;
+            }
+        }
+        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
+        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
+    }
+    if (stopped) return;
+
+    // ---- halo knots (scalar): two in front of the tile, three behind (see k_extract) -------------------------------------
+    int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
+    double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
+    int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
+    {
+        if (h.ub0 >= 0) {
+            hi1 = sgpr(h.b0i1); hx1 = sgpr(h.b0v1); nb = 1;
+            if (h.cb0 >= 2) { hi0 = sgpr(h.b0i0); hx0 = sgpr(h.b0v0); nb = 2; }
+            else if (h.ub1 >= 0) { hi0 = sgpr(h.b1i1); hx0 = sgpr(h.b1v1); nb = 2; }
+        }
+        if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further
+            int far = t - 65;
+            while (nb < 2) {
+                int cu;
+                const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
+                if (u < 0) break;
+                far = u - 1;
+                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+                const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
+                const double v1 = r->tval[1], v0 = r->tval[0];
+                if (nb == 0) { hi1 = i1; hx1 = v1; } else { hi0 = i1; hx0 = v1; }
+                ++nb;
+                if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
+            }
+        }
+        if (h.uf0 >= 0) {
+            hi2 = sgpr(h.f0i0); hx2 = sgpr(h.f0v0); nf = 1;
+            if (h.cf0 >= 2) { hi3 = sgpr(h.f0i1); hx3 = sgpr(h.f0v1); nf = 2; }
+            if (h.cf0 >= 3) { hi4 = sgpr(h.f0i2); hx4 = sgpr(h.f0v2); nf = 3; }
+            if (nf < 3 && h.uf1 >= 0) {
+                if (nf == 1) {
+                    hi3 = sgpr(h.f1i0); hx3 = sgpr(h.f1v0); nf = 2;
+                    if (h.cf1 >= 2) { hi4 = sgpr(h.f1i1); hx4 = sgpr(h.f1v1); nf = 3; }
+                } else {
+                    hi4 = sgpr(h.f1i0); hx4 = sgpr(h.f1v0); nf = 3;
+                }
+                if (nf < 3 && h.uf2 >= 0) { hi4 = sgpr(h.f2i0); hx4 = sgpr(h.f2v0); nf = 3; }
+            }
+        }
+        if (nf < 3 && t + 65 < n_tiles) {
+            int far = t + 65;
+            while (nf < 3) {
+                int cu;
+                const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
+                if (u < 0) break;
+                far = u + 1;
+                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+                const int32_t i0 = r->hidx[0], i1 = r->hidx[1], i2 = r->hidx[2];
+                const double v0 = r->hval[0], v1 = r->hval[1], v2 = r->hval[2];
+                if (nf == 0) {
+                    hi2 = i0; hx2 = v0;
+                    if (cu >= 2) { hi3 = i1; hx3 = v1; }
+                    if (cu >= 3) { hi4 = i2; hx4 = v2; }
+                    nf = min(cu, 3);
+                } else if (nf == 1) {
+                    hi3 = i0; hx3 = v0;
+                    if (cu >= 2) { hi4 = i1; hx4 = v1; }
+                    nf = 1 + min(cu, 2);
+                } else {
+                    hi4 = i0; hx4 = v0;
+                    nf = 3;
+                }
+            }
+        }
+    }
+
+    // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
+    const int c = own_c;
+    WaveMasks wm;
+    if (c > 0 && lane < 2 * G2) { wm.lo = (unsigned)own_word; wm.hi = (unsigned)(own_word >> 32); }
+    // kinfo[g] = ke | bitE << 16 | bitO << 17, ke = knots of the tile at or before the lane's even sample of group g
+    int kinfo[G2];
+    if (c > 0) {
+        int gbase = 0;
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
+            const int bE = lane_bit(E), bO = lane_bit(O);
+            const int ke = mbcnt64(O, mbcnt64(E, gbase)) + bE;
+            kinfo[g] = ke | (bE << 16) | (bO << 17);
+            gbase += __popcll(E) + __popcll(O);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G2; ++g) kinfo[g] = 0;
+    }
+
+    double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
+    double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
+    const bool vec_out = full && ((reinterpret_cast<uintptr_t>(rot_t) & 15) == 0) &&
+                         (FINAL || (reinterpret_cast<uintptr_t>(bas_t) & 15) == 0);
+    const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
+    const bool near_end = (s + TW >= n - 2);
+    const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
+    const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
+    double b_lo = 0.0, b_hi = 0.0;         // baseline at samples s-1 and s+TW (valid in lane 0)
+    bool has_nan = false;
+    double *ends_next = st->ends[(level + 1) & 1];
+
+    // ---- passes --------------------------------------------------------------------------------------------------------
+    int rb = 0, g0 = 0;
+    double carryX = 0.0;
+    int32_t carryI = 0;
+    while (g0 < G2) {
+        int g1 = g0, m = 0;
+        if (c - rb <= CAP) {   // everything that is left fits (one pass per tile unless the tile is dense)
+            g1 = G2;
+            m = c - rb;
+        } else {
+#pragma unroll 1
+            for (int g = g0; g < G2; ++g) {
+                const int cg = __popcll(wm.get(2 * g)) + __popcll(wm.get(2 * g + 1));
+                if (m + cg > CAP) break;
+                m += cg;
+                g1 = g + 1;
+            }
+        }
+        const int nfp = min(3, (c - rb - m) + nf);   // real knots behind the run
+        // own knots by rank (owner lanes), slots 0 .. m+4 of this pass
+        if (c > 0) {
+#pragma unroll
+            for (int g = 0; g < G2; ++g) {
+                const int ke = kinfo[g] & 0xffff, bE = (kinfo[g] >> 16) & 1, bO = (kinfo[g] >> 17) & 1;
+                const int Le = ke - rb + 1;          // slot of the even sample's knot (if it is one): rank ke-1
+                const int Lo = Le + bO;              // slot of the odd sample's knot: rank ke+bO-1
+                if (bE && (unsigned)(Le - 2) < (unsigned)(m + 3)) {
+                    s_X[Le] = xr[g][0];
+                    s_gi[Le] = (int32_t)s + 128 * g + 2 * lane;
+                }
+                if (bO && (unsigned)(Lo - 2) < (unsigned)(m + 3)) {
+                    s_X[Lo] = xr[g][1];
+                    s_gi[Lo] = (int32_t)s + 128 * g + 2 * lane + 1;
+                }
+            }
+        }
+        // slots whose rank lies outside the tile: the halo knots; slots 0,1 of a later pass: the previous run's last two
+        // knots (their owners' registers hold the baseline by now)
+        if (lane < 5) {
+            const int r = lane < 2 ? rb - 2 + lane : rb + m + lane - 2;
+            const int L = lane < 2 ? lane : m + lane;
+            if (r < 0 || r >= c) {
+                const int q = r < 0 ? 2 + r : 2 + (r - c);
+                s_X[L] = q == 0 ? hx0 : q == 1 ? hx1 : q == 2 ? hx2 : q == 3 ? hx3 : hx4;
+                s_gi[L] = q == 0 ? hi0 : q == 1 ? hi1 : q == 2 ? hi2 : q == 3 ? hi3 : hi4;
+            } else if (lane < 2) {
+                s_X[L] = carryX;
+                s_gi[L] = carryI;
+            }
+        }
+        wave_sync();
+        if (g1 < G2 && lane < 2) { carryX = s_X[m + lane]; carryI = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
+        // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
+        for (int L = 1 + lane; L <= m + 3; L += kWave) {
+            const int32_t k0 = s_gi[L - 1], k1 = s_gi[L], k2 = s_gi[L + 1];
+            const double x0 = s_X[L - 1], x1 = s_X[L], x2 = s_X[L + 1];
+            const double frac = (double)(k1 - k0) / (double)(k2 - k0);
+            const double tt = frac * (x2 - x0);
+            const double u = x0 + tt;
+            double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
+            const bool end0 = (L == 1) && (rb == 0) && (nb == 0);             // e[0]   = sample 0
+            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // e[m+1] = sample n-1
+            Bv = end0 ? m0 : (endn ? mn : Bv);
+            s_B[L] = Bv;
+        }
+        wave_sync();
+        // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 --------------------------------
+        for (int L = 1 + lane; L <= m + 2; L += kWave) {
+            const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
+            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // sample n-1 starts no segment
+            if (!endn) s_S[L] = sl;
+        }
+        wave_sync();
+        // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
+        if (lane == 0) {
+            if (g0 == 0 && s >= 1) b_lo = s_B[1] + s_S[1] * (xlo - s_X[1]);
+            const int64_t i = s + TW;
+            if (g1 == G2 && i < n - 1) {
+                const int L = (nf >= 1 && hi2 == (int32_t)i) ? m + 2 : 1 + m;
+                b_hi = s_B[L] + s_S[L] * (xhi - s_X[L]);
+            }
+        }
+        // ---- baseline map + rotation, ITD.py:114-119; the baseline replaces the input in the registers --------------
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            if (g >= g0 && g < g1) {
+                const int ke = kinfo[g] & 0xffff, bO = (kinfo[g] >> 17) & 1;
+                const int Le = ke - rb + 1, Lo = Le + bO;   // 1 + knots of the run at or before the sample
+                const double xe = xr[g][0], xo = xr[g][1];
+                double be = s_B[Le] + s_S[Le] * (xe - s_X[Le]);
+                double bo = s_B[Lo] + s_S[Lo] * (xo - s_X[Lo]);
+                const int64_t i = s + 128 * g + 2 * lane;
+                if (tail_tile) {   // baseline[n-1] is never written (stays 0), ITD.py:112-117
+                    if (i >= n - 1) be = 0.0;
+                    if (i + 1 >= n - 1) bo = 0.0;
+                }
+                const double re = FINAL ? (xe - be) + be : xe - be;   // FINAL: rotation + baseline, ITD.py:420
+                const double rq = FINAL ? (xo - bo) + bo : xo - bo;
+                xr[g][0] = be;
+                xr[g][1] = bo;
+                if (vec_out) {
+                    const D2 rv = {re, rq}, bv = {be, bo};
+                    D2 *rp = reinterpret_cast<D2 *>(rot_t + 128 * g + 2 * lane);
+                    if (ITD_NT & 1) __builtin_nontemporal_store(rv, rp); else *rp = rv;
+                    if constexpr (!FINAL) {
+                        D2 *bp = reinterpret_cast<D2 *>(bas_t + 128 * g + 2 * lane);
+                        if (ITD_NT & 2) __builtin_nontemporal_store(bv, bp); else *bp = bv;
+                    }
+                    has_nan = has_nan || (be != be) || (bo != bo);
+                } else {
+                    const int p = 128 * g + 2 * lane;
+                    if (i < n) {
+                        rot_t[p] = re;
+                        if constexpr (!FINAL) bas_t[p] = be;
+                        has_nan = has_nan || (be != be);
+                    }
+                    if (i + 1 < n) {
+                        rot_t[p + 1] = rq;
+                        if constexpr (!FINAL) bas_t[p + 1] = bo;
+                        has_nan = has_nan || (bo != bo);
+                    }
+                }
+                if (!FINAL && !careful && (near_end || s == 0)) {   // the next level's end samples, ITD.py:101-102
+                    if (i == 0) { ends_next[0] = be; ends_next[1] = bo; }
+                    if (i == n - 2) { ends_next[2] = be; ends_next[3] = bo; }
+                    if (i + 1 == n - 2) ends_next[2] = bo;
+                    if (i == n - 1) ends_next[3] = be;
+                }
+            }
+        }
+        rb += m;
+        g0 = g1;
+        wave_sync();
+    }
+    if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
+    if (careful) return;   // k_careful_apply scans the baseline after the reference's NaN -> inf mutation
+
+    // ---- knots of the baseline just produced = the next level's input, on registers ------------------------------------
+    // differences: d0 = even - left, d1 = odd - even, d2 = right - odd (= the next lane's d0)
+    const double blo_s = bits_d((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dbits(b_lo)),
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dbits(b_lo) >> 32)));
+    const double bhi_s = bits_d((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dbits(b_hi)),
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dbits(b_hi) >> 32)));
+    double d0[G2];
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+        const double fill = (g == 0) ? blo_s : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
+        const double left = wave_dpp<0x138>(fill, xr[g][1]);
+        d0[g] = xr[g][0] - left;
+    }
+    const bool edge = (s == 0) || (s + TW >= n - 1);
+    WaveMasks nm;
+    int total = 0;
+    int gcount[G2];
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+        const double d1 = xr[g][1] - xr[g][0];
+        const double fill = (g == G2 - 1) ? (bhi_s - xr[g][1]) : wave_dpp<0x134>(0.0, d0[g < G2 - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
+        const double d2 = wave_dpp<0x130>(fill, d0[g]);
+        bool fe = ((d1 > 0.0) && (d0[g] <= 0.0)) || ((d1 < 0.0) && (d0[g] >= 0.0));
+        bool fo = ((d2 > 0.0) && (d1 <= 0.0)) || ((d2 < 0.0) && (d1 >= 0.0));
+        if (edge) {   // first and last sample are never knots (ITD.py:70-73); nothing beyond sample n-2
+            const int64_t i = s + 128 * g + 2 * lane;
+            fe = fe && (i >= 1) && (i <= n - 2);
+            fo = fo && (i + 1 <= n - 2);
+        }
+        const unsigned long long E = __ballot(fe), O = __ballot(fo);
+        nm.set(2 * g, E);
+        nm.set(2 * g + 1, O);
+        gcount[g] = __popcll(E) + __popcll(O);
+        total += gcount[g];
+    }
+    const size_t slot = slot0 + t;
+    if (total == 0) {   // nothing to tell the next launch but the count (most tiles of the deep levels)
+        if (lane == 0) { recs_out[slot].count = 0; counts_out[slot] = 0; }
+        return;
+    }
+    // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample)
+    TileRec *lrec = reinterpret_cast<TileRec *>(s_rec);
+    {
+        int gbase = 0;
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            if (gcount[g] > 0 && (gbase < 3 || gbase + gcount[g] > total - 2)) {
+                const unsigned long long E = nm.get(2 * g), O = nm.get(2 * g + 1);
+                const int bE = lane_bit(E), bO = lane_bit(O);
+                const int re = mbcnt64(O, mbcnt64(E, gbase));   // knots before the even sample
+                const int ro_ = re + bE;                        // knots before the odd sample
+                const int32_t ie = (int32_t)s + 128 * g + 2 * lane;
+                if (bE) {
+                    if (re < 3) { lrec->hidx[re] = ie; lrec->hval[re] = xr[g][0]; }
+                    if (re >= total - 2) { lrec->tidx[re - (total - 2)] = ie; lrec->tval[re - (total - 2)] = xr[g][0]; }
+                }
+                if (bO) {
+                    if (ro_ < 3) { lrec->hidx[ro_] = ie + 1; lrec->hval[ro_] = xr[g][1]; }
+                    if (ro_ >= total - 2) { lrec->tidx[ro_ - (total - 2)] = ie + 1; lrec->tval[ro_ - (total - 2)] = xr[g][1]; }
+                }
+            }
+            gbase += gcount[g];
+        }
+    }
+    if (lane == 0) lrec->count = total;
+    if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
+    wave_sync();
+    if (lane < kRecLanes) {   // kRecLanes x 16 bytes = the whole record, one store
+        using I4 = __attribute__((ext_vector_type(4))) int;
+        reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
+    }
+    if (lane == 0) {
+        counts_out[slot] = total;
+        atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,82 @@
+// membench2.hip — streaming floor of the extraction's traffic UNDER THE PIPELINE'S CACHE STATE: level j reads the
+// baseline level j-1 wrote (3 rotating slots), writes a fresh rotation row and the next baseline; launches back to
+// back, no flush.  Variants: store cache policy (plain / nontemporal), bytes per lane, wavefronts per workgroup.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int W, int NT>  // W doubles per lane per access; NT bit0: rotation stores nontemporal, bit1: baseline stores, bit2: loads
+__global__ void k_level(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas, int per_block)
+{
+    using V = double __attribute__((ext_vector_type(W)));
+    const size_t base = (size_t)blockIdx.x * per_block;
+    const V* vi = reinterpret_cast<const V*>(in + base);
+    V* v1 = reinterpret_cast<V*>(rot + base);
+    V* v2 = reinterpret_cast<V*>(bas + base);
+    const int nvec = per_block / W;
+    for (int k = threadIdx.x; k < nvec; k += blockDim.x) {
+        V x = (NT & 4) ? __builtin_nontemporal_load(&vi[k]) : vi[k];
+        V a = x * 0.5;
+        V b = x - a;
+        if (NT & 1) __builtin_nontemporal_store(b, &v1[k]); else v1[k] = b;
+        if (NT & 2) __builtin_nontemporal_store(a, &v2[k]); else v2[k] = a;
+    }
+}
+
+// layout C: every lane owns 8 CONSECUTIVE doubles (64 B) of a 512-sample tile: 4 x 16-byte accesses at a 64-byte lane stride
+template <int NT>
+__global__ void k_level_c(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas)
+{
+    using V = double __attribute__((ext_vector_type(2)));
+    const size_t base = (size_t)blockIdx.x * 512 + threadIdx.x * 8;
+    const V* vi = reinterpret_cast<const V*>(in + base);
+    V* v1 = reinterpret_cast<V*>(rot + base);
+    V* v2 = reinterpret_cast<V*>(bas + base);
+    V x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = (NT & 4) ? __builtin_nontemporal_load(&vi[k]) : vi[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        V a = x[k] * 0.5;
+        V b = x[k] - a;
+        if (NT & 1) __builtin_nontemporal_store(b, &v1[k]); else v1[k] = b;
+        if (NT & 2) __builtin_nontemporal_store(a, &v2[k]); else v2[k] = a;
+    }
+}
+
+int main()
+{
+    const size_t n = 1ull << 24;
+    const int L = 8;
+    double *rows, *bases;
+    CK(hipMalloc(&rows, (L + 1) * n * 8)); CK(hipMalloc(&bases, 3 * n * 8));
+    CK(hipMemset(bases, 0, 3 * n * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char* name, auto launch) {
+        float best = 1e9, sum = 0; const int reps = 10;
+        for (int r = 0; r < reps + 2; ++r) {
+            CK(hipEventRecord(e0));
+            for (int j = 1; j <= L; ++j) launch(bases + (size_t)((j - 1) % 3) * n, rows + (size_t)j * n, bases + (size_t)(j % 3) * n);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= L;
+            if (r >= 2) { best = ms < best ? ms : best; sum += ms; }
+        }
+        printf("%-52s per level: best %6.1f us  avg %6.1f us  -> %5.0f GB/s (avg)\n", name, best * 1e3, sum / reps * 1e3, 24.0 * n / (sum / reps * 1e-3) / 1e9);
+    };
+#define VAR(W, NT, THR, PB)                                                                                         \
+    {                                                                                                               \
+        char nm[128];                                                                                               \
+        snprintf(nm, sizeof nm, "%2dB/lane nt=%d thr=%d per_block=%d", 8 * W, NT, THR, PB);                         \
+        run(nm, [&](const double* i, double* r, double* b) { k_level<W, NT><<<(int)(n / PB), THR>>>(i, r, b, PB); }); \
+    }
+    VAR(1, 0, 64, 512) VAR(2, 0, 64, 512) VAR(2, 1, 64, 512) VAR(2, 5, 64, 512)
+    run("layout C (64 B per lane) nt=0", [&](const double* i, double* r, double* b) { k_level_c<0><<<(int)(n / 512), 64>>>(i, r, b); });
+    run("layout C (64 B per lane) nt=1", [&](const double* i, double* r, double* b) { k_level_c<1><<<(int)(n / 512), 64>>>(i, r, b); });
+    run("layout C (64 B per lane) nt=5", [&](const double* i, double* r, double* b) { k_level_c<5><<<(int)(n / 512), 64>>>(i, r, b); });
+    VAR(2, 0, 64, 512)
+    run("layout C (64 B per lane) nt=0", [&](const double* i, double* r, double* b) { k_level_c<0><<<(int)(n / 512), 64>>>(i, r, b); });
+    return 0;
+}

@@ -13,7 +13,7 @@ rows = torch.empty((9, n), dtype=torch.float64, device="cuda")
 eng = pyitd_amd.Engine(n, 1, 0)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
-names = ["loads+tile0+halo assemble", "commit+sync", "own flags", "(unused)", "(unused)", "passes: fill,B,S,map,stores", "halo write + nan", "detect+record+count"]
+names = ["loads+tile0+halo assemble", "commit+sync", "own flags", "pass: run select + fill by rank", "pass: knot values + slopes", "pass: map + stores", "halo write + nan", "detect+record+count"]
 for rep in range(2):
     L.itd_debug_stamps(None, 1)
     eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, 7, rows.data_ptr(), None, None)
