@@ -1089,6 +1089,9 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     __shared__ double s_B[RK];      // knot value B_L
     __shared__ double s_S[RK];      // slope of the segment that starts at slot L; before the slopes exist: the knots' indices
     __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
+    __shared__ double s_bl[2];
+    __shared__ double s_hX[8];      // the five knots around the tile (value) ...
+    __shared__ int32_t s_hI[8];     // ... and their sample indices
     int32_t *s_gi = reinterpret_cast<int32_t *>(s_S);
 
     const int lane = lane_id();
@@ -1257,6 +1260,15 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         }
     }
 
+    // park the five knots in LDS: they are scalars no longer
+    const bool behind_at_edge = (nf >= 1) && (hi2 == (int32_t)(s + TW));   // sample s+TW is itself a knot
+    if (lane < 5) {
+        s_hX[lane] = lane == 0 ? hx0 : lane == 1 ? hx1 : lane == 2 ? hx2 : lane == 3 ? hx3 : hx4;
+        s_hI[lane] = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
+    }
+    if (lane < 2) s_bl[lane] = 0.0;
+    wave_sync();
+
     // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
     const int c = own_c;
     WaveMasks wm;
@@ -1284,16 +1296,15 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
                          (FINAL || (reinterpret_cast<uintptr_t>(bas_t) & 15) == 0);
     const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
     const bool near_end = (s + TW >= n - 2);
+    const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));   // samples of the signal from s on, clipped: p < nrem <=> s + p < n
     const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
-    double b_lo = 0.0, b_hi = 0.0;         // baseline at samples s-1 and s+TW (valid in lane 0)
+    // s_hX[5], s_hX[6] / s_hI[5], s_hI[6]: the previous run's last two knots; s_bl[0], s_bl[1]: baseline at samples s-1, s+TW
     bool has_nan = false;
     double *ends_next = st->ends[(level + 1) & 1];
 
     // ---- passes --------------------------------------------------------------------------------------------------------
     int rb = 0, g0 = 0;
-    double carryX = 0.0;
-    int32_t carryI = 0;
     while (g0 < G2) {
         int g1 = g0, m = 0;
         if (c - rb <= CAP) {   // everything that is left fits (one pass per tile unless the tile is dense)
@@ -1313,16 +1324,18 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         if (c > 0) {
 #pragma unroll
             for (int g = 0; g < G2; ++g) {
+                int p = 128 * g + 2 * lane;
+                asm volatile("" : "+v"(p));
                 const int ke = kinfo[g] & 0xffff, bE = (kinfo[g] >> 16) & 1, bO = (kinfo[g] >> 17) & 1;
                 const int Le = ke - rb + 1;          // slot of the even sample's knot (if it is one): rank ke-1
                 const int Lo = Le + bO;              // slot of the odd sample's knot: rank ke+bO-1
                 if (bE && (unsigned)(Le - 2) < (unsigned)(m + 3)) {
                     s_X[Le] = xr[g][0];
-                    s_gi[Le] = (int32_t)s + 128 * g + 2 * lane;
+                    s_gi[Le] = (int32_t)s + p;
                 }
                 if (bO && (unsigned)(Lo - 2) < (unsigned)(m + 3)) {
                     s_X[Lo] = xr[g][1];
-                    s_gi[Lo] = (int32_t)s + 128 * g + 2 * lane + 1;
+                    s_gi[Lo] = (int32_t)s + p + 1;
                 }
             }
         }
@@ -1333,15 +1346,15 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             const int L = lane < 2 ? lane : m + lane;
             if (r < 0 || r >= c) {
                 const int q = r < 0 ? 2 + r : 2 + (r - c);
-                s_X[L] = q == 0 ? hx0 : q == 1 ? hx1 : q == 2 ? hx2 : q == 3 ? hx3 : hx4;
-                s_gi[L] = q == 0 ? hi0 : q == 1 ? hi1 : q == 2 ? hi2 : q == 3 ? hi3 : hi4;
+                s_X[L] = s_hX[q];
+                s_gi[L] = s_hI[q];
             } else if (lane < 2) {
-                s_X[L] = carryX;
-                s_gi[L] = carryI;
+                s_X[L] = s_hX[5 + lane];
+                s_gi[L] = s_hI[5 + lane];
             }
         }
         wave_sync();
-        if (g1 < G2 && lane < 2) { carryX = s_X[m + lane]; carryI = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
+        if (g1 < G2 && lane < 2) { s_hX[5 + lane] = s_X[m + lane]; s_hI[5 + lane] = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
         // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
         for (int L = 1 + lane; L <= m + 3; L += kWave) {
             const int32_t k0 = s_gi[L - 1], k1 = s_gi[L], k2 = s_gi[L + 1];
@@ -1365,26 +1378,28 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         wave_sync();
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
-            if (g0 == 0 && s >= 1) b_lo = s_B[1] + s_S[1] * (xlo - s_X[1]);
+            if (g0 == 0 && s >= 1) s_bl[0] = s_B[1] + s_S[1] * (xlo - s_X[1]);
             const int64_t i = s + TW;
             if (g1 == G2 && i < n - 1) {
-                const int L = (nf >= 1 && hi2 == (int32_t)i) ? m + 2 : 1 + m;
-                b_hi = s_B[L] + s_S[L] * (xhi - s_X[L]);
+                const int L = behind_at_edge ? m + 2 : 1 + m;
+                s_bl[1] = s_B[L] + s_S[L] * (xhi - s_X[L]);
             }
         }
         // ---- baseline map + rotation, ITD.py:114-119; the baseline replaces the input in the registers --------------
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
+            __builtin_amdgcn_sched_barrier(0);   // one group's by-rank reads in flight at a time: registers, not latency, are scarce
             if (g >= g0 && g < g1) {
+                int p = 128 * g + 2 * lane;       // tile position of the even sample
+                asm volatile("" : "+v"(p));       // opaque: keeps the per-group masks and addresses out of the pass loop's preheader
                 const int ke = kinfo[g] & 0xffff, bO = (kinfo[g] >> 17) & 1;
                 const int Le = ke - rb + 1, Lo = Le + bO;   // 1 + knots of the run at or before the sample
                 const double xe = xr[g][0], xo = xr[g][1];
                 double be = s_B[Le] + s_S[Le] * (xe - s_X[Le]);
                 double bo = s_B[Lo] + s_S[Lo] * (xo - s_X[Lo]);
-                const int64_t i = s + 128 * g + 2 * lane;
                 if (tail_tile) {   // baseline[n-1] is never written (stays 0), ITD.py:112-117
-                    if (i >= n - 1) be = 0.0;
-                    if (i + 1 >= n - 1) bo = 0.0;
+                    if (p >= nrem - 1) be = 0.0;
+                    if (p + 1 >= nrem - 1) bo = 0.0;
                 }
                 const double re = FINAL ? (xe - be) + be : xe - be;   // FINAL: rotation + baseline, ITD.py:420
                 const double rq = FINAL ? (xo - bo) + bo : xo - bo;
@@ -1392,31 +1407,30 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
                 xr[g][1] = bo;
                 if (vec_out) {
                     const D2 rv = {re, rq}, bv = {be, bo};
-                    D2 *rp = reinterpret_cast<D2 *>(rot_t + 128 * g + 2 * lane);
+                    D2 *rp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(rot_t) + (unsigned)p * 8u);
                     if (ITD_NT & 1) __builtin_nontemporal_store(rv, rp); else *rp = rv;
                     if constexpr (!FINAL) {
-                        D2 *bp = reinterpret_cast<D2 *>(bas_t + 128 * g + 2 * lane);
+                        D2 *bp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(bas_t) + (unsigned)p * 8u);
                         if (ITD_NT & 2) __builtin_nontemporal_store(bv, bp); else *bp = bv;
                     }
                     has_nan = has_nan || (be != be) || (bo != bo);
                 } else {
-                    const int p = 128 * g + 2 * lane;
-                    if (i < n) {
+                    if (p < nrem) {
                         rot_t[p] = re;
                         if constexpr (!FINAL) bas_t[p] = be;
                         has_nan = has_nan || (be != be);
                     }
-                    if (i + 1 < n) {
+                    if (p + 1 < nrem) {
                         rot_t[p + 1] = rq;
                         if constexpr (!FINAL) bas_t[p + 1] = bo;
                         has_nan = has_nan || (bo != bo);
                     }
                 }
                 if (!FINAL && !careful && (near_end || s == 0)) {   // the next level's end samples, ITD.py:101-102
-                    if (i == 0) { ends_next[0] = be; ends_next[1] = bo; }
-                    if (i == n - 2) { ends_next[2] = be; ends_next[3] = bo; }
-                    if (i + 1 == n - 2) ends_next[2] = bo;
-                    if (i == n - 1) ends_next[3] = be;
+                    if (s == 0 && p == 0) { ends_next[0] = be; ends_next[1] = bo; }
+                    if (p == nrem - 2) { ends_next[2] = be; ends_next[3] = bo; }
+                    if (p + 1 == nrem - 2) ends_next[2] = bo;
+                    if (p == nrem - 1) ends_next[3] = be;
                 }
             }
         }
@@ -1429,10 +1443,7 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
 
     // ---- knots of the baseline just produced = the next level's input, on registers ------------------------------------
     // differences: d0 = even - left, d1 = odd - even, d2 = right - odd (= the next lane's d0)
-    const double blo_s = bits_d((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dbits(b_lo)),
-                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dbits(b_lo) >> 32)));
-    const double bhi_s = bits_d((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)dbits(b_hi)),
-                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(dbits(b_hi) >> 32)));
+    const double blo_s = s_bl[0], bhi_s = s_bl[1];   // written by lane 0 before the last wave_sync
     double d0[G2];
 #pragma unroll
     for (int g = 0; g < G2; ++g) {
@@ -1452,9 +1463,9 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         bool fe = ((d1 > 0.0) && (d0[g] <= 0.0)) || ((d1 < 0.0) && (d0[g] >= 0.0));
         bool fo = ((d2 > 0.0) && (d1 <= 0.0)) || ((d2 < 0.0) && (d1 >= 0.0));
         if (edge) {   // first and last sample are never knots (ITD.py:70-73); nothing beyond sample n-2
-            const int64_t i = s + 128 * g + 2 * lane;
-            fe = fe && (i >= 1) && (i <= n - 2);
-            fo = fo && (i + 1 <= n - 2);
+            const int p = 128 * g + 2 * lane;
+            fe = fe && (s > 0 || p >= 1) && (p <= nrem - 2);
+            fo = fo && (p + 1 <= nrem - 2);
         }
         const unsigned long long E = __ballot(fe), O = __ballot(fo);
         nm.set(2 * g, E);
