@@ -765,6 +765,7 @@ int itd_debug_stamps(unsigned long long *out16, int reset)
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_itd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return ITD_ERR_HIP;
     if (reset) {
         unsigned long long z[16] = {0};
+        z[9] = ~0ull;   // slot 9 = earliest wavefront start (atomicMin)
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_itd_stamps), z, sizeof(z)) != hipSuccess) return ITD_ERR_HIP;
     }
     return ITD_OK;

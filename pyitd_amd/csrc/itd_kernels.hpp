@@ -38,7 +38,12 @@
 // nontemporal).  Rotation rows are never read again by the engine and a level's input is read exactly once, so both
 // stream past the caches; the baseline is the next launch's input and stays cacheable (Infinity Cache hit).
 #ifndef ITD_NT
-#define ITD_NT 5
+#define ITD_NT 1
+#endif
+// timing-only ablations of k_extract_r (results are wrong by construction): 1 no count windows, 2 no speculative
+// records, 8 no knots inside the tile, 16 no group-sum atomic, 32 no count store, 64 no record store
+#ifndef ITD_ABL_R
+#define ITD_ABL_R 0
 #endif
 // ITD_STAMPS: diagnostic build only — per-phase shader-clock totals of k_extract (never in the shipped library)
 #ifdef ITD_STAMPS
@@ -59,7 +64,23 @@ __device__ unsigned long long g_itd_stamps[16];
         if ((threadIdx.x & 63) == 0)                                                          \
             for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
     } while (0)
+// k_extract_r: wave lifetime + phase sums of one launch (level ITD_STAMP_LEVEL), every 64th tile
+#ifndef ITD_STAMP_LEVEL
+#define ITD_STAMP_LEVEL 3
+#endif
+#define ITD_STAMP_END(t0__, on__)                                                              \
+    do {                                                                                      \
+        if ((on__) && (threadIdx.x & 63) == 0) {                                              \
+            const unsigned long long t1__ = __builtin_amdgcn_s_memtime();                     \
+            if ((blockIdx.x & 63) == 0) {                                                     \
+                for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
+                atomicAdd(&g_itd_stamps[8], t1__ - (t0__));                                   \
+                atomicAdd(&g_itd_stamps[11], 1ull);                                           \
+            }                                                                                 \
+        }                                                                                     \
+    } while (0)
 #else
+#define ITD_STAMP_END(t0__, on__) do { } while (0)
 #define ITD_STAMP_DECL() do { } while (0)
 #define ITD_STAMP_FLUSH() do { } while (0)
 #define ITD_STAMP(slot) do { } while (0)
@@ -1090,10 +1111,17 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     __shared__ double s_S[RK];      // slope of the segment that starts at slot L; before the slopes exist: the knots' indices
     __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
     __shared__ double s_bl[2];
+    __shared__ int32_t s_rb[9][16];   // first 64 bytes of up to nine neighbour records (speculative four + late five)
     __shared__ double s_hX[8];      // the five knots around the tile (value) ...
     __shared__ int32_t s_hI[8];     // ... and their sample indices
     int32_t *s_gi = reinterpret_cast<int32_t *>(s_S);
 
+    ITD_STAMP_DECL();
+#ifdef ITD_STAMPS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    const bool stamp_on = (level == ITD_STAMP_LEVEL);
+#endif
+    ITD_STAMP_BEGIN();
     const int lane = lane_id();
     const int t = blockIdx.x;
     const int sig = blockIdx.y;
@@ -1127,45 +1155,52 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         }
     }
     double xlo = 0.0, xhi = 0.0;   // samples s-1 and s+TW (wave-uniform addresses)
-    if (s >= 1) xlo = (double)x[s - 1];
-    if (s + TW < n) xhi = (double)x[s + TW];
+    if (s >= 1 && !(ITD_ABL_R & 512)) xlo = (double)x[s - 1];
+    if (s + TW < n && !(ITD_ABL_R & 512)) xhi = (double)x[s + TW];
     const TileRec *ro = recs + t;
-    const int own_c = ro->count;
+    const int own_c = (ITD_ABL_R & 8) ? 0 : ro->count;
     const unsigned long long own_word = ro->flags[lane < 2 * G2 ? lane : 0];   // lane j < 2*G2: flag word j
     const int tb = t - 1 - lane, tf = t + 1 + lane;
-    const int cb = (tb >= 0) ? cnts[tb] : 0;
-    const int cf = (tf < n_tiles) ? cnts[tf] : 0;
+    const int cb = (tb >= 0 && !(ITD_ABL_R & 1)) ? cnts[tb] : 0;
+    const int cf = (tf < n_tiles && !(ITD_ABL_R & 1)) ? cnts[tf] : 0;
 
-    // ---- candidate neighbour records (all requested at once) -----------------------------------------------------------
-    RecRegs h;
+    // ---- the neighbours' records, speculatively: lanes 16q..16q+15 fetch the first 64 bytes (count, first three / last
+    //      two knots) of tiles t-1, t+1, t-2, t+2 in ONE load that leaves with the tile's own — in all but the sparsest
+    //      levels the five knots around the tile are in there, and no load has to wait for the counts to come back --------
+    const int q4 = lane >> 4, w16 = lane & 15;
+    const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
+    int specw = 0;
+    if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & 2)) specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
+
+    // ---- candidate tiles: nearest non-empty ones in the +-64-tile count windows ---------------------------------------------
+    int ub0 = -1, ub1 = -1, uf0 = -1, uf1 = -1, uf2 = -1, cb0 = 0, cf0 = 0, cf1 = 0;
     {
         unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
-        h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
-        h.cb0 = h.cf0 = h.cf1 = 0;
         if (mb) {
             const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-            h.ub0 = t - 1 - l; h.cb0 = __builtin_amdgcn_readlane(cb, l);
-            if (h.cb0 < 2 && mb) h.ub1 = t - 1 - (__ffsll((long long)mb) - 1);
+            ub0 = t - 1 - l; cb0 = __builtin_amdgcn_readlane(cb, l);
+            if (cb0 < 2 && mb) ub1 = t - 1 - (__ffsll((long long)mb) - 1);
         }
         if (mf) {
             const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
-            h.uf0 = t + 1 + l; h.cf0 = __builtin_amdgcn_readlane(cf, l);
-            if (h.cf0 < 3 && mf) {
+            uf0 = t + 1 + l; cf0 = __builtin_amdgcn_readlane(cf, l);
+            if (cf0 < 3 && mf) {
                 const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
-                h.uf1 = t + 1 + l1; h.cf1 = __builtin_amdgcn_readlane(cf, l1);
-                if (h.cf0 + h.cf1 < 3 && mf) h.uf2 = t + 1 + (__ffsll((long long)mf) - 1);
+                uf1 = t + 1 + l1; cf1 = __builtin_amdgcn_readlane(cf, l1);
+                if (cf0 + cf1 < 3 && mf) uf2 = t + 1 + (__ffsll((long long)mf) - 1);
             }
         }
-        const TileRec *rb0 = recs + as_vgpr(max(h.ub0, 0)), *rb1 = recs + as_vgpr(max(h.ub1, 0));
-        const TileRec *rf0 = recs + as_vgpr(max(h.uf0, 0)), *rf1 = recs + as_vgpr(max(h.uf1, 0));
-        const TileRec *rf2 = recs + as_vgpr(max(h.uf2, 0));
-        h.b0i1 = rb0->tidx[1]; h.b0i0 = rb0->tidx[0]; h.b0v1 = rb0->tval[1]; h.b0v0 = rb0->tval[0];
-        h.b1i1 = rb1->tidx[1]; h.b1v1 = rb1->tval[1];
-        h.f0i0 = rf0->hidx[0]; h.f0i1 = rf0->hidx[1]; h.f0i2 = rf0->hidx[2];
-        h.f0v0 = rf0->hval[0]; h.f0v1 = rf0->hval[1]; h.f0v2 = rf0->hval[2];
-        h.f1i0 = rf1->hidx[0]; h.f1i1 = rf1->hidx[1]; h.f1v0 = rf1->hval[0]; h.f1v1 = rf1->hval[1];
-        h.f2i0 = rf2->hidx[0]; h.f2v0 = rf2->hval[0];
     }
+    // staging slots: 0..3 = the speculative records, 4+k = candidate k fetched after all (rare)
+    auto slot_of = [&](int u, int k) { return u == t - 1 ? 0 : u == t + 1 ? 1 : u == t - 2 ? 2 : u == t + 2 ? 3 : 4 + k; };
+    const int sb0 = slot_of(ub0, 0), sb1 = slot_of(ub1, 1), sf0 = slot_of(uf0, 2), sf1 = slot_of(uf1, 3), sf2 = slot_of(uf2, 4);
+    s_rb[q4][w16] = specw;
+    if ((ub0 >= 0 && sb0 >= 4) || (ub1 >= 0 && sb1 >= 4) || (uf0 >= 0 && sf0 >= 4) || (uf1 >= 0 && sf1 >= 4)) {
+        const int uk = q4 == 0 ? ub0 : q4 == 1 ? ub1 : q4 == 2 ? uf0 : uf1;
+        const int sk = q4 == 0 ? sb0 : q4 == 1 ? sb1 : q4 == 2 ? sf0 : sf1;
+        if (uk >= 0 && sk >= 4) s_rb[sk][w16] = reinterpret_cast<const int32_t *>(recs + uk)[w16];
+    }
+    if (uf2 >= 0 && sf2 >= 4 && lane < 16) s_rb[8][lane] = reinterpret_cast<const int32_t *>(recs + uf2)[lane];
 
     const int stopped = st->stopped;
     const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
@@ -1194,81 +1229,79 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     }
     if (stopped) return;
 
-    // ---- halo knots (scalar): two in front of the tile, three behind (see k_extract) -------------------------------------
-    int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
-    double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
+    // ---- halo knots: two in front of the tile (slot 1 starts the segment that enters the tile), three behind; lane k < 5
+    //      picks knot k out of the staged records.  Missing ones are the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).
     int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
-    {
-        if (h.ub0 >= 0) {
-            hi1 = sgpr(h.b0i1); hx1 = sgpr(h.b0v1); nb = 1;
-            if (h.cb0 >= 2) { hi0 = sgpr(h.b0i0); hx0 = sgpr(h.b0v0); nb = 2; }
-            else if (h.ub1 >= 0) { hi0 = sgpr(h.b1i1); hx0 = sgpr(h.b1v1); nb = 2; }
-        }
-        if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further
-            int far = t - 65;
-            while (nb < 2) {
-                int cu;
-                const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
-                if (u < 0) break;
-                far = u - 1;
-                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
-                const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
-                const double v1 = r->tval[1], v0 = r->tval[0];
-                if (nb == 0) { hi1 = i1; hx1 = v1; } else { hi0 = i1; hx0 = v1; }
-                ++nb;
-                if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
-            }
-        }
-        if (h.uf0 >= 0) {
-            hi2 = sgpr(h.f0i0); hx2 = sgpr(h.f0v0); nf = 1;
-            if (h.cf0 >= 2) { hi3 = sgpr(h.f0i1); hx3 = sgpr(h.f0v1); nf = 2; }
-            if (h.cf0 >= 3) { hi4 = sgpr(h.f0i2); hx4 = sgpr(h.f0v2); nf = 3; }
-            if (nf < 3 && h.uf1 >= 0) {
-                if (nf == 1) {
-                    hi3 = sgpr(h.f1i0); hx3 = sgpr(h.f1v0); nf = 2;
-                    if (h.cf1 >= 2) { hi4 = sgpr(h.f1i1); hx4 = sgpr(h.f1v1); nf = 3; }
-                } else {
-                    hi4 = sgpr(h.f1i0); hx4 = sgpr(h.f1v0); nf = 3;
-                }
-                if (nf < 3 && h.uf2 >= 0) { hi4 = sgpr(h.f2i0); hx4 = sgpr(h.f2v0); nf = 3; }
-            }
-        }
-        if (nf < 3 && t + 65 < n_tiles) {
-            int far = t + 65;
-            while (nf < 3) {
-                int cu;
-                const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
-                if (u < 0) break;
-                far = u + 1;
-                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
-                const int32_t i0 = r->hidx[0], i1 = r->hidx[1], i2 = r->hidx[2];
-                const double v0 = r->hval[0], v1 = r->hval[1], v2 = r->hval[2];
-                if (nf == 0) {
-                    hi2 = i0; hx2 = v0;
-                    if (cu >= 2) { hi3 = i1; hx3 = v1; }
-                    if (cu >= 3) { hi4 = i2; hx4 = v2; }
-                    nf = min(cu, 3);
-                } else if (nf == 1) {
-                    hi3 = i0; hx3 = v0;
-                    if (cu >= 2) { hi4 = i1; hx4 = v1; }
-                    nf = 1 + min(cu, 2);
-                } else {
-                    hi4 = i0; hx4 = v0;
-                    nf = 3;
-                }
-            }
-        }
-    }
-
-    // park the five knots in LDS: they are scalars no longer
-    const bool behind_at_edge = (nf >= 1) && (hi2 == (int32_t)(s + TW));   // sample s+TW is itself a knot
+    if (ub0 >= 0) nb = (cb0 >= 2 || ub1 >= 0) ? 2 : 1;
+    if (uf0 >= 0) nf = min(3, cf0 + cf1 + (uf2 >= 0 ? 1 : 0));
+    wave_sync();
     if (lane < 5) {
-        s_hX[lane] = lane == 0 ? hx0 : lane == 1 ? hx1 : lane == 2 ? hx2 : lane == 3 ? hx3 : hx4;
-        s_hI[lane] = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
+        int sl, iw, vw;
+        bool real;
+        if (lane < 2) {
+            real = (lane == 1) ? (nb >= 1) : (nb >= 2);
+            const bool from0 = (lane == 1) || (cb0 >= 2);          // slot 0: ub0's second last knot, or ub1's last
+            const int which = (lane == 1 || !from0) ? 1 : 0;       // tidx[1] / tval[1] = the record's last knot
+            sl = from0 ? sb0 : sb1;
+            iw = 4 + which;
+            vw = 12 + 2 * which;
+        } else {
+            int j = lane - 2;
+            real = j < nf;
+            const int c0 = min(cf0, 3), c1 = min(cf1, 3);
+            if (j < c0) sl = sf0;
+            else if (j - c0 < c1) { sl = sf1; j -= c0; }
+            else { sl = sf2; j -= c0 + c1; }
+            iw = 1 + j;
+            vw = 6 + 2 * j;
+        }
+        int32_t idx = lane < 2 ? 0 : (int32_t)(n - 1);
+        double val = lane < 2 ? e0 : e3;
+        if (real) {
+            idx = s_rb[sl][iw];
+            val = bits_d((unsigned)s_rb[sl][vw], (unsigned)s_rb[sl][vw + 1]);
+        }
+        s_hX[lane] = val;
+        s_hI[lane] = idx;
     }
     if (lane < 2) s_bl[lane] = 0.0;
     wave_sync();
+    // only when a 64-tile window ran dry does the search walk on through the group sums (dependent loads, rare)
+    if (nb < 2 && t - 65 >= 0 && !(ITD_ABL_R & 1024)) {
+        int far = t - 65;
+        while (nb < 2) {
+            int cu;
+            const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
+            if (u < 0) break;
+            far = u - 1;
+            const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+            const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
+            const double v1 = r->tval[1], v0 = r->tval[0];
+            if (lane == 0) { s_hI[nb == 0 ? 1 : 0] = i1; s_hX[nb == 0 ? 1 : 0] = v1; }
+            ++nb;
+            if (nb < 2 && cu >= 2) {
+                if (lane == 0) { s_hI[0] = i0; s_hX[0] = v0; }
+                ++nb;
+            }
+        }
+        wave_sync();
+    }
+    if (nf < 3 && t + 65 < n_tiles && !(ITD_ABL_R & 1024)) {
+        int far = t + 65;
+        while (nf < 3) {
+            int cu;
+            const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
+            if (u < 0) break;
+            far = u + 1;
+            const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+            const int take = min(cu, 3 - nf);
+            if (lane < take) { s_hI[2 + nf + lane] = r->hidx[lane]; s_hX[2 + nf + lane] = r->hval[lane]; }
+            nf += take;
+        }
+        wave_sync();
+    }
 
+    ITD_STAMP(0);
     // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
     const int c = own_c;
     WaveMasks wm;
@@ -1290,6 +1323,7 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         for (int g = 0; g < G2; ++g) kinfo[g] = 0;
     }
 
+    ITD_STAMP(1);
     double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
     double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
     const bool vec_out = full && ((reinterpret_cast<uintptr_t>(rot_t) & 15) == 0) &&
@@ -1354,6 +1388,7 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             }
         }
         wave_sync();
+        ITD_STAMP(2);
         if (g1 < G2 && lane < 2) { s_hX[5 + lane] = s_X[m + lane]; s_hI[5 + lane] = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
         // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
         for (int L = 1 + lane; L <= m + 3; L += kWave) {
@@ -1376,12 +1411,13 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             if (!endn) s_S[L] = sl;
         }
         wave_sync();
+        ITD_STAMP(3);
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
             if (g0 == 0 && s >= 1) s_bl[0] = s_B[1] + s_S[1] * (xlo - s_X[1]);
             const int64_t i = s + TW;
             if (g1 == G2 && i < n - 1) {
-                const int L = behind_at_edge ? m + 2 : 1 + m;
+                const int L = (nf >= 1 && s_hI[2] == (int32_t)i) ? m + 2 : 1 + m;   // sample s+TW is itself a knot
                 s_bl[1] = s_B[L] + s_S[L] * (xhi - s_X[L]);
             }
         }
@@ -1437,6 +1473,7 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         rb += m;
         g0 = g1;
         wave_sync();
+        ITD_STAMP(4);
     }
     if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
     if (careful) return;   // k_careful_apply scans the baseline after the reference's NaN -> inf mutation
@@ -1474,9 +1511,19 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         total += gcount[g];
     }
     const size_t slot = slot0 + t;
+    ITD_STAMP(5);
     if (total == 0) {   // nothing to tell the next launch but the count (most tiles of the deep levels)
         if (lane == 0) { recs_out[slot].count = 0; counts_out[slot] = 0; }
+        ITD_STAMP_END(t_begin, stamp_on);
         return;
+    }
+    // count and group sum leave first: a wavefront cannot retire before its last store is acknowledged, so the late ones
+    // should be as early as possible
+    if (lane == 0) {
+        if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
+        if (ITD_ABL_R & 128) gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch] = total;          // plain store instead
+        else if (ITD_ABL_R & 256) atomicAdd(&gsum_out[((size_t)sig * n_groups + (t & (n_groups - 1))) * kGsumPitch], total);   // spread over the groups
+        else if (!(ITD_ABL_R & 16)) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
     }
     // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample)
     TileRec *lrec = reinterpret_cast<TileRec *>(s_rec);
@@ -1505,14 +1552,12 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     if (lane == 0) lrec->count = total;
     if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
     wave_sync();
-    if (lane < kRecLanes) {   // kRecLanes x 16 bytes = the whole record, one store
+    if (lane < kRecLanes && !(ITD_ABL_R & 64)) {   // kRecLanes x 16 bytes = the whole record, one store
         using I4 = __attribute__((ext_vector_type(4))) int;
         reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
     }
-    if (lane == 0) {
-        counts_out[slot] = total;
-        atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
-    }
+    ITD_STAMP(6);
+    ITD_STAMP_END(t_begin, stamp_on);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -45,6 +45,34 @@ __global__ void k_level_c(const double* __restrict__ in, double* __restrict__ ro
     }
 }
 
+// the extraction's per-tile outputs on top of the streams: EX bit 0 = one device-scope atomicAdd per block on a padded
+// group sum shared by 64 consecutive blocks, bit 1 = one 4-byte count store per block, bit 2 = one 128-byte record per block
+template <int EX>
+__global__ void k_level_x(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas,
+                          int* __restrict__ gsum, int* __restrict__ counts, int4* __restrict__ recs)
+{
+    using V = double __attribute__((ext_vector_type(2)));
+    const size_t base = (size_t)blockIdx.x * 512;
+    const V* vi = reinterpret_cast<const V*>(in + base);
+    V* v1 = reinterpret_cast<V*>(rot + base);
+    V* v2 = reinterpret_cast<V*>(bas + base);
+    double acc = 0;
+    for (int k = threadIdx.x; k < 256; k += 64) {
+        V x = vi[k];
+        V a = x * 0.5;
+        V b = x - a;
+        __builtin_nontemporal_store(b, &v1[k]);
+        v2[k] = a;
+        acc += a.x;
+    }
+    const int total = 1 + (acc > 1e300);
+    if ((EX & 4) && threadIdx.x < 8) recs[(size_t)blockIdx.x * 8 + threadIdx.x] = make_int4(total, 1, 2, 3);
+    if (threadIdx.x == 0) {
+        if (EX & 2) counts[blockIdx.x] = total;
+        if (EX & 1) atomicAdd(&gsum[(blockIdx.x / 64) * 32], total);
+    }
+}
+
 int main()
 {
     const size_t n = 1ull << 24;
@@ -78,5 +106,14 @@ int main()
     run("layout C (64 B per lane) nt=5", [&](const double* i, double* r, double* b) { k_level_c<5><<<(int)(n / 512), 64>>>(i, r, b); });
     VAR(2, 0, 64, 512)
     run("layout C (64 B per lane) nt=0", [&](const double* i, double* r, double* b) { k_level_c<0><<<(int)(n / 512), 64>>>(i, r, b); });
+    int *gsum, *counts; int4* recs;
+    CK(hipMalloc(&gsum, 512 * 32 * 4)); CK(hipMalloc(&counts, 32768 * 4)); CK(hipMalloc(&recs, 32768 * 128));
+    CK(hipMemset(gsum, 0, 512 * 32 * 4));
+    run("16B/lane nt=1 x=0 (streams only)", [&](const double* i, double* r, double* b) { k_level_x<0><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
+    run("16B/lane nt=1 x=1 (+atomic)", [&](const double* i, double* r, double* b) { k_level_x<1><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
+    run("16B/lane nt=1 x=2 (+count store)", [&](const double* i, double* r, double* b) { k_level_x<2><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
+    run("16B/lane nt=1 x=4 (+record store)", [&](const double* i, double* r, double* b) { k_level_x<4><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
+    run("16B/lane nt=1 x=7 (+all three)", [&](const double* i, double* r, double* b) { k_level_x<7><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
+    run("16B/lane nt=1 x=0 (streams only)", [&](const double* i, double* r, double* b) { k_level_x<0><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
     return 0;
 }
