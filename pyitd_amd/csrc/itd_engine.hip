@@ -25,10 +25,6 @@ using namespace itd;
 
 namespace {
 constexpr int T = ITD_TILE;
-#ifndef ITD_PERSIST
-#define ITD_PERSIST 0
-#endif
-constexpr bool kPersist = ITD_PERSIST != 0;  // resident wavefronts loop over tiles with a software pipeline
 static_assert(T % 128 == 0 && T / 64 <= kMaxGroups, "tile geometry: whole 8/16-byte loads per lane, <= 8 flag words per record");
 
 // per-signal state + the (padded) group sums of all three rotating buffers, one launch
@@ -75,7 +71,6 @@ struct itd_engine {
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
     int64_t ws_bytes = 0;
-    int64_t resident_wg = 0;       // workgroups of k_extract that fit on the GPU at once (persistent mode)
     // host-convenience staging (grow only)
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
@@ -146,10 +141,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int n_tiles = (int)tiles_of(n);
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
-    const dim3 blk(kBlock);
-    const dim3 grid_t((n_tiles + kWPB - 1) / kWPB, batch);                      // k_detect: kWPB tiles per workgroup
-    const int64_t all_wg = ((int64_t)n_tiles * batch + kWPB - 1) / kWPB;          // persistent k_extract: flattened (signal, tile)
-    const dim3 grid_p = kPersist ? dim3((unsigned)std::min<int64_t>(all_wg, e->resident_wg)) : grid_t;
+    const dim3 blk(kWave);
+    const dim3 grid_t(n_tiles, batch);   // one one-wavefront workgroup per tile
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
@@ -186,23 +179,16 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *rot_out = rows + (int64_t)j * n;
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
-#if ITD_REGTILE
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
-    k_extract_r<TIN, T, FIN, kRankCapR><<<dim3(n_tiles, batch), kWave, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
+    k_extract<TIN, T, FIN, kRankCap><<<grid_t, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
                                                     cnt(j + 1), rec(j), rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,  \
                                                     rows_stride, base_out, base_stride, e->d_state, j, 0)
-#else
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
-    k_extract<TIN, T, FIN, kPersist, CAPK><<<grid_p, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j), cnt(j + 1), rec(j),        \
-                                                    rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out, rows_stride,     \
-                                                    base_out, base_stride, e->d_state, j, 0)
-#endif
         if (j == 0) {
-            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride, kRankCap0);
-            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride, kRankCap0);
+            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride);
+            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride);
         } else {
-            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap);
-            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap);
+            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride);
+            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride);
         }
 #undef ITD_LAUNCH_EXTRACT
         time_end(e, pair, st);
@@ -247,9 +233,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
-    const dim3 grid_t(n_tiles, 1), blk(kWave);                       // one-wavefront workgroups (k_careful_*)
-    const dim3 grid_d((n_tiles + kWPB - 1) / kWPB, 1), blk_d(kBlock);  // k_detect / k_extract
-    const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
+    const dim3 grid_t(n_tiles, 1), blk(kWave);   // one one-wavefront workgroup per tile
     const Tin *x = (const Tin *)e->last_x + (int64_t)b * e->last_x_stride;
     double *rows = e->last_rows + (int64_t)b * rows_stride;
     double *bases_user = e->last_bases ? e->last_bases + (int64_t)b * rows_stride : nullptr;
@@ -264,7 +248,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     for (int q = 0; q < 3; ++q)
         HIP_TRY(e, hipMemsetAsync(gs(q), 0, sizeof(int32_t) * (size_t)n_groups * kGsumPitch, st));
     if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
-    k_detect<Tin, T><<<grid_d, blk_d, 0, st>>>(x, n, n, n_tiles, (int)kKnots, nullptr, cnt(0), rec(0), gs(0), state);
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, (int)kKnots, nullptr, cnt(0), rec(0), gs(0), state);
     for (int j = 0; j <= M + 1; ++j) {
         double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->max_n;
         const double *base_in = nullptr;
@@ -275,25 +259,14 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         const bool final_level = (j == M + 1);
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
-#if ITD_REGTILE
         if (j == 0)
-            k_extract_r<Tin, T, false, kRankCapR><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+            k_extract<Tin, T, false, kRankCap><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
                                                                         n, base_out, n, state, j, 1);
         else
-            k_extract_r<double, T, false, kRankCapR><<<dim3(n_tiles), kWave, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+            k_extract<double, T, false, kRankCap><<<dim3(n_tiles), kWave, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
                                                                            rec(j), rec(j + 1), gs(j), gs(j + 1),
                                                                            gs(j + 2), rot_out, n, base_out, n, state, j, 1);
-#else
-        if (j == 0)
-            k_extract<Tin, T, false, false, kRankCap0><<<grid_p, blk_d, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
-                                                                        rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
-                                                                        n, base_out, n, state, j, 1);
-        else
-            k_extract<double, T, false, false, kRankCap><<<grid_p, blk_d, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
-                                                                           rec(j), rec(j + 1), gs(j), gs(j + 1),
-                                                                           gs(j + 2), rot_out, n, base_out, n, state, j, 1);
-#endif
         k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
         k_careful_apply<T><<<grid_t, blk, 0, st>>>(base_out, n, n_tiles, cnt(j + 1), rec(j + 1), gs(j + 1), state, j + 1);
         if (final_level)   // ITD.py:420: rotation_ + baseline_ (baseline_ already mutated by the stop test)
@@ -370,16 +343,6 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->max_batch = max_batch;
     e->max_tiles = tiles_of(max_n);
     DevGuard g(device_id);
-    {
-        hipDeviceProp_t prop;
-        int per_cu = 0;
-        if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete e; return ITD_ERR_HIP; }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extract<double, T, false, true, kRankCap>, kBlock, 0) != hipSuccess || per_cu < 1)
-            per_cu = 8;
-        const char *env = getenv("PYITD_WG_PER_CU");
-        if (env && atoi(env) > 0) per_cu = atoi(env);
-        e->resident_wg = (int64_t)prop.multiProcessorCount * per_cu;
-    }
     const size_t B = (size_t)max_batch;
     const int max_groups = groups_of((int)e->max_tiles);
     e->tiles_half = (int64_t)B * e->max_tiles;
@@ -549,10 +512,9 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
 {
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kWave);
-    const dim3 grid_d((n_tiles + kWPB - 1) / kWPB, 1), blk_d(kBlock);
     k_init_state<<<(unsigned)std::min<int64_t>((3 * e->gsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_state, 1, e->d_gsum,
                                                                                                   3 * e->gsum_third);
-    k_detect<Tin, T><<<grid_d, blk_d, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
                                               e->d_recs, e->d_gsum, e->d_state);
     if (compact)
         k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_counts, e->d_gsum, n_tiles, n, e->d_kidx, e->max_n + 2,
@@ -578,23 +540,13 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     const int n_tiles = (int)tiles_of(n);
-    const dim3 blk(kBlock);
     const bool want_list = m_host || knots || want_sync;
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
-    const dim3 grid_p((n_tiles + kWPB - 1) / kWPB);
-#if ITD_REGTILE
-    (void)grid_p;
-    k_extract_r<Tin, T, false, kRankCapR><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+    k_extract<Tin, T, false, kRankCap><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);
-#else
-    k_extract<Tin, T, false, false, kRankCap0><<<grid_p, blk, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
-                                                      e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
-                                                      e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
-                                                      rot, n, base, n, e->d_state, 0, 0);
-#endif
     HIP_TRY(e, hipGetLastError());
     if (want_list) {
         int64_t m = 0;

@@ -31,16 +31,13 @@
 
 #pragma clang fp contract(off)
 
-#ifndef ITD_ABLATE
-#define ITD_ABLATE 0
-#endif
 // cache policy of k_extract's streams (bit 0: rotation stores, bit 1: baseline stores, bit 2: tile loads are
 // nontemporal).  Rotation rows are never read again by the engine and a level's input is read exactly once, so both
 // stream past the caches; the baseline is the next launch's input and stays cacheable (Infinity Cache hit).
 #ifndef ITD_NT
-#define ITD_NT 1
+#define ITD_NT 5
 #endif
-// timing-only ablations of k_extract_r (results are wrong by construction): 1 no count windows, 2 no speculative
+// timing-only ablations of k_extract (results are wrong by construction): 1 no count windows, 2 no speculative
 // records, 8 no knots inside the tile, 16 no group-sum atomic, 32 no count store, 64 no record store
 #ifndef ITD_ABL_R
 #define ITD_ABL_R 0
@@ -64,7 +61,7 @@ __device__ unsigned long long g_itd_stamps[16];
         if ((threadIdx.x & 63) == 0)                                                          \
             for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
     } while (0)
-// k_extract_r: wave lifetime + phase sums of one launch (level ITD_STAMP_LEVEL), every 64th tile
+// k_extract: wave lifetime + phase sums of one launch (level ITD_STAMP_LEVEL), every 64th tile
 #ifndef ITD_STAMP_LEVEL
 #define ITD_STAMP_LEVEL 3
 #endif
@@ -89,29 +86,13 @@ __device__ unsigned long long g_itd_stamps[16];
 
 namespace itd {
 
-constexpr int kWave = 64;              // one wavefront per tile
-#ifndef ITD_WPB
-#define ITD_WPB 1
-#endif
-constexpr int kWPB = ITD_WPB;          // independent wavefronts per workgroup (they share nothing but the launch slot)
-constexpr int kBlock = kWave * kWPB;
-// knots one pass of k_extract can hold by rank (>= 64: a 64-sample group always fits).  Smaller = less LDS = more
-// wavefronts per CU but more passes over a dense tile: the level-0 launch (densest knots) gets the larger one.
-#ifndef ITD_RANK_CAP0
-#define ITD_RANK_CAP0 136
-#endif
+constexpr int kWave = 64;              // one wavefront per tile, one tile per workgroup
+// knots one pass of k_extract holds by rank (>= 128: a 128-sample group always fits); denser tiles take more passes
 #ifndef ITD_RANK_CAP
-#define ITD_RANK_CAP 72
+#define ITD_RANK_CAP 136
 #endif
-constexpr int kRankCap0 = ITD_RANK_CAP0, kRankCap = ITD_RANK_CAP;
-// k_extract_r works in 128-sample groups: one pass must hold a whole group's knots
-#ifndef ITD_RANK_CAP_R
-#define ITD_RANK_CAP_R 136
-#endif
-constexpr int kRankCapR = ITD_RANK_CAP_R;
+constexpr int kRankCap = ITD_RANK_CAP;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-// wave-uniform by construction: tell the compiler so (keeps tile indices, pointers and the halo search on the scalar unit)
-__device__ __forceinline__ int wave_in_block() { return kWPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 
 // Per-signal device state (one per batch element).
@@ -131,32 +112,37 @@ struct SigState {
 #ifndef ITD_TILE
 #define ITD_TILE 512
 #endif
-// ITD_REGTILE = 1 (shipped): k_extract_r keeps the tile in registers and the records use the interleaved flag format:
-// word 2g = knot flags of the EVEN positions of 128-sample group g (bit l <-> position 128 g + 2 l), word 2g+1 = the odd
-// ones.  0: the LDS-tile kernel k_extract with one word per 64-sample group (bit l of word g <-> position 64 g + l).
-#ifndef ITD_REGTILE
-#define ITD_REGTILE 1
-#endif
-constexpr bool kInterleaved = ITD_REGTILE != 0;
-__device__ __forceinline__ int flag_pos(int word, int bit)
-{
-    return kInterleaved ? 128 * (word >> 1) + 2 * bit + (word & 1) : 64 * word + bit;
-}
+// Flag words of a tile (interleaved format): word 2g = knot flags of the EVEN positions of 128-sample group g (bit l <->
+// position 128 g + 2 l), word 2g+1 = the odd ones — the layout in which k_extract holds a tile in registers.
+__device__ __forceinline__ int flag_pos(int word, int bit) { return 128 * (word >> 1) + 2 * bit + (word & 1); }
 constexpr int kMaxGroups = (ITD_TILE / 64 <= 8) ? 8 : 16;   // flag words per record (tiles of up to 512 / 1024 samples)
 
-// What the producer of a tile's knots leaves for the next launch (128 bytes = one line, one per tile): the first 64
-// bytes are for the tile's neighbours, the flag words for the tile itself.
+// What the producer of a tile's knots leaves for the next launch (128 bytes = one line per tile).  The first 64 bytes
+// are for the tile's neighbours: they fetch them speculatively together with their own tile (k_extract), so they hold
+// everything a neighbour can need — including the tile's first and last sample, which are the neighbour's samples s+TW
+// and s-1: re-reading those two from the signal would touch lines the owning tile streams past the caches.
 struct TileRec {
-    int32_t count;     // knots in the tile
-    int32_t hidx[3];   // its first min(count,3) knots ...
-    int32_t tidx[2];   // ... and its last two: tidx[1] = last, tidx[0] = second last (count >= 2)
-    double hval[3];    // values of the level's input at those knots
-    double tval[2];
-    unsigned long long flags[kMaxGroups];   // the tile's knot flags, one 64-bit word per 64-sample group: the consumer of
-                                            // the tile (next launch, same tile) reads them instead of re-running the predicate
+    unsigned long long packed;   // bits 0..10 knot count; 10-bit tile positions of the first three knots at bits 11, 21, 31,
+                                 // of the second-last knot at bit 41 and of the last knot at bit 51
+    double hval[3];              // values of the level's input at the first min(count,3) knots ...
+    double tval[2];              // ... and at the last two: tval[1] = last, tval[0] = second last (count >= 2)
+    double edge[2];              // the tile's first and last sample (positions 0 and TW-1) of the level's input
+    unsigned long long flags[kMaxGroups];   // the tile's knot flags (flag_pos): the consumer of the tile (next launch, same
+                                            // tile) reads them instead of re-running the predicate
 };
 static_assert(sizeof(TileRec) == 64 + 8 * kMaxGroups && sizeof(TileRec) % 16 == 0, "TileRec layout");
+static_assert(ITD_TILE <= 1024, "10-bit knot positions");
 constexpr int kRecLanes = sizeof(TileRec) / 16;   // 16-byte lanes that move one record
+// dword offsets inside the first 64 bytes (what the staged copies in LDS are indexed with)
+constexpr int kRecDwHval = 2, kRecDwTval = 8, kRecDwEdge = 12;
+__host__ __device__ constexpr unsigned long long rec_pack(int count, int h0, int h1, int h2, int t0, int t1)
+{
+    return (unsigned long long)count | ((unsigned long long)h0 << 11) | ((unsigned long long)h1 << 21) |
+           ((unsigned long long)h2 << 31) | ((unsigned long long)t0 << 41) | ((unsigned long long)t1 << 51);
+}
+__host__ __device__ constexpr int rec_count(unsigned long long p) { return (int)(p & 0x7ffull); }
+__host__ __device__ constexpr int rec_hpos(unsigned long long p, int k) { return (int)((p >> (11 + 10 * k)) & 0x3ffull); }   // k = 0..2
+__host__ __device__ constexpr int rec_tpos(unsigned long long p, int k) { return (int)((p >> (41 + 10 * k)) & 0x3ffull); }   // k = 0: second last, 1: last
 
 enum DetectMode : int { kKnots = 0, kValleys = 1, kPeaks = 2 };
 
@@ -327,8 +313,9 @@ __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, i
     return total;
 }
 
-// producer side: the tile's record for the next launch and (optionally, API helpers) its ordered knot list.
-// The first three / last two knots are found with scalar bit scans of the wave-uniform flag words.
+// producer side (LDS tile: level-0 scan, NaN-faithful path, API helpers): the tile's record for the next launch and
+// (optionally) its ordered knot list.  The first three / last two knots are found with scalar bit scans of the
+// wave-uniform flag words, merging the even and odd word of each 128-sample group in sample order.
 template <int TW>
 __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, int mode,
                                            int32_t *__restrict__ list, TileRec *__restrict__ rec,
@@ -339,13 +326,8 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
     const int lane = lane_id();
     WaveMasks wm;
     const int total = scan_flags<TW>(tile, s, n, mode, wm);
-    if (total == 0) {   // nothing to tell the next launch but the count (most tiles of the deep levels)
-        if (lane == 0 && !(ITD_ABLATE & 64)) rec->count = 0;
-        return 0;
-    }
     int h0 = 0, h1 = 0, h2 = 0, t0 = 0, t1 = 0;
-    if constexpr (kInterleaved) {
-        // positions 128 g + 2 b (even word) and 128 g + 2 b + 1 (odd word): merge the two words of a group in sample order
+    if (total > 0) {
         int k = 0;
 #pragma unroll 1
         for (int g = 0; g < G / 2 && k < 3; ++g) {
@@ -372,65 +354,34 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
                 ++k;
             }
         }
-    } else {
-        int k = 0;
-#pragma unroll 1
-        for (int g = 0; g < G && k < 3; ++g) {
-            unsigned long long m = wm.get(g);
-            while (m && k < 3) {
-                const int pos = g * 64 + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (k == 0) h0 = pos; else if (k == 1) h1 = pos; else h2 = pos;
-                ++k;
-            }
-        }
-        k = 0;
-#pragma unroll 1
-        for (int g = G - 1; g >= 0 && k < 2; --g) {
-            unsigned long long m = wm.get(g);
-            while (m && k < 2) {
-                const int b = 63 - __clzll((long long)m);
-                m &= ~(1ull << b);
-                if (k == 0) t1 = g * 64 + b; else t0 = g * 64 + b;
-                ++k;
-            }
-        }
     }
-    // assemble the 128-byte record in LDS, then hand it to HBM with ONE 8-lane x 16-byte store
+    // assemble the record in LDS, then hand it to HBM with one store of 16-byte lanes (an empty tile: the neighbours' half only)
     TileRec *lrec = reinterpret_cast<TileRec *>(rec_lds);
     if (lane < 5) {
         const int pos = lane == 0 ? h0 : lane == 1 ? h1 : lane == 2 ? h2 : lane == 3 ? t0 : t1;
-        const int32_t idx = (int32_t)(s + pos);
         const double v = tile.at(pos);
-        if (lane < 3) { lrec->hidx[lane] = idx; lrec->hval[lane] = v; }
-        else          { lrec->tidx[lane - 3] = idx; lrec->tval[lane - 3] = v; }
+        if (lane < 3) lrec->hval[lane] = v;
+        else          lrec->tval[lane - 3] = v;
     }
-    if (lane == 5) lrec->count = total;
+    if (lane == 5) lrec->packed = rec_pack(total, h0, h1, h2, t0, t1);
+    if (lane == 6) lrec->edge[0] = tile.at(0);
+    if (lane == 7) lrec->edge[1] = tile.at(TW - 1);
     if (lane < G) lrec->flags[lane] = ((unsigned long long)wm.hi << 32) | wm.lo;   // lane g holds word g
     wave_sync();
-    if (lane < kRecLanes && !(ITD_ABLATE & 64)) {   // kRecLanes x 16 bytes = the whole record, one store
+    if (lane < (total > 0 ? kRecLanes : 4)) {
         using I4 = __attribute__((ext_vector_type(4))) int;
         reinterpret_cast<I4 *>(rec)[lane] = reinterpret_cast<const I4 *>(rec_lds)[lane];
     }
     if (list) {
         int base = 0;
-        if constexpr (kInterleaved) {
 #pragma unroll 1
-            for (int g = 0; g < G / 2; ++g) {
-                const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
-                const int before = mbcnt64(O, mbcnt64(E, base));   // knots in front of the lane's even position
-                const int bE = (int)((E >> lane) & 1ull);
-                if (bE) list[before] = (int32_t)(s + 128 * g + 2 * lane);
-                if ((O >> lane) & 1ull) list[before + bE] = (int32_t)(s + 128 * g + 2 * lane + 1);
-                base += __popcll(E) + __popcll(O);
-            }
-        } else {
-#pragma unroll 1
-            for (int g = 0; g < G; ++g) {
-                const unsigned long long mk = wm.get(g);
-                if ((mk >> lane) & 1ull) list[mbcnt64(mk, base)] = (int32_t)(s + g * 64 + lane);
-                base += __popcll(mk);
-            }
+        for (int g = 0; g < G / 2; ++g) {
+            const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
+            const int before = mbcnt64(O, mbcnt64(E, base));   // knots in front of the lane's even position
+            const int bE = (int)((E >> lane) & 1ull);
+            if (bE) list[before] = (int32_t)(s + 128 * g + 2 * lane);
+            if ((O >> lane) & 1ull) list[before + bE] = (int32_t)(s + 128 * g + 2 * lane + 1);
+            base += __popcll(E) + __popcll(O);
         }
     }
     return total;
@@ -452,19 +403,18 @@ __device__ __forceinline__ void publish_ends(Tile<TW> tile, int64_t s, int64_t n
 // grid = (n_tiles, batch), 64 threads.  lists: [batch][n_tiles][TW] int32; counts/recs: [batch][n_tiles].
 // ---------------------------------------------------------------------------------------------
 template <typename Tin, int TW>
-__global__ __launch_bounds__(kBlock) void k_detect(const Tin *__restrict__ x, int64_t x_stride, int64_t n,
+__global__ __launch_bounds__(kWave) void k_detect(const Tin *__restrict__ x, int64_t x_stride, int64_t n,
                                                   int n_tiles, int mode, int32_t *__restrict__ lists,
                                                   int32_t *__restrict__ counts, TileRec *__restrict__ recs,
                                                   int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
 {
-    __shared__ __attribute__((aligned(16))) double s_x[kWPB][Tile<TW>::kSize];
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[kWPB][sizeof(TileRec) / 4];
-    const int t = blockIdx.x * kWPB + wave_in_block();
-    if (t >= n_tiles) return;
+    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
+    const int t = blockIdx.x;
     const int sig = blockIdx.y;
     const int64_t s = (int64_t)t * TW;
     const Tin *xs = x + (int64_t)sig * x_stride;
-    Tile<TW> tile{s_x[wave_in_block()]};
+    Tile<TW> tile{s_x};
     TileRegs<Tin, TW> regs;
     tile_fetch<Tin, TW>(regs, xs, n, s);
     tile_commit<Tin, TW>(regs, xs, n, s, tile);
@@ -480,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_detect(const Tin *__restrict__ x, in
         if (__any(nan_in) && lane_id() == 0) state[sig].in_nan = 1;
     }
     const size_t slot = (size_t)sig * n_tiles + t;
-    const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot, s_rec[wave_in_block()]);
+    const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot, s_rec);
     if (lane_id() == 0) {
         counts[slot] = total;
         if (total) atomicAdd(&gsum_out[((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch], total);
@@ -565,495 +515,16 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_extract: one extraction on one tile, one wavefront; grid = (n_tiles * batch / kWPB), kBlock threads.
+// k_extract: one extraction on one tile, one wavefront, the tile held in REGISTERS; grid = (n_tiles, batch), 64 threads.
 //   xin           level input (float32/float64 caller signal at level 0, float64 baseline afterwards)
-//   counts/recs   per-tile counts and records, double buffered by level parity (neighbours read them)
-//   gsum_in/out/clear   group sums, rotating by level % 3
+//   counts/recs   per-tile knot counts and records, double buffered by level parity (neighbours read them)
+//   gsum_in/out/clear   group sums of the counts, rotating by level % 3
 //   rot_out       rotation row   (FINAL: rotation + baseline, the "Out of time!" row, ITD.py:420)
 //   base_out      baseline row   (FINAL: not written)
 //   careful       NaN-faithful launch sequence: do not emit the next level's scan (k_careful_* does)
-// After the tile is staged everything is wave-synchronous.  Knot data lives in LDS BY RANK j:
-//   j = 0, 1          the two knots in front of the tile (rank 1 starts the segment that enters the tile)
-//   j = 2 .. c+1      the tile's own c knots, ascending
-//   j = c+2 .. c+4    the three knots behind the tile
-// with their sample index gi[j], value Xr[j], knot value Br[j] (ITD.py:100-110) and the slope Sr[j] of the segment
-// that starts there (ITD.py:115-116).  A sample's segment is rank 1 + (knots at or before it) — one v_mbcnt pair
-// on the group's flag word — so the baseline map is three indexed LDS reads and three flops per sample.
-// ---------------------------------------------------------------------------------------------
-// Raw record fields of the candidate neighbour tiles of one tile, fetched with per-lane (vector) loads of a
-// wave-uniform address: they are tracked by vmcnt, in order, so LDS traffic in between does not wait for them.
-struct RecRegs {
-    int ub0, ub1, cb0, uf0, uf1, uf2, cf0, cf1;   // candidate tiles (-1: none in the window) and their knot counts
-    int32_t b0i1, b0i0, b1i1, f0i0, f0i1, f0i2, f1i0, f1i1, f2i0;
-    double b0v1, b0v0, b1v1, f0v0, f0v1, f0v2, f1v0, f1v1, f2v0;
-};
-
-__device__ __forceinline__ int as_vgpr(int v)   // hide uniformity from the compiler: forces a vector (vmcnt) load
-{
-    int r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
-    return r;
-}
-__device__ __forceinline__ int32_t sgpr(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double sgpr(double v)
-{
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-template <typename Tin, int TW, bool FINAL, bool PERSIST, int CAP>
-__global__ __launch_bounds__(kBlock) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
-                                                    int n_tiles, int batch,
-                                                    const int32_t *__restrict__ counts_in,
-                                                    int32_t *__restrict__ counts_out,
-                                                    const TileRec *__restrict__ recs_in,
-                                                    TileRec *__restrict__ recs_out,
-                                                    const int32_t *__restrict__ gsum_in,
-                                                    int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
-                                                    double *__restrict__ rot_out, int64_t rot_stride,
-                                                    double *__restrict__ base_out, int64_t base_stride,
-                                                    SigState *__restrict__ state, int level, int careful)
-{
-    constexpr int G = TW / 64;    // 64-sample groups = 64-bit flag words per tile
-    static_assert(CAP >= 64, "a pass must be able to take one 64-sample group");
-    constexpr int RK = CAP + 8;   // by-rank slots: CAP knots of a pass + 2 in front + 3 behind (+ padding)
-    // one private LDS slice per wavefront of the workgroup
-    __shared__ __attribute__((aligned(16))) double sx_all[kWPB][Tile<TW>::kSize];  // the tile: input, then baseline in place
-    __shared__ double sX_all[kWPB][RK];      // value of the level's input at knot j
-    __shared__ double sB_all[kWPB][RK];      // knot value B_j
-    __shared__ double sS_all[kWPB][RK];      // slope of the segment that starts at knot j; before the slopes exist the same
-                                             // bytes hold the knots' sample indices gi[j] (dead once the B_j are known)
-    __shared__ __attribute__((aligned(16))) int32_t srec_all[kWPB][sizeof(TileRec) / 4];   // staging of the tile's record
-    __shared__ double shX_all[kWPB][2][8];   // [0]: the five knots around the TILE (value), [1]: around the current pass
-    __shared__ int32_t shI_all[kWPB][2][8];  // ... and their sample indices
-#ifdef ITD_LDS_PAD   // diagnostic: occupy extra LDS to study the sensitivity to wavefronts per CU
-    __shared__ int s_pad[ITD_LDS_PAD / 4];
-    if (n == -12345) s_pad[threadIdx.x] = level;
-    if (n == -12346) rot_out[0] = s_pad[threadIdx.x ^ 1];
-#endif
-    double *s_hX = shX_all[wave_in_block()][0], *s_pX = shX_all[wave_in_block()][1];
-    int32_t *s_hI = shI_all[wave_in_block()][0], *s_pI = shI_all[wave_in_block()][1];
-    double *s_x = sx_all[wave_in_block()];
-    double *s_X = sX_all[wave_in_block()], *s_B = sB_all[wave_in_block()], *s_S = sS_all[wave_in_block()];
-    int32_t *s_gi = reinterpret_cast<int32_t *>(sS_all[wave_in_block()]);
-
-    const int lane = lane_id();
-    const int64_t total_tiles = (int64_t)n_tiles * batch;
-    const int64_t NW = PERSIST ? (int64_t)gridDim.x * kWPB : 1;   // resident wavefronts (persistent mode)
-    // flattened (signal, tile) index.  Without PERSIST the grid is (tiles, batch): no division anywhere.
-    int64_t kflat;
-    if constexpr (PERSIST) {
-        kflat = (int64_t)blockIdx.x * kWPB + wave_in_block();
-        if (kflat >= total_tiles) return;
-    } else {
-        const int t_ = blockIdx.x * kWPB + wave_in_block();
-        if (t_ >= n_tiles) return;
-        kflat = (int64_t)blockIdx.y * n_tiles + t_;
-    }
-    auto split = [&](int64_t k, int &sig_o, int &t_o) {
-        if constexpr (PERSIST) {
-            sig_o = (int)((unsigned long long)k / (unsigned)n_tiles);
-            t_o = (int)(k - (int64_t)sig_o * n_tiles);
-        } else {
-            sig_o = blockIdx.y;
-            t_o = (int)(k - (int64_t)sig_o * n_tiles);
-        }
-    };
-    const int n_groups = groups_of(n_tiles);
-    Tile<TW> xt{s_x};
-    ITD_STAMP_DECL();
-
-    // ---- software pipeline (PERSIST): stage A = the neighbours' knot counts of the tile two steps ahead; stage B =
-    //      the next tile itself (registers) and its candidate neighbours' records; stage C = this tile.  Without
-    //      PERSIST (one wavefront per tile) the same code runs once, with the tile's loads issued first. -------------
-    auto stage_a = [&](int64_t k, int &cb, int &cf) {
-        int sig, t;
-        split(k, sig, t);
-        const int32_t *cnts = counts_in + (size_t)sig * n_tiles;
-        const int tb = t - 1 - lane, tf = t + 1 + lane;
-        cb = (tb >= 0) ? cnts[tb] : 0;
-        cf = (tf < n_tiles) ? cnts[tf] : 0;
-    };
-    auto fetch_tile = [&](int64_t k, TileRegs<Tin, TW> &regs) {
-        int sig, t;
-        split(k, sig, t);
-        tile_fetch<Tin, TW, (ITD_NT & 4) != 0>(regs, xin + (int64_t)sig * x_stride, n, (int64_t)t * TW);
-    };
-    auto fetch_recs = [&](int64_t k, int cb, int cf, RecRegs &h) {
-        int sig, t;
-        split(k, sig, t);
-        const TileRec *recs = recs_in + (size_t)sig * n_tiles;
-        unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
-        h.ub0 = h.ub1 = h.uf0 = h.uf1 = h.uf2 = -1;
-        h.cb0 = h.cf0 = h.cf1 = 0;
-        if (mb) {
-            const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-            h.ub0 = t - 1 - l; h.cb0 = __builtin_amdgcn_readlane(cb, l);
-            if (h.cb0 < 2 && mb) h.ub1 = t - 1 - (__ffsll((long long)mb) - 1);
-        }
-        if (mf) {
-            const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
-            h.uf0 = t + 1 + l; h.cf0 = __builtin_amdgcn_readlane(cf, l);
-            if (h.cf0 < 3 && mf) {
-                const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
-                h.uf1 = t + 1 + l1; h.cf1 = __builtin_amdgcn_readlane(cf, l1);
-                if (h.cf0 + h.cf1 < 3 && mf) h.uf2 = t + 1 + (__ffsll((long long)mf) - 1);
-            }
-        }
-        const TileRec *rb0 = recs + as_vgpr(max(h.ub0, 0)), *rb1 = recs + as_vgpr(max(h.ub1, 0));
-        const TileRec *rf0 = recs + as_vgpr(max(h.uf0, 0)), *rf1 = recs + as_vgpr(max(h.uf1, 0));
-        const TileRec *rf2 = recs + as_vgpr(max(h.uf2, 0));
-        h.b0i1 = rb0->tidx[1]; h.b0i0 = rb0->tidx[0]; h.b0v1 = rb0->tval[1]; h.b0v0 = rb0->tval[0];
-        h.b1i1 = rb1->tidx[1]; h.b1v1 = rb1->tval[1];
-        h.f0i0 = rf0->hidx[0]; h.f0i1 = rf0->hidx[1]; h.f0i2 = rf0->hidx[2];
-        h.f0v0 = rf0->hval[0]; h.f0v1 = rf0->hval[1]; h.f0v2 = rf0->hval[2];
-        h.f1i0 = rf1->hidx[0]; h.f1i1 = rf1->hidx[1]; h.f1v0 = rf1->hval[0]; h.f1v1 = rf1->hval[1];
-        h.f2i0 = rf2->hidx[0]; h.f2v0 = rf2->hval[0];
-    };
-
-    TileRegs<Tin, TW> regs;
-    RecRegs rr;
-    int cbA = 0, cfA = 0;
-    fetch_tile(kflat, regs);
-    // this tile's own knot count and flag words (stored by its producer), requested with everything else
-    int own_c = 0;
-    unsigned long long own_word = 0ull;   // lane g < G: flag word g
-    auto fetch_own = [&](int64_t k) {
-        const TileRec *ro = recs_in + k;   // recs are [signal][tile] = flattened index
-        own_c = ro->count;
-        own_word = ro->flags[lane < G ? lane : 0];
-    };
-    fetch_own(kflat);
-    stage_a(kflat, cbA, cfA);
-    fetch_recs(kflat, cbA, cfA, rr);
-    if constexpr (PERSIST)
-        if (kflat + NW < total_tiles) stage_a(kflat + NW, cbA, cfA);
-
-    int sig_cur = -1, stopped = 0;
-    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
-  for (;;) {   // one iteration per tile (exactly one without PERSIST)
-    int sig, t;
-    split(kflat, sig, t);
-    SigState *st = state + sig;
-    const int64_t s = (int64_t)t * TW;
-    const Tin *x = xin + (int64_t)sig * x_stride;
-    const size_t slot0 = (size_t)sig * n_tiles;
-    const int32_t *cnts = counts_in + slot0;
-    const TileRec *recs = recs_in + slot0;
-    const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
-    ITD_STAMP_BEGIN();
-    if (sig != sig_cur) {   // the signal's state: once per signal and wavefront
-        sig_cur = sig;
-        stopped = st->stopped;
-        e0 = st->ends[level & 1][0]; e1 = st->ends[level & 1][1];
-        e2 = st->ends[level & 1][2]; e3 = st->ends[level & 1][3];
-    }
-
-    if (t == 0 && !stopped) {
-        // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
-        int acc = 0;
-        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) {
-            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
-                if (st->c_has_nan) acc = st->c_nan;
-                st->c_nan = 0;
-                st->c_has_nan = 0;
-            }
-            st->m[level] = acc;
-            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
-                st->stop_level = level;
-                st->stopped = 1;
-            }
-        }
-        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
-        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
-    }
-
-    // ---- halo knots (scalar): two in front of the tile, three behind, from the candidate records -------------------
-    // slots: [0],[1] in front (slot 1 starts the segment that enters the tile), [2],[3],[4] behind; missing ones are
-    // the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).  Only when a 64-tile window ran dry does the search walk
-    // on through the group sums (far_nonempty: dependent loads, rare).
-    int32_t hi0 = 0, hi1 = 0, hi2 = (int32_t)(n - 1), hi3 = (int32_t)(n - 1), hi4 = (int32_t)(n - 1);
-    double hx0 = e0, hx1 = e0, hx2 = e3, hx3 = e3, hx4 = e3;
-    int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
-    if (!(ITD_ABLATE & 8) && !stopped) {
-        if (rr.ub0 >= 0) {
-            hi1 = sgpr(rr.b0i1); hx1 = sgpr(rr.b0v1); nb = 1;
-            if (rr.cb0 >= 2) { hi0 = sgpr(rr.b0i0); hx0 = sgpr(rr.b0v0); nb = 2; }
-            else if (rr.ub1 >= 0) { hi0 = sgpr(rr.b1i1); hx0 = sgpr(rr.b1v1); nb = 2; }
-        }
-        if (nb < 2 && t - 65 >= 0) {   // the 64-tile window was not enough: walk further
-            int far = t - 65;
-            while (nb < 2) {
-                int cu;
-                const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
-                if (u < 0) break;
-                far = u - 1;
-                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
-                const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
-                const double v1 = r->tval[1], v0 = r->tval[0];
-                if (nb == 0) { hi1 = i1; hx1 = v1; } else { hi0 = i1; hx0 = v1; }
-                ++nb;
-                if (nb < 2 && cu >= 2) { hi0 = i0; hx0 = v0; ++nb; }
-            }
-        }
-        if (rr.uf0 >= 0) {
-            hi2 = sgpr(rr.f0i0); hx2 = sgpr(rr.f0v0); nf = 1;
-            if (rr.cf0 >= 2) { hi3 = sgpr(rr.f0i1); hx3 = sgpr(rr.f0v1); nf = 2; }
-            if (rr.cf0 >= 3) { hi4 = sgpr(rr.f0i2); hx4 = sgpr(rr.f0v2); nf = 3; }
-            if (nf < 3 && rr.uf1 >= 0) {
-                if (nf == 1) {
-                    hi3 = sgpr(rr.f1i0); hx3 = sgpr(rr.f1v0); nf = 2;
-                    if (rr.cf1 >= 2) { hi4 = sgpr(rr.f1i1); hx4 = sgpr(rr.f1v1); nf = 3; }
-                } else {
-                    hi4 = sgpr(rr.f1i0); hx4 = sgpr(rr.f1v0); nf = 3;
-                }
-                if (nf < 3 && rr.uf2 >= 0) { hi4 = sgpr(rr.f2i0); hx4 = sgpr(rr.f2v0); nf = 3; }
-            }
-        }
-        if (nf < 3 && t + 65 < n_tiles) {
-            int far = t + 65;
-            while (nf < 3) {
-                int cu;
-                const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
-                if (u < 0) break;
-                far = u + 1;
-                const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
-                const int32_t i0 = r->hidx[0], i1 = r->hidx[1], i2 = r->hidx[2];
-                const double v0 = r->hval[0], v1 = r->hval[1], v2 = r->hval[2];
-                if (nf == 0) {
-                    hi2 = i0; hx2 = v0;
-                    if (cu >= 2) { hi3 = i1; hx3 = v1; }
-                    if (cu >= 3) { hi4 = i2; hx4 = v2; }
-                    nf = min(cu, 3);
-                } else if (nf == 1) {
-                    hi3 = i0; hx3 = v0;
-                    if (cu >= 2) { hi4 = i1; hx4 = v1; }
-                    nf = 1 + min(cu, 2);
-                } else {
-                    hi4 = i0; hx4 = v0;
-                    nf = 3;
-                }
-            }
-        }
-    }
-    // park the five knots in LDS (tile copy + current-pass copy): they are scalars no longer
-    if (lane < 5) {
-        const double hv = lane == 0 ? hx0 : lane == 1 ? hx1 : lane == 2 ? hx2 : lane == 3 ? hx3 : hx4;
-        const int32_t hv_i = lane == 0 ? hi0 : lane == 1 ? hi1 : lane == 2 ? hi2 : lane == 3 ? hi3 : hi4;
-        s_hX[lane] = hv; s_pX[lane] = hv;
-        s_hI[lane] = hv_i; s_pI[lane] = hv_i;
-    }
-    ITD_STAMP(0);
-
-    // ---- stage the tile; keep the pipeline full ------------------------------------------------------------------------
-    if (!stopped) tile_commit<Tin, TW>(regs, x, n, s, xt);
-    if constexpr (PERSIST) {
-        const int64_t kn = kflat + NW;
-        if (kn < total_tiles) {
-            fetch_tile(kn, regs);
-            fetch_recs(kn, cbA, cfA, rr);
-            if (kn + NW < total_tiles) stage_a(kn + NW, cbA, cfA);
-        }
-    }
-    wave_sync();
-    ITD_STAMP(1);
-  if (!stopped) {
-
-    // ---- this level's knots inside the tile: the flag words the producer of this tile stored with its record (it ran
-    //      the predicate on exactly these values; first/last sample already excluded, ITD.py:70-73) ------------------
-    const int c = (ITD_ABLATE & 16) ? 0 : own_c;
-    WaveMasks wm;
-    if (c > 0 && lane < G) { wm.lo = (unsigned)own_word; wm.hi = (unsigned)(own_word >> 32); }
-    ITD_STAMP(2);
-
-    // ---- passes: a run of consecutive 64-sample groups whose knots fit the by-rank arrays (one pass unless the tile
-    //      is dense).  A pass is a tile within the tile: local ranks L = 0,1 are the two knots in front of the run,
-    //      L = 2..m+1 its own m knots, L = m+2..m+4 the three knots behind it. -----------------------------------------
-    double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
-    double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
-    const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
-    const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
-    const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
-    int nbp = nb;                           // how many of them are real knots (the rest is the end knot e[0])
-    int own_left = c;                       // the tile's knots not yet consumed by a pass
-    double b_lo = 0.0, b_hi = 0.0;
-    bool has_nan = false;
-    int g0 = 0;
-    while (g0 < G) {
-        // the run [g0, g1) and its knot count m
-        int g1 = g0, m = 0;
-        if (own_left <= CAP) {   // everything that is left fits (the common case: one pass per tile)
-            g1 = G;
-            m = own_left;
-        } else {
-#pragma unroll 1
-            for (int g = g0; g < G; ++g) {
-                const int cg = __popcll(wm.get(g));
-                if (m + cg > CAP) break;
-                m += cg;
-                g1 = g + 1;
-            }
-        }
-        own_left -= m;
-        // the three knots behind the run (s_pX/s_pI[2..4]): the tile's own knots of later groups first, then the tile's
-        // halo knots in order.  One-pass tiles (the common case) keep the tile's halo untouched.
-        int nfp = nf;
-        if (own_left > 0) {
-            int k = 0;
-#pragma unroll 1
-            for (int g = g1; g < G && k < 3; ++g) {
-                unsigned long long mm = wm.get(g);
-                while (mm && k < 3) {
-                    const int pos = g * 64 + __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    if (lane == 0) { s_pX[2 + k] = xt.at(pos); s_pI[2 + k] = (int32_t)s + pos; }
-                    ++k;
-                }
-            }
-            if (lane >= k && lane < 3) { s_pX[2 + lane] = s_hX[2 + lane - k]; s_pI[2 + lane] = s_hI[2 + lane - k]; }
-            nfp = min(3, k + nf);
-            wave_sync();
-        } else if (g0 > 0) {   // last pass of a dense tile
-            if (lane < 3) { s_pX[2 + lane] = s_hX[2 + lane]; s_pI[2 + lane] = s_hI[2 + lane]; }
-            wave_sync();
-        }
-        // fill the by-rank arrays of the pass
-        if (lane < 5) {
-            const int L = lane < 2 ? lane : m + lane;
-            s_X[L] = s_pX[lane];
-            s_gi[L] = s_pI[lane];
-        }
-        if (m > 0) {
-            int base = 2;
-#pragma unroll 1
-            for (int g = g0; g < g1; ++g) {
-                const unsigned long long mk = wm.get(g);
-                const int pos = g * 64 + lane;
-                if ((mk >> lane) & 1ull) {
-                    const int L = mbcnt64(mk, base);
-                    s_X[L] = xt.at(pos);
-                    s_gi[L] = (int32_t)s + pos;
-                }
-                base += __popcll(mk);
-            }
-        }
-        wave_sync();
-        ITD_STAMP(3);
-        // the two knots in front of the NEXT pass = this pass's ranks m, m+1 (taken now: the slopes reuse gi's bytes)
-        if (g1 < G && lane < 2) { s_pX[lane] = s_X[m + lane]; s_pI[lane] = s_gi[m + lane]; }
-        // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
-        for (int L = 1 + lane; L <= m + 3 && !(ITD_ABLATE & 4); L += kWave) {
-            const int32_t k0 = s_gi[L - 1], k1 = s_gi[L], k2 = s_gi[L + 1];
-            const double x0 = s_X[L - 1], x1 = s_X[L], x2 = s_X[L + 1];
-            const double frac = (double)(k1 - k0) / (double)(k2 - k0);
-            const double tt = frac * (x2 - x0);
-            const double u = x0 + tt;
-            double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
-            const bool end0 = (L == 1) && (nbp == 0);                         // e[0]   = sample 0
-            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // e[m+1] = sample n-1
-            Bv = end0 ? m0 : (endn ? mn : Bv);
-            s_B[L] = Bv;
-        }
-        wave_sync();
-        // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 --------------------------------
-        for (int L = 1 + lane; L <= m + 2 && !(ITD_ABLATE & 4); L += kWave) {
-            const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
-            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // sample n-1 starts no segment
-            if (!endn) s_S[L] = sl;
-        }
-        wave_sync();
-        ITD_STAMP(4);
-
-        // ---- baseline map + rotation, ITD.py:114-119 -----------------------------------------------------------------
-        // halo samples first (they read the by-rank arrays and the untouched halo slots): s-1 lives in the segment
-        // entering the tile; s+TW is either a knot itself (rank m+2 of the last pass) or in the tile's last segment
-        if (lane == 0) {
-            if (g0 == 0 && s >= 1) b_lo = s_B[1] + s_S[1] * (xt.at(-1) - s_X[1]);
-            const int64_t i = s + TW;
-            if (g1 == G && i < n - 1) {
-                const int L = (nf >= 1 && hi2 == (int32_t)i) ? m + 2 : 1 + m;
-                b_hi = s_B[L] + s_S[L] * (xt.at(TW) - s_X[L]);
-            }
-        }
-        // A sample needs its own x and its segment's (B, slope, x) by rank, nothing else of the tile: each group
-        // reads, maps, overwrites itself in place and streams both rows out.
-        {
-            const bool one_seg = (m == 0);   // no knot inside the run (most tiles of the deep levels): one affine map
-            int jb = 1;                      // local rank of the knot in front of the group
-#pragma unroll 1
-            for (int g = g0; g < g1; ++g) {
-                {
-                    const int pos = g * 64 + lane;
-                    const unsigned long long mk = one_seg ? 0ull : wm.get(g);
-                    const int L = one_seg ? 1 : mbcnt64(mk >> 1, jb + (int)(mk & 1ull));   // 1 + knots of the run at or before the sample
-                    const double xi = xt.at(pos);
-                    const double Bk = s_B[L], Sk = s_S[L], Xk = s_X[L];
-                    double bi = Bk + Sk * (xi - Xk);
-                    if (tail_tile && s + pos >= n - 1) bi = 0.0;   // baseline[n-1] is never written, ITD.py:112-117
-                    const double ri = xi - bi;
-                    xt.at(pos) = bi;
-                    if (!tail_tile || s + pos < n) {
-                        if (!(ITD_ABLATE & 1) || bi == 1.2345e-300) {
-                            if constexpr (FINAL) {
-                                stream_store<(ITD_NT & 1) != 0>(&rot_t[pos], ri + bi);   // ITD.py:420
-                            } else {
-                                stream_store<(ITD_NT & 1) != 0>(&rot_t[pos], ri);
-                                stream_store<(ITD_NT & 2) != 0>(&bas_t[pos], bi);
-                            }
-                        }
-                        has_nan = has_nan || (bi != bi);
-                    }
-                    jb += __popcll(mk);
-                }
-            }
-        }
-        // next pass
-        nbp = min(2, nbp + m);
-        g0 = g1;
-        wave_sync();
-    }
-    ITD_STAMP(5);
-    if (lane == 0) {
-        xt.at(-1) = b_lo;
-        xt.at(TW) = b_hi;
-    }
-    if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
-    wave_sync();
-    ITD_STAMP(6);
-
-    // ---- knots of the baseline just produced = the next level's input ------------------------------------------
-    // (careful mode: k_careful_apply does this after the reference's NaN -> inf mutation)
-    if (!careful) {
-        if constexpr (!FINAL)
-            if (s == 0 || s + TW >= n - 2) publish_ends<TW>(xt, s, n, st->ends[(level + 1) & 1]);
-        const size_t slot = slot0 + t;
-        const int total = (ITD_ABLATE & 2) ? 0 : detect_tile<TW>(xt, s, n, kKnots, nullptr, recs_out + slot, srec_all[wave_in_block()]);
-        if (lane == 0) {
-            if (!(ITD_ABLATE & 128)) counts_out[slot] = total;
-            if (total && !(ITD_ABLATE & 32)) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
-        }
-    }
-    ITD_STAMP(7);
-  }   // !stopped
-    if constexpr (!PERSIST) break;
-    kflat += NW;
-    if (kflat >= total_tiles) break;
-    fetch_own(kflat);
-    wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
-  }
-    ITD_STAMP_FLUSH();
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_extract_r: the extraction with the tile held in REGISTERS (the shipped main path; k_extract above is the LDS-tile
-// form it replaced, kept while ITD_REGTILE can still be switched off).
 // Lane l owns two consecutive samples of every 128-sample group g: tile positions 128 g + 2 l (even) and + 1 (odd) —
 // exactly what one coalesced 16-byte load/store per lane moves.  Flag word 2g holds the even samples' knot flags of
-// group g, word 2g+1 the odd ones (the "interleaved" record format, kInterleaved).  Consequences:
+// group g, word 2g+1 the odd ones (flag_pos).  Consequences:
 //   * no LDS tile: LDS holds only the by-rank knot arrays (3.7 KB per wavefront -> the CU fills all its wave slots);
 //   * a sample's left/right neighbours are its own lane's other sample or the adjacent lane's (DPP wave shifts):
 //     the next level's knot scan runs on registers, sharing every difference between the two samples that use it;
@@ -1088,7 +559,7 @@ __device__ __forceinline__ int lane_bit(unsigned long long mask)
 }
 
 template <typename Tin, int TW, bool FINAL, int CAP>
-__global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
+__global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
                                                      const int32_t *__restrict__ counts_in,
                                                      int32_t *__restrict__ counts_out,
@@ -1111,6 +582,7 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     __shared__ double s_S[RK];      // slope of the segment that starts at slot L; before the slopes exist: the knots' indices
     __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
     __shared__ double s_bl[2];
+    __shared__ int32_t s_pos[8];      // tile positions of the new record's five knots
     __shared__ int32_t s_rb[9][16];   // first 64 bytes of up to nine neighbour records (speculative four + late five)
     __shared__ double s_hX[8];      // the five knots around the tile (value) ...
     __shared__ int32_t s_hI[8];     // ... and their sample indices
@@ -1154,11 +626,8 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
         }
     }
-    double xlo = 0.0, xhi = 0.0;   // samples s-1 and s+TW (wave-uniform addresses)
-    if (s >= 1 && !(ITD_ABL_R & 512)) xlo = (double)x[s - 1];
-    if (s + TW < n && !(ITD_ABL_R & 512)) xhi = (double)x[s + TW];
     const TileRec *ro = recs + t;
-    const int own_c = (ITD_ABL_R & 8) ? 0 : ro->count;
+    const int own_c = (ITD_ABL_R & 8) ? 0 : rec_count(ro->packed);
     const unsigned long long own_word = ro->flags[lane < 2 * G2 ? lane : 0];   // lane j < 2*G2: flag word j
     const int tb = t - 1 - lane, tf = t + 1 + lane;
     const int cb = (tb >= 0 && !(ITD_ABL_R & 1)) ? cnts[tb] : 0;
@@ -1229,6 +698,8 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     }
     if (stopped) return;
 
+    // staged record slot -> its tile (for the knots' absolute sample indices)
+    auto tile_of = [&](int sl) { return sl == 0 ? t - 1 : sl == 1 ? t + 1 : sl == 2 ? t - 2 : sl == 3 ? t + 2 : sl == 4 ? ub0 : sl == 5 ? ub1 : sl == 6 ? uf0 : sl == 7 ? uf1 : uf2; };
     // ---- halo knots: two in front of the tile (slot 1 starts the segment that enters the tile), three behind; lane k < 5
     //      picks knot k out of the staged records.  Missing ones are the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).
     int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
@@ -1236,15 +707,15 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     if (uf0 >= 0) nf = min(3, cf0 + cf1 + (uf2 >= 0 ? 1 : 0));
     wave_sync();
     if (lane < 5) {
-        int sl, iw, vw;
+        int sl, sh, vw;   // staged slot, bit offset of the knot's position in the packed word, dword of its value
         bool real;
         if (lane < 2) {
             real = (lane == 1) ? (nb >= 1) : (nb >= 2);
             const bool from0 = (lane == 1) || (cb0 >= 2);          // slot 0: ub0's second last knot, or ub1's last
-            const int which = (lane == 1 || !from0) ? 1 : 0;       // tidx[1] / tval[1] = the record's last knot
+            const int which = (lane == 1 || !from0) ? 1 : 0;       // tpos(1) / tval[1] = the record's last knot
             sl = from0 ? sb0 : sb1;
-            iw = 4 + which;
-            vw = 12 + 2 * which;
+            sh = 41 + 10 * which;
+            vw = kRecDwTval + 2 * which;
         } else {
             int j = lane - 2;
             real = j < nf;
@@ -1252,13 +723,14 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             if (j < c0) sl = sf0;
             else if (j - c0 < c1) { sl = sf1; j -= c0; }
             else { sl = sf2; j -= c0 + c1; }
-            iw = 1 + j;
-            vw = 6 + 2 * j;
+            sh = 11 + 10 * j;
+            vw = kRecDwHval + 2 * j;
         }
         int32_t idx = lane < 2 ? 0 : (int32_t)(n - 1);
         double val = lane < 2 ? e0 : e3;
         if (real) {
-            idx = s_rb[sl][iw];
+            const unsigned long long pk = ((unsigned long long)(unsigned)s_rb[sl][1] << 32) | (unsigned)s_rb[sl][0];
+            idx = tile_of(sl) * TW + (int)((pk >> sh) & 0x3ffull);
             val = bits_d((unsigned)s_rb[sl][vw], (unsigned)s_rb[sl][vw + 1]);
         }
         s_hX[lane] = val;
@@ -1274,8 +746,10 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
             if (u < 0) break;
             far = u - 1;
-            const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
-            const int32_t i1 = r->tidx[1], i0 = r->tidx[0];
+            const int uu = __builtin_amdgcn_readfirstlane(u);
+            const TileRec *r = recs + uu;
+            const unsigned long long pk = r->packed;
+            const int32_t i1 = uu * TW + rec_tpos(pk, 1), i0 = uu * TW + rec_tpos(pk, 0);
             const double v1 = r->tval[1], v0 = r->tval[0];
             if (lane == 0) { s_hI[nb == 0 ? 1 : 0] = i1; s_hX[nb == 0 ? 1 : 0] = v1; }
             ++nb;
@@ -1293,9 +767,10 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
             const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
             if (u < 0) break;
             far = u + 1;
-            const TileRec *r = recs + __builtin_amdgcn_readfirstlane(u);
+            const int uu = __builtin_amdgcn_readfirstlane(u);
+            const TileRec *r = recs + uu;
             const int take = min(cu, 3 - nf);
-            if (lane < take) { s_hI[2 + nf + lane] = r->hidx[lane]; s_hX[2 + nf + lane] = r->hval[lane]; }
+            if (lane < take) { s_hI[2 + nf + lane] = uu * TW + rec_hpos(r->packed, lane); s_hX[2 + nf + lane] = r->hval[lane]; }
             nf += take;
         }
         wave_sync();
@@ -1414,10 +889,14 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
         ITD_STAMP(3);
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
-            if (g0 == 0 && s >= 1) s_bl[0] = s_B[1] + s_S[1] * (xlo - s_X[1]);
+            if (g0 == 0 && s >= 1) {   // sample s-1 = the last sample of tile t-1
+                const double xlo = bits_d((unsigned)s_rb[0][kRecDwEdge + 2], (unsigned)s_rb[0][kRecDwEdge + 3]);
+                s_bl[0] = s_B[1] + s_S[1] * (xlo - s_X[1]);
+            }
             const int64_t i = s + TW;
             if (g1 == G2 && i < n - 1) {
                 const int L = (nf >= 1 && s_hI[2] == (int32_t)i) ? m + 2 : 1 + m;   // sample s+TW is itself a knot
+                const double xhi = bits_d((unsigned)s_rb[1][kRecDwEdge], (unsigned)s_rb[1][kRecDwEdge + 1]);   // first sample of tile t+1
                 s_bl[1] = s_B[L] + s_S[L] * (xhi - s_X[L]);
             }
         }
@@ -1512,22 +991,18 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
     }
     const size_t slot = slot0 + t;
     ITD_STAMP(5);
-    if (total == 0) {   // nothing to tell the next launch but the count (most tiles of the deep levels)
-        if (lane == 0) { recs_out[slot].count = 0; counts_out[slot] = 0; }
-        ITD_STAMP_END(t_begin, stamp_on);
-        return;
-    }
-    // count and group sum leave first: a wavefront cannot retire before its last store is acknowledged, so the late ones
-    // should be as early as possible
+    // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
     if (lane == 0) {
         if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
-        if (ITD_ABL_R & 128) gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch] = total;          // plain store instead
-        else if (ITD_ABL_R & 256) atomicAdd(&gsum_out[((size_t)sig * n_groups + (t & (n_groups - 1))) * kGsumPitch], total);   // spread over the groups
-        else if (!(ITD_ABL_R & 16)) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
+        if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
     }
-    // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample)
+    // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample); the tile's
+    // first and last sample for the neighbours
     TileRec *lrec = reinterpret_cast<TileRec *>(s_rec);
-    {
+    if (lane < 5) s_pos[lane] = 0;
+    if (lane == 0) lrec->edge[0] = xr[0][0];
+    if (lane == 63) lrec->edge[1] = xr[G2 - 1][1];
+    if (total > 0) {
         int gbase = 0;
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
@@ -1536,23 +1011,24 @@ __global__ __launch_bounds__(kWave) void k_extract_r(const Tin *__restrict__ xin
                 const int bE = lane_bit(E), bO = lane_bit(O);
                 const int re = mbcnt64(O, mbcnt64(E, gbase));   // knots before the even sample
                 const int ro_ = re + bE;                        // knots before the odd sample
-                const int32_t ie = (int32_t)s + 128 * g + 2 * lane;
+                const int pe = 128 * g + 2 * lane;
                 if (bE) {
-                    if (re < 3) { lrec->hidx[re] = ie; lrec->hval[re] = xr[g][0]; }
-                    if (re >= total - 2) { lrec->tidx[re - (total - 2)] = ie; lrec->tval[re - (total - 2)] = xr[g][0]; }
+                    if (re < 3) { s_pos[re] = pe; lrec->hval[re] = xr[g][0]; }
+                    if (re >= total - 2) { s_pos[3 + re - (total - 2)] = pe; lrec->tval[re - (total - 2)] = xr[g][0]; }
                 }
                 if (bO) {
-                    if (ro_ < 3) { lrec->hidx[ro_] = ie + 1; lrec->hval[ro_] = xr[g][1]; }
-                    if (ro_ >= total - 2) { lrec->tidx[ro_ - (total - 2)] = ie + 1; lrec->tval[ro_ - (total - 2)] = xr[g][1]; }
+                    if (ro_ < 3) { s_pos[ro_] = pe + 1; lrec->hval[ro_] = xr[g][1]; }
+                    if (ro_ >= total - 2) { s_pos[3 + ro_ - (total - 2)] = pe + 1; lrec->tval[ro_ - (total - 2)] = xr[g][1]; }
                 }
             }
             gbase += gcount[g];
         }
+        if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
     }
-    if (lane == 0) lrec->count = total;
-    if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
     wave_sync();
-    if (lane < kRecLanes && !(ITD_ABL_R & 64)) {   // kRecLanes x 16 bytes = the whole record, one store
+    if (lane == 0) lrec->packed = rec_pack(total, s_pos[0], s_pos[1], s_pos[2], s_pos[3], s_pos[4]);
+    wave_sync();
+    if (lane < (total > 0 ? kRecLanes : 4) && !(ITD_ABL_R & 64)) {   // 16-byte lanes; an empty tile: the neighbours' half only
         using I4 = __attribute__((ext_vector_type(4))) int;
         reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
     }
