@@ -558,6 +558,155 @@ __device__ __forceinline__ int lane_bit(unsigned long long mask)
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// scan_publish: knot scan of a tile held in registers (xr[g][0/1] = positions 128 g + 2 lane / + 1) and everything the
+// next launch needs from it: count, group sum, the 128-byte record.  x_lo / x_hi are samples s-1 and s+TW (wave-uniform).
+// Differences: d0 = even - left, d1 = odd - even, d2 = right - odd (= the next lane's d0): every difference is computed
+// once and shared by the two samples whose predicate uses it (ITD.py:59 on raw differences).
+// ---------------------------------------------------------------------------------------------
+template <int TW>
+__device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], double x_lo, double x_hi, int64_t s, int nrem,
+                                            size_t slot, size_t gsum_index, int32_t *__restrict__ counts_out,
+                                            TileRec *__restrict__ recs_out, int32_t *__restrict__ gsum_out,
+                                            int32_t *s_rec /* sizeof(TileRec) bytes, 16-byte aligned */, int32_t *s_pos /* 8 ints */)
+{
+    constexpr int G2 = TW / 128;
+    const int lane = lane_id();
+    double d0[G2];
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+        const double fill = (g == 0) ? x_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
+        const double left = wave_dpp<0x138>(fill, xr[g][1]);
+        d0[g] = xr[g][0] - left;
+    }
+    const bool edge = (s == 0) || (nrem <= TW + 1);   // the tile holds sample 0, or sample n-2 or later
+    WaveMasks nm;
+    int total = 0;
+    int gcount[G2];
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+        const double d1 = xr[g][1] - xr[g][0];
+        const double fill = (g == G2 - 1) ? (x_hi - xr[g][1]) : wave_dpp<0x134>(0.0, d0[g < G2 - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
+        const double d2 = wave_dpp<0x130>(fill, d0[g]);
+        bool fe = ((d1 > 0.0) && (d0[g] <= 0.0)) || ((d1 < 0.0) && (d0[g] >= 0.0));
+        bool fo = ((d2 > 0.0) && (d1 <= 0.0)) || ((d2 < 0.0) && (d1 >= 0.0));
+        if (edge) {   // first and last sample are never knots (ITD.py:70-73); nothing beyond sample n-2
+            const int p = 128 * g + 2 * lane;
+            fe = fe && (s > 0 || p >= 1) && (p <= nrem - 2);
+            fo = fo && (p + 1 <= nrem - 2);
+        }
+        const unsigned long long E = __ballot(fe), O = __ballot(fo);
+        nm.set(2 * g, E);
+        nm.set(2 * g + 1, O);
+        gcount[g] = __popcll(E) + __popcll(O);
+        total += gcount[g];
+    }
+    // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
+    if (lane == 0) {
+        if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
+        if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[gsum_index], total);
+    }
+    // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample); the tile's
+    // first and last sample for the neighbours
+    TileRec *lrec = reinterpret_cast<TileRec *>(s_rec);
+    if (lane < 5) s_pos[lane] = 0;
+    if (lane == 0) lrec->edge[0] = xr[0][0];
+    if (lane == 63) lrec->edge[1] = xr[G2 - 1][1];
+    if (total > 0) {
+        int gbase = 0;
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            if (gcount[g] > 0 && (gbase < 3 || gbase + gcount[g] > total - 2)) {
+                const unsigned long long E = nm.get(2 * g), O = nm.get(2 * g + 1);
+                const int bE = lane_bit(E), bO = lane_bit(O);
+                const int re = mbcnt64(O, mbcnt64(E, gbase));   // knots before the even sample
+                const int ro_ = re + bE;                        // knots before the odd sample
+                const int pe = 128 * g + 2 * lane;
+                if (bE) {
+                    if (re < 3) { s_pos[re] = pe; lrec->hval[re] = xr[g][0]; }
+                    if (re >= total - 2) { s_pos[3 + re - (total - 2)] = pe; lrec->tval[re - (total - 2)] = xr[g][0]; }
+                }
+                if (bO) {
+                    if (ro_ < 3) { s_pos[ro_] = pe + 1; lrec->hval[ro_] = xr[g][1]; }
+                    if (ro_ >= total - 2) { s_pos[3 + ro_ - (total - 2)] = pe + 1; lrec->tval[ro_ - (total - 2)] = xr[g][1]; }
+                }
+            }
+            gbase += gcount[g];
+        }
+        if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
+    }
+    wave_sync();
+    if (lane == 0) lrec->packed = rec_pack(total, s_pos[0], s_pos[1], s_pos[2], s_pos[3], s_pos[4]);
+    wave_sync();
+    if (lane < (total > 0 ? kRecLanes : 4) && !(ITD_ABL_R & 64)) {   // 16-byte lanes; an empty tile: the neighbours' half only
+        using I4 = __attribute__((ext_vector_type(4))) int;
+        reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan0: level-0 knot scan of the caller's signal for a decomposition (the register form of k_detect: knots only, no
+// lists).  grid = (n_tiles, batch), 64 threads.  Also publishes the signal's four end samples and the NaN-input flag.
+// ---------------------------------------------------------------------------------------------
+template <typename Tin, int TW>
+__global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, int64_t x_stride, int64_t n, int n_tiles,
+                                                 int32_t *__restrict__ counts, TileRec *__restrict__ recs,
+                                                 int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
+{
+    constexpr int G2 = TW / 128;
+    using In2 = Tin __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
+    __shared__ int32_t s_pos[8];
+    const int lane = lane_id();
+    const int t = blockIdx.x, sig = blockIdx.y;
+    const int64_t s = (int64_t)t * TW;
+    const Tin *x = xin + (int64_t)sig * x_stride;
+    SigState *st = state + sig;
+    const bool full = (s + TW <= n);
+    const bool vec_in = full && ((reinterpret_cast<uintptr_t>(x + s) & (2 * sizeof(Tin) - 1)) == 0);
+    double xr[G2][2];
+    if (vec_in) {
+        const In2 *v = reinterpret_cast<const In2 *>(x + s);
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const In2 q = v[g * 64 + lane];
+            xr[g][0] = (double)q.x;
+            xr[g][1] = (double)q.y;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int64_t i = s + 128 * g + 2 * lane;
+            xr[g][0] = (i < n) ? (double)x[i] : 0.0;
+            xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
+        }
+    }
+    double xlo = 0.0, xhi = 0.0;   // samples s-1 and s+TW (wave-uniform addresses; this kernel's loads are all cacheable)
+    if (s >= 1) xlo = (double)x[s - 1];
+    if (s + TW < n) xhi = (double)x[s + TW];
+    const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));
+    bool nan_in = false;
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {
+        const int p = 128 * g + 2 * lane;
+        nan_in = nan_in || (p < nrem && xr[g][0] != xr[g][0]) || (p + 1 < nrem && xr[g][1] != xr[g][1]);
+    }
+    if (__any(nan_in) && lane == 0) st->in_nan = 1;
+    if (s == 0 || nrem <= TW + 1) {   // the signal's end samples x[0], x[1], x[n-2], x[n-1] (ITD.py:101-102)
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int p = 128 * g + 2 * lane;
+            if (s == 0 && p == 0) { st->ends[0][0] = xr[g][0]; st->ends[0][1] = xr[g][1]; }
+            if (p == nrem - 2) { st->ends[0][2] = xr[g][0]; st->ends[0][3] = xr[g][1]; }
+            if (p + 1 == nrem - 2) st->ends[0][2] = xr[g][1];
+            if (p == nrem - 1) st->ends[0][3] = xr[g][0];
+        }
+    }
+    scan_publish<TW>(xr, xlo, xhi, s, nrem, (size_t)sig * n_tiles + t,
+                     ((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch, counts, recs, gsum_out, s_rec, s_pos);
+}
+
 template <typename Tin, int TW, bool FINAL, int CAP>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
@@ -833,9 +982,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         if (c > 0) {
 #pragma unroll
             for (int g = 0; g < G2; ++g) {
-                int p = 128 * g + 2 * lane;
-                asm volatile("" : "+v"(p));
-                const int ke = kinfo[g] & 0xffff, bE = (kinfo[g] >> 16) & 1, bO = (kinfo[g] >> 17) & 1;
+                int p = 128 * g + 2 * lane, ki = kinfo[g];
+                asm volatile("" : "+v"(p), "+v"(ki));   // opaque: decoded per use, not kept decoded across the pass loop
+                const int ke = ki & 0xffff, bE = (ki >> 16) & 1, bO = (ki >> 17) & 1;
                 const int Le = ke - rb + 1;          // slot of the even sample's knot (if it is one): rank ke-1
                 const int Lo = Le + bO;              // slot of the odd sample's knot: rank ke+bO-1
                 if (bE && (unsigned)(Le - 2) < (unsigned)(m + 3)) {
@@ -905,9 +1054,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         for (int g = 0; g < G2; ++g) {
             __builtin_amdgcn_sched_barrier(0);   // one group's by-rank reads in flight at a time: registers, not latency, are scarce
             if (g >= g0 && g < g1) {
-                int p = 128 * g + 2 * lane;       // tile position of the even sample
-                asm volatile("" : "+v"(p));       // opaque: keeps the per-group masks and addresses out of the pass loop's preheader
-                const int ke = kinfo[g] & 0xffff, bO = (kinfo[g] >> 17) & 1;
+                int p = 128 * g + 2 * lane, ki = kinfo[g];   // tile position of the even sample; its rank word
+                asm volatile("" : "+v"(p), "+v"(ki));        // opaque: keeps per-group masks, addresses and decoded ranks out of the pass loop's preheader
+                const int ke = ki & 0xffff, bO = (ki >> 17) & 1;
                 const int Le = ke - rb + 1, Lo = Le + bO;   // 1 + knots of the run at or before the sample
                 const double xe = xr[g][0], xo = xr[g][1];
                 double be = s_B[Le] + s_S[Le] * (xe - s_X[Le]);
@@ -958,80 +1107,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     if (careful) return;   // k_careful_apply scans the baseline after the reference's NaN -> inf mutation
 
     // ---- knots of the baseline just produced = the next level's input, on registers ------------------------------------
-    // differences: d0 = even - left, d1 = odd - even, d2 = right - odd (= the next lane's d0)
-    const double blo_s = s_bl[0], bhi_s = s_bl[1];   // written by lane 0 before the last wave_sync
-    double d0[G2];
-#pragma unroll
-    for (int g = 0; g < G2; ++g) {
-        const double fill = (g == 0) ? blo_s : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
-        const double left = wave_dpp<0x138>(fill, xr[g][1]);
-        d0[g] = xr[g][0] - left;
-    }
-    const bool edge = (s == 0) || (s + TW >= n - 1);
-    WaveMasks nm;
-    int total = 0;
-    int gcount[G2];
-#pragma unroll
-    for (int g = 0; g < G2; ++g) {
-        const double d1 = xr[g][1] - xr[g][0];
-        const double fill = (g == G2 - 1) ? (bhi_s - xr[g][1]) : wave_dpp<0x134>(0.0, d0[g < G2 - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
-        const double d2 = wave_dpp<0x130>(fill, d0[g]);
-        bool fe = ((d1 > 0.0) && (d0[g] <= 0.0)) || ((d1 < 0.0) && (d0[g] >= 0.0));
-        bool fo = ((d2 > 0.0) && (d1 <= 0.0)) || ((d2 < 0.0) && (d1 >= 0.0));
-        if (edge) {   // first and last sample are never knots (ITD.py:70-73); nothing beyond sample n-2
-            const int p = 128 * g + 2 * lane;
-            fe = fe && (s > 0 || p >= 1) && (p <= nrem - 2);
-            fo = fo && (p + 1 <= nrem - 2);
-        }
-        const unsigned long long E = __ballot(fe), O = __ballot(fo);
-        nm.set(2 * g, E);
-        nm.set(2 * g + 1, O);
-        gcount[g] = __popcll(E) + __popcll(O);
-        total += gcount[g];
-    }
-    const size_t slot = slot0 + t;
     ITD_STAMP(5);
-    // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
-    if (lane == 0) {
-        if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
-        if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch], total);
-    }
-    // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample); the tile's
-    // first and last sample for the neighbours
-    TileRec *lrec = reinterpret_cast<TileRec *>(s_rec);
-    if (lane < 5) s_pos[lane] = 0;
-    if (lane == 0) lrec->edge[0] = xr[0][0];
-    if (lane == 63) lrec->edge[1] = xr[G2 - 1][1];
-    if (total > 0) {
-        int gbase = 0;
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            if (gcount[g] > 0 && (gbase < 3 || gbase + gcount[g] > total - 2)) {
-                const unsigned long long E = nm.get(2 * g), O = nm.get(2 * g + 1);
-                const int bE = lane_bit(E), bO = lane_bit(O);
-                const int re = mbcnt64(O, mbcnt64(E, gbase));   // knots before the even sample
-                const int ro_ = re + bE;                        // knots before the odd sample
-                const int pe = 128 * g + 2 * lane;
-                if (bE) {
-                    if (re < 3) { s_pos[re] = pe; lrec->hval[re] = xr[g][0]; }
-                    if (re >= total - 2) { s_pos[3 + re - (total - 2)] = pe; lrec->tval[re - (total - 2)] = xr[g][0]; }
-                }
-                if (bO) {
-                    if (ro_ < 3) { s_pos[ro_] = pe + 1; lrec->hval[ro_] = xr[g][1]; }
-                    if (ro_ >= total - 2) { s_pos[3 + ro_ - (total - 2)] = pe + 1; lrec->tval[ro_ - (total - 2)] = xr[g][1]; }
-                }
-            }
-            gbase += gcount[g];
-        }
-        if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
-    }
-    wave_sync();
-    if (lane == 0) lrec->packed = rec_pack(total, s_pos[0], s_pos[1], s_pos[2], s_pos[3], s_pos[4]);
-    wave_sync();
-    if (lane < (total > 0 ? kRecLanes : 4) && !(ITD_ABL_R & 64)) {   // 16-byte lanes; an empty tile: the neighbours' half only
-        using I4 = __attribute__((ext_vector_type(4))) int;
-        reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
-    }
+    scan_publish<TW>(xr, s_bl[0], s_bl[1], s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
+                     counts_out, recs_out, gsum_out, s_rec, s_pos);
     ITD_STAMP(6);
     ITD_STAMP_END(t_begin, stamp_on);
 }
