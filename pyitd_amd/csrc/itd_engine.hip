@@ -178,16 +178,16 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *rot_out = rows + (int64_t)j * n;
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE)                                                                   \
-    k_extract<TIN, T, FIN, kRankCap><<<grid_t, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
+    k_extract<TIN, T, FIN, CAPK><<<grid_t, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
                                                     cnt(j + 1), rec(j), rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,  \
                                                     rows_stride, base_out, base_stride, e->d_state, j, 0)
         if (j == 0) {
-            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride);
-            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride);
+            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride, kRankCap0);
+            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride, kRankCap0);
         } else {
-            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride);
-            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride);
+            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap);
+            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap);
         }
 #undef ITD_LAUNCH_EXTRACT
         time_end(e, pair, st);
@@ -259,7 +259,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
         if (j == 0)
-            k_extract<Tin, T, false, kRankCap><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+            k_extract<Tin, T, false, kRankCap0><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
                                                                         n, base_out, n, state, j, 1);
         else
@@ -542,7 +542,7 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     const bool want_list = m_host || knots || want_sync;
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
-    k_extract<Tin, T, false, kRankCap><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+    k_extract<Tin, T, false, kRankCap0><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);

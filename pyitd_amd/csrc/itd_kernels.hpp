@@ -92,6 +92,11 @@ constexpr int kWave = 64;              // one wavefront per tile, one tile per w
 #define ITD_RANK_CAP 136
 #endif
 constexpr int kRankCap = ITD_RANK_CAP;
+// the level-0 launch reads the caller's signal, usually the densest knots of the decomposition: it gets more slots
+#ifndef ITD_RANK_CAP0
+#define ITD_RANK_CAP0 264
+#endif
+constexpr int kRankCap0 = ITD_RANK_CAP0;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 

@@ -15,8 +15,8 @@ eng = pyitd_amd.Engine(n, 1, 0)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
 init = (ctypes.c_ulonglong * 16)(*([0] * 16))
-names = ["loads + candidate records + halo knots", "park halo, ranks", "pass: fill by rank", "pass: knot values + slopes",
-         "pass: map + stores", "next level's knot scan", "record + counts", "(unused)"]
+names = ["loads + candidate records + halo knots", "tile-relative ranks", "pass: fill by rank", "pass: knot values + slopes",
+         "pass: map + stores", "(pass loop exit)", "next level's knot scan + record + counts", "(unused)"]
 for rep in range(3):
     L.itd_debug_stamps(None, 1)
     # slot 9 = min(start): preset to max
