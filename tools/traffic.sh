@@ -1,0 +1,40 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/traffic.sh <round-tag>
+# HBM-side bytes per launch of every kernel of bench.py from the PMC counters FETCH_SIZE and WRITE_SIZE (separate passes,
+# kernel-trace only), with the gfx950 correction of MI355X_MICROARCH.md applied; writes gpurun_out/traffic.json
+tag=${1:-r01}
+out=$GRAFT_REPO_ROOT/gpurun_out/traffic_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/$c.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python3 - "$out" "$tag" <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+allk = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(out + "/" + c + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    allk[c] = {k: {"dispatches": len(v), "mean_KB": sum(v) / len(v)} for k, v in acc.items()}
+dom = [k for k in allk["FETCH_SIZE"] if "k_extract<double" in k and ", false," in k]
+dom = dom[0] if dom else None
+res = {"round": tag, "kernel": dom, "all_kernels": allk,
+       "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section) -> reads = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact for streaming stores",
+       "commands": ["rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1",
+                    "rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1"]}
+if dom:
+    f, w = allk["FETCH_SIZE"][dom]["mean_KB"], allk["WRITE_SIZE"][dom]["mean_KB"]
+    res["counters_KB_per_launch"] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
+    res["k_extract_f64_bytes_per_launch"] = 2 * f * 1024 + w * 1024
+    res["algorithmic_bytes_per_launch"] = 24.0 * (1 << 24)
+    res["ratio_traffic_over_algorithmic"] = res["k_extract_f64_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+    res["note"] = ("reads above the algorithmic 8 B/sample: the +-64-tile count windows (512 B per 512-sample tile), the tile's own 128-byte "
+                   "record and the first 64 bytes of four neighbours' records; FETCH_SIZE counts requests that leave L2, Infinity-Cache hits included")
+json.dump(res, open(out + "/../traffic.json", "w"), indent=1)
+print(json.dumps({k: res.get(k) for k in ("kernel", "counters_KB_per_launch", "k_extract_f64_bytes_per_launch", "ratio_traffic_over_algorithmic")}))
+PY
