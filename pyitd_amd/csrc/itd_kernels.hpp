@@ -38,9 +38,14 @@
 #define ITD_NT 5
 #endif
 // timing-only ablations of k_extract (results are wrong by construction): 1 no count windows, 2 no speculative
-// records, 8 no knots inside the tile, 16 no group-sum atomic, 32 no count store, 64 no record store
+// records, 8 no knots inside the tile, 16 no group-sum atomic, 32 no count store, 64 no record store, 512 (unused), 1024 no far
+// search, 2048 no knot phases (one constant segment), 4096 no knot scan, 8192 no candidate selection / halo assembly,
+// 16384 no writes to the signal's state
 #ifndef ITD_ABL_R
 #define ITD_ABL_R 0
+#endif
+#ifndef ITD_PRIO
+#define ITD_PRIO 0
 #endif
 // ITD_STAMPS: diagnostic build only — per-phase shader-clock totals of k_extract (never in the shipped library)
 #ifdef ITD_STAMPS
@@ -569,7 +574,7 @@ __device__ __forceinline__ int lane_bit(unsigned long long mask)
 // Differences: d0 = even - left, d1 = odd - even, d2 = right - odd (= the next lane's d0): every difference is computed
 // once and shared by the two samples whose predicate uses it (ITD.py:59 on raw differences).
 // ---------------------------------------------------------------------------------------------
-template <int TW>
+template <int TW, bool COUNT_ONLY = false>
 __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], double x_lo, double x_hi, int64_t s, int nrem,
                                             size_t slot, size_t gsum_index, int32_t *__restrict__ counts_out,
                                             TileRec *__restrict__ recs_out, int32_t *__restrict__ gsum_out,
@@ -579,7 +584,7 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
     const int lane = lane_id();
     double d0[G2];
 #pragma unroll
-    for (int g = 0; g < G2; ++g) {
+    for (int g = 0; g < G2 && !(ITD_ABL_R & 4096); ++g) {
         const double fill = (g == 0) ? x_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
         const double left = wave_dpp<0x138>(fill, xr[g][1]);
         d0[g] = xr[g][0] - left;
@@ -588,8 +593,13 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
     WaveMasks nm;
     int total = 0;
     int gcount[G2];
+    if (ITD_ABL_R & 4096) {   // timing skeleton: no scan, a constant non-zero count so that no level stops
+        total = 3;
 #pragma unroll
-    for (int g = 0; g < G2; ++g) {
+        for (int g = 0; g < G2; ++g) gcount[g] = 0;
+    }
+#pragma unroll
+    for (int g = 0; g < G2 && !(ITD_ABL_R & 4096); ++g) {
         const double d1 = xr[g][1] - xr[g][0];
         const double fill = (g == G2 - 1) ? (x_hi - xr[g][1]) : wave_dpp<0x134>(0.0, d0[g < G2 - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
         const double d2 = wave_dpp<0x130>(fill, d0[g]);
@@ -611,6 +621,7 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
         if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
         if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[gsum_index], total);
     }
+    if constexpr (COUNT_ONLY) return total;   // the "Out of time!" launch: only the stop test reads this level's knots
     // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample); the tile's
     // first and last sample for the neighbours
     TileRec *lrec = reinterpret_cast<TileRec *>(s_rec);
@@ -797,7 +808,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 
     // ---- candidate tiles: nearest non-empty ones in the +-64-tile count windows ---------------------------------------------
     int ub0 = -1, ub1 = -1, uf0 = -1, uf1 = -1, uf2 = -1, cb0 = 0, cf0 = 0, cf1 = 0;
-    {
+    if (ITD_ABL_R & 8192) {   // timing skeleton: keep the loads alive, skip the selection
+        if (cb + cf + specw == 0x7fffffff) ub0 = 0;
+    } else {
         unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
         if (mb) {
             const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
@@ -818,7 +831,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     auto slot_of = [&](int u, int k) { return u == t - 1 ? 0 : u == t + 1 ? 1 : u == t - 2 ? 2 : u == t + 2 ? 3 : 4 + k; };
     const int sb0 = slot_of(ub0, 0), sb1 = slot_of(ub1, 1), sf0 = slot_of(uf0, 2), sf1 = slot_of(uf1, 3), sf2 = slot_of(uf2, 4);
     s_rb[q4][w16] = specw;
-    if ((ub0 >= 0 && sb0 >= 4) || (ub1 >= 0 && sb1 >= 4) || (uf0 >= 0 && sf0 >= 4) || (uf1 >= 0 && sf1 >= 4)) {
+    if (!(ITD_ABL_R & 8192) && ((ub0 >= 0 && sb0 >= 4) || (ub1 >= 0 && sb1 >= 4) || (uf0 >= 0 && sf0 >= 4) || (uf1 >= 0 && sf1 >= 4))) {
         const int uk = q4 == 0 ? ub0 : q4 == 1 ? ub1 : q4 == 2 ? uf0 : uf1;
         const int sk = q4 == 0 ? sb0 : q4 == 1 ? sb1 : q4 == 2 ? sf0 : sf1;
         if (uk >= 0 && sk >= 4) s_rb[sk][w16] = reinterpret_cast<const int32_t *>(recs + uk)[w16];
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
     const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
 
-    if (t == 0 && !stopped) {
+    if (t == 0 && !stopped && !(ITD_ABL_R & 16384)) {
         // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
         int acc = 0;
         for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
@@ -860,7 +873,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     if (ub0 >= 0) nb = (cb0 >= 2 || ub1 >= 0) ? 2 : 1;
     if (uf0 >= 0) nf = min(3, cf0 + cf1 + (uf2 >= 0 ? 1 : 0));
     wave_sync();
-    if (lane < 5) {
+    if (lane < 5 && !(ITD_ABL_R & 8192)) {
         int sl, sh, vw;   // staged slot, bit offset of the knot's position in the packed word, dword of its value
         bool real;
         if (lane < 2) {
@@ -932,7 +945,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 
     ITD_STAMP(0);
     // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
-    const int c = own_c;
+    const int c = (ITD_ABL_R & 2048) ? 0 : own_c;
     WaveMasks wm;
     if (c > 0 && lane < 2 * G2) { wm.lo = (unsigned)own_word; wm.hi = (unsigned)(own_word >> 32); }
     // kinfo[g] = ke | bitE << 16 | bitO << 17, ke = knots of the tile at or before the lane's even sample of group g
@@ -959,6 +972,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                          (FINAL || (reinterpret_cast<uintptr_t>(bas_t) & 15) == 0);
     const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
     const bool near_end = (s + TW >= n - 2);
+    const bool interior = vec_out && !near_end && s != 0;   // nothing but whole-vector stores to do in the map
     const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));   // samples of the signal from s on, clipped: p < nrem <=> s + p < n
     const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
@@ -983,6 +997,10 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             }
         }
         const int nfp = min(3, (c - rb - m) + nf);   // real knots behind the run
+      if (ITD_ABL_R & 2048) {   // timing skeleton: one constant segment instead of the knot phases
+        if (lane == 0) { s_B[1] = 1.0; s_S[1] = 0.5; s_X[1] = 0.25; }
+        wave_sync();
+      } else {
         // own knots by rank (owner lanes), slots 0 .. m+4 of this pass
         if (c > 0) {
 #pragma unroll
@@ -1040,6 +1058,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             if (!endn) s_S[L] = sl;
         }
         wave_sync();
+      }
         ITD_STAMP(3);
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
@@ -1054,10 +1073,39 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 s_bl[1] = s_B[L] + s_S[L] * (xhi - s_X[L]);
             }
         }
+#if ITD_PRIO
+        __builtin_amdgcn_s_setprio(ITD_PRIO);   // a wavefront that has reached its store phase goes first: it retires sooner
+#endif
         // ---- baseline map + rotation, ITD.py:114-119; the baseline replaces the input in the registers --------------
+        if (interior && g0 == 0 && g1 == G2) {
+            // the common case, straight-line: a full, aligned tile away from both ends of the signal, one pass
+#pragma unroll
+            for (int g = 0; g < G2; ++g) {
+                __builtin_amdgcn_sched_barrier(0);   // one group's by-rank reads in flight at a time: registers, not latency, are scarce
+                int p = 128 * g + 2 * lane, ki = kinfo[g];
+                asm volatile("" : "+v"(p), "+v"(ki));
+                const int ke = ki & 0xffff, bO = (ki >> 17) & 1;
+                const int Le = ke + 1, Lo = Le + bO;   // rb = 0
+                const double xe = xr[g][0], xo = xr[g][1];
+                const double be = s_B[Le] + s_S[Le] * (xe - s_X[Le]);
+                const double bo = s_B[Lo] + s_S[Lo] * (xo - s_X[Lo]);
+                const double re = FINAL ? (xe - be) + be : xe - be;   // FINAL: rotation + baseline, ITD.py:420
+                const double rq = FINAL ? (xo - bo) + bo : xo - bo;
+                xr[g][0] = be;
+                xr[g][1] = bo;
+                const D2 rv = {re, rq}, bv = {be, bo};
+                D2 *rp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(rot_t) + (unsigned)p * 8u);
+                if (ITD_NT & 1) __builtin_nontemporal_store(rv, rp); else *rp = rv;
+                if constexpr (!FINAL) {
+                    D2 *bp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(bas_t) + (unsigned)p * 8u);
+                    if (ITD_NT & 2) __builtin_nontemporal_store(bv, bp); else *bp = bv;
+                }
+                has_nan = has_nan || __builtin_isunordered(be, bo);   // one unordered compare covers both samples
+            }
+        } else
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
-            __builtin_amdgcn_sched_barrier(0);   // one group's by-rank reads in flight at a time: registers, not latency, are scarce
+            __builtin_amdgcn_sched_barrier(0);
             if (g >= g0 && g < g1) {
                 int p = 128 * g + 2 * lane, ki = kinfo[g];   // tile position of the even sample; its rank word
                 asm volatile("" : "+v"(p), "+v"(ki));        // opaque: keeps per-group masks, addresses and decoded ranks out of the pass loop's preheader
@@ -1095,7 +1143,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                         has_nan = has_nan || (bo != bo);
                     }
                 }
-                if (!FINAL && !careful && (near_end || s == 0)) {   // the next level's end samples, ITD.py:101-102
+                if (!FINAL && !careful && (near_end || s == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples, ITD.py:101-102
                     if (s == 0 && p == 0) { ends_next[0] = be; ends_next[1] = bo; }
                     if (p == nrem - 2) { ends_next[2] = be; ends_next[3] = bo; }
                     if (p + 1 == nrem - 2) ends_next[2] = bo;
@@ -1113,7 +1161,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 
     // ---- knots of the baseline just produced = the next level's input, on registers ------------------------------------
     ITD_STAMP(5);
-    scan_publish<TW>(xr, s_bl[0], s_bl[1], s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
+    scan_publish<TW, FINAL>(xr, s_bl[0], s_bl[1], s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
                      counts_out, recs_out, gsum_out, s_rec, s_pos);
     ITD_STAMP(6);
     ITD_STAMP_END(t_begin, stamp_on);

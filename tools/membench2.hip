@@ -73,6 +73,75 @@ __global__ void k_level_x(const double* __restrict__ in, double* __restrict__ ro
     }
 }
 
+// nt=5 streams + the extraction's side traffic and shape, one bit each:
+//  1 count windows (2 x 64 lanes x 4 B, unaligned)   2 first 64 B of four neighbour records   4 own record (flag words)
+//  8 record + count + group-sum outputs   16 ~3 us of dependent ALU work between the loads and the stores
+//  32 4.3 KB of LDS and ~64 VGPRs per wavefront (k_extract's footprint)
+template <int Y>
+__global__ __launch_bounds__(64) void k_level_y(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas,
+                                                const int* __restrict__ counts_in, int* __restrict__ counts_out,
+                                                const int4* __restrict__ recs_in, int4* __restrict__ recs_out, int* __restrict__ gsum,
+                                                int n_tiles, int spin)
+{
+    using V = double __attribute__((ext_vector_type(2)));
+    __shared__ int lds[(Y & 32) ? 1100 : 16];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const size_t base = (size_t)t * 512;
+    const V* vi = reinterpret_cast<const V*>(in + base);
+    V* v1 = reinterpret_cast<V*>(rot + base);
+    V* v2 = reinterpret_cast<V*>(bas + base);
+    V x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = __builtin_nontemporal_load(&vi[k * 64 + lane]);
+    int side = 0;
+    if (Y & 64) {   // every wavefront reads one shared state line through the scalar cache; wavefront 0 writes it
+        const int* st = gsum + 512 * 32;
+        side += st[0] + st[5] + st[9];
+    }
+    if (Y & 128) {
+        int* st = gsum + 512 * 32;
+        if (t == 0 && lane == 0) st[3] = side;
+    }
+    if (Y & 256) {   // the same three words, but read with vector loads (uniform address)
+        const volatile int* st = gsum + 512 * 32 + (lane >> 6);
+        side += st[0] + st[5] + st[9];
+    }
+    if (Y & 1) {
+        const int tb = t - 1 - lane, tf = t + 1 + lane;
+        side += (tb >= 0 ? counts_in[tb] : 0) + (tf < n_tiles ? counts_in[tf] : 0);
+    }
+    if (Y & 2) {
+        const int q = lane >> 4, w = lane & 15;
+        const int u = q == 0 ? t - 1 : q == 1 ? t + 1 : q == 2 ? t - 2 : t + 2;
+        if (u >= 0 && u < n_tiles) side += reinterpret_cast<const int*>(recs_in + (size_t)u * 8)[w];
+    }
+    if (Y & 4) side += (int)reinterpret_cast<const unsigned long long*>(recs_in + (size_t)t * 8)[lane < 8 ? 8 + lane : 0];
+    double acc = (double)side;
+    if (Y & 32) {
+        lds[lane] = side; lds[lane + 64 * 16] = side;
+        __builtin_amdgcn_wave_barrier();
+        acc += lds[(lane * 7) & 63];
+    }
+    if (Y & 16) {
+        double z = x[0].x + acc;
+        for (int i = 0; i < spin; ++i) z = z * 1.0000001 + 1e-9;   // dependent fp64 chain
+        acc += (z > 1e300) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        V a = x[k] * 0.5;
+        a.x += (acc > 1e300) ? 1.0 : 0.0;
+        V b = x[k] - a;
+        __builtin_nontemporal_store(b, &v1[k * 64 + lane]);
+        v2[k * 64 + lane] = a;
+    }
+    if (Y & 8) {
+        const int total = 1 + (acc > 1e300);
+        if (lane < 8) recs_out[(size_t)t * 8 + lane] = make_int4(total, 1, 2, 3);
+        if (lane == 0) { counts_out[t] = total; atomicAdd(&gsum[(t / 64) * 32], total); }
+    }
+}
+
 int main()
 {
     const size_t n = 1ull << 24;
@@ -107,7 +176,7 @@ int main()
     VAR(2, 0, 64, 512)
     run("layout C (64 B per lane) nt=0", [&](const double* i, double* r, double* b) { k_level_c<0><<<(int)(n / 512), 64>>>(i, r, b); });
     int *gsum, *counts; int4* recs;
-    CK(hipMalloc(&gsum, 512 * 32 * 4)); CK(hipMalloc(&counts, 32768 * 4)); CK(hipMalloc(&recs, 32768 * 128));
+    CK(hipMalloc(&gsum, 512 * 32 * 4 + 4096)); CK(hipMalloc(&counts, 32768 * 4)); CK(hipMalloc(&recs, 32768 * 128));
     CK(hipMemset(gsum, 0, 512 * 32 * 4));
     run("16B/lane nt=1 x=0 (streams only)", [&](const double* i, double* r, double* b) { k_level_x<0><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
     run("16B/lane nt=1 x=1 (+atomic)", [&](const double* i, double* r, double* b) { k_level_x<1><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
@@ -115,5 +184,34 @@ int main()
     run("16B/lane nt=1 x=4 (+record store)", [&](const double* i, double* r, double* b) { k_level_x<4><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
     run("16B/lane nt=1 x=7 (+all three)", [&](const double* i, double* r, double* b) { k_level_x<7><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
     run("16B/lane nt=1 x=0 (streams only)", [&](const double* i, double* r, double* b) { k_level_x<0><<<32768, 64>>>(i, r, b, gsum, counts, recs); });
+    {
+        const int n_tiles = 32768;
+        int *cin, *cout; int4 *rin, *rout;
+        CK(hipMalloc(&cin, n_tiles * 4)); CK(hipMalloc(&cout, n_tiles * 4)); CK(hipMalloc(&rin, n_tiles * 128)); CK(hipMalloc(&rout, n_tiles * 128));
+        CK(hipMemset(cin, 0, n_tiles * 4)); CK(hipMemset(rin, 0, n_tiles * 128));
+        int lvl = 0;
+#define YV(Y, SPIN, NAME) run(NAME, [&](const double* i, double* r, double* b) { ++lvl; k_level_y<Y><<<n_tiles, 64>>>(i, r, b, (lvl & 1) ? cin : cout, (lvl & 1) ? cout : cin, (lvl & 1) ? rin : rout, (lvl & 1) ? rout : rin, gsum, n_tiles, SPIN); });
+        YV(0, 0, "y=0  nt=5 streams only")
+        YV(1, 0, "y=1  + count windows")
+        YV(2, 0, "y=2  + neighbour records")
+        YV(7, 0, "y=7  + windows, neighbour and own records")
+        YV(8, 0, "y=8  + outputs (record, count, atomic)")
+        YV(15, 0, "y=15 + all side traffic")
+        YV(16, 300, "y=16 + 300-step ALU chain between loads and stores")
+        YV(16, 1000, "y=16 + 1000-step ALU chain")
+        YV(48, 300, "y=48 + 300-step chain, 4.3 KB LDS")
+        YV(32, 0, "y=32 + 4.3 KB LDS only")
+        YV(47, 0, "y=47 + all side traffic + LDS")
+        YV(79, 0, "y=79 + all side traffic + shared state line")
+        YV(111, 0, "y=111 + side traffic + LDS + state line")
+        YV(63, 100, "y=63 side + LDS, 100-step chain")
+        YV(63, 300, "y=63 side + LDS, 300-step chain")
+        YV(127, 300, "y=127 side + LDS + chain + state loads (scalar)")
+        YV(191, 300, "y=191 side + LDS + chain + state write only")
+        YV(255, 300, "y=255 side + LDS + chain + state loads + write")
+        YV(319, 300, "y=319 side + LDS + chain + state loads (vector)")
+        YV(80, 300, "y=80  chain + state loads (scalar) only")
+        YV(0, 0, "y=0  nt=5 streams only")
+    }
     return 0;
 }
