@@ -792,11 +792,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
     }
     const TileRec *ro = recs + t;
-    const int own_c = (ITD_ABL_R & 8) ? 0 : rec_count(ro->packed);
-    const unsigned long long own_word = ro->flags[lane < 2 * G2 ? lane : 0];   // lane j < 2*G2: flag word j
+    const int own_c = (ITD_ABL_R & (8 | 32768)) ? 0 : rec_count(ro->packed);
+    const unsigned long long own_word = (ITD_ABL_R & 32768) ? 0ull : ro->flags[lane < 2 * G2 ? lane : 0];   // lane j < 2*G2: flag word j
     const int tb = t - 1 - lane, tf = t + 1 + lane;
-    const int cb = (tb >= 0 && !(ITD_ABL_R & 1)) ? cnts[tb] : 0;
-    const int cf = (tf < n_tiles && !(ITD_ABL_R & 1)) ? cnts[tf] : 0;
+    const int cb = (tb >= 0 && !(ITD_ABL_R & (1 | 32768))) ? cnts[tb] : 0;
+    const int cf = (tf < n_tiles && !(ITD_ABL_R & (1 | 32768))) ? cnts[tf] : 0;
 
     // ---- the neighbours' records, speculatively: lanes 16q..16q+15 fetch the first 64 bytes (count, first three / last
     //      two knots) of tiles t-1, t+1, t-2, t+2 in ONE load that leaves with the tile's own — in all but the sparsest
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int q4 = lane >> 4, w16 = lane & 15;
     const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
     int specw = 0;
-    if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & 2)) specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
+    if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & (2 | 32768))) specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
 
     // ---- candidate tiles: nearest non-empty ones in the +-64-tile count windows ---------------------------------------------
     int ub0 = -1, ub1 = -1, uf0 = -1, uf1 = -1, uf2 = -1, cb0 = 0, cf0 = 0, cf1 = 0;
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         ITD_STAMP(4);
     }
     if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
-    if (careful) return;   // k_careful_apply scans the baseline after the reference's NaN -> inf mutation
+    if (careful || (ITD_ABL_R & 65536)) return;   // k_careful_apply scans the baseline after the reference's NaN -> inf mutation
 
     // ---- knots of the baseline just produced = the next level's input, on registers ------------------------------------
     ITD_STAMP(5);

@@ -142,6 +142,34 @@ __global__ __launch_bounds__(64) void k_level_y(const double* __restrict__ in, d
     }
 }
 
+// stream subsets of the nt=5 pipeline kernel: Z bit 0 read the input (nontemporal), 1 write the rotation row (nontemporal),
+// 2 write the baseline (cacheable), 8 the input is float32 (half the read bytes)
+template <int Z>
+__global__ __launch_bounds__(64) void k_level_z(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas)
+{
+    using V = double __attribute__((ext_vector_type(2)));
+    using F = float __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * 512;
+    V x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = V{1.0 + lane, 2.0 + k};
+        if (Z & 1) {
+            if (Z & 8) { F f = __builtin_nontemporal_load(&reinterpret_cast<const F*>(reinterpret_cast<const float*>(in) + base)[k * 64 + lane]); x[k] = V{(double)f.x, (double)f.y}; }
+            else x[k] = __builtin_nontemporal_load(&reinterpret_cast<const V*>(in + base)[k * 64 + lane]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        V a = x[k] * 0.5;
+        V b = x[k] - a;
+        if (Z & 2) __builtin_nontemporal_store(b, &reinterpret_cast<V*>(rot + base)[k * 64 + lane]);
+        if (Z & 4) reinterpret_cast<V*>(bas + base)[k * 64 + lane] = a;
+        if (!(Z & 6) && a.x == 1.2345e300) rot[base] = a.x;
+    }
+}
+
 int main()
 {
     const size_t n = 1ull << 24;
@@ -213,5 +241,13 @@ int main()
         YV(80, 300, "y=80  chain + state loads (scalar) only")
         YV(0, 0, "y=0  nt=5 streams only")
     }
+    run("z=7  read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(i, r, b); });
+    run("z=3  read + rotation(nt)", [&](const double* i, double* r, double* b) { k_level_z<3><<<32768, 64>>>(i, r, b); });
+    run("z=5  read + baseline", [&](const double* i, double* r, double* b) { k_level_z<5><<<32768, 64>>>(i, r, b); });
+    run("z=6  rotation(nt) + baseline, no read", [&](const double* i, double* r, double* b) { k_level_z<6><<<32768, 64>>>(i, r, b); });
+    run("z=1  read only", [&](const double* i, double* r, double* b) { k_level_z<1><<<32768, 64>>>(i, r, b); });
+    run("z=2  rotation(nt) only", [&](const double* i, double* r, double* b) { k_level_z<2><<<32768, 64>>>(i, r, b); });
+    run("z=4  baseline only", [&](const double* i, double* r, double* b) { k_level_z<4><<<32768, 64>>>(i, r, b); });
+    run("z=15 f32 read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<15><<<32768, 64>>>(i, r, b); });
     return 0;
 }
