@@ -11,6 +11,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--log2n", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--stream-pool", type=int, default=8, help="also time one-signal launches over this many streams/engines (0 = skip)")
+ap.add_argument("--cpu-signals", type=int, default=0, help="also time the C oracle on this many signals over all host cores (0 = skip)")
 args = ap.parse_args()
 B, n, M = args.batch, 1 << args.log2n, 7
 distinct = np.stack([sines_noise(n, seed=b) for b in range(16)])       # 16 distinct noise draws, tiled
@@ -36,3 +38,29 @@ eng.summary(B)
 dt = (time.perf_counter() - t0) / args.steps
 print("batch %d x 2^%d, 8 levels: %.2f ms per batch decomposition = %.0f Msamples/s, %.0f GB/s algorithmic" % (
     B, args.log2n, dt * 1e3, B * n / dt / 1e6, 188.0 * B * n / dt / 1e9))
+
+if args.stream_pool > 0:
+    # SURVEY 8d config 3, second variant: one signal per launch sequence, round-robin over a pool of streams (one engine each)
+    S = args.stream_pool
+    pool = [(pyitd_amd.Engine(n, 1, 0), torch.cuda.Stream()) for _ in range(S)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(B):
+        e_, st_ = pool[b % S]
+        e_.decompose_dev(x[b].data_ptr(), np.float32, n, 1, n, M, rows[b].data_ptr(), None, st_.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for e_, _ in pool[:1]:
+        e_.summary(1)
+    print("stream pool (%d streams, %d one-signal decompositions): %.2f ms = %.0f Msamples/s" % (S, B, dt * 1e3, B * n / dt / 1e6))
+if args.cpu_signals > 0:
+    # CPU baseline over independent signals on all host cores (ctypes releases the GIL inside the C oracle)
+    from concurrent.futures import ThreadPoolExecutor
+    K, T = args.cpu_signals, os.cpu_count()
+    work = [distinct[b % 16] for b in range(K)]
+    cpu_oracle.itd_lean(work[0], M)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(T, K)) as ex:
+        list(ex.map(lambda v: cpu_oracle.itd_lean(v, M)["rows"].shape[0], work))
+    dt = time.perf_counter() - t0
+    print("CPU oracle, %d signals x 2^%d over %d threads: %.2f s = %.1f Msamples/s" % (K, args.log2n, min(T, K), dt, K * n / dt / 1e6))
