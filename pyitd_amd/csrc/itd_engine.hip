@@ -143,6 +143,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int64_t rows_stride = R * n;
     const dim3 blk(kWave);
     const dim3 grid_t(n_tiles, batch);   // one one-wavefront workgroup per tile
+    const dim3 grid_x((n_tiles + kTilesPerWave - 1) / kTilesPerWave, batch);   // k_extract: kTilesPerWave consecutive tiles per wavefront
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
     auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
     auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
@@ -179,7 +180,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         const bool final_level = (j == M + 1);
         const int pair = time_begin(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT), st);
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
-    k_extract<TIN, T, FIN, CAPK><<<grid_t, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
+    k_extract<TIN, T, FIN, CAPK, kTilesPerWave><<<grid_x, blk, 0, st>>>(XIN, XSTRIDE, n, n_tiles, batch, cnt(j),  \
                                                     cnt(j + 1), rec(j), rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,  \
                                                     rows_stride, base_out, base_stride, e->d_state, j, 0)
         if (j == 0) {
@@ -259,11 +260,11 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
         if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
         double *rot_out = rows + (int64_t)j * n;
         if (j == 0)
-            k_extract<Tin, T, false, kRankCap0><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
+            k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
                                                                         rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
                                                                         n, base_out, n, state, j, 1);
         else
-            k_extract<double, T, false, kRankCap><<<dim3(n_tiles), kWave, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
+            k_extract<double, T, false, kRankCap, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
                                                                            rec(j), rec(j + 1), gs(j), gs(j + 1),
                                                                            gs(j + 2), rot_out, n, base_out, n, state, j, 1);
         k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
@@ -542,7 +543,7 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     const bool want_list = m_host || knots || want_sync;
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
-    k_extract<Tin, T, false, kRankCap0><<<dim3(n_tiles), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
+    k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
                                                       e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
                                                       e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
                                                       rot, n, base, n, e->d_state, 0, 0);
@@ -709,19 +710,6 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
     return ITD_OK;
 }
 
-#ifdef ITD_STAMPS
-// diagnostic builds only (not declared in the public header)
-int itd_debug_stamps(unsigned long long *out16, int reset)
-{
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_itd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return ITD_ERR_HIP;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        z[9] = ~0ull;   // slot 9 = earliest wavefront start (atomicMin)
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_itd_stamps), z, sizeof(z)) != hipSuccess) return ITD_ERR_HIP;
-    }
-    return ITD_OK;
-}
-#endif
 
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
 {

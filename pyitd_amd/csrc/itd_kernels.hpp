@@ -47,48 +47,6 @@
 #ifndef ITD_PRIO
 #define ITD_PRIO 0
 #endif
-// ITD_STAMPS: diagnostic build only — per-phase shader-clock totals of k_extract (never in the shipped library)
-#ifdef ITD_STAMPS
-__device__ unsigned long long g_itd_stamps[16];
-#define ITD_STAMP(slot)                                                                       \
-    do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                        \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        stamp_acc__[slot] += now__ - stamp_prev__;                                            \
-        stamp_prev__ = __builtin_amdgcn_s_memtime();                                          \
-    } while (0)
-#define ITD_STAMP_BEGIN() stamp_prev__ = __builtin_amdgcn_s_memtime()
-#define ITD_STAMP_DECL() unsigned long long stamp_acc__[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_prev__ = 0
-#define ITD_STAMP_FLUSH()                                                                     \
-    do {                                                                                      \
-        if ((threadIdx.x & 63) == 0)                                                          \
-            for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
-    } while (0)
-// k_extract: wave lifetime + phase sums of one launch (level ITD_STAMP_LEVEL), every 64th tile
-#ifndef ITD_STAMP_LEVEL
-#define ITD_STAMP_LEVEL 3
-#endif
-#define ITD_STAMP_END(t0__, on__)                                                              \
-    do {                                                                                      \
-        if ((on__) && (threadIdx.x & 63) == 0) {                                              \
-            const unsigned long long t1__ = __builtin_amdgcn_s_memtime();                     \
-            if ((blockIdx.x & 63) == 0) {                                                     \
-                for (int q__ = 0; q__ < 8; ++q__) atomicAdd(&g_itd_stamps[q__], stamp_acc__[q__]); \
-                atomicAdd(&g_itd_stamps[8], t1__ - (t0__));                                   \
-                atomicAdd(&g_itd_stamps[11], 1ull);                                           \
-            }                                                                                 \
-        }                                                                                     \
-    } while (0)
-#else
-#define ITD_STAMP_END(t0__, on__) do { } while (0)
-#define ITD_STAMP_DECL() do { } while (0)
-#define ITD_STAMP_FLUSH() do { } while (0)
-#define ITD_STAMP(slot) do { } while (0)
-#define ITD_STAMP_BEGIN() do { } while (0)
-#endif
-
 namespace itd {
 
 constexpr int kWave = 64;              // one wavefront per tile, one tile per workgroup
@@ -102,6 +60,12 @@ constexpr int kRankCap = ITD_RANK_CAP;
 #define ITD_RANK_CAP0 264
 #endif
 constexpr int kRankCap0 = ITD_RANK_CAP0;
+// tiles per wavefront of k_extract (all their loads are issued up front).  2 hides the second tile's load latency and the
+// first tile's store acknowledgements, but needs 109 VGPRs (4 wavefronts per SIMD) and measured 74 vs 70 us per level: 1 ships.
+#ifndef ITD_KT
+#define ITD_KT 1
+#endif
+constexpr int kTilesPerWave = ITD_KT;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 
@@ -723,7 +687,7 @@ __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, in
                      ((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch, counts, recs, gsum_out, s_rec, s_pos);
 }
 
-template <typename Tin, int TW, bool FINAL, int CAP>
+template <typename Tin, int TW, bool FINAL, int CAP, int KT>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
                                                      const int32_t *__restrict__ counts_in,
@@ -753,17 +717,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     __shared__ int32_t s_hI[8];     // ... and their sample indices
     int32_t *s_gi = reinterpret_cast<int32_t *>(s_S);
 
-    ITD_STAMP_DECL();
-#ifdef ITD_STAMPS
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    const bool stamp_on = (level == ITD_STAMP_LEVEL);
-#endif
-    ITD_STAMP_BEGIN();
-    const int lane = lane_id();
-    const int t = blockIdx.x;
     const int sig = blockIdx.y;
     SigState *st = state + sig;
-    const int64_t s = (int64_t)t * TW;
     const Tin *x = xin + (int64_t)sig * x_stride;
     const size_t slot0 = (size_t)sig * n_tiles;
     const int32_t *cnts = counts_in + slot0;
@@ -771,19 +726,93 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int n_groups = groups_of(n_tiles);
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
 
-    // ---- requests first: the tile, its own record, the neighbours' knot counts -----------------------------------------
+    // ---- everything the wavefront's KT tiles need from HBM is requested up front (vector loads only: they retire in order,
+    //      so the wait for one tile's data leaves the later tiles' requests — and the earlier tiles' stores — in flight):
+    //      the second tile's load latency hides behind the first tile's work, the first tile's store acknowledgements behind
+    //      the second tile's ---------------------------------------------------------------------------------------------
+    struct TileLoads {
+        In2 q[G2];                  // the tile: two consecutive samples per lane and 128-sample group
+        unsigned long long own;     // lane j < 2*G2: the tile's flag word j; the other lanes: its packed knot word
+        int cb, cf;                 // knot counts of tiles t-1-lane / t+1+lane
+        int specw;                  // lanes 16q..16q+15: first 64 bytes of the record of tile t-1, t+1, t-2, t+2 (speculative)
+    };
+    auto vec_tile = [&](int t) {
+        const int64_t s = (int64_t)t * TW;
+        return (s + TW <= n) && ((reinterpret_cast<uintptr_t>(x + s) & (2 * sizeof(Tin) - 1)) == 0);
+    };
+    TileLoads pre[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int t = blockIdx.x * KT + k;
+        const int lane = lane_id();
+        if (t < n_tiles) {
+            if (vec_tile(t)) {
+                const In2 *v = reinterpret_cast<const In2 *>(x + (int64_t)t * TW);
+#pragma unroll
+                for (int g = 0; g < G2; ++g) pre[k].q[g] = (ITD_NT & 4) ? __builtin_nontemporal_load(&v[g * 64 + lane]) : v[g * 64 + lane];
+            }
+            pre[k].own = (ITD_ABL_R & 32768) ? 0ull : reinterpret_cast<const unsigned long long *>(recs + t)[lane < 2 * G2 ? 8 + lane : 0];
+            const int tb = t - 1 - lane, tf = t + 1 + lane;
+            pre[k].cb = (tb >= 0 && !(ITD_ABL_R & (1 | 32768))) ? cnts[tb] : 0;
+            pre[k].cf = (tf < n_tiles && !(ITD_ABL_R & (1 | 32768))) ? cnts[tf] : 0;
+            const int q4 = lane >> 4, w16 = lane & 15;
+            const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
+            pre[k].specw = 0;
+            if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & (2 | 32768))) pre[k].specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
+        }
+    }
+
+    const int stopped = st->stopped;
+    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
+    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
+
+    if (blockIdx.x == 0 && !stopped && !(ITD_ABL_R & 16384)) {
+        // ---- tile 0's wavefront: total knot count of this level and the stop rule (ITD.py:400-404) ------------
+        const int lane = lane_id();
+        int acc = 0;
+        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) {
+            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
+                if (st->c_has_nan) acc = st->c_nan;
+                st->c_nan = 0;
+                st->c_has_nan = 0;
+            }
+            st->m[level] = acc;
+            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
+                st->stop_level = level;
+                st->stopped = 1;
+            }
+        }
+        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
+        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
+    }
+    if (stopped) return;
+    const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
+    const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
+    double *ends_next = st->ends[(level + 1) & 1];
+    bool has_nan = false;
+
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int t = blockIdx.x * KT + kt;
+    if (t >= n_tiles) break;
+    __builtin_amdgcn_sched_barrier(0);   // no code motion between the tiles: the later tile only keeps its loaded registers alive
+    int lane_v = lane_id();
+    asm volatile("" : "+v"(lane_v));   // opaque per tile: nothing derived from the lane index is shared between the tiles' code
+    const int lane = lane_v;
+    const int q4 = lane >> 4, w16 = lane & 15;
+    const int64_t s = (int64_t)t * TW;
     const bool full = (s + TW <= n);
-    const bool vec_in = full && ((reinterpret_cast<uintptr_t>(x + s) & (2 * sizeof(Tin) - 1)) == 0);
     double xr[G2][2];
-    if (vec_in) {
-        const In2 *v = reinterpret_cast<const In2 *>(x + s);
+    if (vec_tile(t)) {
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
-            const In2 q = (ITD_NT & 4) ? __builtin_nontemporal_load(&v[g * 64 + lane]) : v[g * 64 + lane];
-            xr[g][0] = (double)q.x;
-            xr[g][1] = (double)q.y;
+            xr[g][0] = (double)pre[kt].q[g].x;
+            xr[g][1] = (double)pre[kt].q[g].y;
         }
-    } else {
+    } else {   // ragged or unaligned tile: element loads
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
             const int64_t i = s + 128 * g + 2 * lane;
@@ -791,20 +820,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
         }
     }
-    const TileRec *ro = recs + t;
-    const int own_c = (ITD_ABL_R & (8 | 32768)) ? 0 : rec_count(ro->packed);
-    const unsigned long long own_word = (ITD_ABL_R & 32768) ? 0ull : ro->flags[lane < 2 * G2 ? lane : 0];   // lane j < 2*G2: flag word j
-    const int tb = t - 1 - lane, tf = t + 1 + lane;
-    const int cb = (tb >= 0 && !(ITD_ABL_R & (1 | 32768))) ? cnts[tb] : 0;
-    const int cf = (tf < n_tiles && !(ITD_ABL_R & (1 | 32768))) ? cnts[tf] : 0;
-
-    // ---- the neighbours' records, speculatively: lanes 16q..16q+15 fetch the first 64 bytes (count, first three / last
-    //      two knots) of tiles t-1, t+1, t-2, t+2 in ONE load that leaves with the tile's own — in all but the sparsest
-    //      levels the five knots around the tile are in there, and no load has to wait for the counts to come back --------
-    const int q4 = lane >> 4, w16 = lane & 15;
-    const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
-    int specw = 0;
-    if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & (2 | 32768))) specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
+    const unsigned long long own_word = pre[kt].own;
+    const unsigned long long own_packed = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(own_word >> 32), 63) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)own_word, 63);
+    const int own_c = (ITD_ABL_R & (8 | 32768)) ? 0 : rec_count(own_packed);
+    const int cb = pre[kt].cb, cf = pre[kt].cf, specw = pre[kt].specw;
 
     // ---- candidate tiles: nearest non-empty ones in the +-64-tile count windows ---------------------------------------------
     int ub0 = -1, ub1 = -1, uf0 = -1, uf1 = -1, uf2 = -1, cb0 = 0, cf0 = 0, cf1 = 0;
@@ -837,33 +857,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         if (uk >= 0 && sk >= 4) s_rb[sk][w16] = reinterpret_cast<const int32_t *>(recs + uk)[w16];
     }
     if (uf2 >= 0 && sf2 >= 4 && lane < 16) s_rb[8][lane] = reinterpret_cast<const int32_t *>(recs + uf2)[lane];
-
-    const int stopped = st->stopped;
-    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
-    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
-
-    if (t == 0 && !stopped && !(ITD_ABL_R & 16384)) {
-        // ---- tile 0: total knot count of this level and the stop rule (ITD.py:400-404) ----------------------
-        int acc = 0;
-        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) {
-            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
-                if (st->c_has_nan) acc = st->c_nan;
-                st->c_nan = 0;
-                st->c_has_nan = 0;
-            }
-            st->m[level] = acc;
-            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
-                st->stop_level = level;
-                st->stopped = 1;
-            }
-        }
-        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
-        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
-    }
-    if (stopped) return;
 
     // staged record slot -> its tile (for the knots' absolute sample indices)
     auto tile_of = [&](int sl) { return sl == 0 ? t - 1 : sl == 1 ? t + 1 : sl == 2 ? t - 2 : sl == 3 ? t + 2 : sl == 4 ? ub0 : sl == 5 ? ub1 : sl == 6 ? uf0 : sl == 7 ? uf1 : uf2; };
@@ -943,7 +936,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         wave_sync();
     }
 
-    ITD_STAMP(0);
     // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
     const int c = (ITD_ABL_R & 2048) ? 0 : own_c;
     WaveMasks wm;
@@ -965,7 +957,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         for (int g = 0; g < G2; ++g) kinfo[g] = 0;
     }
 
-    ITD_STAMP(1);
     double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
     double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
     const bool vec_out = full && ((reinterpret_cast<uintptr_t>(rot_t) & 15) == 0) &&
@@ -974,11 +965,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const bool near_end = (s + TW >= n - 2);
     const bool interior = vec_out && !near_end && s != 0;   // nothing but whole-vector stores to do in the map
     const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));   // samples of the signal from s on, clipped: p < nrem <=> s + p < n
-    const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
-    const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
     // s_hX[5], s_hX[6] / s_hI[5], s_hI[6]: the previous run's last two knots; s_bl[0], s_bl[1]: baseline at samples s-1, s+TW
-    bool has_nan = false;
-    double *ends_next = st->ends[(level + 1) & 1];
 
     // ---- passes --------------------------------------------------------------------------------------------------------
     int rb = 0, g0 = 0;
@@ -1035,7 +1022,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             }
         }
         wave_sync();
-        ITD_STAMP(2);
         if (g1 < G2 && lane < 2) { s_hX[5 + lane] = s_X[m + lane]; s_hI[5 + lane] = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
         // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
         for (int L = 1 + lane; L <= m + 3; L += kWave) {
@@ -1059,7 +1045,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
         wave_sync();
       }
-        ITD_STAMP(3);
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
             if (g0 == 0 && s >= 1) {   // sample s-1 = the last sample of tile t-1
@@ -1154,17 +1139,15 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         rb += m;
         g0 = g1;
         wave_sync();
-        ITD_STAMP(4);
     }
-    if (__any(has_nan) && lane == 0) atomicOr(&st->nan_mask, 1 << level);
-    if (careful || (ITD_ABL_R & 65536)) return;   // k_careful_apply scans the baseline after the reference's NaN -> inf mutation
-
-    // ---- knots of the baseline just produced = the next level's input, on registers ------------------------------------
-    ITD_STAMP(5);
-    scan_publish<TW, FINAL>(xr, s_bl[0], s_bl[1], s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
-                     counts_out, recs_out, gsum_out, s_rec, s_pos);
-    ITD_STAMP(6);
-    ITD_STAMP_END(t_begin, stamp_on);
+    // ---- knots of the baseline just produced = the next level's input, on registers (careful mode: k_careful_apply scans
+    //      the baseline after the reference's NaN -> inf mutation) -----------------------------------------------------------
+    if (!careful && !(ITD_ABL_R & 65536))
+        scan_publish<TW, FINAL>(xr, s_bl[0], s_bl[1], s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
+                                counts_out, recs_out, gsum_out, s_rec, s_pos);
+    wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
+  }
+    if (__any(has_nan) && lane_id() == 0) atomicOr(&st->nan_mask, 1 << level);
 }
 
 // ---------------------------------------------------------------------------------------------
