@@ -746,11 +746,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         const int t = blockIdx.x * KT + k;
         const int lane = lane_id();
         if (t < n_tiles) {
-            if (vec_tile(t)) {
-                const In2 *v = reinterpret_cast<const In2 *>(x + (int64_t)t * TW);
-#pragma unroll
-                for (int g = 0; g < G2; ++g) pre[k].q[g] = (ITD_NT & 4) ? __builtin_nontemporal_load(&v[g * 64 + lane]) : v[g * 64 + lane];
-            }
+            // the small loads first: loads retire in order, and the halo logic that needs them should not wait for the tile
             pre[k].own = (ITD_ABL_R & 32768) ? 0ull : reinterpret_cast<const unsigned long long *>(recs + t)[lane < 2 * G2 ? 8 + lane : 0];
             const int tb = t - 1 - lane, tf = t + 1 + lane;
             pre[k].cb = (tb >= 0 && !(ITD_ABL_R & (1 | 32768))) ? cnts[tb] : 0;
@@ -759,6 +755,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
             pre[k].specw = 0;
             if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & (2 | 32768))) pre[k].specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
+            if (vec_tile(t)) {
+                const In2 *v = reinterpret_cast<const In2 *>(x + (int64_t)t * TW);
+#pragma unroll
+                for (int g = 0; g < G2; ++g) pre[k].q[g] = (ITD_NT & 4) ? __builtin_nontemporal_load(&v[g * 64 + lane]) : v[g * 64 + lane];
+            }
         }
     }
 
@@ -805,21 +806,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int q4 = lane >> 4, w16 = lane & 15;
     const int64_t s = (int64_t)t * TW;
     const bool full = (s + TW <= n);
-    double xr[G2][2];
-    if (vec_tile(t)) {
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            xr[g][0] = (double)pre[kt].q[g].x;
-            xr[g][1] = (double)pre[kt].q[g].y;
-        }
-    } else {   // ragged or unaligned tile: element loads
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const int64_t i = s + 128 * g + 2 * lane;
-            xr[g][0] = (i < n) ? (double)x[i] : 0.0;
-            xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
-        }
-    }
     const unsigned long long own_word = pre[kt].own;
     const unsigned long long own_packed = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(own_word >> 32), 63) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)own_word, 63);
@@ -936,6 +922,22 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         wave_sync();
     }
 
+    // ---- the tile itself, needed from here on ---------------------------------------------------------------------------
+    double xr[G2][2];
+    if (vec_tile(t)) {
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            xr[g][0] = (double)pre[kt].q[g].x;
+            xr[g][1] = (double)pre[kt].q[g].y;
+        }
+    } else {   // ragged or unaligned tile: element loads
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int64_t i = s + 128 * g + 2 * lane;
+            xr[g][0] = (i < n) ? (double)x[i] : 0.0;
+            xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
+        }
+    }
     // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
     const int c = (ITD_ABL_R & 2048) ? 0 : own_c;
     WaveMasks wm;
