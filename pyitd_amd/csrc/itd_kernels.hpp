@@ -687,6 +687,47 @@ __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, in
                      ((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch, counts, recs, gsum_out, s_rec, s_pos);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bounds-checked streaming accesses of one tile through a raw buffer descriptor (base = the tile's first element, extent =
+// what is left of the row): elements beyond the row read as 0 and are not written, any 4-byte alignment is legal.  One code
+// path for full, ragged and unaligned tiles, and every access is unconditional — so the compiler can count them and wait for
+// exactly the load it needs (vmcnt) instead of for all of them.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBufNT = 2;   // aux bits of the raw buffer builtins on gfx94x/gfx950: 2 = nt
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *base, int64_t bytes_left)
+{
+    const int64_t lim = bytes_left < 0 ? 0 : (bytes_left > 0x7fffffffll ? 0x7fffffffll : bytes_left);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)lim, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ void tile_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff, double &a, double &b)
+{
+    using U4 = unsigned __attribute__((ext_vector_type(4)));
+    using D2v = double __attribute__((ext_vector_type(2)));
+    const U4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, NT ? kBufNT : 0);
+    const D2v d = __builtin_bit_cast(D2v, v);
+    a = d.x;
+    b = d.y;
+}
+template <bool NT>
+__device__ __forceinline__ void tile_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff, float &a, float &b)
+{
+    using U2 = unsigned __attribute__((ext_vector_type(2)));
+    using F2v = float __attribute__((ext_vector_type(2)));
+    const U2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, NT ? kBufNT : 0);
+    const F2v d = __builtin_bit_cast(F2v, v);
+    a = d.x;
+    b = d.y;
+}
+template <bool NT>
+__device__ __forceinline__ void tile_store2(__amdgpu_buffer_rsrc_t r, int voff, double a, double b)
+{
+    using U4 = unsigned __attribute__((ext_vector_type(4)));
+    using D2v = double __attribute__((ext_vector_type(2)));
+    const D2v d = {a, b};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, d), r, voff, 0, NT ? kBufNT : 0);
+}
+
 template <typename Tin, int TW, bool FINAL, int CAP, int KT>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
@@ -704,8 +745,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
     static_assert(CAP >= 128, "a pass must be able to take one 128-sample group");
     constexpr int RK = CAP + 8;
-    using D2 = double __attribute__((ext_vector_type(2)));
-    using In2 = Tin __attribute__((ext_vector_type(2)));
     __shared__ double s_X[RK];      // value of the level's input at knot slot L
     __shared__ double s_B[RK];      // knot value B_L
     __shared__ double s_S[RK];      // slope of the segment that starts at slot L; before the slopes exist: the knots' indices
@@ -731,14 +770,10 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     //      the second tile's load latency hides behind the first tile's work, the first tile's store acknowledgements behind
     //      the second tile's ---------------------------------------------------------------------------------------------
     struct TileLoads {
-        In2 q[G2];                  // the tile: two consecutive samples per lane and 128-sample group
+        Tin q[G2][2];               // the tile: two consecutive samples per lane and 128-sample group
         unsigned long long own;     // lane j < 2*G2: the tile's flag word j; the other lanes: its packed knot word
         int cb, cf;                 // knot counts of tiles t-1-lane / t+1+lane
         int specw;                  // lanes 16q..16q+15: first 64 bytes of the record of tile t-1, t+1, t-2, t+2 (speculative)
-    };
-    auto vec_tile = [&](int t) {
-        const int64_t s = (int64_t)t * TW;
-        return (s + TW <= n) && ((reinterpret_cast<uintptr_t>(x + s) & (2 * sizeof(Tin) - 1)) == 0);
     };
     TileLoads pre[KT];
 #pragma unroll
@@ -755,11 +790,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
             pre[k].specw = 0;
             if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & (2 | 32768))) pre[k].specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
-            if (vec_tile(t)) {
-                const In2 *v = reinterpret_cast<const In2 *>(x + (int64_t)t * TW);
+            const int64_t s = (int64_t)t * TW;
+            const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x + s, (n - s) * (int64_t)sizeof(Tin));
 #pragma unroll
-                for (int g = 0; g < G2; ++g) pre[k].q[g] = (ITD_NT & 4) ? __builtin_nontemporal_load(&v[g * 64 + lane]) : v[g * 64 + lane];
-            }
+            for (int g = 0; g < G2; ++g)
+                tile_load2<(ITD_NT & 4) != 0>(rx, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), pre[k].q[g][0], pre[k].q[g][1]);
         }
     }
 
@@ -767,28 +802,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
     const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
 
-    if (blockIdx.x == 0 && !stopped && !(ITD_ABL_R & 16384)) {
-        // ---- tile 0's wavefront: total knot count of this level and the stop rule (ITD.py:400-404) ------------
-        const int lane = lane_id();
-        int acc = 0;
-        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) {
-            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
-                if (st->c_has_nan) acc = st->c_nan;
-                st->c_nan = 0;
-                st->c_has_nan = 0;
-            }
-            st->m[level] = acc;
-            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
-                st->stop_level = level;
-                st->stopped = 1;
-            }
-        }
-        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
-        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
-    }
     if (stopped) return;
     const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
@@ -923,20 +936,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     }
 
     // ---- the tile itself, needed from here on ---------------------------------------------------------------------------
-    double xr[G2][2];
-    if (vec_tile(t)) {
+    double xr[G2][2];   // samples beyond the row were read as 0
 #pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            xr[g][0] = (double)pre[kt].q[g].x;
-            xr[g][1] = (double)pre[kt].q[g].y;
-        }
-    } else {   // ragged or unaligned tile: element loads
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const int64_t i = s + 128 * g + 2 * lane;
-            xr[g][0] = (i < n) ? (double)x[i] : 0.0;
-            xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
-        }
+    for (int g = 0; g < G2; ++g) {
+        xr[g][0] = (double)pre[kt].q[g][0];
+        xr[g][1] = (double)pre[kt].q[g][1];
     }
     // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
     const int c = (ITD_ABL_R & 2048) ? 0 : own_c;
@@ -961,11 +965,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 
     double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
     double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
-    const bool vec_out = full && ((reinterpret_cast<uintptr_t>(rot_t) & 15) == 0) &&
-                         (FINAL || (reinterpret_cast<uintptr_t>(bas_t) & 15) == 0);
+    const __amdgpu_buffer_rsrc_t r_rot = tile_rsrc(rot_t, (n - s) * 8);
+    const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc(FINAL ? rot_t : bas_t, FINAL ? 0 : (n - s) * 8);
     const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
     const bool near_end = (s + TW >= n - 2);
-    const bool interior = vec_out && !near_end && s != 0;   // nothing but whole-vector stores to do in the map
+    const bool interior = full && !near_end && s != 0;   // no end-of-signal rule applies to any sample of the tile
     const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));   // samples of the signal from s on, clipped: p < nrem <=> s + p < n
     // s_hX[5], s_hX[6] / s_hI[5], s_hI[6]: the previous run's last two knots; s_bl[0], s_bl[1]: baseline at samples s-1, s+TW
 
@@ -1080,13 +1084,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 const double rq = FINAL ? (xo - bo) + bo : xo - bo;
                 xr[g][0] = be;
                 xr[g][1] = bo;
-                const D2 rv = {re, rq}, bv = {be, bo};
-                D2 *rp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(rot_t) + (unsigned)p * 8u);
-                if (ITD_NT & 1) __builtin_nontemporal_store(rv, rp); else *rp = rv;
-                if constexpr (!FINAL) {
-                    D2 *bp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(bas_t) + (unsigned)p * 8u);
-                    if (ITD_NT & 2) __builtin_nontemporal_store(bv, bp); else *bp = bv;
-                }
+                tile_store2<(ITD_NT & 1) != 0>(r_rot, p * 8, re, rq);
+                if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, be, bo);
                 has_nan = has_nan || __builtin_isunordered(be, bo);   // one unordered compare covers both samples
             }
         } else
@@ -1109,27 +1108,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 const double rq = FINAL ? (xo - bo) + bo : xo - bo;
                 xr[g][0] = be;
                 xr[g][1] = bo;
-                if (vec_out) {
-                    const D2 rv = {re, rq}, bv = {be, bo};
-                    D2 *rp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(rot_t) + (unsigned)p * 8u);
-                    if (ITD_NT & 1) __builtin_nontemporal_store(rv, rp); else *rp = rv;
-                    if constexpr (!FINAL) {
-                        D2 *bp = reinterpret_cast<D2 *>(reinterpret_cast<char *>(bas_t) + (unsigned)p * 8u);
-                        if (ITD_NT & 2) __builtin_nontemporal_store(bv, bp); else *bp = bv;
-                    }
-                    has_nan = has_nan || (be != be) || (bo != bo);
-                } else {
-                    if (p < nrem) {
-                        rot_t[p] = re;
-                        if constexpr (!FINAL) bas_t[p] = be;
-                        has_nan = has_nan || (be != be);
-                    }
-                    if (p + 1 < nrem) {
-                        rot_t[p + 1] = rq;
-                        if constexpr (!FINAL) bas_t[p + 1] = bo;
-                        has_nan = has_nan || (bo != bo);
-                    }
-                }
+                tile_store2<(ITD_NT & 1) != 0>(r_rot, p * 8, re, rq);   // samples beyond the row are dropped by the bounds check
+                if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, be, bo);
+                has_nan = has_nan || (p < nrem && be != be) || (p + 1 < nrem && bo != bo);
                 if (!FINAL && !careful && (near_end || s == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples, ITD.py:101-102
                     if (s == 0 && p == 0) { ends_next[0] = be; ends_next[1] = bo; }
                     if (p == nrem - 2) { ends_next[2] = be; ends_next[3] = bo; }
@@ -1150,6 +1131,30 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
   }
     if (__any(has_nan) && lane_id() == 0) atomicOr(&st->nan_mask, 1 << level);
+    if (blockIdx.x == 0 && !(ITD_ABL_R & 16384)) {
+        // ---- tile 0's wavefront, after its own tile (kept off the path between the loads and their first use: a branch
+        //      with memory operations there makes the compiler wait for ALL loads at the join): total knot count of this
+        //      level and the stop rule (ITD.py:400-404); nothing in this launch reads what it writes -----------------
+        const int lane = lane_id();
+        int acc = 0;
+        for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) {
+            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
+                if (st->c_has_nan) acc = st->c_nan;
+                st->c_nan = 0;
+                st->c_has_nan = 0;
+            }
+            st->m[level] = acc;
+            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
+                st->stop_level = level;
+                st->stopped = 1;
+            }
+        }
+        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
+        for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
