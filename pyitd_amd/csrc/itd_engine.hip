@@ -159,7 +159,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
-    k_scan0<Tin, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, n_tiles, cnt(0), rec(0), gs(0), e->d_state);
+    k_scan0<Tin, T, kScanTilesPerWave><<<dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, batch), blk, 0, st>>>(x, x_stride, n, n_tiles, cnt(0), rec(0), gs(0), e->d_state);
 
     for (int j = 0; j <= M + 1; ++j) {
         // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
@@ -248,7 +248,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     for (int q = 0; q < 3; ++q)
         HIP_TRY(e, hipMemsetAsync(gs(q), 0, sizeof(int32_t) * (size_t)n_groups * kGsumPitch, st));
     if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
-    k_scan0<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, cnt(0), rec(0), gs(0), state);
+    k_scan0<Tin, T, kScanTilesPerWave><<<dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave), blk, 0, st>>>(x, n, n, n_tiles, cnt(0), rec(0), gs(0), state);
     for (int j = 0; j <= M + 1; ++j) {
         double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->max_n;
         const double *base_in = nullptr;

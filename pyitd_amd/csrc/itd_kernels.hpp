@@ -66,6 +66,10 @@ constexpr int kRankCap0 = ITD_RANK_CAP0;
 #define ITD_KT 1
 #endif
 constexpr int kTilesPerWave = ITD_KT;
+#ifndef ITD_KT0
+#define ITD_KT0 1
+#endif
+constexpr int kScanTilesPerWave = ITD_KT0;   // tiles per wavefront of the level-0 scan (4 measured 30 us vs 26 us at 1: the scan is instruction bound)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 
@@ -626,68 +630,6 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan0: level-0 knot scan of the caller's signal for a decomposition (the register form of k_detect: knots only, no
-// lists).  grid = (n_tiles, batch), 64 threads.  Also publishes the signal's four end samples and the NaN-input flag.
-// ---------------------------------------------------------------------------------------------
-template <typename Tin, int TW>
-__global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, int64_t x_stride, int64_t n, int n_tiles,
-                                                 int32_t *__restrict__ counts, TileRec *__restrict__ recs,
-                                                 int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
-{
-    constexpr int G2 = TW / 128;
-    using In2 = Tin __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
-    __shared__ int32_t s_pos[8];
-    const int lane = lane_id();
-    const int t = blockIdx.x, sig = blockIdx.y;
-    const int64_t s = (int64_t)t * TW;
-    const Tin *x = xin + (int64_t)sig * x_stride;
-    SigState *st = state + sig;
-    const bool full = (s + TW <= n);
-    const bool vec_in = full && ((reinterpret_cast<uintptr_t>(x + s) & (2 * sizeof(Tin) - 1)) == 0);
-    double xr[G2][2];
-    if (vec_in) {
-        const In2 *v = reinterpret_cast<const In2 *>(x + s);
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const In2 q = v[g * 64 + lane];
-            xr[g][0] = (double)q.x;
-            xr[g][1] = (double)q.y;
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const int64_t i = s + 128 * g + 2 * lane;
-            xr[g][0] = (i < n) ? (double)x[i] : 0.0;
-            xr[g][1] = (i + 1 < n) ? (double)x[i + 1] : 0.0;
-        }
-    }
-    double xlo = 0.0, xhi = 0.0;   // samples s-1 and s+TW (wave-uniform addresses; this kernel's loads are all cacheable)
-    if (s >= 1) xlo = (double)x[s - 1];
-    if (s + TW < n) xhi = (double)x[s + TW];
-    const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));
-    bool nan_in = false;
-#pragma unroll
-    for (int g = 0; g < G2; ++g) {
-        const int p = 128 * g + 2 * lane;
-        nan_in = nan_in || (p < nrem && xr[g][0] != xr[g][0]) || (p + 1 < nrem && xr[g][1] != xr[g][1]);
-    }
-    if (__any(nan_in) && lane == 0) st->in_nan = 1;
-    if (s == 0 || nrem <= TW + 1) {   // the signal's end samples x[0], x[1], x[n-2], x[n-1] (ITD.py:101-102)
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const int p = 128 * g + 2 * lane;
-            if (s == 0 && p == 0) { st->ends[0][0] = xr[g][0]; st->ends[0][1] = xr[g][1]; }
-            if (p == nrem - 2) { st->ends[0][2] = xr[g][0]; st->ends[0][3] = xr[g][1]; }
-            if (p + 1 == nrem - 2) st->ends[0][2] = xr[g][1];
-            if (p == nrem - 1) st->ends[0][3] = xr[g][0];
-        }
-    }
-    scan_publish<TW>(xr, xlo, xhi, s, nrem, (size_t)sig * n_tiles + t,
-                     ((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch, counts, recs, gsum_out, s_rec, s_pos);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Bounds-checked streaming accesses of one tile through a raw buffer descriptor (base = the tile's first element, extent =
 // what is left of the row): elements beyond the row read as 0 and are not written, any 4-byte alignment is legal.  One code
 // path for full, ragged and unaligned tiles, and every access is unconditional — so the compiler can count them and wait for
@@ -727,6 +669,83 @@ __device__ __forceinline__ void tile_store2(__amdgpu_buffer_rsrc_t r, int voff, 
     const D2v d = {a, b};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, d), r, voff, 0, NT ? kBufNT : 0);
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_scan0: level-0 knot scan of the caller's signal for a decomposition (the register form of k_detect: knots only, no
+// lists).  grid = (ceil(n_tiles / KT), batch), 64 threads: a wavefront takes KT consecutive tiles and requests all of them
+// up front.  The sample next to a tile
+// is the neighbouring tile's edge sample, already in a register, except at the two ends of the wavefront's range.  Also
+// publishes the signal's four end samples and the NaN-input flag.  Loads are cacheable: level 0 reads the signal again.
+// ---------------------------------------------------------------------------------------------
+template <typename Tin, int TW, int KT>
+__global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, int64_t x_stride, int64_t n, int n_tiles,
+                                                 int32_t *__restrict__ counts, TileRec *__restrict__ recs,
+                                                 int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
+{
+    constexpr int G2 = TW / 128;
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
+    __shared__ int32_t s_pos[8];
+    const int lane = lane_id();
+    const int t0 = blockIdx.x * KT, sig = blockIdx.y;
+    const Tin *x = xin + (int64_t)sig * x_stride;
+    SigState *st = state + sig;
+    Tin q[KT][G2][2];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int64_t s = (int64_t)(t0 + k) * TW;
+        const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x + s, (n - s) * (int64_t)sizeof(Tin));   // empty beyond the signal: reads 0
+#pragma unroll
+        for (int g = 0; g < G2; ++g) tile_load2<false>(rx, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), q[k][g][0], q[k][g][1]);
+    }
+    const int64_t s_first = (int64_t)t0 * TW, s_end = (int64_t)(t0 + KT) * TW;
+    double x_before = 0.0, x_after = 0.0;   // the samples next to the wavefront's range (wave-uniform addresses)
+    if (s_first >= 1) x_before = (double)x[s_first - 1];
+    if (s_end < n) x_after = (double)x[s_end];
+    bool nan_in = false;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int t = t0 + k;
+        if (t >= n_tiles) break;
+        const int64_t s = (int64_t)t * TW;
+        double xr[G2][2];
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            xr[g][0] = (double)q[k][g][0];
+            xr[g][1] = (double)q[k][g][1];
+        }
+        // samples s-1 and s+TW: the neighbouring tile's last / first sample (lane 63 / lane 0 of its registers)
+        double xlo = x_before, xhi = x_after;
+        if (k > 0) {
+            const double v = (double)q[k > 0 ? k - 1 : 0][G2 - 1][1];
+            xlo = bits_d((unsigned)__builtin_amdgcn_readlane((int)(unsigned)dbits(v), 63), (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(dbits(v) >> 32), 63));
+        }
+        if (k + 1 < KT) {
+            const double v = (double)q[k + 1 < KT ? k + 1 : k][0][0];
+            xhi = bits_d((unsigned)__builtin_amdgcn_readlane((int)(unsigned)dbits(v), 0), (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(dbits(v) >> 32), 0));
+        }
+        const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int p = 128 * g + 2 * lane;
+            nan_in = nan_in || (p < nrem && xr[g][0] != xr[g][0]) || (p + 1 < nrem && xr[g][1] != xr[g][1]);
+        }
+        if (s == 0 || nrem <= TW + 1) {   // the signal's end samples x[0], x[1], x[n-2], x[n-1] (ITD.py:101-102)
+#pragma unroll
+            for (int g = 0; g < G2; ++g) {
+                const int p = 128 * g + 2 * lane;
+                if (s == 0 && p == 0) { st->ends[0][0] = xr[g][0]; st->ends[0][1] = xr[g][1]; }
+                if (p == nrem - 2) { st->ends[0][2] = xr[g][0]; st->ends[0][3] = xr[g][1]; }
+                if (p + 1 == nrem - 2) st->ends[0][2] = xr[g][1];
+                if (p == nrem - 1) st->ends[0][3] = xr[g][0];
+            }
+        }
+        scan_publish<TW>(xr, xlo, xhi, s, nrem, (size_t)sig * n_tiles + t,
+                         ((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch, counts, recs, gsum_out, s_rec, s_pos);
+        wave_sync();   // the next tile reuses the record staging
+    }
+    if (__any(nan_in) && lane == 0) st->in_nan = 1;
+}
+
 
 template <typename Tin, int TW, bool FINAL, int CAP, int KT>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
