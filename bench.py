@@ -11,7 +11,7 @@ the synthetic input already resident in HBM.
           signal (seed = rank) with no data-path collective -> weak scaling; value = all samples / max time.
 
 Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kernel k_extract, levels >= 1:
-24 algorithmic B/sample, timed with hipEvents on the launch stream inside the timed region) + "cpu_baseline"
+24 algorithmic B/sample, timed with the launches' own hipEvents on the launch stream inside the timed region) + "cpu_baseline"
 (the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1).
 """
 import argparse
@@ -94,8 +94,8 @@ def main():
     torch.cuda.synchronize()
     summ = eng.summary(1)
 
-    # hipEvent pairs around the extraction launches of every 4th step of the timed region (an event record
-    # costs ~5 us of stream time, so instrumenting every step would slow the region it measures by ~7 %)
+    # on every 4th step of the timed region the extraction launches carry their own hipEvent pair (hipExtLaunchKernel: the
+    # dispatch's begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
     eng.set_timing(args.steps, stride=4)
     barrier()
     torch.cuda.synchronize()

@@ -144,15 +144,17 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
                              int64_t m, double *bk_host);
 
 /* ---- introspection for benchmarks -------------------------------------------------------------
- * hipEvent pairs recorded on the launch stream around selected launches.  itd_set_kernel_timing(e, K)
- * enables recording for up to K decompositions (K = 0 disables) and resets the tallies;
- * itd_get_kernel_timing sums the elapsed time of every recorded launch of class `which`. */
+ * hipEvent pairs on the launch stream.  Extraction launches are dispatched with their own start/stop events
+ * (hipExtLaunchKernel: the events take the dispatch's own begin/end timestamps, so they agree with rocprofv3's kernel durations); the
+ * whole-decomposition span uses two marker records.  itd_set_kernel_timing(e, K) enables recording for up to K
+ * decompositions (K = 0 disables) and resets the tallies; itd_get_kernel_timing sums the elapsed time of every
+ * recorded launch of class `which`. */
 #define ITD_TIME_EXTRACT 0        /* k_extract<float64 in>: levels >= 1, the dominant kernel (24 B/sample) */
 #define ITD_TIME_EXTRACT_L0 1     /* k_extract on the caller's signal (level 0; 20 B/sample for float32) */
 #define ITD_TIME_EXTRACT_FINAL 2  /* k_extract of the "Out of time!" level (writes rotation+baseline only) */
 #define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
-/* instrument only every stride-th decomposition (an event record costs ~5 us of stream time) */
+/* instrument only every stride-th decomposition (launches with events cost ~2 us more each, the span's marker records ~5 us each) */
 int itd_set_kernel_timing_stride(itd_engine *e, int stride);
 int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches);
 
