@@ -72,10 +72,13 @@ def test_batch_matches_oracle_per_signal(P, torch, oracle, keep, dtype):
             assert_bits_equal(bases[b, :nb], ref["baselines"], "signal %d baselines" % b)
 
 
-def test_unaligned_stride_falls_back_to_scalar_loads(P, torch, oracle):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_unaligned_rows_and_ragged_tiles(P, torch, oracle, dtype):
+    # odd element stride: signals 1.. start at addresses that are not 16-byte aligned, and N is not a multiple of the tile —
+    # the bounds-checked buffer accesses of k_extract / k_scan0 take these through the same path as full aligned tiles
     n, B, m = 4099, 3, 3
-    x = np.stack([sines_noise(n, seed=10 + b, dtype=np.float32) for b in range(B)])
-    rows, _, s = _run(P, torch, x, m, False, stride_pad=1)   # odd stride: rows 1.. are not 16-byte aligned
+    x = np.stack([sines_noise(n, seed=10 + b, dtype=np.float64) for b in range(B)]).astype(dtype)
+    rows, _, s = _run(P, torch, x, m, False, stride_pad=1)
     for b in range(B):
         ref = oracle.itd(x[b], m)
         assert_bits_equal(rows[b, : int(s["n_rows"][b])], ref["rows"], "signal %d" % b)
@@ -180,3 +183,33 @@ def test_itd_batch_python_api(P, torch, oracle):
     bad[1, 7] = np.nan
     with pytest.raises(ValueError):
         P.itd_batch(bad, 3)
+
+
+def test_kernel_timing_api(P, torch, oracle):
+    # itd_set_kernel_timing / _stride / itd_get_kernel_timing: instrumented decompositions launch the extraction kernels with
+    # their own events; results must not change and the tallies must count exactly the instrumented launches
+    from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0
+    n, m = 1 << 16, 5
+    x = sines_noise(n, seed=2, dtype=np.float32)
+    ref = oracle.itd(x, m)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.empty((m + 2, n), dtype=torch.float64, device="cuda")
+    eng = P.Engine(n, 1, 0)
+    torch.cuda.synchronize()
+    steps, stride = 6, 2
+    eng.set_timing(steps, stride=stride)
+    for _ in range(steps):
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+    s = eng.summary(1)
+    timed = steps // stride
+    ms, cnt = eng.kernel_timing(TIME_EXTRACT)
+    assert cnt == timed * m and ms > 0.0                      # levels 1..m
+    assert eng.kernel_timing(TIME_EXTRACT_L0)[1] == timed
+    assert eng.kernel_timing(TIME_EXTRACT_FINAL)[1] == timed
+    span_ms, span_cnt = eng.kernel_timing(TIME_DECOMPOSE)
+    assert span_cnt == timed and span_ms >= ms                # the span contains the launches it brackets
+    eng.set_timing(0)
+    nr = int(s["n_rows"][0])
+    assert nr == ref["rows"].shape[0]
+    assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "rows with instrumented launches")
+    eng.close()
