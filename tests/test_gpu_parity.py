@@ -235,3 +235,43 @@ def test_very_sparse_knots_over_many_tiles(P, oracle, log2n, cycles):
         assert dec.stop_reason == ref["stop"] and rows.shape[0] == ref["rows"].shape[0]
         assert_bits_equal(rows, ref["rows"], "sparse 2^%d x%g m=%d" % (log2n, cycles, m))
         assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
+
+
+def _zigzag_with_knots(n, knots, seed):
+    """Piecewise-linear signal whose level-0 knots are exactly `knots` (strictly alternating slopes, random amplitudes)."""
+    rng = np.random.default_rng(seed)
+    e = np.array([0] + sorted(knots) + [n - 1])
+    v = np.zeros(len(e))
+    sign = 1.0
+    for k in range(1, len(e)):
+        v[k] = v[k - 1] + sign * (0.5 + rng.random()) * (1 + (e[k] - e[k - 1]) / 64.0)
+        sign = -sign
+    return np.interp(np.arange(n), e, v)
+
+
+@pytest.mark.parametrize("case", ["edges", "pairs", "every_tile_edge", "second_and_last"])
+def test_knots_on_tile_boundaries(P, oracle, case):
+    """Knots placed exactly on the first / last sample of 512-sample tiles and next to them: the sample next to a tile
+    is itself a knot, the two halo samples come out of the neighbours' records, the packed record positions are 0 / 511,
+    tiles in between hold no knot at all."""
+    T, n = 512, 512 * 40 + 37
+    if case == "edges":
+        knots = [T - 1, T, 3 * T - 1, 5 * T, 9 * T - 1, 9 * T, 9 * T + 1, 20 * T, 31 * T - 1]
+    elif case == "pairs":
+        knots = [k * T + d for k in (2, 7, 8, 15, 33) for d in (-2, -1, 0, 1, 2)]
+    elif case == "every_tile_edge":
+        knots = sorted({k * T - 1 for k in range(1, 40)} | {k * T for k in range(1, 40, 3)})
+    else:
+        knots = [1, 2, 3, T - 2, n - 4, n - 3, n - 2]
+    x = _zigzag_with_knots(n, knots, seed=len(knots))
+    ref0 = oracle.itd_lean(x, 0, want_knots=True)
+    assert ref0["knots"][0].tolist() == sorted(knots)        # the construction really puts the knots there
+    for dtype in (np.float64, np.float32):
+        xx = x.astype(dtype)
+        for m in (0, 2, 5):
+            dec = P.ITD()
+            rows = dec.itd(xx, max_iteration=m)
+            ref = oracle.itd_lean(xx, m, want_knots=True)
+            assert dec.stop_reason == ref["stop"] and rows.shape[0] == ref["rows"].shape[0]
+            assert_bits_equal(rows, ref["rows"], "%s %s m=%d" % (case, np.dtype(dtype).name, m))
+            assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
