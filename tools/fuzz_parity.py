@@ -1,0 +1,63 @@
+"""Randomised parity sweep of the GPU path against the CPU oracle (bit-exact rows, knot counts, stop reason).
+usage (GPU box): python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pyitd_amd
+from oracle import cpu_oracle
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+cpu_oracle.lib()
+
+
+def make(kind, n):
+    t = np.arange(n) / max(n - 1, 1)
+    if kind == 0:   # white noise
+        return rng.standard_normal(n)
+    if kind == 1:   # random walk
+        return np.cumsum(rng.standard_normal(n))
+    if kind == 2:   # quantised (plateaus)
+        return np.round(rng.standard_normal(n) * rng.integers(1, 6)) / 4.0
+    if kind == 3:   # smooth + few knots
+        return np.sin(2 * np.pi * rng.uniform(0.3, 30) * t) + rng.uniform(-1, 1) * t * t
+    if kind == 4:   # sines + noise at random level
+        return np.sin(2 * np.pi * rng.uniform(5, 500) * t) + rng.uniform(0, 0.3) * rng.standard_normal(n)
+    if kind == 5:   # long constant stretches with bursts
+        x = np.zeros(n)
+        for _ in range(rng.integers(1, 6)):
+            a = rng.integers(0, n)
+            b = min(n, a + rng.integers(2, max(3, n // 4)))
+            x[a:b] = rng.standard_normal(b - a)
+        return x
+    if kind == 6:   # alternating with random amplitudes (every sample a knot)
+        return ((-1.0) ** np.arange(n)) * (1 + rng.random(n))
+    return rng.standard_normal(n) * np.exp(rng.uniform(-300, 300))   # extreme magnitudes
+
+
+bad = 0
+t0 = time.time()
+for c in range(cases):
+    kind = int(rng.integers(0, 8))
+    n = int(rng.choice([3, 4, 5, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 4097, int(rng.integers(3, 70000)), int(rng.integers(3, 300000))]))
+    m = int(rng.integers(0, 12))
+    dtype = np.float32 if rng.random() < 0.5 and kind != 7 else np.float64
+    x = make(kind, n).astype(dtype)
+    if not np.all(np.isfinite(x)):
+        continue
+    ref = cpu_oracle.itd(x, m)
+    dec = pyitd_amd.ITD()
+    try:
+        rows = dec.itd(x, max_iteration=m)
+    except Exception as e:   # noqa
+        print("case %d kind %d n %d m %d %s: EXCEPTION %r" % (c, kind, n, m, dtype.__name__, e))
+        bad += 1
+        continue
+    ok = rows.shape == ref["rows"].shape and np.array_equal(
+        np.where(np.isnan(rows), 0x7ff8000000000000, rows.view(np.uint64)),
+        np.where(np.isnan(ref["rows"]), 0x7ff8000000000000, ref["rows"].view(np.uint64))) and dec.stop_reason == ref["stop"]
+    if not ok:
+        bad += 1
+        print("case %d kind %d n %d m %d %s: MISMATCH rows %s vs %s stop %s vs %s" % (c, kind, n, m, dtype.__name__, rows.shape, ref["rows"].shape, dec.stop_reason, ref["stop"]))
+print("%d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
