@@ -493,7 +493,8 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_extract: one extraction on one tile, one wavefront, the tile held in REGISTERS; grid = (n_tiles, batch), 64 threads.
+// k_extract (further down, after the helpers it shares with k_scan0): one extraction on one tile, one wavefront, the tile
+// held in REGISTERS; grid = (ceil(n_tiles / KT), batch), 64 threads, KT = kTilesPerWave consecutive tiles per wavefront.
 //   xin           level input (float32/float64 caller signal at level 0, float64 baseline afterwards)
 //   counts/recs   per-tile knot counts and records, double buffered by level parity (neighbours read them)
 //   gsum_in/out/clear   group sums of the counts, rotating by level % 3
@@ -503,7 +504,7 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
 // Lane l owns two consecutive samples of every 128-sample group g: tile positions 128 g + 2 l (even) and + 1 (odd) —
 // exactly what one coalesced 16-byte load/store per lane moves.  Flag word 2g holds the even samples' knot flags of
 // group g, word 2g+1 the odd ones (flag_pos).  Consequences:
-//   * no LDS tile: LDS holds only the by-rank knot arrays (3.7 KB per wavefront -> the CU fills all its wave slots);
+//   * no LDS tile: LDS holds only the by-rank knot arrays and small staging buffers (4.3 KB per wavefront);
 //   * a sample's left/right neighbours are its own lane's other sample or the adjacent lane's (DPP wave shifts):
 //     the next level's knot scan runs on registers, sharing every difference between the two samples that use it;
 //   * half as many group iterations, each moving 16 bytes per lane.
