@@ -144,13 +144,18 @@ __global__ __launch_bounds__(64) void k_level_y(const double* __restrict__ in, d
 
 // stream subsets of the nt=5 pipeline kernel: Z bit 0 read the input (nontemporal), 1 write the rotation row (nontemporal),
 // 2 write the baseline (cacheable), 8 the input is float32 (half the read bytes)
-template <int Z>
+template <int Z, int CHUNK = 0>
 __global__ __launch_bounds__(64) void k_level_z(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas)
 {
     using V = double __attribute__((ext_vector_type(2)));
     using F = float __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * 512;
+    int tile = blockIdx.x;
+    if (CHUNK > 0) {   // XCD-aware mapping: CHUNK consecutive tiles per XCD inside every span of 8 x CHUNK workgroups
+        const int span = 8 * CHUNK, b0 = (tile / span) * span, r = tile - b0;
+        tile = b0 + (r % 8) * CHUNK + r / 8;
+    }
+    const size_t base = (size_t)tile * 512;
     V x[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -241,6 +246,11 @@ int main()
         YV(80, 300, "y=80  chain + state loads (scalar) only")
         YV(0, 0, "y=0  nt=5 streams only")
     }
+    run("z=7  read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(i, r, b); });
+    run("z=7  same, 8 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 8><<<32768, 64>>>(i, r, b); });
+    run("z=7  same, 64 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 64><<<32768, 64>>>(i, r, b); });
+    run("z=7  same, 256 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 256><<<32768, 64>>>(i, r, b); });
+    run("z=7  same, 4096 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 4096><<<32768, 64>>>(i, r, b); });
     run("z=7  read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(i, r, b); });
     run("z=3  read + rotation(nt)", [&](const double* i, double* r, double* b) { k_level_z<3><<<32768, 64>>>(i, r, b); });
     run("z=5  read + baseline", [&](const double* i, double* r, double* b) { k_level_z<5><<<32768, 64>>>(i, r, b); });
