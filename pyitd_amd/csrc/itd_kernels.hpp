@@ -652,6 +652,17 @@ __device__ __forceinline__ int xcd_item(int b, int n_items)
     return base + (r % kXcd) * c + r / kXcd;
 }
 
+// ITD_SERPENTINE=1: odd levels walk the signal backwards, so a launch starts with the tiles the previous one wrote last
+// (still the hottest lines of the Infinity Cache): step 0.626 -> 0.615 ms, level 0 79 -> 73 us (same-box A/B)
+#ifndef ITD_SERPENTINE
+#define ITD_SERPENTINE 1
+#endif
+__device__ __forceinline__ int launch_item(int b, int n_items, int level)
+{
+    const int it = xcd_item(b, n_items);
+    return (ITD_SERPENTINE && (level & 1)) ? n_items - 1 - it : it;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Bounds-checked streaming accesses of one tile through a raw buffer descriptor (base = the tile's first element, extent =
 // what is left of the row): elements beyond the row read as 0 and are not written, any 4-byte alignment is legal.  One code
@@ -820,7 +831,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     TileLoads pre[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-        const int t = xcd_item(blockIdx.x, gridDim.x) * KT + k;
+        const int t = launch_item(blockIdx.x, gridDim.x, level) * KT + k;
         const int lane = lane_id();
         if (t < n_tiles) {
             // the small loads first: loads retire in order, and the halo logic that needs them should not wait for the tile
@@ -852,7 +863,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    const int t = xcd_item(blockIdx.x, gridDim.x) * KT + kt;
+    const int t = launch_item(blockIdx.x, gridDim.x, level) * KT + kt;
     if (t >= n_tiles) break;
     __builtin_amdgcn_sched_barrier(0);   // no code motion between the tiles: the later tile only keeps its loaded registers alive
     int lane_v = lane_id();
