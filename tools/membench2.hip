@@ -252,6 +252,8 @@ int main()
     run("z=7  same, 256 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 256><<<32768, 64>>>(i, r, b); });
     run("z=7  same, 4096 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 4096><<<32768, 64>>>(i, r, b); });
     run("z=7  read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(i, r, b); });
+    run("z=7  IN PLACE: baseline written over the input it was read from", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(bases, r, bases); });
+    run("z=7  IN PLACE, 256 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 256><<<32768, 64>>>(bases, r, bases); });
     run("z=3  read + rotation(nt)", [&](const double* i, double* r, double* b) { k_level_z<3><<<32768, 64>>>(i, r, b); });
     run("z=5  read + baseline", [&](const double* i, double* r, double* b) { k_level_z<5><<<32768, 64>>>(i, r, b); });
     run("z=6  rotation(nt) + baseline, no read", [&](const double* i, double* r, double* b) { k_level_z<6><<<32768, 64>>>(i, r, b); });
