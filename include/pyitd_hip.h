@@ -63,8 +63,9 @@ const char *itd_status_string(int status);
 const char *itd_last_error(const itd_engine *e);
 
 /* Create an engine on HIP device `device_id` able to decompose up to `max_batch` signals of up to
- * `max_n` samples per call.  Allocates the device workspace once (three rotating baseline slots, per-tile
- * records and counts, and the API helpers' knot lists: about 36 B per sample).  No allocation happens
+ * `max_n` samples per call.  Allocates the device workspace once (three rotating float64 baseline slots per signal =
+ * 24 B per sample, 0.3 B per sample of per-tile records and counts, and one signal's worth of knot lists for the
+ * single-level helpers).  No allocation happens
  * in the decompose calls (they are graph-capturable). */
 int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t max_batch);
 void itd_engine_destroy(itd_engine *e);
