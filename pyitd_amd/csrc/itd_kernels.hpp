@@ -40,7 +40,8 @@
 // timing-only ablations of k_extract (results are wrong by construction): 1 no count windows, 2 no speculative
 // records, 8 no knots inside the tile, 16 no group-sum atomic, 32 no count store, 64 no record store, 512 (unused), 1024 no far
 // search, 2048 no knot phases (one constant segment), 4096 no knot scan, 8192 no candidate selection / halo assembly,
-// 16384 no writes to the signal's state
+// 16384 no writes to the signal's state, 32768 no side loads, 65536 no knot scan / outputs at all, 131072 / 262144 only the
+// three streams (before / after the scalar state loads)
 #ifndef ITD_ABL_R
 #define ITD_ABL_R 0
 #endif
@@ -851,11 +852,27 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
     }
 
+    auto bare = [&]() {   // timing only (ITD_ABL_R 131072 / 262144): the three streams and nothing else, like tools/membench2
+        const int lane = lane_id();
+        const int t = launch_item(blockIdx.x, gridDim.x, level) * KT;
+        const int64_t s = (int64_t)t * TW;
+        double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
+        double *bas_t = FINAL ? rot_t : base_out + (int64_t)sig * base_stride + s;
+        const __amdgpu_buffer_rsrc_t r_rot = tile_rsrc(rot_t, (n - s) * 8), r_bas = tile_rsrc(bas_t, FINAL ? 0 : (n - s) * 8);
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const double a = (double)pre[0].q[g][0] * 0.5 + (double)(pre[0].cb + pre[0].cf + pre[0].specw) + (double)(int)pre[0].own, b = (double)pre[0].q[g][1] * 0.5;
+            tile_store2<(ITD_NT & 1) != 0>(r_rot, (128 * g + 2 * lane) * 8, a, b);
+            if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, (128 * g + 2 * lane) * 8, b, a);
+        }
+    };
+    if (ITD_ABL_R & 131072) { bare(); return; }
     const int stopped = st->stopped;
     const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
     const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
 
     if (stopped) return;
+    if (ITD_ABL_R & 262144) { if (e0 + e3 != 1.2345e300) bare(); return; }
     const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
     double *ends_next = st->ends[(level + 1) & 1];

@@ -175,6 +175,28 @@ __global__ __launch_bounds__(64) void k_level_z(const double* __restrict__ in, d
     }
 }
 
+// the nt=5 streams through raw buffer descriptors (bounds-checked buffer_load / buffer_store), as the engine issues them
+__global__ __launch_bounds__(64) void k_level_buf(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas, long n)
+{
+    using U4 = unsigned __attribute__((ext_vector_type(4)));
+    using V = double __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * 512;
+    __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)(in + base), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(rot + base), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bas + base), 0, 0x7fffffff, 0x00020000);
+    V x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, k * 1024, 2));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        V a = x[k] * 0.5;
+        V b = x[k] - a;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, b), rr, lane * 16 + k * 1024, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, a), rb, lane * 16 + k * 1024, 0, 0);
+    }
+}
+
 int main()
 {
     const size_t n = 1ull << 24;
@@ -254,6 +276,8 @@ int main()
     run("z=7  read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(i, r, b); });
     run("z=7  IN PLACE: baseline written over the input it was read from", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(bases, r, bases); });
     run("z=7  IN PLACE, 256 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 256><<<32768, 64>>>(bases, r, bases); });
+    run("buffer_load/store form of z=7", [&](const double* i, double* r, double* b) { k_level_buf<<<32768, 64>>>(i, r, b, (long)n); });
+    run("buffer form, 2-D grid (32768, 1)", [&](const double* i, double* r, double* b) { k_level_buf<<<dim3(32768, 1), 64>>>(i, r, b, (long)n); });
     run("z=3  read + rotation(nt)", [&](const double* i, double* r, double* b) { k_level_z<3><<<32768, 64>>>(i, r, b); });
     run("z=5  read + baseline", [&](const double* i, double* r, double* b) { k_level_z<5><<<32768, 64>>>(i, r, b); });
     run("z=6  rotation(nt) + baseline, no read", [&](const double* i, double* r, double* b) { k_level_z<6><<<32768, 64>>>(i, r, b); });
