@@ -26,6 +26,10 @@ using namespace itd;
 
 namespace {
 constexpr int T = ITD_TILE;
+#ifndef ITD_SLOT_PAD
+#define ITD_SLOT_PAD 0
+#endif
+constexpr int64_t kSlotPad = ITD_SLOT_PAD;   // elements (multiple of 2 keeps the slots 16-byte aligned)
 static_assert(T % 128 == 0 && T / 64 <= kMaxGroups, "tile geometry: whole 8/16-byte loads per lane, <= 8 flag words per record");
 
 // per-signal state + the (padded) group sums of all three rotating buffers, one launch
@@ -68,7 +72,8 @@ struct itd_engine {
     int64_t gsum_third = 0;        // elements per buffer
     int32_t *d_kidx = nullptr;     // [max_n + 2]  ordered knot indices for the API helpers (single signal)
     int32_t *d_total = nullptr;    // [1] knot total written by k_compact
-    double *d_pp = nullptr;        // [batch][3][max_n] rotating baselines (slot = level % 3)
+    double *d_pp = nullptr;        // [batch][3][pp_pitch] rotating baselines (slot = level % 3)
+    int64_t pp_pitch = 0;          // elements between consecutive slots: max_n + kSlotPad (breaks the power-of-two distance)
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
     int64_t ws_bytes = 0;
@@ -184,9 +189,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             base_stride = rows_stride;
             if (j >= 1) { base_in = bases_user + (int64_t)(j - 1) * n; base_in_stride = rows_stride; }
         } else {
-            base_out = e->d_pp + (int64_t)(j % 3) * e->max_n;
-            base_stride = 3 * e->max_n;
-            if (j >= 1) { base_in = e->d_pp + (int64_t)((j - 1) % 3) * e->max_n; base_in_stride = 3 * e->max_n; }
+            base_out = e->d_pp + (int64_t)(j % 3) * e->pp_pitch;
+            base_stride = 3 * e->pp_pitch;
+            if (j >= 1) { base_in = e->d_pp + (int64_t)((j - 1) % 3) * e->pp_pitch; base_in_stride = 3 * e->pp_pitch; }
         }
         double *rot_out = rows + (int64_t)j * n;
         const bool final_level = (j == M + 1);
@@ -222,8 +227,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0,
                                                                       gs(M + 2), n_tiles, M + 2, 0, e->d_state);
         else
-            k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->max_n,
-                                                                      e->max_n, 3, gs(M + 2), n_tiles, M + 2, 0, e->d_state);
+            k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->pp_pitch,
+                                                                      e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, 0, e->d_state);
     }
     time_end(e, span_pair, st);
     HIP_TRY(e, hipGetLastError());
@@ -259,7 +264,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     const Tin *x = (const Tin *)e->last_x + (int64_t)b * e->last_x_stride;
     double *rows = e->last_rows + (int64_t)b * rows_stride;
     double *bases_user = e->last_bases ? e->last_bases + (int64_t)b * rows_stride : nullptr;
-    double *pp = e->d_pp + (int64_t)b * 3 * e->max_n;
+    double *pp = e->d_pp + (int64_t)b * 3 * e->pp_pitch;
     SigState *state = e->d_state + b;
     const int B = e->last_batch;
     auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b * n_groups * kGsumPitch; };
@@ -272,14 +277,14 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
     if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
     k_scan0<Tin, T, kScanTilesPerWave><<<dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave), blk, 0, st>>>(x, n, n, n_tiles, cnt(0), rec(0), gs(0), state);
     for (int j = 0; j <= M + 1; ++j) {
-        double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->max_n;
+        double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->pp_pitch;
         const double *base_in = nullptr;
-        if (j >= 1) base_in = bases_user ? bases_user + (int64_t)(j - 1) * n : pp + (int64_t)((j - 1) % 3) * e->max_n;
+        if (j >= 1) base_in = bases_user ? bases_user + (int64_t)(j - 1) * n : pp + (int64_t)((j - 1) % 3) * e->pp_pitch;
         // the "Out of time!" level keeps its pending baseline too: the stop test and the mutation come first.
         // With the caller's baselines buffer that row (index M+1) must end up zero (ITD.py:424), so the pending
         // baseline of the last level goes to the engine's rotating slot instead.
         const bool final_level = (j == M + 1);
-        if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->max_n;
+        if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->pp_pitch;
         double *rot_out = rows + (int64_t)j * n;
         if (j == 0)
             k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
@@ -300,7 +305,7 @@ int enqueue_careful(itd_engine *e, int b, hipStream_t st)
             k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, gs(M + 2),
                                                                   n_tiles, M + 2, 1, state);
         else
-            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, pp, 3 * e->max_n, e->max_n, 3, gs(M + 2),
+            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, pp, 3 * e->pp_pitch, e->pp_pitch, 3, gs(M + 2),
                                                                   n_tiles, M + 2, 1, state);
     }
     HIP_TRY(e, hipGetLastError());
@@ -377,7 +382,8 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     alloc((void **)&e->d_gsum, 3 * (size_t)e->gsum_third * sizeof(int32_t));
     alloc((void **)&e->d_kidx, (size_t)(max_n + 2) * sizeof(int32_t));
     alloc((void **)&e->d_total, 64);
-    alloc((void **)&e->d_pp, B * 3 * (size_t)max_n * sizeof(double));
+    e->pp_pitch = max_n + kSlotPad;
+    alloc((void **)&e->d_pp, B * 3 * (size_t)e->pp_pitch * sizeof(double));
     alloc((void **)&e->d_state, B * sizeof(SigState));
     const size_t st_b = B * sizeof(SigState);
     if (rc == hipSuccess) rc = hipHostMalloc((void **)&e->h_state, st_b);

@@ -285,5 +285,23 @@ int main()
     run("z=2  rotation(nt) only", [&](const double* i, double* r, double* b) { k_level_z<2><<<32768, 64>>>(i, r, b); });
     run("z=4  baseline only", [&](const double* i, double* r, double* b) { k_level_z<4><<<32768, 64>>>(i, r, b); });
     run("z=15 f32 read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<15><<<32768, 64>>>(i, r, b); });
+    {   // the engine's whole launch sequence with the bare streams: scan (float32 read), level 0 (float32 read + both writes),
+        // levels 1..7, FINAL (read + rotation); only the seven middle launches are timed
+        float* xf; CK(hipMalloc(&xf, n * 4)); CK(hipMemset(xf, 0, n * 4));
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        float sum = 0; int cnt = 0;
+        for (int r = 0; r < 12; ++r) {
+            k_level_z<1 | 8><<<32768, 64>>>((const double*)xf, rows, bases);                       // scan: reads x
+            k_level_z<15><<<32768, 64>>>((const double*)xf, rows, bases);                          // level 0 -> slot 0
+            CK(hipEventRecord(a0));
+            for (int j = 1; j <= 7; ++j) k_level_z<7><<<32768, 64>>>(bases + (size_t)((j - 1) % 3) * n, rows + (size_t)j * n, bases + (size_t)(j % 3) * n);
+            CK(hipEventRecord(a1));
+            k_level_z<3><<<32768, 64>>>(bases + (size_t)(7 % 3) * n, rows + (size_t)8 * n, bases);  // FINAL
+            CK(hipEventSynchronize(a1));
+            float ms; CK(hipEventElapsedTime(&ms, a0, a1));
+            if (r >= 2) { sum += ms / 7; ++cnt; }
+        }
+        printf("engine-like sequence (scan, level 0, 7 levels, FINAL): levels 1..7 avg %6.1f us per level\n", sum / cnt * 1e3);
+    }
     return 0;
 }
