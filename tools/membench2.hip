@@ -2,6 +2,7 @@
 // baseline level j-1 wrote (3 rotating slots), writes a fresh rotation row and the next baseline; launches back to
 // back, no flush.  Variants: store cache policy (plain / nontemporal), bytes per lane, wavefronts per workgroup.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -278,6 +279,14 @@ int main()
     run("z=7  IN PLACE, 256 consecutive tiles per XCD", [&](const double* i, double* r, double* b) { k_level_z<7, 256><<<32768, 64>>>(bases, r, bases); });
     run("buffer_load/store form of z=7", [&](const double* i, double* r, double* b) { k_level_buf<<<32768, 64>>>(i, r, b, (long)n); });
     run("buffer form, 2-D grid (32768, 1)", [&](const double* i, double* r, double* b) { k_level_buf<<<dim3(32768, 1), 64>>>(i, r, b, (long)n); });
+    run("z=7 launched with hipExtLaunchKernel (no events)", [&](const double* i, double* r, double* b) {
+        void* args[] = {(void*)&i, (void*)&r, (void*)&b};
+        CK(hipExtLaunchKernel(reinterpret_cast<const void*>(&k_level_z<7, 0>), dim3(32768), dim3(64), args, 0, 0, nullptr, nullptr, 0)); });
+    {
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        run("z=7 on a created stream (events on the null stream bracket it via sync)", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64, 0, st2>>>(i, r, b); });
+        CK(hipStreamSynchronize(st2));
+    }
     run("z=3  read + rotation(nt)", [&](const double* i, double* r, double* b) { k_level_z<3><<<32768, 64>>>(i, r, b); });
     run("z=5  read + baseline", [&](const double* i, double* r, double* b) { k_level_z<5><<<32768, 64>>>(i, r, b); });
     run("z=6  rotation(nt) + baseline, no read", [&](const double* i, double* r, double* b) { k_level_z<6><<<32768, 64>>>(i, r, b); });
