@@ -1,13 +1,16 @@
 """Randomised parity sweep of the GPU path against the CPU oracle (bit-exact rows, knot counts, stop reason).
-usage (GPU box): python tools/fuzz_parity.py [cases] [seed]"""
+usage (GPU box): python tools/fuzz_parity.py [cases] [seed]          single signals through ITD.itd
+                 python tools/fuzz_parity.py batch [cases] [seed]    random batches through itd_batch (grid.y = signal)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pyitd_amd
 from oracle import cpu_oracle
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+batch_mode = len(sys.argv) > 1 and sys.argv[1] == "batch"
+argv = sys.argv[2:] if batch_mode else sys.argv[1:]
+cases = int(argv[0]) if len(argv) > 0 else 200
+rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
 cpu_oracle.lib()
 
 
@@ -34,6 +37,36 @@ def make(kind, n):
         return ((-1.0) ** np.arange(n)) * (1 + rng.random(n))
     return rng.standard_normal(n) * np.exp(rng.uniform(-300, 300))   # extreme magnitudes
 
+
+def canon(a):
+    return np.where(np.isnan(a), 0x7ff8000000000000, a.view(np.uint64))
+
+
+if batch_mode:
+    bad = 0
+    t0 = time.time()
+    for c in range(cases):
+        B = int(rng.integers(1, 40))
+        n = int(rng.choice([3, 17, 511, 512, 513, 4095, 4096, 4097, int(rng.integers(3, 40000))]))
+        m = int(rng.integers(0, 9))
+        dtype = np.float32 if rng.random() < 0.5 else np.float64
+        x = np.stack([make(int(rng.integers(0, 7)), n) for _ in range(B)]).astype(dtype)
+        if not np.all(np.isfinite(x)):
+            continue
+        out = pyitd_amd.itd_batch(x, m, keep_baselines=bool(rng.random() < 0.3))
+        for b in range(B):
+            ref = cpu_oracle.itd(x[b], m)
+            nr = int(out["n_rows"][b])
+            ok = nr == ref["rows"].shape[0] and ("natural", "timeout")[int(out["stop"][b])] == ref["stop"] and \
+                np.array_equal(canon(out["rows"][b, :nr]), canon(ref["rows"]))
+            if ok and "baselines" in out:
+                nb = int(out["n_baselines"][b])
+                ok = nb == ref["baselines"].shape[0] and np.array_equal(canon(out["baselines"][b, :nb]), canon(ref["baselines"]))
+            if not ok:
+                bad += 1
+                print("batch case %d B %d n %d m %d %s signal %d: MISMATCH" % (c, B, n, m, dtype.__name__, b))
+    print("%d batches, %d mismatching signals, %.1f s" % (cases, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
 
 bad = 0
 t0 = time.time()
