@@ -18,8 +18,8 @@ __global__ void k_level(const double* __restrict__ in, double* __restrict__ rot,
     const int nvec = per_block / W;
     for (int k = threadIdx.x; k < nvec; k += blockDim.x) {
         V x = (NT & 4) ? __builtin_nontemporal_load(&vi[k]) : vi[k];
-        V a = x * 0.5;
-        V b = x - a;
+        V a = -x;          // value-preserving: the streams keep the entropy of their initial data
+        V b = x;
         if (NT & 1) __builtin_nontemporal_store(b, &v1[k]); else v1[k] = b;
         if (NT & 2) __builtin_nontemporal_store(a, &v2[k]); else v2[k] = a;
     }
@@ -39,8 +39,8 @@ __global__ void k_level_c(const double* __restrict__ in, double* __restrict__ ro
     for (int k = 0; k < 4; ++k) x[k] = (NT & 4) ? __builtin_nontemporal_load(&vi[k]) : vi[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        V a = x[k] * 0.5;
-        V b = x[k] - a;
+        V a = -x[k];
+        V b = x[k];
         if (NT & 1) __builtin_nontemporal_store(b, &v1[k]); else v1[k] = b;
         if (NT & 2) __builtin_nontemporal_store(a, &v2[k]); else v2[k] = a;
     }
@@ -60,8 +60,8 @@ __global__ void k_level_x(const double* __restrict__ in, double* __restrict__ ro
     double acc = 0;
     for (int k = threadIdx.x; k < 256; k += 64) {
         V x = vi[k];
-        V a = x * 0.5;
-        V b = x - a;
+        V a = -x;          // value-preserving: the streams keep the entropy of their initial data
+        V b = x;
         __builtin_nontemporal_store(b, &v1[k]);
         v2[k] = a;
         acc += a.x;
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(64) void k_level_y(const double* __restrict__ in, d
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        V a = x[k] * 0.5;
+        V a = -x[k];
         a.x += (acc > 1e300) ? 1.0 : 0.0;
-        V b = x[k] - a;
+        V b = x[k];
         __builtin_nontemporal_store(b, &v1[k * 64 + lane]);
         v2[k * 64 + lane] = a;
     }
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(64) void k_level_z(const double* __restrict__ in, d
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        V a = x[k] * 0.5;
-        V b = x[k] - a;
+        V a = -x[k];
+        V b = x[k];
         if (Z & 2) __builtin_nontemporal_store(b, &reinterpret_cast<V*>(rot + base)[k * 64 + lane]);
         if (Z & 4) reinterpret_cast<V*>(bas + base)[k * 64 + lane] = a;
         if (!(Z & 6) && a.x == 1.2345e300) rot[base] = a.x;
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(64) void k_level_buf(const double* __restrict__ in,
     for (int k = 0; k < 4; ++k) x[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ri, lane * 16, k * 1024, 2));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        V a = x[k] * 0.5;
-        V b = x[k] - a;
+        V a = -x[k];
+        V b = x[k];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, b), rr, lane * 16 + k * 1024, 0, 2);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, a), rb, lane * 16 + k * 1024, 0, 0);
     }
@@ -204,7 +204,13 @@ int main()
     const int L = 8;
     double *rows, *bases;
     CK(hipMalloc(&rows, (L + 1) * n * 8)); CK(hipMalloc(&bases, 3 * n * 8));
-    CK(hipMemset(bases, 0, 3 * n * 8));
+    {   // RANDOM data in the streams: throughput on this GPU depends on the bits that move (all-zero buffers stream ~23 % faster)
+        double* hostr = (double*)malloc(n * 8);
+        unsigned long long st64 = 88172645463325252ull;
+        for (size_t i = 0; i < n; ++i) { st64 ^= st64 << 13; st64 ^= st64 >> 7; st64 ^= st64 << 17; hostr[i] = (double)(st64 >> 11) * (1.0 / 9007199254740992.0) + 1.0; }
+        for (int sidx = 0; sidx < 3; ++sidx) CK(hipMemcpy(bases + (size_t)sidx * n, hostr, n * 8, hipMemcpyHostToDevice));
+        free(hostr);
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](const char* name, auto launch) {
         float best = 1e9, sum = 0; const int reps = 10;
@@ -294,6 +300,10 @@ int main()
     run("z=2  rotation(nt) only", [&](const double* i, double* r, double* b) { k_level_z<2><<<32768, 64>>>(i, r, b); });
     run("z=4  baseline only", [&](const double* i, double* r, double* b) { k_level_z<4><<<32768, 64>>>(i, r, b); });
     run("z=15 f32 read + rotation(nt) + baseline", [&](const double* i, double* r, double* b) { k_level_z<15><<<32768, 64>>>(i, r, b); });
+    {   // contrast: the same streams over all-zero buffers
+        CK(hipMemset(bases, 0, 3 * n * 8));
+        run("z=7 over ALL-ZERO data", [&](const double* i, double* r, double* b) { k_level_z<7><<<32768, 64>>>(i, r, b); });
+    }
     {   // the engine's whole launch sequence with the bare streams: scan (float32 read), level 0 (float32 read + both writes),
         // levels 1..7, FINAL (read + rotation); only the seven middle launches are timed
         float* xf; CK(hipMalloc(&xf, n * 4)); CK(hipMemset(xf, 0, n * 4));
