@@ -78,14 +78,14 @@ __global__ void k_level_x(const double* __restrict__ in, double* __restrict__ ro
 //  1 count windows (2 x 64 lanes x 4 B, unaligned)   2 first 64 B of four neighbour records   4 own record (flag words)
 //  8 record + count + group-sum outputs   16 ~3 us of dependent ALU work between the loads and the stores
 //  32 4.3 KB of LDS and ~64 VGPRs per wavefront (k_extract's footprint)
-template <int Y>
+template <int Y, int LDSW = 1100>
 __global__ __launch_bounds__(64) void k_level_y(const double* __restrict__ in, double* __restrict__ rot, double* __restrict__ bas,
                                                 const int* __restrict__ counts_in, int* __restrict__ counts_out,
                                                 const int4* __restrict__ recs_in, int4* __restrict__ recs_out, int* __restrict__ gsum,
                                                 int n_tiles, int spin)
 {
     using V = double __attribute__((ext_vector_type(2)));
-    __shared__ int lds[(Y & 32) ? 1100 : 16];
+    __shared__ int lds[(Y & 32) ? LDSW : 16];
     const int t = blockIdx.x, lane = threadIdx.x;
     const size_t base = (size_t)t * 512;
     const V* vi = reinterpret_cast<const V*>(in + base);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_level_y(const double* __restrict__ in, d
     if (Y & 4) side += (int)reinterpret_cast<const unsigned long long*>(recs_in + (size_t)t * 8)[lane < 8 ? 8 + lane : 0];
     double acc = (double)side;
     if (Y & 32) {
-        lds[lane] = side; lds[lane + 64 * 16] = side;
+        lds[lane] = side; lds[lane + LDSW - 64] = side;
         __builtin_amdgcn_wave_barrier();
         acc += lds[(lane * 7) & 63];
     }
@@ -263,6 +263,14 @@ int main()
         YV(16, 1000, "y=16 + 1000-step ALU chain")
         YV(48, 300, "y=48 + 300-step chain, 4.3 KB LDS")
         YV(32, 0, "y=32 + 4.3 KB LDS only")
+#define YL(W, NAME) run(NAME, [&](const double* i, double* r, double* b) { ++lvl; k_level_y<47, W><<<n_tiles, 64>>>(i, r, b, (lvl & 1) ? cin : cout, (lvl & 1) ? cout : cin, (lvl & 1) ? rin : rout, (lvl & 1) ? rout : rin, gsum, n_tiles, 0); });
+        YL(128, "y=47 side traffic + 0.5 KB LDS")
+        YL(256, "y=47 side traffic + 1 KB LDS")
+        YL(512, "y=47 side traffic + 2 KB LDS")
+        YL(768, "y=47 side traffic + 3 KB LDS")
+        YL(1100, "y=47 side traffic + 4.3 KB LDS")
+        YL(1280, "y=47 side traffic + 5 KB LDS")
+        YL(2048, "y=47 side traffic + 8 KB LDS")
         YV(47, 0, "y=47 + all side traffic + LDS")
         YV(79, 0, "y=79 + all side traffic + shared state line")
         YV(111, 0, "y=111 + side traffic + LDS + state line")
