@@ -2,21 +2,31 @@
 """bench.py — headline benchmark of the ITD hot path on MI355X.
 
 Metric (BASELINE.json): Msamples/s of the full 8-level ITD + achieved HBM GB/s.
-One "step" = one complete decomposition (level-0 knot scan, 9 extractions, stop rules, row fix-up) of
-the synthetic input already resident in HBM.
+One "step" = one complete decomposition (level-0 knot scan, 9 extractions, stop rules, row fix-up) of the synthetic
+input already resident in HBM.
 
   N = 1   workload = BASELINE configs[1]: one 2^24-sample float32 sum-of-sines+noise signal, 8 levels
           (max_iteration = 7 -> 9 rows), one MI355X.
-  N > 1   the path shards over independent signals only: every rank decomposes its own 2^24
-          signal (seed = rank) with no data-path collective -> weak scaling; value = all samples / max time.
+  N > 1   workload = BASELINE configs[3]'s shard: the batch of N x 1024 signals x 2^20 samples (signal b: noise draw
+          b mod 16, frequencies scaled by 1 + b/8192), contiguous shards of 1024 signals per GPU
+          (pyitd_amd.distributed.ShardedBatch), NO data-path collective; the only communication is the RCCL all-gather of
+          the per-signal summaries.  Weak scaling: value = all ranks' samples / max-over-ranks time.
 
-Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kernel k_extract, levels >= 1:
-24 algorithmic B/sample, timed with the launches' own hipEvents on the launch stream inside the timed region) + "cpu_baseline"
-(the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1).
+`python bench.py --gpus N` run plainly starts the N ranks itself: the parent process never touches the GPU, it spawns N
+fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child) and relays rank 0's line.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE already in the environment) the
+process IS one rank.
+
+Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kernel k_extract<double>, levels >= 1: 24
+algorithmic B/sample, timed with the launches' own hipEvents on the launch stream inside the timed region) + the per-kernel
+fractions + "cpu_baseline" (the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1)
+and the other CPU legs SURVEY 8d lists (all host cores over independent signals, numpy restatement, numba restatement).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,16 +39,36 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achie
 LEVELS = 8                  # BASELINE configs[1]
 MAX_ITERATION = LEVELS - 1  # -> LEVELS rotations + residual = 9 rows
 LOG2N = 24
+SINES = ((1, 110, 0.1), (0.5, 440, 1.3), (0.25, 1760, 2.1), (0.125, 7040, 0.7))
 
 
 def sines_noise(n, seed=0, fscale=1.0, fs=48000.0):
     """BASELINE config 2 recipe, float64 math cast to float32."""
     t = np.arange(n, dtype=np.float64) / fs
     x = np.zeros(n, dtype=np.float64)
-    for a, f, p in ((1, 110, 0.1), (0.5, 440, 1.3), (0.25, 1760, 2.1), (0.125, 7040, 0.7)):
+    for a, f, p in SINES:
         x += a * np.sin(2 * np.pi * (f * fscale) * t + p)
     x += 0.05 * np.random.default_rng(seed).standard_normal(n)
     return x.astype(np.float32)
+
+
+def batch_signals_device(torch, dev, b_lo, b_hi, n, fs=48000.0, rows_per_call=64):
+    """Signals b_lo..b_hi-1 of the config 3 / 4 batch, synthesised on the GPU with the same recipe (noise draw b mod 16
+    from numpy's default_rng on the host, sines in float64 on the device, cast to float32).  Values may differ from the host
+    recipe in the last float64 ulp of sin(): this is synthetic bench input, the parity tests build theirs on the host."""
+    noise = torch.from_numpy(np.stack([0.05 * np.random.default_rng(s).standard_normal(n) for s in range(16)])).to(dev)
+    t = torch.arange(n, dtype=torch.float64, device=dev) / fs
+    x = torch.empty((b_hi - b_lo, n), dtype=torch.float32, device=dev)
+    for c0 in range(b_lo, b_hi, rows_per_call):
+        c1 = min(c0 + rows_per_call, b_hi)
+        b = torch.arange(c0, c1, dtype=torch.float64, device=dev)
+        fsc = (1.0 + b / 8192.0)[:, None]
+        acc = torch.zeros((c1 - c0, n), dtype=torch.float64, device=dev)
+        for a, f, p in SINES:
+            acc += a * torch.sin(2 * np.pi * (f * fsc) * t[None, :] + p)
+        acc += noise[(torch.arange(c0, c1, device=dev) % 16)]
+        x[c0 - b_lo:c1 - b_lo] = acc.to(torch.float32)
+    return x
 
 
 def algorithmic_bytes_per_sample(levels):
@@ -46,101 +76,175 @@ def algorithmic_bytes_per_sample(levels):
     return 20 + 24 * (levels - 1)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=LOG2N)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
+
+def spawn_ranks(args):
+    """The parent of a plain `bench.py --gpus N`: start N rank processes and relay rank 0's JSON line.  This process never
+    initialises HIP (fresh children, no exec of a GPU-holding process)."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()          # the exact child this process started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+class _StubEngine:
+    """Stand-in for pyitd_amd.Engine in the CPU test of the launcher (tests/test_bench_launcher_cpu.py, --stub): no GPU,
+    no compute; the summary encodes which signals the rank owned."""
+
+    def __init__(self, lo, hi, rows):
+        self.lo, self.hi, self.rows = lo, hi, rows
+
+    def decompose_dev(self, *a):
+        pass
+
+    def set_timing(self, *a, **k):
+        pass
+
+    def summary(self, k):
+        from pyitd_amd.distributed import MAX_ROWS
+        kc = np.full((k, MAX_ROWS + 1), -1, np.int64)
+        kc[:, 0] = np.arange(self.lo, self.hi)          # signal id in the first knot-count column
+        return {"n_rows": np.full(k, self.rows, np.int32), "n_baselines": np.full(k, self.rows, np.int32),
+                "stop": np.ones(k, np.int32), "nan_levels": np.full(k, -1, np.int32), "knot_counts": kc}
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    stub = args.stub
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo" if stub else "nccl", rank=rank, world_size=world)
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
-    import pyitd_amd
-    from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0
+    from pyitd_amd.distributed import ShardedBatch
 
-    n = 1 << args.log2n
     M = MAX_ITERATION
     R = M + 2
-    x_host = sines_noise(n, seed=rank, fscale=1.0 + rank / 8192.0)
-    x = torch.from_numpy(x_host).to(dev)
-    rows = torch.empty((R, n), dtype=torch.float64, device=dev)
-    eng = pyitd_amd.Engine(n, 1, local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    sp = stream.cuda_stream
+    sharded = world > 1
+    if sharded:
+        n = 1 << (args.log2n if args.log2n != LOG2N else 20)
+        per_gpu = args.batch
+    else:
+        n = 1 << args.log2n
+        per_gpu = 1
+    batch = per_gpu * world
+    if stub:
+        lo, hi = rank * per_gpu, (rank + 1) * per_gpu
+        sb = ShardedBatch(batch, n, M, world, rank, engine=_StubEngine(lo, hi, R))
+        x = rows = None
+        x_ptr = rows_ptr = sp = 0
+        x_host = None
+    else:
+        import pyitd_amd
+        sb = ShardedBatch(batch, n, M, world, rank, device=local_rank)
+        if sharded:
+            x = batch_signals_device(torch, dev, sb.lo, sb.hi, n)
+            x_host = None
+        else:
+            x_host = sines_noise(n, seed=0)
+            x = torch.from_numpy(x_host).to(dev)[None]
+        rows = torch.empty((sb.n_local, R, n), dtype=torch.float64, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        sp = stream.cuda_stream
+        x_ptr, rows_ptr = x.data_ptr(), rows.data_ptr()
+    eng = sb.engine
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     def barrier():
         if dist.is_initialized():
             dist.barrier()
 
     def step():
-        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, sp)
+        sb.decompose(x_ptr, np.float32, n, rows_ptr, None, sp)
 
-    torch.cuda.synchronize()
+    sync()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    summ = eng.summary(1)
+    sync()
+    summ = sb.local_summary()
 
-    # on every 4th step of the timed region the extraction launches carry their own hipEvent pair (hipExtLaunchKernel: the
-    # dispatch's begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
-    eng.set_timing(args.steps, stride=4)
+    # on every 4th step of the timed region the launches carry their own hipEvent pair (hipExtLaunchKernel: the dispatch's
+    # begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
+    if not sharded:
+        eng.set_timing(args.steps, stride=4)
     barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed_local = t1 - t0
+    elapsed = elapsed_local
+    per_rank_ms = [elapsed_local / args.steps * 1e3]
     if dist.is_initialized():
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        parts = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        per_rank_ms = [float(p.item()) / args.steps * 1e3 for p in parts]
+        elapsed = max(float(p.item()) for p in parts)
 
-    # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal)
-    table = None
-    if dist.is_initialized():
-        from pyitd_amd.distributed import gather_summaries
-        table = gather_summaries(eng.summary(1), world, device=dev)
+    # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal), all-gathered
+    table = sb.gather(device=dev) if dist.is_initialized() else None
 
-    ext_ms, ext_cnt = eng.kernel_timing(TIME_EXTRACT)
-    l0_ms, l0_cnt = eng.kernel_timing(TIME_EXTRACT_L0)
-    fin_ms, fin_cnt = eng.kernel_timing(TIME_EXTRACT_FINAL)
-    dec_ms, dec_cnt = eng.kernel_timing(TIME_DECOMPOSE)
-    eng.set_timing(0)
+    if not sharded and not stub:
+        from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
+        timing = {k: eng.kernel_timing(t) for k, t in (("ext", TIME_EXTRACT), ("l0", TIME_EXTRACT_L0), ("fin", TIME_EXTRACT_FINAL),
+                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0))}
+        eng.set_timing(0)
+    else:
+        timing = None
 
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
-        return
+        return 0
 
-    samples_per_step = n * world
+    samples_per_step = n * batch
     value = samples_per_step * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
-    # dominant kernel: k_extract<float64> (levels 1..M): reads 8 B, writes rotation 8 B + baseline 8 B per sample
-    avg_ms = ext_ms / max(ext_cnt, 1)
-    achieved = 24.0 * n / (avg_ms * 1e-3) / 1e9 if ext_cnt else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_extract_f64_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if sharded:
+        workload = ("batch of %d x %d signals x 2^%d float32 samples (sines+noise, draw b mod 16, f*(1+b/8192)), %d ITD levels "
+                    "(max_iteration=%d, %d rows), contiguous shards of %d signals per GPU, device resident"
+                    % (world, per_gpu, n.bit_length() - 1, LEVELS, M, R, per_gpu))
+    else:
+        workload = ("single 2^%d-sample float32 sum-of-sines+noise, %d ITD levels (max_iteration=%d, %d rows), device resident"
+                    % (args.log2n, LEVELS, M, R))
     out = {
         "metric": "Msamples/s full ITD (8 levels) + achieved HBM GB/s",
         "value": round(value, 3),
@@ -155,17 +259,43 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "single 2^%d-sample float32 sum-of-sines+noise per GPU, %d ITD levels (max_iteration=%d, "
-                        "%d rows), device resident" % (args.log2n, LEVELS, M, R),
-            "signals_per_gpu": 1,
+            "workload": workload,
+            "signals_per_gpu": per_gpu,
             "samples_per_signal": n,
             "rows": int(summ["n_rows"][0]),
             "knots_per_level": [int(v) for v in summ["knot_counts"][0] if v >= 0],
-            "sharding": "one independent signal per GPU, no data-path collective",
-            "rows_all_ranks": None if table is None else [int(v) for v in table["n_rows"]],
+            "sharding": "contiguous ranges of independent signals per GPU (ShardedBatch), no data-path collective; "
+                        "all-gather of the per-signal summaries only",
+            "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+            "rows_all_ranks": None if table is None else sorted(set(int(v) for v in table["n_rows"])),
+            "signals_in_gathered_table": None if table is None else int(len(table["n_rows"])),
         },
         "hbm_algorithmic_GBps": round(algorithmic_bytes_per_sample(LEVELS) * samples_per_step * args.steps / elapsed / 1e9, 1),
-        "roofline": {
+    }
+    if stub:
+        out["config"]["stub"] = True
+        out["config"]["table_signal_ids"] = [int(v) for v in table["knot_counts"][:, 0]] if table is not None else None
+    if timing is not None:
+        def avg_us(k):
+            ms, cnt = timing[k]
+            return ms / max(cnt, 1) * 1e3
+        ext_cnt = timing["ext"][1]
+        ext_us = avg_us("ext")
+        achieved = 24.0 * n / (ext_us * 1e-6) / 1e9 if ext_cnt else 0.0
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_extract_f64_bytes_per_launch")
+                traffic_src = "profiles/traffic.json (%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction; " \
+                              "a recorded measurement of the same build, not of this run)" % tj.get("round")
+            except Exception:
+                traffic = None
+
+        def frac(bytes_per_sample, us):
+            return round(bytes_per_sample * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us > 0 else 0.0
+        out["roofline"] = {
             "bound": "hbm",
             "kernel": "k_extract<double> (levels>=1: read 8 B + write 16 B per sample)",
             "achieved": round(achieved, 1),
@@ -173,44 +303,122 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
-            "avg_launch_us": round(avg_ms * 1e3, 2),
+            "traffic_source": traffic_src,
+            "avg_launch_us": round(ext_us, 2),
             "launches_timed": ext_cnt,
-            "read_frac": round(8.0 * n / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ext_cnt else 0.0,
-            "level0_launch_us": round(l0_ms / max(l0_cnt, 1) * 1e3, 2),
-            "final_launch_us": round(fin_ms / max(fin_cnt, 1) * 1e3, 2),
-            "decompose_gpu_us": round(dec_ms / max(dec_cnt, 1) * 1e3, 2),
-        },
-    }
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import cpu_oracle   # checker/baseline only: never part of the measured GPU path
-        cpu_oracle.lib()
-        # bounded sample: whole-signal runs of the oracle until ~10 s of CPU work (at most 8 runs); best run counts
-        tc, runs, spent = None, 0, 0.0
-        while runs < 8 and spent < 10.0:
-            tc0 = time.perf_counter()
-            ref = cpu_oracle.itd_lean(x_host, M)
-            dt = time.perf_counter() - tc0
-            tc = dt if tc is None else min(tc, dt)
-            runs += 1
-            spent += dt
-        out["cpu_baseline"] = {
-            "value": round(n / tc / 1e6, 3),
-            "unit": "Msamples/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": "the same 2^%d-sample signal, %d levels, best of %d whole-signal runs of the C oracle (single thread: "
-                      "the reference's level recursion is serial), %.2f s per run" % (args.log2n, LEVELS, runs, tc),
-            "host_cpus": os.cpu_count(),
+            "read_frac": frac(8.0, ext_us) if ext_cnt else 0.0,
+            "read_frac_note": "the north star's '>= 40 % of HBM-read roofline' read as 8 B/sample / t / peak (SURVEY 8d) needs t <= 42 us "
+                              "per 2^24-sample level, i.e. 24 B/sample of total traffic at 9.6 TB/s: above the 8 TB/s peak, unreachable "
+                              "for any kernel that also writes the two float64 rows; frac (all 24 algorithmic bytes) is the figure to read",
+            "level0_launch_us": round(avg_us("l0"), 2),
+            "scan0_launch_us": round(avg_us("scan0"), 2),
+            "final_launch_us": round(avg_us("fin"), 2),
+            "decompose_gpu_us": round(avg_us("dec"), 2),
+            "per_kernel_frac": {
+                "extract_levels_ge1 (24 B/sample)": frac(24.0, ext_us),
+                "level0 pair: k_scan0 + k_extract<float> (20 B/sample)": frac(20.0, avg_us("scan0") + avg_us("l0")),
+                "k_extract<float> level 0 alone (20 B/sample)": frac(20.0, avg_us("l0")),
+                "k_scan0 (4 B/sample)": frac(4.0, avg_us("scan0")),
+                "final extract (16 B/sample)": frac(16.0, avg_us("fin")),
+                "whole decomposition (188 B/sample)": frac(float(algorithmic_bytes_per_sample(LEVELS)), avg_us("dec")),
+            },
         }
-        out["parity"] = {
-            "knot_counts_equal": [int(v) for v in summ["knot_counts"][0][: len(ref["knot_counts"])]] == ref["knot_counts"].tolist(),
-            "rows_bit_exact": bool(np.array_equal(rows[: ref["rows"].shape[0]].cpu().numpy().view(np.uint64),
-                                                  ref["rows"].view(np.uint64))),
-        }
+    if world == 1 and not stub and not args.no_cpu_baseline:
+        out.update(cpu_legs(x_host, n, M, summ, rows, args))
     print(json.dumps(out))
+    sys.stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
+    return 0
+
+
+def cpu_legs(x_host, n, M, summ, rows, args):
+    """CPU baselines timed on this box's host cores (rank 0, N = 1 only), each on a bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import cpu_oracle, numba_itd, numpy_itd   # checkers/baselines only: never part of the measured GPU path
+    cpu_oracle.lib()
+    out = {}
+    # (1) the C oracle, one thread (the reference's level recursion is serial), the full signal: whole-signal runs until
+    #     ~10 s of CPU work (at most 8 runs); the best run counts
+    tc, runs, spent, ref = None, 0, 0.0, None
+    while runs < 8 and spent < 10.0:
+        tc0 = time.perf_counter()
+        ref = cpu_oracle.itd_lean(x_host, M)
+        dt = time.perf_counter() - tc0
+        tc = dt if tc is None else min(tc, dt)
+        runs += 1
+        spent += dt
+    out["cpu_baseline"] = {
+        "value": round(n / tc / 1e6, 3),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "the same 2^%d-sample signal, %d levels, best of %d whole-signal runs of the C oracle (gcc -O3 -ffp-contract=off, single "
+                  "thread: the reference's level recursion is serial), %.2f s per run" % (args.log2n, LEVELS, runs, tc),
+        "host_cpus": os.cpu_count(),
+    }
+    out["parity"] = {
+        "knot_counts_equal": [int(v) for v in summ["knot_counts"][0][: len(ref["knot_counts"])]] == ref["knot_counts"].tolist(),
+        "rows_bit_exact": bool(np.array_equal(rows[0, : ref["rows"].shape[0]].cpu().numpy().view(np.uint64),
+                                              ref["rows"].view(np.uint64))),
+    }
+    del ref
+    # (2) all host cores over independent signals (the batch form: one 2^20 signal per task, ctypes releases the GIL)
+    cores = os.cpu_count() or 1
+    k_sig = max(64, cores)
+    n1 = 1 << 20
+    work = [sines_noise(n1, seed=s) for s in range(16)]
+    cpu_oracle.itd_lean(work[0], M)
+    tc0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda i: cpu_oracle.itd_lean(work[i % 16], M)["rows"].shape[0], range(k_sig)))
+    dt = time.perf_counter() - tc0
+    out["cpu_baseline_all_cores"] = {
+        "value": round(k_sig * n1 / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": "%d independent 2^20-sample signals (16 distinct draws), %d levels, C oracle on %d host threads, %.2f s"
+                  % (k_sig, LEVELS, cores, dt),
+    }
+    # (3) the numpy restatement (oracle/numpy_itd.py), one thread, one 2^20 signal
+    numpy_itd.itd(work[0][: 1 << 16], M)
+    tc0 = time.perf_counter()
+    numpy_itd.itd(work[0], M)
+    dt = time.perf_counter() - tc0
+    out["cpu_baseline_numpy"] = {
+        "value": round(n1 / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "sample": "one 2^20-sample signal, %d levels, vectorised numpy restatement (oracle/numpy_itd.py), %.2f s" % (LEVELS, dt),
+    }
+    # (4) numba: the upstream ITD_numba.py cannot be imported anywhere (SURVEY section 0); the build's own njit restatement
+    #     of it (oracle/numba_itd.py) is timed when numba is importable on this box
+    if numba_itd.AVAILABLE:
+        numba_itd.itd(work[0][: 1 << 14], M)     # compile
+        tc0 = time.perf_counter()
+        numba_itd.itd(work[0], M)
+        dt = time.perf_counter() - tc0
+        out["cpu_baseline_numba"] = {
+            "value": round(n1 / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "one 2^20-sample signal, %d levels, njit restatement of ITD_numba.py's algorithm (oracle/numba_itd.py), %.2f s" % (LEVELS, dt),
+        }
+    else:
+        out["cpu_baseline_numba"] = {"value": None, "unit": "Msamples/s", "available": False,
+                                     "note": "numba is not importable on this box (not in the image, no network); "
+                                             "oracle/numba_itd.py holds the njit restatement that would be timed"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=LOG2N, help="N = 1: samples of the single signal (24); N > 1: samples per signal (20)")
+    ap.add_argument("--batch", type=int, default=1024, help="N > 1: signals per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher only
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 1
+#define ITD_ABI_VERSION 2
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -72,6 +72,13 @@ void itd_engine_destroy(itd_engine *e);
 int64_t itd_engine_workspace_bytes(const itd_engine *e);
 int itd_engine_device(const itd_engine *e);
 
+/* Plain device-memory helpers for bindings that own no GPU allocator (the numpy path of pyitd_amd.itd_batch, the C
+ * client of tests/c_client): hipMalloc / hipFree / synchronous hipMemcpy on `device_id`.  to_device: 1 = host -> device,
+ * 0 = device -> host.  Callers that already hold device buffers (torch tensors, their own hipMalloc) never need these. */
+int itd_dev_alloc(int device_id, int64_t bytes, void **out);
+int itd_dev_free(int device_id, void *p);
+int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32_t to_device);
+
 /* ---- full decomposition, device resident: replaces ITD.itd (ITD.py:351-432) -------------------
  * x_dev          [batch] signals, signal b starts at x_dev + b*x_stride (elements), n samples each
  * rows_dev       [batch][max_iteration+2][n] float64.  On return (after the stream has run) rows
@@ -94,19 +101,25 @@ int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t bat
  *                (j = 0: the signal itself; j >= 1: the number the reference prints at ITD.py:403);
  *                entries past the last evaluated level are -1
  *   nan_levels   [batch]      -1 = results follow the reference; -2 = the input signal itself contains a NaN
- *                (rejected, rows undefined); j >= 0 (only with the fallback disabled) = first extraction
- *                whose baseline contained a NaN
- * NaN fallback: a baseline acquires NaNs when the signal starts with a plateau (ITD.py:115-116 divides by
- * x[e_1]-x[0] = 0).  The reference then counts knots under detect_peaks' NaN rules (ITD.py:46-51,64-68) and
- * overwrites NaN with +inf in place.  itd_get_summary re-runs exactly those signals through the NaN-faithful
- * launch sequence before it returns, so x_dev / rows_dev / baselines_dev must stay valid until then. */
+ *                (rejected, rows undefined)
+ * NaNs that arise inside a decomposition are followed exactly: a baseline acquires NaNs when the signal starts with a
+ * plateau (ITD.py:115-116 divides by x[e_1]-x[0] = 0); the reference's stop test then counts knots under detect_peaks'
+ * NaN rules (ITD.py:46-51,64-68) and overwrites NaN with +inf in place (ITD.py:50).  Since ABI revision 2 the extraction
+ * kernel applies these rules itself, tile by tile, in the same launch (no re-run, no extra pass over the signal). */
 int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
                     int64_t *knot_counts, int32_t *nan_levels);
-/* enable (default) / disable the NaN-faithful re-run inside itd_get_summary */
+/* ABI revision 1 switched a NaN-faithful re-run on and off here; kept as a no-op (always faithful now) */
 int itd_set_nan_fallback(itd_engine *e, int enable);
+/* Batched decompositions run as launch sequences over chunks of `signals_per_chunk` signals, all levels of a chunk before
+ * the next chunk (0 = automatic: about 2^24 samples per chunk, so a level's baseline is still in the 256 MiB Infinity
+ * Cache when the next level reads it).  Results do not depend on the chunk size. */
+int itd_set_batch_chunk(itd_engine *e, int32_t signals_per_chunk);
 
 /* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
- * launch); to inspect them run itd_detect_* on the input or on a stored baseline row. */
+ * launch); to inspect them run itd_detect_* on the input or on a stored baseline row.  The single-level operators
+ * below work in a workspace of their own: calling them between itd_decompose_* and itd_get_summary (on any stream)
+ * does not disturb the decomposition.  They return ITD_ERR_NONFINITE for a signal that contains a NaN (the reference's
+ * detect_peaks would take its NaN branch and write +inf into the caller's array, ITD.py:46-51). */
 
 /* ---- one-call host convenience (numpy in -> numpy out, what the reference's callers see) -------
  * Copies x to the GPU, decomposes, copies rows (and baselines if non-NULL) back.
@@ -154,6 +167,7 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
 #define ITD_TIME_EXTRACT_L0 1     /* k_extract on the caller's signal (level 0; 20 B/sample for float32) */
 #define ITD_TIME_EXTRACT_FINAL 2  /* k_extract of the "Out of time!" level (writes rotation+baseline only) */
 #define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
+#define ITD_TIME_SCAN0 4          /* k_scan0: the level-0 knot scan of the caller's signal (4 B/sample for float32) */
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
 /* instrument only every stride-th decomposition (launches with events cost ~2 us more each, the span's marker records ~5 us each) */
 int itd_set_kernel_timing_stride(itd_engine *e, int stride);

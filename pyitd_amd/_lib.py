@@ -15,6 +15,7 @@ HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"),
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -39,6 +40,10 @@ ABI = {
     "itd_detect_host_f64": (_INT, [_P, _P, _I64, _I32, _P, _P]),
     "itd_knot_values_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P]),
     "itd_set_nan_fallback": (_INT, [_P, _INT]),
+    "itd_set_batch_chunk": (_INT, [_P, _I32]),
+    "itd_dev_alloc": (_INT, [_INT, _I64, ctypes.POINTER(_P)]),
+    "itd_dev_free": (_INT, [_INT, _P]),
+    "itd_dev_copy": (_INT, [_INT, _P, _P, _I64, _I32]),
     "itd_set_kernel_timing": (_INT, [_P, _INT]),
     "itd_set_kernel_timing_stride": (_INT, [_P, _INT]),
     "itd_get_kernel_timing": (_INT, [_P, _I32, _P, _P]),
@@ -82,7 +87,7 @@ def load():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             f.restype = res
             f.argtypes = args
-        if L.itd_abi_version() != 1:
+        if L.itd_abi_version() != ABI_VERSION:
             raise RuntimeError("pyitd_amd: ABI version mismatch")
         _lib = L
     return _lib

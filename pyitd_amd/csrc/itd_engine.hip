@@ -39,13 +39,10 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
         gsum[i] = 0;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    for (int j = 0; j < kMaxLevels; ++j) st[b].m[j] = -1;
-    st[b].stopped = 0;
+    for (int j = 0; j < kMaxLevels; ++j) { st[b].m[j] = -1; st[b].c_delta[j] = 0; }
     st[b].stop_level = -1;
     st[b].nan_mask = 0;
     st[b].in_nan = 0;
-    st[b].c_nan = 0;
-    st[b].c_has_nan = 0;
     st[b].fin_stopped = 0;
     st[b].fin_stop_level = -1;
 }
@@ -76,6 +73,14 @@ struct itd_engine {
     int64_t pp_pitch = 0;          // elements between consecutive slots: max_n + kSlotPad (breaks the power-of-two distance)
     SigState *d_state = nullptr;   // [batch]
     SigState *h_state = nullptr;   // pinned
+    // workspace of the single-level helpers (itd_detect_*, itd_baseline_extract_*): one signal, apart from the
+    // decomposition's, so a helper call never disturbs a decomposition that is still in flight or not yet summarised
+    int32_t *d_hcounts = nullptr;  // [2][tiles]
+    TileRec *d_hrecs = nullptr;    // [2][tiles]
+    int32_t *d_hgsum = nullptr;    // [3][groups*pitch]
+    int64_t hgsum_third = 0;
+    SigState *d_hstate = nullptr;  // [1]
+    int32_t chunk = 0;             // signals per launch sequence of a batched decomposition (0 = automatic, see enqueue_decompose)
     int64_t ws_bytes = 0;
     // host-convenience staging (grow only)
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
@@ -86,11 +91,6 @@ struct itd_engine {
     int32_t last_batch = 0, last_m = 0;
     int64_t last_n = 0;
     hipStream_t last_stream = nullptr;
-    const void *last_x = nullptr;      // the caller's device signal of the last decomposition (careful re-runs)
-    bool last_x_f32 = false;
-    int64_t last_x_stride = 0;
-    double *last_rows = nullptr, *last_bases = nullptr;
-    bool nan_fallback = true;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // event pairs: [2k] start, [2k+1] stop
@@ -149,19 +149,25 @@ void time_end(itd_engine *e, int k, hipStream_t st)
     if (k >= 0) (void)hipEventRecord(e->ev[2 * (size_t)k + 1], st);
 }
 
+// signals per launch sequence of a batched decomposition.  All levels of a chunk run before the next chunk starts, so
+// the baseline a level writes (8 B per sample per signal) is still in the 256 MiB Infinity Cache when the next level reads it
+// — the state the single 2^24-sample signal is in.  Automatic: about 2^24 samples per chunk.
+int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
+{
+    if (e->chunk > 0) return std::min<int32_t>(e->chunk, batch);
+    const int64_t c = std::max<int64_t>(1, ((int64_t)1 << 24) / n);
+    return (int)std::min<int64_t>(c, batch);
+}
+
 template <typename Tin>
 int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M,
                       double *rows, double *bases_user, hipStream_t st)
 {
     const int n_tiles = (int)tiles_of(n);
+    const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
     const int64_t rows_stride = R * n;
     const dim3 blk(kWave);
-    const dim3 grid_t(n_tiles, batch);   // one one-wavefront workgroup per tile
-    const dim3 grid_x((n_tiles + kTilesPerWave - 1) / kTilesPerWave, batch);   // k_extract: kTilesPerWave consecutive tiles per wavefront
-    auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third; };
-    auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half; };
-    auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half; };
 
     // instrument every timing_stride-th decomposition only: a launch that carries events needs a completion signal of its own
     // (~2 us per launch, measured), the whole-decomposition span two marker records (~5 us each)
@@ -176,59 +182,81 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
-    k_scan0<Tin, T, kScanTilesPerWave><<<dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, batch), blk, 0, st>>>(x, x_stride, n, n_tiles, cnt(0), rec(0), gs(0), e->d_state);
-
-    for (int j = 0; j <= M + 1; ++j) {
-        // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
-        double *base_out;
-        int64_t base_stride;
-        const double *base_in = nullptr;
-        int64_t base_in_stride = 0;
-        if (bases_user) {
-            base_out = bases_user + (int64_t)j * n;
-            base_stride = rows_stride;
-            if (j >= 1) { base_in = bases_user + (int64_t)(j - 1) * n; base_in_stride = rows_stride; }
-        } else {
-            base_out = e->d_pp + (int64_t)(j % 3) * e->pp_pitch;
-            base_stride = 3 * e->pp_pitch;
-            if (j >= 1) { base_in = e->d_pp + (int64_t)((j - 1) % 3) * e->pp_pitch; base_in_stride = 3 * e->pp_pitch; }
+    const int chunk = chunk_of(e, n, batch);
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = std::min(chunk, batch - b0);   // signals b0 .. b0+nb-1: grid.y, every per-signal pointer offset by b0
+        const dim3 grid_x((n_tiles + kTilesPerWave - 1) / kTilesPerWave, nb);   // k_extract: kTilesPerWave consecutive tiles per wavefront
+        auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b0 * n_groups * kGsumPitch; };
+        auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
+        auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
+        SigState *state = e->d_state + b0;
+        const Tin *xc = x + (int64_t)b0 * x_stride;
+        double *rows_c = rows + (int64_t)b0 * rows_stride;
+        double *bases_c = bases_user ? bases_user + (int64_t)b0 * rows_stride : nullptr;
+        double *pp_c = e->d_pp + (int64_t)b0 * 3 * e->pp_pitch;
+        {
+            const int pair = time_slot(e, ITD_TIME_SCAN0);
+            const Tin *a_x = xc; int64_t a_xs = x_stride, a_n = n; int a_nt = n_tiles;
+            int32_t *a_c = cnt(0), *a_g = gs(0); TileRec *a_r = rec(0); SigState *a_st = state;
+            void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_c, &a_r, &a_g, &a_st};
+            HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_scan0<Tin, T, kScanTilesPerWave>),
+                                          dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, nb), blk, args, 0, st,
+                                          pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,
+                                          pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
         }
-        double *rot_out = rows + (int64_t)j * n;
-        const bool final_level = (j == M + 1);
-        const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
-        // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
-        // begin / end timestamps (no marker packets in the stream: nothing is added to the timed region)
+
+        for (int j = 0; j <= M + 1; ++j) {
+            // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
+            double *base_out;
+            int64_t base_stride;
+            const double *base_in = nullptr;
+            int64_t base_in_stride = 0;
+            if (bases_c) {
+                base_out = bases_c + (int64_t)j * n;
+                base_stride = rows_stride;
+                if (j >= 1) { base_in = bases_c + (int64_t)(j - 1) * n; base_in_stride = rows_stride; }
+            } else {
+                base_out = pp_c + (int64_t)(j % 3) * e->pp_pitch;
+                base_stride = 3 * e->pp_pitch;
+                if (j >= 1) { base_in = pp_c + (int64_t)((j - 1) % 3) * e->pp_pitch; base_in_stride = 3 * e->pp_pitch; }
+            }
+            double *rot_out = rows_c + (int64_t)j * n;
+            const bool final_level = (j == M + 1);
+            const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
+            // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
+            // begin / end timestamps (no marker packets in the stream: nothing is added to the timed region)
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
     do {                                                                                                                   \
         const TIN *a_x = XIN; int64_t a_xs = XSTRIDE, a_n = n, a_rs = rows_stride, a_bs = base_stride;                     \
-        int a_nt = n_tiles, a_b = batch, a_lvl = j, a_careful = 0;                                                         \
+        int a_nt = n_tiles, a_b = nb, a_lvl = j;                                                                           \
         const int32_t *a_ci = cnt(j), *a_gi = gs(j); int32_t *a_co = cnt(j + 1), *a_go = gs(j + 1), *a_gc = gs(j + 2);      \
         const TileRec *a_ri = rec(j); TileRec *a_ro = rec(j + 1); double *a_rot = rot_out, *a_bas = base_out;              \
-        SigState *a_st = e->d_state;                                                                                       \
+        SigState *a_st = state;                                                                                            \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
-                        &a_bas, &a_bs, &a_st, &a_lvl, &a_careful};                                                         \
+                        &a_bas, &a_bs, &a_st, &a_lvl};                                                                     \
         HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, kTilesPerWave>), grid_x, \
                                       blk, args, 0, st, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                     \
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
     } while (0)
-        if (j == 0) {
-            if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, x, x_stride, kRankCap0);
-            else ITD_LAUNCH_EXTRACT(Tin, false, x, x_stride, kRankCap0);
-        } else {
-            if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap);
-            else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap);
-        }
+            if (j == 0) {
+                if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, xc, x_stride, kRankCap0);
+                else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0);
+            } else {
+                if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap);
+                else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap);
+            }
 #undef ITD_LAUNCH_EXTRACT
-    }
-    // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
-    {
-        const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
-        if (bases_user)
-            k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0,
-                                                                      gs(M + 2), n_tiles, M + 2, 0, e->d_state);
-        else
-            k_finalize<<<dim3(fb, batch), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, e->d_pp, 3 * e->pp_pitch,
-                                                                      e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, 0, e->d_state);
+        }
+        // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
+        {
+            const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
+            if (bases_c)
+                k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, st>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
+                                                                       gs(M + 2), n_tiles, M + 2, state);
+            else
+                k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, st>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
+                                                                       e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, state);
+        }
     }
     time_end(e, span_pair, st);
     HIP_TRY(e, hipGetLastError());
@@ -237,78 +265,6 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_m = M;
     e->last_n = n;
     e->last_stream = st;
-    e->last_x = x;
-    e->last_x_f32 = sizeof(Tin) == 4;
-    e->last_x_stride = x_stride;
-    e->last_rows = rows;
-    e->last_bases = bases_user;
-    return ITD_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The NaN-faithful path for ONE signal (batch slot b), used after the fast path reported a NaN in one of that
-// signal's baselines.  Same launches as the fast path, except that the next level's knot scan is not fused into
-// the extraction: between two extractions the reference's stop test counts knots under its NaN rules and turns
-// NaN into +inf in place (k_careful_count / k_careful_apply).  Enqueued asynchronously on `st`.
-// ---------------------------------------------------------------------------------------------
-template <typename Tin>
-int enqueue_careful(itd_engine *e, int b, hipStream_t st)
-{
-    const int64_t n = e->last_n;
-    const int32_t M = e->last_m;
-    const int n_tiles = (int)tiles_of(n);
-    const int n_groups = groups_of(n_tiles);
-    const int64_t R = (int64_t)M + 2;
-    const int64_t rows_stride = R * n;
-    const dim3 grid_t(n_tiles, 1), blk(kWave);   // one one-wavefront workgroup per tile
-    const Tin *x = (const Tin *)e->last_x + (int64_t)b * e->last_x_stride;
-    double *rows = e->last_rows + (int64_t)b * rows_stride;
-    double *bases_user = e->last_bases ? e->last_bases + (int64_t)b * rows_stride : nullptr;
-    double *pp = e->d_pp + (int64_t)b * 3 * e->pp_pitch;
-    SigState *state = e->d_state + b;
-    const int B = e->last_batch;
-    auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b * n_groups * kGsumPitch; };
-    auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b * n_tiles; };
-    auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b * n_tiles; };
-    (void)B;
-    k_init_state<<<1, 64, 0, st>>>(state, 1, nullptr, 0);
-    for (int q = 0; q < 3; ++q)
-        HIP_TRY(e, hipMemsetAsync(gs(q), 0, sizeof(int32_t) * (size_t)n_groups * kGsumPitch, st));
-    if (bases_user) HIP_TRY(e, hipMemsetAsync(bases_user + (R - 1) * n, 0, sizeof(double) * (size_t)n, st));
-    k_scan0<Tin, T, kScanTilesPerWave><<<dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave), blk, 0, st>>>(x, n, n, n_tiles, cnt(0), rec(0), gs(0), state);
-    for (int j = 0; j <= M + 1; ++j) {
-        double *base_out = bases_user ? bases_user + (int64_t)j * n : pp + (int64_t)(j % 3) * e->pp_pitch;
-        const double *base_in = nullptr;
-        if (j >= 1) base_in = bases_user ? bases_user + (int64_t)(j - 1) * n : pp + (int64_t)((j - 1) % 3) * e->pp_pitch;
-        // the "Out of time!" level keeps its pending baseline too: the stop test and the mutation come first.
-        // With the caller's baselines buffer that row (index M+1) must end up zero (ITD.py:424), so the pending
-        // baseline of the last level goes to the engine's rotating slot instead.
-        const bool final_level = (j == M + 1);
-        if (final_level && bases_user) base_out = pp + (int64_t)(j % 3) * e->pp_pitch;
-        double *rot_out = rows + (int64_t)j * n;
-        if (j == 0)
-            k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, cnt(j), cnt(j + 1), rec(j),
-                                                                        rec(j + 1), gs(j), gs(j + 1), gs(j + 2), rot_out,
-                                                                        n, base_out, n, state, j, 1);
-        else
-            k_extract<double, T, false, kRankCap, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(base_in, n, n, n_tiles, 1, cnt(j), cnt(j + 1),
-                                                                           rec(j), rec(j + 1), gs(j), gs(j + 1),
-                                                                           gs(j + 2), rot_out, n, base_out, n, state, j, 1);
-        k_careful_count<T><<<grid_t, blk, 0, st>>>(base_out, n, state);
-        k_careful_apply<T><<<grid_t, blk, 0, st>>>(base_out, n, n_tiles, cnt(j + 1), rec(j + 1), gs(j + 1), state, j + 1);
-        if (final_level)   // ITD.py:420: rotation_ + baseline_ (baseline_ already mutated by the stop test)
-            k_add_rows<<<(unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, st>>>(rot_out, base_out, n);
-    }
-    {
-        const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
-        if (bases_user)
-            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, bases_user, rows_stride, n, 0, gs(M + 2),
-                                                                  n_tiles, M + 2, 1, state);
-        else
-            k_finalize<<<dim3(fb, 1), kFinalizeThreads, 0, st>>>(rows, rows_stride, n, pp, 3 * e->pp_pitch, e->pp_pitch, 3, gs(M + 2),
-                                                                  n_tiles, M + 2, 1, state);
-    }
-    HIP_TRY(e, hipGetLastError());
     return ITD_OK;
 }
 
@@ -385,6 +341,11 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->pp_pitch = max_n + kSlotPad;
     alloc((void **)&e->d_pp, B * 3 * (size_t)e->pp_pitch * sizeof(double));
     alloc((void **)&e->d_state, B * sizeof(SigState));
+    e->hgsum_third = (int64_t)max_groups * kGsumPitch;
+    alloc((void **)&e->d_hcounts, 2 * (size_t)e->max_tiles * sizeof(int32_t));
+    alloc((void **)&e->d_hrecs, 2 * (size_t)e->max_tiles * sizeof(TileRec));
+    alloc((void **)&e->d_hgsum, 3 * (size_t)e->hgsum_third * sizeof(int32_t));
+    alloc((void **)&e->d_hstate, sizeof(SigState));
     const size_t st_b = B * sizeof(SigState);
     if (rc == hipSuccess) rc = hipHostMalloc((void **)&e->h_state, st_b);
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -404,6 +365,7 @@ void itd_engine_destroy(itd_engine *e)
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
     (void)hipFree(e->d_lists); (void)hipFree(e->d_counts); (void)hipFree(e->d_recs); (void)hipFree(e->d_total);
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
+    (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -412,6 +374,34 @@ void itd_engine_destroy(itd_engine *e)
 }
 
 int64_t itd_engine_workspace_bytes(const itd_engine *e) { return e ? e->ws_bytes : 0; }
+
+// ---- plain device-memory helpers: a host binding that owns no GPU allocator of its own (numpy callers, the C client) ----
+int itd_dev_alloc(int device_id, int64_t bytes, void **out)
+{
+    if (!out || bytes <= 0) return ITD_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return ITD_ERR_NO_DEVICE;
+    DevGuard g(device_id);
+    const hipError_t rc = hipMalloc(out, (size_t)bytes);
+    if (rc == hipErrorOutOfMemory) return ITD_ERR_NOMEM;
+    return rc == hipSuccess ? ITD_OK : ITD_ERR_HIP;
+}
+
+int itd_dev_free(int device_id, void *p)
+{
+    if (!p) return ITD_OK;
+    DevGuard g(device_id);
+    return hipFree(p) == hipSuccess ? ITD_OK : ITD_ERR_HIP;
+}
+
+int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32_t to_device)
+{
+    if (!dst || !src || bytes < 0) return ITD_ERR_INVALID_ARG;
+    DevGuard g(device_id);
+    return hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess
+               ? ITD_OK : ITD_ERR_HIP;
+}
 int itd_engine_device(const itd_engine *e) { return e ? e->device : -1; }
 
 int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batch, int64_t x_stride,
@@ -443,29 +433,6 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     const int B = e->last_batch;
     HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
-    auto rows_of = [&](const SigState &s) { return s.fin_stopped ? s.fin_stop_level : e->last_m + 2; };
-    auto first_nan = [&](const SigState &s) {
-        // a NaN in a baseline whose knots no decision looked at (extraction >= rows) is harmless
-        for (int j = 0; j < rows_of(s) && j < kMaxLevels; ++j)
-            if (s.nan_mask & (1 << j)) return j;
-        return -1;
-    };
-    // ---- NaN-faithful re-run of the signals whose baselines went NaN (the reference's NaN -> inf path) ----
-    if (e->nan_fallback) {
-        bool any = false;
-        for (int b = 0; b < B; ++b) {
-            const SigState &s = e->h_state[b];
-            if (s.in_nan || first_nan(s) < 0) continue;
-            const int rc = e->last_x_f32 ? enqueue_careful<float>(e, b, e->last_stream)
-                                         : enqueue_careful<double>(e, b, e->last_stream);
-            if (rc) return rc;
-            any = true;
-        }
-        if (any) {
-            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
-            HIP_TRY(e, hipStreamSynchronize(e->last_stream));
-        }
-    }
     for (int b = 0; b < B; ++b) {
         const SigState &s = e->h_state[b];
         int rows, nb, why;
@@ -484,15 +451,23 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         if (stop_reason) stop_reason[b] = why;
         if (knot_counts)
             for (int j = 0; j <= ITD_MAX_ROWS; ++j) knot_counts[(size_t)b * (ITD_MAX_ROWS + 1) + j] = s.m[j];
-        if (nan_levels) nan_levels[b] = s.in_nan ? -2 : (e->nan_fallback ? -1 : first_nan(s));
+        if (nan_levels) nan_levels[b] = s.in_nan ? -2 : -1;
     }
     return ITD_OK;
 }
 
 int itd_set_nan_fallback(itd_engine *e, int enable)
 {
-    if (!e) return ITD_ERR_INVALID_ARG;
-    e->nan_fallback = enable != 0;
+    // kept for ABI compatibility: since ABI revision 2 the extraction kernel itself follows the reference's NaN rules
+    // (nan_rules in itd_kernels.hpp), there is no separate re-run to switch off
+    (void)enable;
+    return e ? ITD_OK : ITD_ERR_INVALID_ARG;
+}
+
+int itd_set_batch_chunk(itd_engine *e, int32_t signals_per_chunk)
+{
+    if (!e || signals_per_chunk < 0) return ITD_ERR_INVALID_ARG;
+    e->chunk = signals_per_chunk;
     return ITD_OK;
 }
 
@@ -540,24 +515,27 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
 {
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kWave);
-    k_init_state<<<(unsigned)std::min<int64_t>((3 * e->gsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_state, 1, e->d_gsum,
-                                                                                                  3 * e->gsum_third);
-    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_counts,
-                                              e->d_recs, e->d_gsum, e->d_state);
+    // the helpers' own state, counts, records and group sums: a decomposition's workspace is never touched
+    k_init_state<<<(unsigned)std::min<int64_t>((3 * e->hgsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_hstate, 1, e->d_hgsum,
+                                                                                                   3 * e->hgsum_third);
+    k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_hcounts,
+                                              e->d_hrecs, e->d_hgsum, e->d_hstate);
     if (compact)
-        k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_counts, e->d_gsum, n_tiles, n, e->d_kidx, e->max_n + 2,
-                                              e->d_total);
+        k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_hcounts, e->d_hgsum, n_tiles, n, e->d_kidx, e->max_n + 2,
+                                              e->d_total, e->d_hstate);
     HIP_TRY(e, hipGetLastError());
     return ITD_OK;
 }
 
+// the knot total of the last helper scan; d_total[1] = the scanned signal held a NaN (the reference's detect_peaks would
+// take its NaN branch and write +inf into the caller's array: rejected, like NaN input of a decomposition)
 int fetch_total(itd_engine *e, hipStream_t st, int64_t *m_host)
 {
-    int32_t m32 = 0;
-    HIP_TRY(e, hipMemcpyAsync(&m32, e->d_total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t m32[2] = {0, 0};
+    HIP_TRY(e, hipMemcpyAsync(m32, e->d_total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
-    *m_host = m32;
-    return ITD_OK;
+    *m_host = m32[0];
+    return m32[1] ? ITD_ERR_NONFINITE : ITD_OK;
 }
 
 template <typename Tin>
@@ -571,10 +549,10 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     const bool want_list = m_host || knots || want_sync;
     int rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st);   // the ordered list must be taken before
     if (rc) return rc;                                                 // k_extract rewrites the per-tile lists
-    k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_counts,
-                                                      e->d_counts + e->tiles_half, e->d_recs, e->d_recs + e->tiles_half,
-                                                      e->d_gsum, e->d_gsum + e->gsum_third, e->d_gsum + 2 * e->gsum_third,
-                                                      rot, n, base, n, e->d_state, 0, 0);
+    k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_hcounts,
+                                                      e->d_hcounts + e->max_tiles, e->d_hrecs, e->d_hrecs + e->max_tiles,
+                                                      e->d_hgsum, e->d_hgsum + e->hgsum_third, e->d_hgsum + 2 * e->hgsum_third,
+                                                      rot, n, base, n, e->d_hstate, 0);
     HIP_TRY(e, hipGetLastError());
     if (want_list) {
         int64_t m = 0;
@@ -747,7 +725,7 @@ int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
     e->timing_seq = 0;
     e->n_timed = 0;
     e->timing_overflow = false;
-    const size_t want = 2 * (size_t)max_decompositions * (ITD_MAX_ROWS + 2);
+    const size_t want = 2 * (size_t)max_decompositions * (ITD_MAX_ROWS + 3);
     while (e->ev.size() < want) {
         hipEvent_t ev = nullptr;
         HIP_TRY(e, hipEventCreate(&ev));
@@ -766,7 +744,7 @@ int itd_set_kernel_timing_stride(itd_engine *e, int stride)
 
 int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches)
 {
-    if (!e || which < 0 || which > ITD_TIME_DECOMPOSE) return ITD_ERR_INVALID_ARG;
+    if (!e || which < 0 || which > ITD_TIME_SCAN0) return ITD_ERR_INVALID_ARG;
     if (!e->ran || !e->timing) return ITD_ERR_NOT_RUN;
     DevGuard g(e->device);
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));

@@ -48,6 +48,10 @@
 #ifndef ITD_PRIO
 #define ITD_PRIO 0
 #endif
+// 1: k_extract reads the signal's stop level before it issues its loads (stopped signals cost no traffic); 0: after
+#ifndef ITD_EARLY_STOP
+#define ITD_EARLY_STOP 1
+#endif
 namespace itd {
 
 constexpr int kWave = 64;              // one wavefront per tile, one tile per workgroup
@@ -76,15 +80,21 @@ constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + 
 
 // Per-signal device state (one per batch element).
 struct SigState {
-    int32_t m[kMaxLevels];   // m[j] = interior knot count of the input of extraction j+1; -1 = not evaluated
-    int32_t stopped;         // 1 once the natural stop rule fired (later kernels return at once)
-    int32_t stop_level;      // level j (>= 1) whose input had < 2 knots: the reference stops at counter j-1
-    int32_t nan_mask;        // bit j set: the baseline written by extraction j+1 contains a NaN
+    int32_t m[kMaxLevels];   // m[j] = interior knot count of the input of extraction j+1 (under the reference's counting
+                             // rules, NaN rules included); -1 = not evaluated
+    int32_t c_delta[kMaxLevels];   // [j]: what the reference's NaN rules add to the plain knot count of the baseline written by
+                             // launch j (valleys of detect_peaks' NaN branch minus plain valleys of the mutated array,
+                             // ITD.py:46-51,64-68); applies only if that baseline holds a NaN (nan_mask bit j)
+    int32_t stop_level;      // -1, or the level j (>= 1) whose input had < 2 knots: the reference stops at counter j-1.
+                             // Written by workgroup 0 of launch j; launches test `stop_level >= 0 && stop_level < level`,
+                             // so the stop takes effect from launch j+1 on and launch j itself runs to completion in
+                             // every workgroup (its results are discarded through n_rows, but they are deterministic)
+    int32_t nan_mask;        // bit j set: the baseline written by launch j (extraction j+1) contained a NaN before the
+                             // reference's in-place NaN -> +inf mutation (ITD.py:50)
     int32_t in_nan;          // the caller's signal contains a NaN (rejected: ITD_ERR_NONFINITE)
-    int32_t c_nan;           // careful mode: knot count of the pending baseline under the reference's NaN rules
-    int32_t c_has_nan;       // careful mode: the pending baseline contained a NaN (c_nan applies)
     int32_t fin_stopped;     // written by k_finalize only: the verdict after the last pending baseline's stop test
-    int32_t fin_stop_level;  // (kept apart from stopped/stop_level, which k_finalize's own workgroups still read)
+    int32_t fin_stop_level;  // (kept apart from stop_level, which k_finalize's own workgroups still read)
+    int32_t pad_;
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
                                                    const int32_t *__restrict__ counts,
                                                    const int32_t *__restrict__ gsum_in, int n_tiles, int64_t n,
                                                    int32_t *__restrict__ kidx, int64_t kidx_stride,
-                                                   int32_t *__restrict__ total_out)
+                                                   int32_t *__restrict__ total_out, const SigState *__restrict__ state)
 {
     const int sig = blockIdx.y;
     const int t = blockIdx.x;
@@ -449,7 +459,8 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
         const int m = base + c;
         e[0] = 0;                    // ITD.py:96
         e[m + 1] = (int32_t)(n - 1); // ITD.py:98
-        total_out[sig] = m;
+        total_out[2 * sig] = m;
+        total_out[2 * sig + 1] = state[sig].in_nan;   // set by k_detect, which has completed
     }
 }
 
@@ -501,7 +512,6 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
 //   gsum_in/out/clear   group sums of the counts, rotating by level % 3
 //   rot_out       rotation row   (FINAL: rotation + baseline, the "Out of time!" row, ITD.py:420)
 //   base_out      baseline row   (FINAL: not written)
-//   careful       NaN-faithful launch sequence: do not emit the next level's scan (k_careful_* does)
 // Lane l owns two consecutive samples of every 128-sample group g: tile positions 128 g + 2 l (even) and + 1 (odd) —
 // exactly what one coalesced 16-byte load/store per lane moves.  Flag word 2g holds the even samples' knot flags of
 // group g, word 2g+1 the odd ones (flag_pos).  Consequences:
@@ -629,6 +639,78 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
         reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
     }
     return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// nan_rules: the reference's stop test on a baseline that holds non-finite values (rare).  detect_peaks(b) takes its NaN
+// branch when b holds a NaN anywhere (ITD.py:46-51, 64-68): differences that are NaN count as +inf, NaN samples and their two
+// neighbours cannot be peaks, and b is mutated in place, NaN -> +inf (ITD.py:50; there is no copy at ITD.py:41).
+// detect_peaks(-b) (ITD.py:401) and the next extraction (ITD.py:87-88) then see a NaN-free array: plain rules on the mutated
+// values.  For a tile in registers (xr: the baseline just produced, x_lo / x_hi: its samples s-1 and s+TW) this returns
+//     (valleys under the NaN-branch rules on the original values) - (valleys under the plain rules on the mutated values)
+// = what must be added to scan_publish's plain knot count of the mutated tile to get the reference's num_extrema, and mutates
+// xr, x_lo, x_hi.  Only tiles that hold a NaN or an infinity can differ (finite - finite is never NaN), so callers skip all
+// others; the level's sum is used only if some tile of the level saw a NaN (SigState::nan_mask) — the reference's
+// `if indl.size != 0`.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool nonfinite(double v) { return __builtin_amdgcn_class(v, 0x207); }   // sNaN | qNaN | -inf | +inf
+template <int TW>
+__device__ __forceinline__ int nan_rules(double (&xr)[TW / 128][2], double &x_lo, double &x_hi, int64_t s, int nrem)
+{
+    constexpr int G2 = TW / 128;
+    const int lane = lane_id();
+    const double inf = __builtin_huge_val();
+    const bool edge = (s == 0) || (nrem <= TW + 1);
+    auto valleys = [&](bool nan_branch) {
+        double d0[G2];
+        unsigned long long NE[G2], NO[G2];
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const double fill = (g == 0) ? x_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);
+            const double left = wave_dpp<0x138>(fill, xr[g][1]);
+            d0[g] = xr[g][0] - left;
+            NE[g] = __ballot(xr[g][0] != xr[g][0]);
+            NO[g] = __ballot(xr[g][1] != xr[g][1]);
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            double a0 = d0[g];
+            double a1 = xr[g][1] - xr[g][0];
+            const double fill = (g == G2 - 1) ? (x_hi - xr[g][1]) : wave_dpp<0x134>(0.0, d0[g < G2 - 1 ? g + 1 : g]);
+            double a2 = wave_dpp<0x130>(fill, d0[g]);
+            if (nan_branch) {   // ITD.py:51
+                a0 = a0 != a0 ? inf : a0;
+                a1 = a1 != a1 ? inf : a1;
+                a2 = a2 != a2 ? inf : a2;
+            }
+            bool fe = (a1 > 0.0) && (a0 <= 0.0);   // ITD.py:59
+            bool fo = (a2 > 0.0) && (a1 <= 0.0);
+            if (edge) {   // ITD.py:70-73
+                const int p = 128 * g + 2 * lane;
+                fe = fe && (s > 0 || p >= 1) && (p <= nrem - 2);
+                fo = fo && (p + 1 <= nrem - 2);
+            }
+            unsigned long long VE = __ballot(fe), VO = __ballot(fo);
+            if (nan_branch) {   // ITD.py:64-68: NaN samples and their neighbours cannot be peaks
+                const unsigned long long cin = (g == 0) ? (__ballot(x_lo != x_lo) ? 1ull : 0ull) : (NO[g > 0 ? g - 1 : 0] >> 63);
+                const unsigned long long cout = (g == G2 - 1) ? (__ballot(x_hi != x_hi) ? 1ull : 0ull) : (NE[g < G2 - 1 ? g + 1 : g] & 1ull);
+                VE &= ~(NE[g] | NO[g] | (NO[g] << 1) | cin);
+                VO &= ~(NE[g] | NO[g] | (NE[g] >> 1) | (cout << 63));
+            }
+            cnt += __popcll(VE) + __popcll(VO);
+        }
+        return cnt;
+    };
+    const int v_nan = valleys(true);
+#pragma unroll
+    for (int g = 0; g < G2; ++g) {   // ITD.py:50
+        xr[g][0] = xr[g][0] != xr[g][0] ? inf : xr[g][0];
+        xr[g][1] = xr[g][1] != xr[g][1] ? inf : xr[g][1];
+    }
+    x_lo = x_lo != x_lo ? inf : x_lo;
+    x_hi = x_hi != x_hi ? inf : x_hi;
+    return v_nan - valleys(false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -793,7 +875,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                                                      int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
                                                      double *__restrict__ rot_out, int64_t rot_stride,
                                                      double *__restrict__ base_out, int64_t base_stride,
-                                                     SigState *__restrict__ state, int level, int careful)
+                                                     SigState *__restrict__ state, int level)
 {
     constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
@@ -818,6 +900,14 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const TileRec *recs = recs_in + slot0;
     const int n_groups = groups_of(n_tiles);
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
+#if ITD_EARLY_STOP
+    // a signal that stopped at an earlier level streams nothing: the test comes before any load is issued (one scalar
+    // load in front of the wavefront's requests; A/B in profiles/r02_ablation.txt)
+    {
+        const int sl = st->stop_level;
+        if (sl >= 0 && sl < level) return;
+    }
+#endif
 
     // ---- everything the wavefront's KT tiles need from HBM is requested up front (vector loads only: they retire in order,
     //      so the wait for one tile's data leaves the later tiles' requests — and the earlier tiles' stores — in flight):
@@ -867,16 +957,19 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
     };
     if (ITD_ABL_R & 131072) { bare(); return; }
-    const int stopped = st->stopped;
+#if !ITD_EARLY_STOP
+    const int sl_late = st->stop_level;
+#endif
     const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
     const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
-
-    if (stopped) return;
+#if !ITD_EARLY_STOP
+    if (sl_late >= 0 && sl_late < level) return;
+#endif
     if (ITD_ABL_R & 262144) { if (e0 + e3 != 1.2345e300) bare(); return; }
     const double m0 = (e0 + e1) / 2.0;     // numpy.mean(x[:2]),  ITD.py:101
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
     double *ends_next = st->ends[(level + 1) & 1];
-    bool has_nan = false;
+    const double inf = __builtin_huge_val();
 
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -1041,6 +1134,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const bool near_end = (s + TW >= n - 2);
     const bool interior = full && !near_end && s != 0;   // no end-of-signal rule applies to any sample of the tile
     const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));   // samples of the signal from s on, clipped: p < nrem <=> s + p < n
+    bool odd_vals = false, own_nan = false;   // wave-uniform: the new baseline tile holds a NaN or an infinity / a NaN
     // s_hX[5], s_hX[6] / s_hI[5], s_hI[6]: the previous run's last two knots; s_bl[0], s_bl[1]: baseline at samples s-1, s+TW
 
     // ---- passes --------------------------------------------------------------------------------------------------------
@@ -1155,8 +1249,14 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 xr[g][0] = be;
                 xr[g][1] = bo;
                 tile_store2<(ITD_NT & 1) != 0>(r_rot, p * 8, re, rq);
-                if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, be, bo);
-                has_nan = has_nan || __builtin_isunordered(be, bo);   // one unordered compare covers both samples
+                double se = be, so = bo;
+                if (__builtin_expect(__any(nonfinite(be) || nonfinite(bo)), 0)) {   // rare: the stored baseline is the mutated one, ITD.py:50
+                    odd_vals = true;
+                    own_nan = own_nan || __any(__builtin_isunordered(be, bo));
+                    se = be != be ? inf : be;
+                    so = bo != bo ? inf : bo;
+                }
+                if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, se, so);
             }
         } else
 #pragma unroll
@@ -1179,13 +1279,19 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 xr[g][0] = be;
                 xr[g][1] = bo;
                 tile_store2<(ITD_NT & 1) != 0>(r_rot, p * 8, re, rq);   // samples beyond the row are dropped by the bounds check
-                if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, be, bo);
-                has_nan = has_nan || (p < nrem && be != be) || (p + 1 < nrem && bo != bo);
-                if (!FINAL && !careful && (near_end || s == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples, ITD.py:101-102
-                    if (s == 0 && p == 0) { ends_next[0] = be; ends_next[1] = bo; }
-                    if (p == nrem - 2) { ends_next[2] = be; ends_next[3] = bo; }
-                    if (p + 1 == nrem - 2) ends_next[2] = bo;
-                    if (p == nrem - 1) ends_next[3] = be;
+                double se = be, so = bo;
+                if (__builtin_expect(__any(nonfinite(be) || nonfinite(bo)), 0)) {   // rare: the stored baseline is the mutated one, ITD.py:50
+                    odd_vals = true;
+                    own_nan = own_nan || __any(__builtin_isunordered(be, bo));
+                    se = be != be ? inf : be;
+                    so = bo != bo ? inf : bo;
+                }
+                if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, se, so);
+                if (!FINAL && (near_end || s == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples (of the mutated array), ITD.py:101-102
+                    if (s == 0 && p == 0) { ends_next[0] = se; ends_next[1] = so; }
+                    if (p == nrem - 2) { ends_next[2] = se; ends_next[3] = so; }
+                    if (p + 1 == nrem - 2) ends_next[2] = so;
+                    if (p == nrem - 1) ends_next[3] = se;
                 }
             }
         }
@@ -1193,14 +1299,23 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         g0 = g1;
         wave_sync();
     }
-    // ---- knots of the baseline just produced = the next level's input, on registers (careful mode: k_careful_apply scans
-    //      the baseline after the reference's NaN -> inf mutation) -----------------------------------------------------------
-    if (!careful && !(ITD_ABL_R & 65536))
-        scan_publish<TW, FINAL>(xr, s_bl[0], s_bl[1], s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
+    // ---- knots of the baseline just produced = the next level's input, on registers.  A tile that holds (or borders on) a
+    //      NaN or an infinity first goes through the reference's NaN rules: what they add to the plain count, and the
+    //      NaN -> +inf mutation the next level sees (nan_rules) ------------------------------------------------------------
+    if (!(ITD_ABL_R & 65536)) {
+        double x_lo = s_bl[0], x_hi = s_bl[1];
+        if (__builtin_expect(odd_vals || __any(nonfinite(x_lo) || nonfinite(x_hi)), 0)) {
+            const int delta = nan_rules<TW>(xr, x_lo, x_hi, s, nrem);
+            if (lane == 0) {
+                if (delta) atomicAdd(&st->c_delta[level], delta);
+                if (own_nan) atomicOr(&st->nan_mask, 1 << level);
+            }
+        }
+        scan_publish<TW, FINAL>(xr, x_lo, x_hi, s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
                                 counts_out, recs_out, gsum_out, s_rec, s_pos);
+    }
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
   }
-    if (__any(has_nan) && lane_id() == 0) atomicOr(&st->nan_mask, 1 << level);
     if (blockIdx.x == 0 && !(ITD_ABL_R & 16384)) {
         // ---- tile 0's wavefront, after its own tile (kept off the path between the loads and their first use: a branch
         //      with memory operations there makes the compiler wait for ALL loads at the join): total knot count of this
@@ -1211,118 +1326,15 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
         if (lane == 0) {
-            if (careful) {   // the reference counted this level's knots under its NaN rules (k_careful_count)
-                if (st->c_has_nan) acc = st->c_nan;
-                st->c_nan = 0;
-                st->c_has_nan = 0;
-            }
+            // the baseline this level reads held a NaN: the reference counted its knots under the NaN rules (nan_rules)
+            if (level >= 1 && ((st->nan_mask >> (level - 1)) & 1)) acc += st->c_delta[level - 1];
             st->m[level] = acc;
-            if (level >= 1 && acc < 2) {   // the pending baseline is not decomposable: later launches do nothing
-                st->stop_level = level;
-                st->stopped = 1;
-            }
+            // the pending baseline is not decomposable: launches from level + 1 on do nothing (this one completes)
+            if (level >= 1 && acc < 2 && st->stop_level < 0) st->stop_level = level;
         }
         int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
         for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_careful_count + k_careful_apply: the reference's stop test on a pending baseline that may contain NaNs, then the
-// knot scan the next extraction will see.  Restates, per tile of the float64 row `xio`:
-//   (1) num_extrema = len(detect_peaks(b)) + len(detect_peaks(-b))  (ITD.py:400-402) with detect_peaks' NaN
-//       rules (ITD.py:46-51, 64-68): differences that are NaN become +inf, NaN samples and their neighbours
-//       cannot be peaks — these rules apply only if the array holds a NaN at all (`indl.size != 0`), so the
-//       count is accumulated separately and used only when some tile reports a NaN;
-//   (2) the in-place mutation NaN -> +inf of the array (ITD.py:50; no copy is made at ITD.py:41);
-//   (3) the plain predicate on the mutated array = what itd_baseline_extract(baseline_) evaluates next
-//       (ITD.py:87-88 see no NaN any more), feeding the usual counts / records / group sums / end samples.
-// grid = (n_tiles, 1), 64 threads; pointers are already offset to the signal.
-// ---------------------------------------------------------------------------------------------
-template <int TW>
-__global__ __launch_bounds__(kWave) void k_careful_count(const double *__restrict__ xin, int64_t n,
-                                                         SigState *__restrict__ st)
-{
-    // step (1): read-only, so no tile can observe a neighbour's mutation
-    constexpr int G = TW / 64;
-    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
-    if (st->stopped) return;
-    const int t = blockIdx.x;
-    const int lane = lane_id();
-    const int64_t s = (int64_t)t * TW;
-    Tile<TW> tile{s_x};
-    TileRegs<double, TW> regs;
-    tile_fetch<double, TW>(regs, xin, n, s);
-    tile_commit<double, TW>(regs, xin, n, s, tile);
-    wave_sync();
-    const double inf = __builtin_huge_val();
-    int cnt_nan = 0;
-    bool any_nan = false;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int pos = g * 64 + lane;
-        const int64_t i = s + pos;
-        const double xm = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
-        const bool nm = xm != xm, n0 = x0 != x0, np = xp != xp;
-        // detect_peaks(b): dx from the original values, NaN differences -> +inf (ITD.py:44,51)
-        double d1 = xp - x0, d0 = x0 - xm;
-        if (d1 != d1) d1 = inf;
-        if (d0 != d0) d0 = inf;
-        const bool in = (i >= 1) && (i <= n - 2);
-        const bool fa = in && (d1 > 0.0) && (d0 <= 0.0) && !(nm || n0 || np);   // ITD.py:59, 64-68
-        // detect_peaks(-b) on the mutated array (ITD.py:401): plain rules, raw differences
-        const double ym = nm ? inf : xm, y0 = n0 ? inf : x0, yp = np ? inf : xp;
-        const double e1 = yp - y0, e0 = y0 - ym;
-        const bool fb = in && (e1 < 0.0) && (e0 >= 0.0);
-        cnt_nan += __popcll(__ballot(fa)) + __popcll(__ballot(fb));
-        any_nan = any_nan || (n0 && i < n);
-    }
-    if (lane == 0 && cnt_nan) atomicAdd(&st->c_nan, cnt_nan);
-    if (__any(any_nan) && lane == 0) atomicOr(&st->c_has_nan, 1);
-}
-
-template <int TW>
-__global__ __launch_bounds__(kWave) void k_careful_apply(double *__restrict__ xio, int64_t n, int n_tiles,
-                                                         int32_t *__restrict__ counts, TileRec *__restrict__ recs,
-                                                         int32_t *__restrict__ gsum_out, SigState *__restrict__ st,
-                                                         int level)
-{
-    // steps (2) and (3).  Every NaN the tile sees (its own samples or a neighbour's halo sample, mutated yet or
-    // not) is read as +inf, so the result does not depend on the order in which tiles run.
-    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
-    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
-    if (st->stopped) return;
-    const int t = blockIdx.x;
-    const int lane = lane_id();
-    const int64_t s = (int64_t)t * TW;
-    Tile<TW> tile{s_x};
-    TileRegs<double, TW> regs;
-    tile_fetch<double, TW>(regs, xio, n, s);
-    tile_commit<double, TW>(regs, xio, n, s, tile);
-    wave_sync();
-    const double inf = __builtin_huge_val();
-    for (int pos = lane - 1; pos <= TW; pos += kWave) {
-        const double v = tile.at(pos);
-        if (v != v) {
-            tile.at(pos) = inf;
-            const int64_t i = s + pos;
-            if (pos >= 0 && pos < TW && i < n) xio[i] = inf;   // ITD.py:50
-        }
-    }
-    wave_sync();
-    publish_ends<TW>(tile, s, n, st->ends[level & 1]);
-    const int total = detect_tile<TW>(tile, s, n, kKnots, nullptr, recs + t, s_rec);
-    if (lane == 0) {
-        counts[t] = total;
-        if (total) atomicAdd(&gsum_out[(size_t)(t / kTilesPerGroup) * kGsumPitch], total);
-    }
-}
-
-// rows[i] += add[i]: the "Out of time!" row of the careful path (ITD.py:420 with the mutated baseline)
-__global__ void k_add_rows(double *__restrict__ row, const double *__restrict__ add, int64_t n)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        row[i] = row[i] + add[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1338,13 +1350,14 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restric
                                                                int64_t n, const double *__restrict__ bases,
                                                                int64_t bases_stride, int64_t bases_row_pitch,
                                                                int bases_rotate, const int32_t *__restrict__ gsum_last,
-                                                               int n_tiles, int level_last, int careful,
+                                                               int n_tiles, int level_last,
                                                                SigState *__restrict__ state)
 {
     __shared__ int s_red[kFinalizeThreads / 64];
     const int sig = blockIdx.y;
     SigState *st = state + sig;
-    int stopped = st->stopped, stop_level = st->stop_level;
+    int stop_level = st->stop_level;
+    int stopped = stop_level >= 0;
     if (!stopped) {
         const int n_groups = groups_of(n_tiles);
         const int32_t *gs = gsum_last + (size_t)sig * n_groups * kGsumPitch;
@@ -1357,7 +1370,8 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restric
         int m_last = 0;
 #pragma unroll
         for (int k = 0; k < kFinalizeThreads / 64; ++k) m_last += s_red[k];
-        if (careful && st->c_has_nan) m_last = st->c_nan;   // the reference's NaN-rule count (k_careful_count)
+        // the last pending baseline held a NaN: the reference counted its knots under the NaN rules (nan_rules)
+        if (level_last >= 1 && ((st->nan_mask >> (level_last - 1)) & 1)) m_last += st->c_delta[level_last - 1];
         if (m_last < 2) { stopped = 1; stop_level = level_last; }
         if (blockIdx.x == 0 && threadIdx.x == 0) st->m[level_last] = m_last;
     }

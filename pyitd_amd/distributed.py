@@ -20,20 +20,24 @@ def shard_range(batch, world_size, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+WIDTH = 4 + MAX_ROWS + 1
+
+
 def pack_summary(summary):
-    """Engine.summary() dict -> one int64 array [n_local, 3 + MAX_ROWS + 1] (n_rows, n_baselines, stop, knot counts)."""
+    """Engine.summary() dict -> one int64 array [n_local, WIDTH] (n_rows, n_baselines, stop, nan_levels, knot counts)."""
     n = len(summary["n_rows"])
-    out = np.empty((n, 3 + MAX_ROWS + 1), np.int64)
+    out = np.empty((n, WIDTH), np.int64)
     out[:, 0] = summary["n_rows"]
     out[:, 1] = summary["n_baselines"]
     out[:, 2] = summary["stop"]
-    out[:, 3:] = summary["knot_counts"]
+    out[:, 3] = summary.get("nan_levels", -1)      # -2: that signal's input held a NaN (rejected on its rank)
+    out[:, 4:] = summary["knot_counts"]
     return out
 
 
 def unpack_summary(arr):
     return {"n_rows": arr[:, 0].astype(np.int32), "n_baselines": arr[:, 1].astype(np.int32),
-            "stop": arr[:, 2].astype(np.int32), "knot_counts": arr[:, 3:].copy()}
+            "stop": arr[:, 2].astype(np.int32), "nan_levels": arr[:, 3].astype(np.int32), "knot_counts": arr[:, 4:].copy()}
 
 
 def gather_summaries(local_summary, batch, group=None, device=None):
@@ -41,7 +45,7 @@ def gather_summaries(local_summary, batch, group=None, device=None):
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    width = 3 + MAX_ROWS + 1
+    width = WIDTH
     cap = -(-batch // world)                      # equal-sized slots: all_gather needs one shape
     lo, hi = shard_range(batch, world, rank)
     slot = torch.full((cap, width), -1, dtype=torch.int64, device=device)
@@ -54,3 +58,43 @@ def gather_summaries(local_summary, batch, group=None, device=None):
         l, h = shard_range(batch, world, r)
         rows.append(p[: h - l].cpu().numpy())
     return unpack_summary(np.concatenate(rows, axis=0))
+
+
+class ShardedBatch:
+    """One rank's part of a batch of `batch` independent signals of `n` samples, sharded over `world` ranks (one process
+    per GPU).  The rank owns signals [lo, hi) = shard_range(batch, world, rank), decomposes them with ITS engine in one
+    launch sequence and takes part in ONE collective: the all-gather of the per-signal summaries.  Samples never leave the
+    GPU that produced them (full float64 outputs stay sharded).
+
+        sb = ShardedBatch(8192, 1 << 20, 7, world, rank, device=local_rank)
+        sb.decompose(x_local_ptr, numpy.float32, x_stride, rows_local_ptr)       # pointers to the LOCAL shard
+        table = sb.gather(device=torch.device("cuda", local_rank))                # every rank: all 8192 summaries
+
+    `engine` may be injected (tests run the sharding logic against a stand-in on CPU ranks).
+    """
+
+    def __init__(self, batch, n, max_iteration, world, rank, device=0, engine=None):
+        self.batch, self.n, self.max_iteration = int(batch), int(n), int(max_iteration)
+        self.world, self.rank = int(world), int(rank)
+        self.lo, self.hi = shard_range(self.batch, self.world, self.rank)
+        self.n_local = self.hi - self.lo
+        if engine is None:
+            from .engine import Engine
+            engine = Engine(self.n, max(self.n_local, 1), device)
+        self.engine = engine
+
+    def decompose(self, x_ptr, dtype, x_stride, rows_ptr, baselines_ptr=None, stream=None):
+        """Enqueue the decomposition of the local shard (no host sync, no communication)."""
+        if self.n_local:
+            self.engine.decompose_dev(x_ptr, dtype, self.n, self.n_local, x_stride, self.max_iteration, rows_ptr,
+                                      baselines_ptr, stream)
+
+    def local_summary(self):
+        if self.n_local:
+            return self.engine.summary(self.n_local)
+        return {"n_rows": np.zeros(0, np.int32), "n_baselines": np.zeros(0, np.int32), "stop": np.zeros(0, np.int32),
+                "nan_levels": np.zeros(0, np.int32), "knot_counts": np.zeros((0, MAX_ROWS + 1), np.int64)}
+
+    def gather(self, group=None, device=None):
+        """Synchronise with the local decomposition and all-gather the summaries: the whole batch's table, in batch order."""
+        return gather_summaries(self.local_summary(), self.batch, group=group, device=device)

@@ -14,7 +14,7 @@ from ._lib import ITDError, MAX_ROWS
 STOP_NATURAL, STOP_TIMEOUT = 0, 1
 DETECT_KNOTS, DETECT_VALLEYS, DETECT_PEAKS = 0, 1, 2
 ITD_OK, ITD_ERR_INVALID_ARG, ITD_ERR_NONFINITE = 0, 1, 6
-TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE = 0, 1, 2, 3
+TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0 = 0, 1, 2, 3, 4
 
 
 def _np_ptr(a):
@@ -77,7 +77,12 @@ class Engine:
         self._check(self._L.itd_set_kernel_timing(self._h, int(max_decompositions)))
 
     def set_nan_fallback(self, on):
+        """No-op since ABI revision 2 (the extraction kernel follows the reference's NaN rules itself)."""
         self._check(self._L.itd_set_nan_fallback(self._h, 1 if on else 0))
+
+    def set_batch_chunk(self, signals_per_chunk):
+        """Signals per launch sequence of a batched decomposition (0 = automatic, about 2^24 samples per chunk)."""
+        self._check(self._L.itd_set_batch_chunk(self._h, int(signals_per_chunk)))
 
     def kernel_timing(self, which=TIME_EXTRACT):
         """(total ms, launches) of the recorded launches of class `which` (TIME_*)."""
@@ -132,3 +137,42 @@ class Engine:
         self._check(self._L.itd_knot_values_host_f64(self._h, _np_ptr(x), x.shape[0], _np_ptr(e), e.shape[0] - 2,
                                                      _np_ptr(bk)))
         return bk
+
+
+class DeviceBuffer:
+    """hipMalloc'd bytes on one GPU through the C ABI (itd_dev_alloc / itd_dev_copy / itd_dev_free): what the numpy
+    entry points use for device-resident staging when the caller brings no allocator of its own (no torch needed)."""
+
+    def __init__(self, nbytes, device=0):
+        self._L = _lib.load()
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = ctypes.c_void_p()
+        rc = self._L.itd_dev_alloc(self.device, max(self.nbytes, 1), ctypes.byref(p))
+        if rc:
+            raise ITDError(rc, "itd_dev_alloc(%d bytes, device %d)" % (nbytes, device))
+        self.ptr = p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        rc = self._L.itd_dev_copy(self.device, self.ptr, _np_ptr(a), a.nbytes, 1)
+        if rc:
+            raise ITDError(rc, "itd_dev_copy(host -> device)")
+
+    def download(self, out, offset=0):
+        assert out.flags["C_CONTIGUOUS"] and offset + out.nbytes <= self.nbytes
+        rc = self._L.itd_dev_copy(self.device, _np_ptr(out), self.ptr + offset, out.nbytes, 0)
+        if rc:
+            raise ITDError(rc, "itd_dev_copy(device -> host)")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._L.itd_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -17,17 +17,46 @@ from .engine import DETECT_KNOTS, DETECT_PEAKS, DETECT_VALLEYS, STOP_TIMEOUT, En
 _engines = {}
 
 
+_MAX_N = 2 ** 31 - 2     # the ABI's limit: int32 knot indices
+
+
 def _engine_for(n, device=0):
-    """Engines are cached per device and grown in powers of two."""
-    cap = 1 << max(12, int(n - 1).bit_length())
+    """Single-signal engines are cached per device and grown by 1.5x (a power of two to start with), never beyond the
+    ABI's sample limit."""
     key = int(device)
     eng = _engines.get(key)
     if eng is None or eng.max_n < n:
+        cap = 1 << max(12, int(n - 1).bit_length()) if eng is None else max(n, eng.max_n + eng.max_n // 2)
+        cap = n if cap > _MAX_N else cap
         if eng is not None:
             eng.close()
         eng = Engine(cap, 1, device)
         _engines[key] = eng
     return eng
+
+
+_batch_engines = {}
+
+
+def _batch_engine_for(n, batch, device=0):
+    """Batch engines are cached per device and reused while they are large enough (creating one allocates 24 B per
+    sample and signal; destroying one synchronises the GPU)."""
+    key = int(device)
+    eng = _batch_engines.get(key)
+    if eng is None or eng.max_n < n or eng.max_batch < batch:
+        if eng is not None:
+            eng.close()
+        eng = Engine(n, batch, device)
+        _batch_engines[key] = eng
+    return eng
+
+
+def release_engines():
+    """Free every cached engine (their HBM workspaces)."""
+    for cache in (_engines, _batch_engines):
+        for eng in cache.values():
+            eng.close()
+        cache.clear()
 
 
 def _as_signal(data):
@@ -153,52 +182,72 @@ def itd_batch(x, max_iteration: int = 11, keep_baselines: bool = False, device=N
     for the whole batch — the batched form of ITD.itd the reference only has as `numba.prange` over rows,
     siftED2D.ipynb cell 1).
 
-    x: numpy array (copied to the GPU) or a torch CUDA tensor (used in place), float32 or float64.
+    x: numpy array (staged through hipMalloc'd buffers of the C ABI; torch is not needed) or a torch CUDA tensor (used in
+    place), float32 or float64.
     Returns a dict: rows [B, max_iteration+2, N] float64 (numpy, or a torch CUDA tensor when x is one), n_rows [B],
     stop [B] (0 natural / 1 timeout), knot_counts [B, 23], and baselines [B, max_iteration+2, N] + n_baselines [B]
     when keep_baselines.  Row r of signal b is valid for r < n_rows[b].
     """
-    import torch
     if max_iteration < 0 or max_iteration > _lib.MAX_ITERATION:
         raise ValueError("max_iteration must be in 0..20 (the reference's buffers hold 22 rows, ITD.py:384-385)")
-    was_torch = _is_torch(x)
-    if was_torch:
+    R = max_iteration + 2
+    if _is_torch(x):
+        import torch
         if not x.is_cuda or x.dim() != 2:
             raise ValueError("expected a 2-D CUDA tensor")
         xt = x if x.dtype in (torch.float32, torch.float64) else x.double()
         if xt.stride(1) != 1:
             xt = xt.contiguous()
         dev = xt.device.index
-    else:
-        a = numpy.asarray(x)
-        if a.ndim != 2:
-            raise ValueError("expected x[B, N]")
-        if a.dtype != numpy.float32:
-            a = numpy.asarray(a, dtype=numpy.float64)
-        dev = 0 if device is None else int(device)
-        xt = torch.from_numpy(numpy.ascontiguousarray(a)).to("cuda:%d" % dev)
-    B, n = xt.shape
-    if n < 3:
-        raise ValueError("ITD needs at least 3 samples")
-    R = max_iteration + 2
-    rows = torch.empty((B, R, n), dtype=torch.float64, device=xt.device)
-    bases = torch.zeros((B, R, n), dtype=torch.float64, device=xt.device) if keep_baselines else None
-    eng = Engine(n, B, dev)
-    try:
+        B, n = xt.shape
+        if n < 3:
+            raise ValueError("ITD needs at least 3 samples")
+        rows = torch.empty((B, R, n), dtype=torch.float64, device=xt.device)
+        bases = torch.zeros((B, R, n), dtype=torch.float64, device=xt.device) if keep_baselines else None
+        eng = _batch_engine_for(n, B, dev)
         torch.cuda.synchronize(xt.device)   # the engine runs on its own stream
         eng.decompose_dev(xt.data_ptr(), numpy.float32 if xt.dtype == torch.float32 else numpy.float64, n, B,
                           xt.stride(0), max_iteration, rows.data_ptr(), bases.data_ptr() if keep_baselines else None, None)
         s = eng.summary(B)
+        if (s["nan_levels"] == -2).any():
+            raise ValueError("an input signal contains NaN")
+        out = {"n_rows": s["n_rows"], "stop": s["stop"], "knot_counts": s["knot_counts"], "rows": rows}
+        if keep_baselines:
+            out["baselines"] = bases
+            out["n_baselines"] = s["n_baselines"]
+        return out
+    from .engine import DeviceBuffer
+    a = numpy.asarray(x)
+    if a.ndim != 2:
+        raise ValueError("expected x[B, N]")
+    if a.dtype != numpy.float32:
+        a = numpy.asarray(a, dtype=numpy.float64)
+    a = numpy.ascontiguousarray(a)
+    dev = 0 if device is None else int(device)
+    B, n = a.shape
+    if n < 3:
+        raise ValueError("ITD needs at least 3 samples")
+    d_x = DeviceBuffer(a.nbytes, dev)
+    d_rows = DeviceBuffer(B * R * n * 8, dev)
+    d_bases = DeviceBuffer(B * R * n * 8, dev) if keep_baselines else None
+    try:
+        d_x.upload(a)
+        eng = _batch_engine_for(n, B, dev)
+        eng.decompose_dev(d_x.ptr, a.dtype, n, B, n, max_iteration, d_rows.ptr, d_bases.ptr if keep_baselines else None, None)
+        s = eng.summary(B)
+        if (s["nan_levels"] == -2).any():
+            raise ValueError("an input signal contains NaN")
+        out = {"n_rows": s["n_rows"], "stop": s["stop"], "knot_counts": s["knot_counts"],
+               "rows": d_rows.download(numpy.empty((B, R, n), numpy.float64))}
+        if keep_baselines:
+            out["baselines"] = d_bases.download(numpy.empty((B, R, n), numpy.float64))
+            out["n_baselines"] = s["n_baselines"]
+        return out
     finally:
-        eng.close()
-    if (s["nan_levels"] == -2).any():
-        raise ValueError("an input signal contains NaN")
-    out = {"n_rows": s["n_rows"], "stop": s["stop"], "knot_counts": s["knot_counts"],
-           "rows": rows if was_torch else rows.cpu().numpy()}
-    if keep_baselines:
-        out["baselines"] = bases if was_torch else bases.cpu().numpy()
-        out["n_baselines"] = s["n_baselines"]
-    return out
+        d_x.free()
+        d_rows.free()
+        if d_bases is not None:
+            d_bases.free()
 
 
 def itd(data, max_iteration: int = 22, device=0):

@@ -52,3 +52,33 @@ def sines_noise(n, seed=0, fscale=1.0, dtype=np.float32, fs=48000.0):
         x += a * np.sin(2 * np.pi * (f * fscale) * t + p)
     x += 0.05 * np.random.default_rng(seed).standard_normal(n)
     return x.astype(dtype)
+
+
+def fuzz_signal(rng, kind, n):
+    """Random signal families of the parity fuzz (tools/fuzz_parity.py and tests/test_gpu_configs.py)."""
+    t = np.arange(n) / max(n - 1, 1)
+    if kind == 0:   # white noise
+        return rng.standard_normal(n)
+    if kind == 1:   # random walk
+        return np.cumsum(rng.standard_normal(n))
+    if kind == 2:   # quantised (plateaus)
+        return np.round(rng.standard_normal(n) * rng.integers(1, 6)) / 4.0
+    if kind == 3:   # smooth + few knots
+        return np.sin(2 * np.pi * rng.uniform(0.3, 30) * t) + rng.uniform(-1, 1) * t * t
+    if kind == 4:   # sines + noise at random level
+        return np.sin(2 * np.pi * rng.uniform(5, 500) * t) + rng.uniform(0, 0.3) * rng.standard_normal(n)
+    if kind == 5:   # long constant stretches with bursts (leading plateaus -> the reference's NaN branch)
+        x = np.zeros(n)
+        for _ in range(rng.integers(1, 6)):
+            a = rng.integers(0, n)
+            b = min(n, a + rng.integers(2, max(3, n // 4)))
+            x[a:b] = rng.standard_normal(b - a)
+        return x
+    if kind == 6:   # alternating with random amplitudes (every sample a knot)
+        return ((-1.0) ** np.arange(n)) * (1 + rng.random(n))
+    return rng.standard_normal(n) * np.exp(rng.uniform(-300, 300))   # extreme magnitudes
+
+
+def canon_u64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return np.where(np.isnan(a), np.uint64(0x7FF8000000000000), a.view(np.uint64))

@@ -1,0 +1,38 @@
+"""`python bench.py --gpus N`, run plainly, must start N ranks itself (the parent never touches the GPU), shard the batch
+over them and gather the per-signal table.  Here with --stub: gloo ranks on CPU, the engine replaced by a stand-in that
+only reports which signals the rank owned — this test is about the launcher and the sharding, not about compute."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "2", "--warmup", "1"] + extra,
+                       capture_output=True, text=True, timeout=300, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_gathers_the_table():
+    d = _run(["--gpus", "2", "--batch", "3", "--log2n", "10"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["signals_per_gpu"] == 3 and d["config"]["samples_per_signal"] == 1024
+    assert d["config"]["signals_in_gathered_table"] == 6
+    assert d["config"]["table_signal_ids"] == [0, 1, 2, 3, 4, 5]          # batch order: rank 0's shard, then rank 1's
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2
+    assert "1024 signals" not in d["config"]["workload"] and "2 x 3 signals" in d["config"]["workload"]
+
+
+def test_under_an_external_launcher_the_process_is_one_rank():
+    # what the driver does for N > 1: WORLD_SIZE etc. are already set -> no spawning; a 1-rank world runs alone
+    d = _run(["--gpus", "1", "--log2n", "10"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert d["n_gpus"] == 1 and d["config"]["signals_in_gathered_table"] is None

@@ -1,5 +1,5 @@
-"""N>1 path on CPU: two gloo processes shard a batch and gather the per-signal summaries (no GPU compute:
-each rank fills its shard's summary from the CPU oracle, which is what the engine's summary must equal)."""
+"""N>1 path on CPU: two gloo processes run pyitd_amd.distributed.ShardedBatch — each decomposes ITS shard of the batch
+(through an engine stand-in backed by the CPU oracle: no GPU here) and the summaries are all-gathered in batch order."""
 import os
 import socket
 
@@ -28,32 +28,52 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class _OracleEngine:
+    """Stand-in for pyitd_amd.Engine on a CPU rank: `decompose_dev` runs the CPU oracle on the shard it is handed (a numpy
+    array instead of a device pointer), `summary` reports what the real engine's summary must equal."""
+
+    def __init__(self):
+        self.res = []
+
+    def decompose_dev(self, x, dtype, n, batch, x_stride, max_iteration, rows, baselines=None, stream=None):
+        from oracle import cpu_oracle
+        self.res = [cpu_oracle.itd_lean(x[j], max_iteration) for j in range(batch)]
+        for j, r in enumerate(self.res):
+            rows[j, : r["rows"].shape[0]] = r["rows"]
+
+    def summary(self, k):
+        from pyitd_amd.distributed import MAX_ROWS
+        assert k == len(self.res)
+        out = {"n_rows": np.zeros(k, np.int32), "n_baselines": np.zeros(k, np.int32), "stop": np.zeros(k, np.int32),
+               "nan_levels": np.full(k, -1, np.int32), "knot_counts": np.full((k, MAX_ROWS + 1), -1, np.int64)}
+        for j, r in enumerate(self.res):
+            out["n_rows"][j] = r["rows"].shape[0]
+            out["stop"][j] = 0 if r["stop"] == "natural" else 1
+            out["knot_counts"][j, : len(r["knot_counts"])] = r["knot_counts"]
+        return out
+
+
 def _worker(rank, world, port, batch, n, m, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import cpu_oracle
-        from pyitd_amd.distributed import MAX_ROWS, gather_summaries, shard_range
-        lo, hi = shard_range(batch, world, rank)
-        k = hi - lo
-        local = {"n_rows": np.zeros(k, np.int32), "n_baselines": np.zeros(k, np.int32), "stop": np.zeros(k, np.int32),
-                 "knot_counts": np.full((k, MAX_ROWS + 1), -1, np.int64)}
-        for j, b in enumerate(range(lo, hi)):
-            r = cpu_oracle.itd_lean(sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0), m)
-            local["n_rows"][j] = r["rows"].shape[0]
-            local["stop"][j] = 0 if r["stop"] == "natural" else 1
-            local["knot_counts"][j, : len(r["knot_counts"])] = r["knot_counts"]
+        from pyitd_amd.distributed import ShardedBatch
+        sb = ShardedBatch(batch, n, m, world, rank, engine=_OracleEngine())
+        x = np.stack([sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0) for b in range(sb.lo, sb.hi)]) if sb.n_local \
+            else np.zeros((0, n), np.float32)
+        rows = np.zeros((sb.n_local, m + 2, n))
+        sb.decompose(x, np.float32, n, rows)          # the rank's own shard, no communication
         dist.barrier()
-        full = gather_summaries(local, batch)
+        full = sb.gather()                            # the one collective of the path
         if rank == 0:
             q.put({k: v.tolist() for k, v in full.items()})
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_gather_summaries_in_batch_order():
+def test_two_ranks_decompose_their_shards_and_gather_in_batch_order():
     import torch.multiprocessing as mp
     batch, n, m = 5, 4096, 4      # odd batch: ranks own 3 and 2 signals
     ctx = mp.get_context("spawn")
@@ -67,7 +87,17 @@ def test_two_ranks_gather_summaries_in_batch_order():
         p.join(timeout=60)
         assert p.exitcode == 0
     from oracle import cpu_oracle
+    assert len(got["n_rows"]) == batch and got["nan_levels"] == [-1] * batch
     for b in range(batch):
         r = cpu_oracle.itd_lean(sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0), m)
         assert got["n_rows"][b] == r["rows"].shape[0]
         assert got["knot_counts"][b][: len(r["knot_counts"])] == r["knot_counts"].tolist()
+
+
+def test_summary_packing_keeps_nan_levels():
+    from pyitd_amd.distributed import MAX_ROWS, pack_summary, unpack_summary
+    s = {"n_rows": np.array([3, 1], np.int32), "n_baselines": np.array([2, 0], np.int32), "stop": np.array([1, 0], np.int32),
+         "nan_levels": np.array([-1, -2], np.int32), "knot_counts": np.full((2, MAX_ROWS + 1), 7, np.int64)}
+    u = unpack_summary(pack_summary(s))
+    for k in s:
+        assert u[k].tolist() == s[k].tolist(), k

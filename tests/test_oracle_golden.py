@@ -81,3 +81,34 @@ def test_rejects_bad_arguments():
         cpu_oracle.itd(np.zeros(100), 21)  # row 22 would not fit (ITD.py:384,421)
     with pytest.raises(ValueError):
         cpu_oracle.detect_peaks(np.zeros(2))
+
+
+def _finite_cases():
+    return [n for n in golden_cases() if bool(load_golden(n)["finite"])]
+
+
+@pytest.mark.parametrize("name", _finite_cases())
+def test_numpy_restatement_matches_reference(name):
+    """oracle/numpy_itd.py (bench.py's numpy CPU leg) against the reference's golden vectors, bit for bit."""
+    from oracle import numpy_itd
+    g = load_golden(name)
+    try:
+        res = numpy_itd.itd(g["x"], int(g["max_iteration"]))
+    except ValueError as e:
+        if "NaN" in str(e):
+            pytest.skip("a baseline goes NaN: outside this leg's domain (the C oracle restates the NaN branch)")
+        raise
+    assert res["stop"] == str(g["stop"]) and res["rows"].shape[0] == int(g["n_rows"])
+    assert sha(res["rows"]) == str(g["rows_sha256"])
+
+
+@pytest.mark.parametrize("name", [n for n in _finite_cases() if load_golden(n)["x"].shape[0] <= 8000])
+def test_numba_restatement_matches_reference(name):
+    """oracle/numba_itd.py (bench.py's numba CPU leg; plain Python here when numba is absent) on the small goldens."""
+    from oracle import numba_itd
+    g = load_golden(name)
+    if not np.all(np.isfinite(cpu_oracle.itd(g["x"], int(g["max_iteration"]))["rows"])):
+        pytest.skip("a baseline goes NaN: outside this leg's domain")
+    res = numba_itd.itd(g["x"], int(g["max_iteration"]))
+    assert res["stop"] == str(g["stop"]) and res["rows"].shape[0] == int(g["n_rows"])
+    assert sha(res["rows"]) == str(g["rows_sha256"])

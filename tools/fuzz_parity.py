@@ -14,28 +14,12 @@ rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
 cpu_oracle.lib()
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import fuzz_signal
+
+
 def make(kind, n):
-    t = np.arange(n) / max(n - 1, 1)
-    if kind == 0:   # white noise
-        return rng.standard_normal(n)
-    if kind == 1:   # random walk
-        return np.cumsum(rng.standard_normal(n))
-    if kind == 2:   # quantised (plateaus)
-        return np.round(rng.standard_normal(n) * rng.integers(1, 6)) / 4.0
-    if kind == 3:   # smooth + few knots
-        return np.sin(2 * np.pi * rng.uniform(0.3, 30) * t) + rng.uniform(-1, 1) * t * t
-    if kind == 4:   # sines + noise at random level
-        return np.sin(2 * np.pi * rng.uniform(5, 500) * t) + rng.uniform(0, 0.3) * rng.standard_normal(n)
-    if kind == 5:   # long constant stretches with bursts
-        x = np.zeros(n)
-        for _ in range(rng.integers(1, 6)):
-            a = rng.integers(0, n)
-            b = min(n, a + rng.integers(2, max(3, n // 4)))
-            x[a:b] = rng.standard_normal(b - a)
-        return x
-    if kind == 6:   # alternating with random amplitudes (every sample a knot)
-        return ((-1.0) ** np.arange(n)) * (1 + rng.random(n))
-    return rng.standard_normal(n) * np.exp(rng.uniform(-300, 300))   # extreme magnitudes
+    return fuzz_signal(rng, kind, n)
 
 
 def canon(a):
