@@ -49,6 +49,12 @@ def lib():
             f = getattr(L, name)
             f.restype = ctypes.c_int
             f.argtypes = [P, i64, i32, P, P, P, P, P, P]
+        for name in ("oracle_find_extrema", "oracle_extrema_cpp"):
+            f = getattr(L, name)
+            f.restype = i64
+            f.argtypes = [P, i64, P]
+        L.oracle_itd_baseline_extract_fast.restype = ctypes.c_int
+        L.oracle_itd_baseline_extract_fast.argtypes = [P, i64, P, i64, P, P, P]
         _lib = L
     return _lib
 
@@ -156,3 +162,40 @@ def itd_lean(x, max_iteration, want_knots=False, rows_out=None):
         out["knots"] = [kn[j, : km[j]].copy() for j in range(n_rows.value)]
     out["knot_counts"] = km[: n_rows.value].copy()
     return out
+
+
+# ---- cubic-spline baseline variant (itd_fourier_decomposition.py:17-31, :49-122; itd.cpp:156-239) ----------------------
+def find_extrema(signal):
+    """find_extrema (itd_fourier_decomposition.py:17-31): (extrema int64[n], idx)."""
+    s = np.ascontiguousarray(signal, dtype=np.float64)
+    e = np.empty(s.shape[0], dtype=np.int64)
+    idx = lib().oracle_find_extrema(_p(s), s.shape[0], _p(e))
+    if idx < 0:
+        raise ValueError("find_extrema needs at least 2 samples")
+    return e, int(idx)
+
+
+def extrema_cpp(x):
+    """The knot predicate of itd.cpp:161-168 (compute_extrema = true): (extrema int64[n] zero padded, idx)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    e = np.empty(x.shape[0], dtype=np.int64)
+    idx = lib().oracle_extrema_cpp(_p(x), x.shape[0], _p(e))
+    if idx < 0:
+        raise ValueError("needs at least 3 samples")
+    return e, int(idx)
+
+
+def itd_baseline_extract_fast(I, extrema_input, idx, want_coef=False):
+    """itd_baseline_extract_fast (itd_fourier_decomposition.py:49-122): baseline float64[n]."""
+    I = np.ascontiguousarray(I, dtype=np.float64)
+    e = np.ascontiguousarray(extrema_input, dtype=np.int64)
+    n = I.shape[0]
+    if e.shape[0] < idx + 1:
+        raise ValueError("extrema_input needs idx+1 entries")
+    base = np.empty(n)
+    K = np.empty(n) if want_coef else None
+    b = np.empty(n) if want_coef else None
+    rc = lib().oracle_itd_baseline_extract_fast(_p(I), n, _p(e), int(idx), _p(base), _p(K), _p(b))
+    if rc:
+        raise ValueError("oracle_itd_baseline_extract_fast failed: %d" % rc)
+    return (base, K, b) if want_coef else base

@@ -179,6 +179,44 @@ def make_case(ns1, ref_mod, name, x, max_iteration, out_dir, full_limit=1 << 13)
         list(rec.get("knot_counts", []))))
 
 
+def load_cubic_reference(ref_dir):
+    """itd_fourier_decomposition.py (natural-cubic baseline with externally supplied knots: find_extrema :17-31,
+    itd_baseline_extract_fast :49-122 — the Python twin of itd.cpp:156-239), imported under the same numba stand-in."""
+    _install_numba_shim()
+    sys.path.insert(0, ref_dir)
+    try:
+        import itd_fourier_decomposition as ref_cubic
+    finally:
+        sys.path.pop(0)
+    return ref_cubic
+
+
+def extrema_cpp(x):
+    """The knot predicate of itd.cpp:161-168 (compute_extrema = true; strict on the left, non-strict on the right), as
+    numpy index arithmetic; zero padded to len(x) like the file's static arrays at first call.  itd.cpp itself is a
+    non-compilable fragment: this one-line predicate feeds the reference's own Python twin of the rest."""
+    f = ((x[:-2] < x[1:-1]) & (x[1:-1] >= x[2:])) | ((x[:-2] > x[1:-1]) & (x[1:-1] <= x[2:]))
+    k = np.flatnonzero(f) + 1
+    e = np.zeros(x.shape[0], dtype=np.int64)
+    e[: k.shape[0]] = k
+    return e, int(k.shape[0])
+
+
+def make_cubic_case(ref_cubic, name, I, extrema, idx, out_dir, knots_from):
+    I = np.asarray(I, dtype=np.float64)
+    try:
+        with np.errstate(all="ignore"):
+            base = np.asarray(ref_cubic.itd_baseline_extract_fast(I.copy(), extrema.copy(), idx))
+    except IndexError as ex:
+        # find_extrema's extrapolated last index (itd_fourier_decomposition.py:29) can lie beyond the signal: the
+        # reference itself fails there (IndexError here, an out-of-bounds read under numba) — not a usable vector
+        print("%-28s skipped: the reference raises %s" % (name, ex))
+        return
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), I=I, extrema=extrema[: idx + 1].astype(np.int64),
+                        idx=np.int64(idx), baseline=base, knots_from=np.array(knots_from))
+    print("%-28s N=%-7d idx=%-6d knots from %s, finite=%s" % (name, I.shape[0], idx, knots_from, bool(np.isfinite(base).all())))
+
+
 def chirp(n, dtype=np.float32):
     t = np.arange(n, dtype=np.float64) / n
     return np.sin(2 * np.pi * (50 * t + 0.5 * (8000 - 50) * t * t)).astype(dtype)
@@ -249,6 +287,30 @@ def main():
     case("edge_denormal", rng.standard_normal(512) * 1e-310, 5)
     case("edge_large", rng.standard_normal(512) * 1e300, 5)
     case("edge_int_valued", rng.integers(-3, 4, 4000).astype(np.float64), 9)
+
+    # (7) cubic-spline baseline variant with externally supplied knots: the reference's
+    #     itd_baseline_extract_fast fed (a) by its own find_extrema on synthetic sines, as itd_sine_wrapper does
+    #     (itd_fourier_decomposition.py:33-47), (b) by itd.cpp's knot predicate on the signal itself
+    cub = load_cubic_reference(args.ref)
+    cdir = os.path.join(args.out, "cubic")
+    os.makedirs(cdir, exist_ok=True)
+    rng = np.random.default_rng(4321)
+    sr = 8000
+    sig = radio[:4000]
+    for f in (7.0, 50.0, 440.0, 1234.5, 2000.0, 3990.0):
+        s = cub.generate_sine_wave(f, sr, len(sig) / sr)
+        e, idx = cub.find_extrema(s)
+        make_cubic_case(cub, "cubic_radio4000_sine%g" % f, sig, np.asarray(e), int(idx), cdir, "find_extrema(sine %g Hz)" % f)
+    x = np.cumsum(rng.standard_normal(6000))
+    s = cub.generate_sine_wave(97.0, 48000, len(x) / 48000)
+    e, idx = cub.find_extrema(s)
+    make_cubic_case(cub, "cubic_walk6000_sine97", x, np.asarray(e), int(idx), cdir, "find_extrema(sine 97 Hz @48k)")
+    for nm, x in (("cubic_detect_radio8000", radio), ("cubic_detect_walk3000", np.cumsum(rng.standard_normal(3000))),
+                  ("cubic_detect_quant5000", np.round(rng.standard_normal(5000) * 3) / 2.0),
+                  ("cubic_detect_sines16384", sines_noise(1 << 14, dtype=np.float64)),
+                  ("cubic_detect_smooth2000", np.sin(np.linspace(0, 9 * np.pi, 2000)) + 0.1 * np.linspace(0, 1, 2000) ** 2)):
+        e, idx = extrema_cpp(np.asarray(x, dtype=np.float64))
+        make_cubic_case(cub, nm, x, e, idx, cdir, "itd.cpp:161-168 predicate")
 
 
 if __name__ == "__main__":
