@@ -110,6 +110,19 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                     int64_t *knot_counts, int32_t *nan_levels);
 /* ABI revision 1 switched a NaN-faithful re-run on and off here; kept as a no-op (always faithful now) */
 int itd_set_nan_fallback(itd_engine *e, int enable);
+/* Level 0 of a decomposition (the caller's signal) finds its knots in one of two ways:
+ *   fused    the level-0 extraction launch evaluates the knot predicate itself and takes each tile's neighbouring knots from
+ *            the 128 samples either side of the tile (walking on through up to ~4000 samples where those hold too few): the
+ *            signal is read once, there is no separate scan pass;
+ *   records  a scan pass (k_scan0) leaves per-tile knot records, the extraction launch reads them (any knot spacing).
+ * ITD_LEVEL0_AUTO (default): fused; if a tile's knots lie beyond the fused launch's reach (input smoother than ~4000
+ * samples between extrema), itd_get_summary repeats the call record-driven before it returns — so, as before, x_dev /
+ * rows_dev / baselines_dev must stay valid until itd_get_summary — and the engine's next 16 decompositions start
+ * record-driven.  Results are identical in every mode. */
+#define ITD_LEVEL0_AUTO 0
+#define ITD_LEVEL0_RECORDS 1
+#define ITD_LEVEL0_FUSED 2   /* never repeat: itd_get_summary fails with ITD_ERR_HIP if the reach was exceeded (benchmarks) */
+int itd_set_level0_mode(itd_engine *e, int32_t mode);
 /* Batched decompositions run as launch sequences over chunks of `signals_per_chunk` signals, all levels of a chunk before
  * the next chunk (0 = automatic: about 2^24 samples per chunk, so a level's baseline is still in the 256 MiB Infinity
  * Cache when the next level reads it).  Results do not depend on the chunk size. */

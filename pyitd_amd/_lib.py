@@ -41,6 +41,7 @@ ABI = {
     "itd_knot_values_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P]),
     "itd_set_nan_fallback": (_INT, [_P, _INT]),
     "itd_set_batch_chunk": (_INT, [_P, _I32]),
+    "itd_set_level0_mode": (_INT, [_P, _I32]),
     "itd_dev_alloc": (_INT, [_INT, _I64, ctypes.POINTER(_P)]),
     "itd_dev_free": (_INT, [_INT, _P]),
     "itd_dev_copy": (_INT, [_INT, _P, _P, _I64, _I32]),

@@ -43,6 +43,7 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
     st[b].stop_level = -1;
     st[b].nan_mask = 0;
     st[b].in_nan = 0;
+    st[b].l0_fail = 0;
     st[b].fin_stopped = 0;
     st[b].fin_stop_level = -1;
 }
@@ -81,6 +82,8 @@ struct itd_engine {
     int64_t hgsum_third = 0;
     SigState *d_hstate = nullptr;  // [1]
     int32_t chunk = 0;             // signals per launch sequence of a batched decomposition (0 = automatic, see enqueue_decompose)
+    int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
+    int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
     // host-convenience staging (grow only)
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
@@ -91,6 +94,11 @@ struct itd_engine {
     int32_t last_batch = 0, last_m = 0;
     int64_t last_n = 0;
     hipStream_t last_stream = nullptr;
+    const void *last_x = nullptr;      // the last decomposition's arguments: itd_get_summary repeats it record-driven when the
+    bool last_x_f32 = false;           // fused level-0 launch fell short of a tile's halo knots
+    int64_t last_x_stride = 0;
+    double *last_rows = nullptr, *last_bases = nullptr;
+    bool last_fused = false;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // event pairs: [2k] start, [2k+1] stop
@@ -161,7 +169,7 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 
 template <typename Tin>
 int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M,
-                      double *rows, double *bases_user, hipStream_t st)
+                      double *rows, double *bases_user, hipStream_t st, bool fuse0)
 {
     const int n_tiles = (int)tiles_of(n);
     const int n_groups = groups_of(n_tiles);
@@ -194,7 +202,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *rows_c = rows + (int64_t)b0 * rows_stride;
         double *bases_c = bases_user ? bases_user + (int64_t)b0 * rows_stride : nullptr;
         double *pp_c = e->d_pp + (int64_t)b0 * 3 * e->pp_pitch;
-        {
+        if (!fuse0) {
             const int pair = time_slot(e, ITD_TIME_SCAN0);
             const Tin *a_x = xc; int64_t a_xs = x_stride, a_n = n; int a_nt = n_tiles;
             int32_t *a_c = cnt(0), *a_g = gs(0); TileRec *a_r = rec(0); SigState *a_st = state;
@@ -225,7 +233,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
             // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
             // begin / end timestamps (no marker packets in the stream: nothing is added to the timed region)
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK)                                                                   \
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE)                                                             \
     do {                                                                                                                   \
         const TIN *a_x = XIN; int64_t a_xs = XSTRIDE, a_n = n, a_rs = rows_stride, a_bs = base_stride;                     \
         int a_nt = n_tiles, a_b = nb, a_lvl = j;                                                                           \
@@ -234,16 +242,16 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         SigState *a_st = state;                                                                                            \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
                         &a_bas, &a_bs, &a_st, &a_lvl};                                                                     \
-        HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, kTilesPerWave>), grid_x, \
+        HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, kTilesPerWave, FUSE>), grid_x, \
                                       blk, args, 0, st, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                     \
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
     } while (0)
-            if (j == 0) {
-                if (final_level) ITD_LAUNCH_EXTRACT(Tin, true, xc, x_stride, kRankCap0);
-                else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0);
+            if (j == 0) {   // never the last level: M >= 0
+                if (fuse0) ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, true);
+                else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, false);
             } else {
-                if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap);
-                else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap);
+                if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap, false);
+                else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap, false);
             }
 #undef ITD_LAUNCH_EXTRACT
         }
@@ -265,7 +273,23 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_m = M;
     e->last_n = n;
     e->last_stream = st;
+    e->last_x = x;
+    e->last_x_f32 = sizeof(Tin) == 4;
+    e->last_x_stride = x_stride;
+    e->last_rows = rows;
+    e->last_bases = bases_user;
+    e->last_fused = fuse0;
     return ITD_OK;
+}
+
+// how the next decomposition's level 0 finds its knots: fused (one pass over the signal) unless the engine was told
+// otherwise or a recent fused launch fell short (smooth input: the following decompositions go record-driven directly)
+bool want_fused(itd_engine *e)
+{
+    if (e->l0_mode == ITD_LEVEL0_RECORDS) return false;
+    if (e->l0_mode == ITD_LEVEL0_FUSED) return true;
+    if (e->l0_records_left > 0) { --e->l0_records_left; return false; }
+    return true;
 }
 
 int check_args(itd_engine *e, const void *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, const void *rows)
@@ -411,7 +435,7 @@ int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batc
     if (rc) return rc;
     DevGuard g(e->device);
     return enqueue_decompose<float>(e, x_dev, n, batch, x_stride, max_iteration, rows_dev, baselines_dev,
-                                    stream ? (hipStream_t)stream : e->own_stream);
+                                    stream ? (hipStream_t)stream : e->own_stream, want_fused(e));
 }
 
 int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
@@ -421,7 +445,7 @@ int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t bat
     if (rc) return rc;
     DevGuard g(e->device);
     return enqueue_decompose<double>(e, x_dev, n, batch, x_stride, max_iteration, rows_dev, baselines_dev,
-                                     stream ? (hipStream_t)stream : e->own_stream);
+                                     stream ? (hipStream_t)stream : e->own_stream, want_fused(e));
 }
 
 int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
@@ -433,6 +457,26 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     const int B = e->last_batch;
     HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    if (e->last_fused) {
+        // the fused level-0 launch reaches kReach windows beyond a tile for its halo knots; a signal smoother than that
+        // (knots more than ~4000 samples apart at level 0) raised l0_fail: repeat the call record-driven (k_scan0 + records),
+        // and let the next decompositions of this engine start record-driven — workloads tend to be homogeneous
+        bool fell_short = false;
+        for (int b = 0; b < B; ++b) fell_short = fell_short || (e->h_state[b].l0_fail && !e->h_state[b].in_nan);
+        if (fell_short) {
+            if (e->l0_mode == ITD_LEVEL0_FUSED) {
+                snprintf(e->err, sizeof(e->err), "fused level 0: a tile's halo knots lie beyond its reach (ITD_LEVEL0_FUSED forbids the record-driven repeat)");
+                return ITD_ERR_HIP;
+            }
+            e->l0_records_left = 16;
+            const int rc = e->last_x_f32
+                ? enqueue_decompose<float>(e, (const float *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, false)
+                : enqueue_decompose<double>(e, (const double *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, false);
+            if (rc) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+            HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+        }
+    }
     for (int b = 0; b < B; ++b) {
         const SigState &s = e->h_state[b];
         int rows, nb, why;
@@ -464,6 +508,14 @@ int itd_set_nan_fallback(itd_engine *e, int enable)
     return e ? ITD_OK : ITD_ERR_INVALID_ARG;
 }
 
+int itd_set_level0_mode(itd_engine *e, int32_t mode)
+{
+    if (!e || mode < ITD_LEVEL0_AUTO || mode > ITD_LEVEL0_FUSED) return ITD_ERR_INVALID_ARG;
+    e->l0_mode = mode;
+    e->l0_records_left = 0;
+    return ITD_OK;
+}
+
 int itd_set_batch_chunk(itd_engine *e, int32_t signals_per_chunk)
 {
     if (!e || signals_per_chunk < 0) return ITD_ERR_INVALID_ARG;
@@ -492,7 +544,7 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
     }
     hipStream_t st = e->own_stream;
     HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(Tin), hipMemcpyHostToDevice, st));
-    rc = enqueue_decompose<Tin>(e, (const Tin *)e->d_io_x, n, 1, n, M, e->d_io_rows, bases_host ? e->d_io_bases : nullptr, st);
+    rc = enqueue_decompose<Tin>(e, (const Tin *)e->d_io_x, n, 1, n, M, e->d_io_rows, bases_host ? e->d_io_bases : nullptr, st, want_fused(e));
     if (rc) return rc;
     int32_t nr = 0, nb = 0, why = 0, nanlv = -1;
     int64_t kc[ITD_MAX_ROWS + 1];

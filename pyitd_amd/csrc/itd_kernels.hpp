@@ -92,9 +92,10 @@ struct SigState {
     int32_t nan_mask;        // bit j set: the baseline written by launch j (extraction j+1) contained a NaN before the
                              // reference's in-place NaN -> +inf mutation (ITD.py:50)
     int32_t in_nan;          // the caller's signal contains a NaN (rejected: ITD_ERR_NONFINITE)
+    int32_t l0_fail;         // the fused level-0 launch met a tile whose halo knots lie beyond its reach (kReach windows):
+                             // level 0 has to be repeated through k_scan0 + the record-driven launch
     int32_t fin_stopped;     // written by k_finalize only: the verdict after the last pending baseline's stop test
     int32_t fin_stop_level;  // (kept apart from stop_level, which k_finalize's own workgroups still read)
-    int32_t pad_;
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
@@ -540,6 +541,11 @@ __device__ __forceinline__ double wave_dpp(double old, double v)
     const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
     return bits_d((unsigned)lo, (unsigned)hi);
 }
+template <int CTRL>
+__device__ __forceinline__ float wave_dpp(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 // this lane's bit of a wave-uniform 64-bit mask: one v_cndmask with the mask as the select operand
 __device__ __forceinline__ int lane_bit(unsigned long long mask)
 {
@@ -639,6 +645,45 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
         reinterpret_cast<I4 *>(recs_out + slot)[lane] = reinterpret_cast<const I4 *>(s_rec)[lane];
     }
     return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// knot_masks: the knot predicate (ITD.py:59 on x and on -x) over NG consecutive 128-sample groups held in registers
+// (v[g][0/1] = positions 128 g + 2 lane / + 1 of the window), evaluated in the samples' own precision T.  For float input
+// this is exact: the float32 difference of two float32 values is zero, positive, negative or NaN exactly when the float64
+// difference of the widened values is (subtraction is correctly rounded and float32 denormals are not flushed), so the
+// flags equal those of the reference's float64 differences.
+// The window's first and last position have an unknown neighbour: their flags are cleared (callers overlap windows).
+// `lo`, `hi`: window-relative positions allowed to flag (the signal's first/last-sample rule ITD.py:70-73, clipping).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NG>
+__device__ __forceinline__ void knot_masks(const T (&v)[NG][2], int lo, int hi, unsigned long long (&E)[NG], unsigned long long (&O)[NG])
+{
+    (void)0;
+    T d0[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const T fill = (g == 0) ? v[0][0] : wave_dpp<0x13C>((T)0, v[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
+        const T left = wave_dpp<0x138>(fill, v[g][1]);
+        d0[g] = v[g][0] - left;
+    }
+    const bool clip = lo > 1 || hi < 128 * NG - 2;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const T d1 = v[g][1] - v[g][0];
+        const T fill = (g == NG - 1) ? (T)0 : wave_dpp<0x134>((T)0, d0[g < NG - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
+        const T d2 = wave_dpp<0x130>(fill, d0[g]);
+        const bool fe = ((d1 > (T)0) && (d0[g] <= (T)0)) || ((d1 < (T)0) && (d0[g] >= (T)0));
+        const bool fo = ((d2 > (T)0) && (d1 <= (T)0)) || ((d2 < (T)0) && (d1 >= (T)0));
+        E[g] = __ballot(fe);
+        O[g] = __ballot(fo);
+        if (g == 0) E[g] &= ~1ull;                      // window position 0: left neighbour unknown
+        if (g == NG - 1) O[g] &= ~(1ull << 63);         // last window position: right neighbour unknown
+        if (clip) {   // wave-uniform lane ranges: even position 128 g + 2 l in [lo, hi], odd position 128 g + 2 l + 1 in [lo, hi]
+            E[g] &= bit_range((lo - 128 * g + 1) >> 1, (hi - 128 * g) >> 1);
+            O[g] &= bit_range((lo - 128 * g) >> 1, (hi - 128 * g - 1) >> 1);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -864,7 +909,14 @@ __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, in
 }
 
 
-template <typename Tin, int TW, bool FINAL, int CAP, int KT>
+// FUSE0 (level 0 only): the launch reads no records at all.  The wavefront loads one 128-sample group in front of and one
+// behind its tile with the tile, evaluates the knot predicate of the caller's signal itself (knot_masks, in the signal's
+// own precision) and takes the two knots in front / three behind from those halo groups; only if a halo group holds too
+// few does it walk on through the signal in overlapping 512-sample windows (at most kReach per side), and if even that
+// finds too few away from the signal's ends it raises SigState::l0_fail — the engine then repeats the level-0 step with
+// k_scan0 + the record-driven launch (itd_engine.hip).  The signal is read once: the separate scan pass disappears.
+constexpr int kReach = 8;   // extension windows per side (510 new samples each)
+template <typename Tin, int TW, bool FINAL, int CAP, int KT, bool FUSE0 = false>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
                                                      const int32_t *__restrict__ counts_in,
@@ -880,6 +932,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
     static_assert(CAP >= 128, "a pass must be able to take one 128-sample group");
+    static_assert(!FUSE0 || (KT == 1 && !FINAL), "the fused level-0 launch: one tile per wavefront, never the last level");
     constexpr int RK = CAP + 8;
     __shared__ double s_X[RK];      // value of the level's input at knot slot L
     __shared__ double s_B[RK];      // knot value B_L
@@ -887,7 +940,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
     __shared__ double s_bl[2];
     __shared__ int32_t s_pos[8];      // tile positions of the new record's five knots
-    __shared__ int32_t s_rb[9][16];   // first 64 bytes of up to nine neighbour records (speculative four + late five)
+    __shared__ __attribute__((aligned(16))) int32_t s_rb[9][16];   // first 64 bytes of up to nine neighbour records (speculative four + late five)
     __shared__ double s_hX[8];      // the five knots around the tile (value) ...
     __shared__ int32_t s_hI[8];     // ... and their sample indices
     int32_t *s_gi = reinterpret_cast<int32_t *>(s_S);
@@ -918,12 +971,28 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         unsigned long long own;     // lane j < 2*G2: the tile's flag word j; the other lanes: its packed knot word
         int cb, cf;                 // knot counts of tiles t-1-lane / t+1+lane
         int specw;                  // lanes 16q..16q+15: first 64 bytes of the record of tile t-1, t+1, t-2, t+2 (speculative)
+        Tin hq[2][2];               // FUSE0: the 128 samples in front of the tile and the 128 behind it
     };
     TileLoads pre[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const int t = launch_item(blockIdx.x, gridDim.x, level) * KT + k;
         const int lane = lane_id();
+        if constexpr (FUSE0) {
+            if (t < n_tiles) {
+                const int64_t s = (int64_t)t * TW;
+                // halo groups through descriptors of their own: an empty one (extent 0) reads zeros, so tile 0 / the last
+                // tiles need no branch
+                const __amdgpu_buffer_rsrc_t rl = tile_rsrc(x + (s >= 128 ? s - 128 : 0), s >= 128 ? 128 * (int64_t)sizeof(Tin) : 0);
+                const __amdgpu_buffer_rsrc_t rh = tile_rsrc(x + (s + TW < n ? s + TW : 0), s + TW < n ? (n - s - TW) * (int64_t)sizeof(Tin) : 0);
+                const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x + s, (n - s) * (int64_t)sizeof(Tin));
+                tile_load2<false>(rl, lane * 2 * (int)sizeof(Tin), 0, pre[k].hq[0][0], pre[k].hq[0][1]);
+#pragma unroll
+                for (int g = 0; g < G2; ++g)
+                    tile_load2<(ITD_NT & 4) != 0>(rx, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), pre[k].q[g][0], pre[k].q[g][1]);
+                tile_load2<false>(rh, lane * 2 * (int)sizeof(Tin), 0, pre[k].hq[1][0], pre[k].hq[1][1]);
+            }
+        } else
         if (t < n_tiles) {
             // the small loads first: loads retire in order, and the halo logic that needs them should not wait for the tile
             pre[k].own = (ITD_ABL_R & 32768) ? 0ull : reinterpret_cast<const unsigned long long *>(recs + t)[lane < 2 * G2 ? 8 + lane : 0];
@@ -960,8 +1029,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 #if !ITD_EARLY_STOP
     const int sl_late = st->stop_level;
 #endif
-    const double e0 = st->ends[level & 1][0], e1 = st->ends[level & 1][1];
-    const double e2 = st->ends[level & 1][2], e3 = st->ends[level & 1][3];
+    // the four end samples of the level's input (ITD.py:101-102): published by the launch that wrote it; FUSE0: the signal's own
+    const double e0 = FUSE0 ? (double)x[0] : st->ends[level & 1][0], e1 = FUSE0 ? (double)x[1] : st->ends[level & 1][1];
+    const double e2 = FUSE0 ? (double)x[n - 2] : st->ends[level & 1][2], e3 = FUSE0 ? (double)x[n - 1] : st->ends[level & 1][3];
 #if !ITD_EARLY_STOP
     if (sl_late >= 0 && sl_late < level) return;
 #endif
@@ -982,122 +1052,259 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int q4 = lane >> 4, w16 = lane & 15;
     const int64_t s = (int64_t)t * TW;
     const bool full = (s + TW <= n);
-    const unsigned long long own_word = pre[kt].own;
-    const unsigned long long own_packed = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(own_word >> 32), 63) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)own_word, 63);
-    const int own_c = (ITD_ABL_R & (8 | 32768)) ? 0 : rec_count(own_packed);
-    const int cb = pre[kt].cb, cf = pre[kt].cf, specw = pre[kt].specw;
+    int nb = 0, nf = 0, own_c = 0;   // real knots found in front (0..2) / behind (0..3); the tile's own knots
+    // the tile's own knots, decoded once: kinfo[g] = ke | bitE << 16 | bitO << 17 with ke = knots of the tile at or before the
+    // lane's even sample of group g; gcnt = the groups' knot counts, 8 bits each
+    int kinfo[G2];
+    unsigned gcnt = 0;
+    if constexpr (!FUSE0) {
+        const unsigned long long own_word = pre[kt].own;
+        const unsigned long long own_packed = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(own_word >> 32), 63) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)(unsigned)own_word, 63);
+        own_c = (ITD_ABL_R & (8 | 32768)) ? 0 : rec_count(own_packed);
+        const int cb = pre[kt].cb, cf = pre[kt].cf, specw = pre[kt].specw;
 
-    // ---- candidate tiles: nearest non-empty ones in the +-64-tile count windows ---------------------------------------------
-    int ub0 = -1, ub1 = -1, uf0 = -1, uf1 = -1, uf2 = -1, cb0 = 0, cf0 = 0, cf1 = 0;
-    if (ITD_ABL_R & 8192) {   // timing skeleton: keep the loads alive, skip the selection
-        if (cb + cf + specw == 0x7fffffff) ub0 = 0;
-    } else {
-        unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
-        if (mb) {
-            const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
-            ub0 = t - 1 - l; cb0 = __builtin_amdgcn_readlane(cb, l);
-            if (cb0 < 2 && mb) ub1 = t - 1 - (__ffsll((long long)mb) - 1);
-        }
-        if (mf) {
-            const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
-            uf0 = t + 1 + l; cf0 = __builtin_amdgcn_readlane(cf, l);
-            if (cf0 < 3 && mf) {
-                const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
-                uf1 = t + 1 + l1; cf1 = __builtin_amdgcn_readlane(cf, l1);
-                if (cf0 + cf1 < 3 && mf) uf2 = t + 1 + (__ffsll((long long)mf) - 1);
-            }
-        }
-    }
-    // staging slots: 0..3 = the speculative records, 4+k = candidate k fetched after all (rare)
-    auto slot_of = [&](int u, int k) { return u == t - 1 ? 0 : u == t + 1 ? 1 : u == t - 2 ? 2 : u == t + 2 ? 3 : 4 + k; };
-    const int sb0 = slot_of(ub0, 0), sb1 = slot_of(ub1, 1), sf0 = slot_of(uf0, 2), sf1 = slot_of(uf1, 3), sf2 = slot_of(uf2, 4);
-    s_rb[q4][w16] = specw;
-    if (!(ITD_ABL_R & 8192) && ((ub0 >= 0 && sb0 >= 4) || (ub1 >= 0 && sb1 >= 4) || (uf0 >= 0 && sf0 >= 4) || (uf1 >= 0 && sf1 >= 4))) {
-        const int uk = q4 == 0 ? ub0 : q4 == 1 ? ub1 : q4 == 2 ? uf0 : uf1;
-        const int sk = q4 == 0 ? sb0 : q4 == 1 ? sb1 : q4 == 2 ? sf0 : sf1;
-        if (uk >= 0 && sk >= 4) s_rb[sk][w16] = reinterpret_cast<const int32_t *>(recs + uk)[w16];
-    }
-    if (uf2 >= 0 && sf2 >= 4 && lane < 16) s_rb[8][lane] = reinterpret_cast<const int32_t *>(recs + uf2)[lane];
-
-    // staged record slot -> its tile (for the knots' absolute sample indices)
-    auto tile_of = [&](int sl) { return sl == 0 ? t - 1 : sl == 1 ? t + 1 : sl == 2 ? t - 2 : sl == 3 ? t + 2 : sl == 4 ? ub0 : sl == 5 ? ub1 : sl == 6 ? uf0 : sl == 7 ? uf1 : uf2; };
-    // ---- halo knots: two in front of the tile (slot 1 starts the segment that enters the tile), three behind; lane k < 5
-    //      picks knot k out of the staged records.  Missing ones are the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).
-    int nb = 0, nf = 0;   // real knots found in front (0..2) / behind (0..3)
-    if (ub0 >= 0) nb = (cb0 >= 2 || ub1 >= 0) ? 2 : 1;
-    if (uf0 >= 0) nf = min(3, cf0 + cf1 + (uf2 >= 0 ? 1 : 0));
-    wave_sync();
-    if (lane < 5 && !(ITD_ABL_R & 8192)) {
-        int sl, sh, vw;   // staged slot, bit offset of the knot's position in the packed word, dword of its value
-        bool real;
-        if (lane < 2) {
-            real = (lane == 1) ? (nb >= 1) : (nb >= 2);
-            const bool from0 = (lane == 1) || (cb0 >= 2);          // slot 0: ub0's second last knot, or ub1's last
-            const int which = (lane == 1 || !from0) ? 1 : 0;       // tpos(1) / tval[1] = the record's last knot
-            sl = from0 ? sb0 : sb1;
-            sh = 41 + 10 * which;
-            vw = kRecDwTval + 2 * which;
+        // ---- candidate tiles: nearest non-empty ones in the +-64-tile count windows ---------------------------------------------
+        int ub0 = -1, ub1 = -1, uf0 = -1, uf1 = -1, uf2 = -1, cb0 = 0, cf0 = 0, cf1 = 0;
+        if (ITD_ABL_R & 8192) {   // timing skeleton: keep the loads alive, skip the selection
+            if (cb + cf + specw == 0x7fffffff) ub0 = 0;
         } else {
-            int j = lane - 2;
-            real = j < nf;
-            const int c0 = min(cf0, 3), c1 = min(cf1, 3);
-            if (j < c0) sl = sf0;
-            else if (j - c0 < c1) { sl = sf1; j -= c0; }
-            else { sl = sf2; j -= c0 + c1; }
-            sh = 11 + 10 * j;
-            vw = kRecDwHval + 2 * j;
-        }
-        int32_t idx = lane < 2 ? 0 : (int32_t)(n - 1);
-        double val = lane < 2 ? e0 : e3;
-        if (real) {
-            const unsigned long long pk = ((unsigned long long)(unsigned)s_rb[sl][1] << 32) | (unsigned)s_rb[sl][0];
-            idx = tile_of(sl) * TW + (int)((pk >> sh) & 0x3ffull);
-            val = bits_d((unsigned)s_rb[sl][vw], (unsigned)s_rb[sl][vw + 1]);
-        }
-        s_hX[lane] = val;
-        s_hI[lane] = idx;
-    }
-    if (lane < 2) s_bl[lane] = 0.0;
-    wave_sync();
-    // only when a 64-tile window ran dry does the search walk on through the group sums (dependent loads, rare)
-    if (nb < 2 && t - 65 >= 0 && !(ITD_ABL_R & 1024)) {
-        int far = t - 65;
-        while (nb < 2) {
-            int cu;
-            const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
-            if (u < 0) break;
-            far = u - 1;
-            const int uu = __builtin_amdgcn_readfirstlane(u);
-            const TileRec *r = recs + uu;
-            const unsigned long long pk = r->packed;
-            const int32_t i1 = uu * TW + rec_tpos(pk, 1), i0 = uu * TW + rec_tpos(pk, 0);
-            const double v1 = r->tval[1], v0 = r->tval[0];
-            if (lane == 0) { s_hI[nb == 0 ? 1 : 0] = i1; s_hX[nb == 0 ? 1 : 0] = v1; }
-            ++nb;
-            if (nb < 2 && cu >= 2) {
-                if (lane == 0) { s_hI[0] = i0; s_hX[0] = v0; }
-                ++nb;
+            unsigned long long mb = __ballot(cb != 0), mf = __ballot(cf != 0);
+            if (mb) {
+                const int l = __ffsll((long long)mb) - 1; mb &= mb - 1;
+                ub0 = t - 1 - l; cb0 = __builtin_amdgcn_readlane(cb, l);
+                if (cb0 < 2 && mb) ub1 = t - 1 - (__ffsll((long long)mb) - 1);
+            }
+            if (mf) {
+                const int l = __ffsll((long long)mf) - 1; mf &= mf - 1;
+                uf0 = t + 1 + l; cf0 = __builtin_amdgcn_readlane(cf, l);
+                if (cf0 < 3 && mf) {
+                    const int l1 = __ffsll((long long)mf) - 1; mf &= mf - 1;
+                    uf1 = t + 1 + l1; cf1 = __builtin_amdgcn_readlane(cf, l1);
+                    if (cf0 + cf1 < 3 && mf) uf2 = t + 1 + (__ffsll((long long)mf) - 1);
+                }
             }
         }
+        // staging slots: 0..3 = the speculative records, 4+k = candidate k fetched after all (rare)
+        auto slot_of = [&](int u, int k) { return u == t - 1 ? 0 : u == t + 1 ? 1 : u == t - 2 ? 2 : u == t + 2 ? 3 : 4 + k; };
+        const int sb0 = slot_of(ub0, 0), sb1 = slot_of(ub1, 1), sf0 = slot_of(uf0, 2), sf1 = slot_of(uf1, 3), sf2 = slot_of(uf2, 4);
+        s_rb[q4][w16] = specw;
+        if (!(ITD_ABL_R & 8192) && ((ub0 >= 0 && sb0 >= 4) || (ub1 >= 0 && sb1 >= 4) || (uf0 >= 0 && sf0 >= 4) || (uf1 >= 0 && sf1 >= 4))) {
+            const int uk = q4 == 0 ? ub0 : q4 == 1 ? ub1 : q4 == 2 ? uf0 : uf1;
+            const int sk = q4 == 0 ? sb0 : q4 == 1 ? sb1 : q4 == 2 ? sf0 : sf1;
+            if (uk >= 0 && sk >= 4) s_rb[sk][w16] = reinterpret_cast<const int32_t *>(recs + uk)[w16];
+        }
+        if (uf2 >= 0 && sf2 >= 4 && lane < 16) s_rb[8][lane] = reinterpret_cast<const int32_t *>(recs + uf2)[lane];
+
+        // staged record slot -> its tile (for the knots' absolute sample indices)
+        auto tile_of = [&](int sl) { return sl == 0 ? t - 1 : sl == 1 ? t + 1 : sl == 2 ? t - 2 : sl == 3 ? t + 2 : sl == 4 ? ub0 : sl == 5 ? ub1 : sl == 6 ? uf0 : sl == 7 ? uf1 : uf2; };
+        // ---- halo knots: two in front of the tile (slot 1 starts the segment that enters the tile), three behind; lane k < 5
+        //      picks knot k out of the staged records.  Missing ones are the end knots e[0] = 0 / e[m+1] = n-1 (ITD.py:96,98).
+        if (ub0 >= 0) nb = (cb0 >= 2 || ub1 >= 0) ? 2 : 1;
+        if (uf0 >= 0) nf = min(3, cf0 + cf1 + (uf2 >= 0 ? 1 : 0));
         wave_sync();
-    }
-    if (nf < 3 && t + 65 < n_tiles && !(ITD_ABL_R & 1024)) {
-        int far = t + 65;
-        while (nf < 3) {
-            int cu;
-            const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
-            if (u < 0) break;
-            far = u + 1;
-            const int uu = __builtin_amdgcn_readfirstlane(u);
-            const TileRec *r = recs + uu;
-            const int take = min(cu, 3 - nf);
-            if (lane < take) { s_hI[2 + nf + lane] = uu * TW + rec_hpos(r->packed, lane); s_hX[2 + nf + lane] = r->hval[lane]; }
-            nf += take;
+        if (lane < 5 && !(ITD_ABL_R & 8192)) {
+            int sl, sh, vw;   // staged slot, bit offset of the knot's position in the packed word, dword of its value
+            bool real;
+            if (lane < 2) {
+                real = (lane == 1) ? (nb >= 1) : (nb >= 2);
+                const bool from0 = (lane == 1) || (cb0 >= 2);          // slot 0: ub0's second last knot, or ub1's last
+                const int which = (lane == 1 || !from0) ? 1 : 0;       // tpos(1) / tval[1] = the record's last knot
+                sl = from0 ? sb0 : sb1;
+                sh = 41 + 10 * which;
+                vw = kRecDwTval + 2 * which;
+            } else {
+                int j = lane - 2;
+                real = j < nf;
+                const int c0 = min(cf0, 3), c1 = min(cf1, 3);
+                if (j < c0) sl = sf0;
+                else if (j - c0 < c1) { sl = sf1; j -= c0; }
+                else { sl = sf2; j -= c0 + c1; }
+                sh = 11 + 10 * j;
+                vw = kRecDwHval + 2 * j;
+            }
+            int32_t idx = lane < 2 ? 0 : (int32_t)(n - 1);
+            double val = lane < 2 ? e0 : e3;
+            if (real) {
+                const unsigned long long pk = ((unsigned long long)(unsigned)s_rb[sl][1] << 32) | (unsigned)s_rb[sl][0];
+                idx = tile_of(sl) * TW + (int)((pk >> sh) & 0x3ffull);
+                val = bits_d((unsigned)s_rb[sl][vw], (unsigned)s_rb[sl][vw + 1]);
+            }
+            s_hX[lane] = val;
+            s_hI[lane] = idx;
+        }
+        if (lane < 2) s_bl[lane] = 0.0;
+        wave_sync();
+        // only when a 64-tile window ran dry does the search walk on through the group sums (dependent loads, rare)
+        if (nb < 2 && t - 65 >= 0 && !(ITD_ABL_R & 1024)) {
+            int far = t - 65;
+            while (nb < 2) {
+                int cu;
+                const int u = far_nonempty<-1>(cnts, gs, n_tiles, far, &cu);
+                if (u < 0) break;
+                far = u - 1;
+                const int uu = __builtin_amdgcn_readfirstlane(u);
+                const TileRec *r = recs + uu;
+                const unsigned long long pk = r->packed;
+                const int32_t i1 = uu * TW + rec_tpos(pk, 1), i0 = uu * TW + rec_tpos(pk, 0);
+                const double v1 = r->tval[1], v0 = r->tval[0];
+                if (lane == 0) { s_hI[nb == 0 ? 1 : 0] = i1; s_hX[nb == 0 ? 1 : 0] = v1; }
+                ++nb;
+                if (nb < 2 && cu >= 2) {
+                    if (lane == 0) { s_hI[0] = i0; s_hX[0] = v0; }
+                    ++nb;
+                }
+            }
+            wave_sync();
+        }
+        if (nf < 3 && t + 65 < n_tiles && !(ITD_ABL_R & 1024)) {
+            int far = t + 65;
+            while (nf < 3) {
+                int cu;
+                const int u = far_nonempty<1>(cnts, gs, n_tiles, far, &cu);
+                if (u < 0) break;
+                far = u + 1;
+                const int uu = __builtin_amdgcn_readfirstlane(u);
+                const TileRec *r = recs + uu;
+                const int take = min(cu, 3 - nf);
+                if (lane < take) { s_hI[2 + nf + lane] = uu * TW + rec_hpos(r->packed, lane); s_hX[2 + nf + lane] = r->hval[lane]; }
+                nf += take;
+            }
+            wave_sync();
+        }
+
+        if (own_c > 0 && !(ITD_ABL_R & 2048)) {
+            WaveMasks wm;   // lane j < 2*G2 holds flag word j
+            if (lane < 2 * G2) { wm.lo = (unsigned)own_word; wm.hi = (unsigned)(own_word >> 32); }
+            int gbase = 0;
+#pragma unroll
+            for (int g = 0; g < G2; ++g) {
+                const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
+                const int bE = lane_bit(E), bO = lane_bit(O);
+                const int ke = mbcnt64(O, mbcnt64(E, gbase)) + bE;
+                kinfo[g] = ke | (bE << 16) | (bO << 17);
+                const int cg = __popcll(E) + __popcll(O);
+                gcnt |= (unsigned)cg << (8 * g);
+                gbase += cg;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G2; ++g) kinfo[g] = 0;
+        }
+    } else {
+        // ---- FUSE0 front end: knots of the caller's signal from the registers, halo knots from the two halo groups -----
+        Tin v[G2 + 2][2];
+        v[0][0] = pre[kt].hq[0][0]; v[0][1] = pre[kt].hq[0][1];
+#pragma unroll
+        for (int g = 0; g < G2; ++g) { v[g + 1][0] = pre[kt].q[g][0]; v[g + 1][1] = pre[kt].q[g][1]; }
+        v[G2 + 1][0] = pre[kt].hq[1][0]; v[G2 + 1][1] = pre[kt].hq[1][1];
+        {   // NaN input is rejected (ITD_ERR_NONFINITE): the reference would write +inf into the caller's array, ITD.py:46-51
+            bool nan_in = false;   // samples beyond the row were read as zeros: one unordered compare per sample pair
+#pragma unroll
+            for (int g = 0; g < G2; ++g) nan_in = nan_in || __builtin_isunordered(pre[kt].q[g][0], pre[kt].q[g][1]);
+            if (__any(nan_in) && lane == 0) st->in_nan = 1;
+        }
+        // window = [s-128, s+TW+128): positions allowed to flag are the signal's 1 .. n-2 (ITD.py:70-73)
+        unsigned long long E[G2 + 2], O[G2 + 2];
+        knot_masks<Tin, G2 + 2>(v, (int)max((int64_t)1, 129 - s), (int)min((int64_t)(TW + 255), n - 2 - s + 128), E, O);
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const int bE = lane_bit(E[g + 1]), bO = lane_bit(O[g + 1]);
+            const int ke = mbcnt64(O[g + 1], mbcnt64(E[g + 1], own_c)) + bE;
+            kinfo[g] = ke | (bE << 16) | (bO << 17);
+            const int cg = __popcll(E[g + 1]) + __popcll(O[g + 1]);
+            gcnt |= (unsigned)cg << (8 * g);
+            own_c += cg;
+        }
+        if (lane == 0 && own_c) atomicAdd(const_cast<int32_t *>(&gs[(size_t)(t / kTilesPerGroup) * kGsumPitch]), own_c);   // for m[0] only
+        const int cL = __popcll(E[0]) + __popcll(O[0]), cR = __popcll(E[G2 + 1]) + __popcll(O[G2 + 1]);
+        nb = min(cL, 2);
+        nf = min(cR, 3);
+        if (lane < 5) {   // defaults: the end knots e[0] = 0, e[m+1] = n-1 (ITD.py:96,98)
+            s_hX[lane] = lane < 2 ? e0 : e3;
+            s_hI[lane] = lane < 2 ? 0 : (int32_t)(n - 1);
+        }
+        if (lane < 2) s_bl[lane] = 0.0;
+        // the samples next to the tile, where the record-driven launch keeps them (s_rb[0] / s_rb[1] edge fields)
+        if (lane == 63) *reinterpret_cast<double *>(&s_rb[0][kRecDwEdge + 2]) = (double)v[0][1];
+        if (lane == 0) *reinterpret_cast<double *>(&s_rb[1][kRecDwEdge]) = (double)v[G2 + 1][0];
+        wave_sync();
+        {   // owner lanes: the last two knots of the front halo group, the first three of the rear one
+            const int bE = lane_bit(E[0]), bO = lane_bit(O[0]);
+            const int re = mbcnt64(O[0], mbcnt64(E[0], 0));   // knots of the group before the even sample
+            const int se = re - cL + 2, so = re + bE - cL + 2;
+            const int32_t pe = (int32_t)s - 128 + 2 * lane;
+            if (bE && se >= 0) { s_hX[se] = (double)v[0][0]; s_hI[se] = pe; }
+            if (bO && so >= 0) { s_hX[so] = (double)v[0][1]; s_hI[so] = pe + 1; }
+        }
+        {
+            const int bE = lane_bit(E[G2 + 1]), bO = lane_bit(O[G2 + 1]);
+            const int re = mbcnt64(O[G2 + 1], mbcnt64(E[G2 + 1], 0));
+            const int ro_ = re + bE;
+            const int32_t pe = (int32_t)s + TW + 2 * lane;
+            if (bE && re < 3) { s_hX[2 + re] = (double)v[G2 + 1][0]; s_hI[2 + re] = pe; }
+            if (bO && ro_ < 3) { s_hX[2 + ro_] = (double)v[G2 + 1][1]; s_hI[2 + ro_] = pe + 1; }
         }
         wave_sync();
+        // ---- a halo group with too few knots (smooth stretches): walk on through the signal.  Windows of 512 samples that
+        //      overlap by two, so every position is an inner position of some window; wave-uniform, rare for noisy input ----
+        int64_t ql = s - 128;                  // front: first position not yet evaluated (everything above it is)
+        int64_t qr = s + TW + 127;             // rear: last position not yet evaluated
+        bool fail = false;
+        if ((nb < 2 && ql > 0) || (nf < 3 && qr < n - 1)) {
+            Tin w[4][2];
+            unsigned long long WE[4], WO[4];
+            for (int step = 0; nb < 2 && ql > 0 && step < kReach; ++step) {
+                const int64_t p0 = ql > 510 ? ql - 510 : 0;                 // window [p0, p0+512): inner positions p0+1 .. p0+510
+                const __amdgpu_buffer_rsrc_t rw = tile_rsrc(x + p0, (n - p0) * (int64_t)sizeof(Tin));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tile_load2<false>(rw, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), w[g][0], w[g][1]);
+                knot_masks<Tin, 4>(w, (int)max((int64_t)1, 1 - p0), (int)(ql - p0), WE, WO);
+                for (int g = 3; g >= 0 && nb < 2; --g) {                     // nearest first: from the top
+                    unsigned long long Eg = WE[g], Og = WO[g];
+                    while ((Eg | Og) && nb < 2) {
+                        const int be = Eg ? 63 - __clzll((long long)Eg) : -1, bo = Og ? 63 - __clzll((long long)Og) : -1;
+                        const bool odd = bo >= be;
+                        const int l = odd ? bo : be;
+                        if (odd) Og &= ~(1ull << l); else Eg &= ~(1ull << l);
+                        if (lane == l) {
+                            const Tin val = odd ? (g == 0 ? w[0][1] : g == 1 ? w[1][1] : g == 2 ? w[2][1] : w[3][1]) : (g == 0 ? w[0][0] : g == 1 ? w[1][0] : g == 2 ? w[2][0] : w[3][0]);
+                            s_hX[1 - nb] = (double)val;
+                            s_hI[1 - nb] = (int32_t)(p0 + 128 * g + 2 * l + (odd ? 1 : 0));
+                        }
+                        ++nb;
+                    }
+                }
+                ql = p0;
+            }
+            for (int step = 0; nf < 3 && qr < n - 1 && step < kReach; ++step) {
+                const int64_t p0 = qr - 1;                                   // inner positions qr .. qr+509
+                const __amdgpu_buffer_rsrc_t rw = tile_rsrc(x + p0, (n - p0) * (int64_t)sizeof(Tin));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tile_load2<false>(rw, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), w[g][0], w[g][1]);
+                knot_masks<Tin, 4>(w, 1, (int)min((int64_t)510, n - 2 - p0), WE, WO);
+                for (int g = 0; g < 4 && nf < 3; ++g) {
+                    unsigned long long Eg = WE[g], Og = WO[g];
+                    while ((Eg | Og) && nf < 3) {
+                        const int be = Eg ? __ffsll((long long)Eg) - 1 : 64, bo = Og ? __ffsll((long long)Og) - 1 : 64;
+                        const bool odd = bo < be;
+                        const int l = odd ? bo : be;
+                        if (odd) Og &= Og - 1; else Eg &= Eg - 1;
+                        if (lane == l) {
+                            const Tin val = odd ? (g == 0 ? w[0][1] : g == 1 ? w[1][1] : g == 2 ? w[2][1] : w[3][1]) : (g == 0 ? w[0][0] : g == 1 ? w[1][0] : g == 2 ? w[2][0] : w[3][0]);
+                            s_hX[2 + nf] = (double)val;
+                            s_hI[2 + nf] = (int32_t)(p0 + 128 * g + 2 * l + (odd ? 1 : 0));
+                        }
+                        ++nf;
+                    }
+                }
+                qr += 510;
+            }
+            fail = (nb < 2 && ql > 0) || (nf < 3 && qr < n - 1);
+            wave_sync();
+        }
+        if (fail && lane == 0) atomicOr(&st->l0_fail, 1);   // the engine repeats level 0 through k_scan0 + the record-driven launch
     }
-
     // ---- the tile itself, needed from here on ---------------------------------------------------------------------------
     double xr[G2][2];   // samples beyond the row were read as 0
 #pragma unroll
@@ -1105,27 +1312,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         xr[g][0] = (double)pre[kt].q[g][0];
         xr[g][1] = (double)pre[kt].q[g][1];
     }
-    // ---- this level's knots inside the tile: the producer's flag words; tile-relative ranks, once -----------------------
+    // ---- this level's knots inside the tile (the producer's flag words, or FUSE0's own scan); tile-relative ranks, once ----
     const int c = (ITD_ABL_R & 2048) ? 0 : own_c;
-    WaveMasks wm;
-    if (c > 0 && lane < 2 * G2) { wm.lo = (unsigned)own_word; wm.hi = (unsigned)(own_word >> 32); }
-    // kinfo[g] = ke | bitE << 16 | bitO << 17, ke = knots of the tile at or before the lane's even sample of group g
-    int kinfo[G2];
-    if (c > 0) {
-        int gbase = 0;
-#pragma unroll
-        for (int g = 0; g < G2; ++g) {
-            const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
-            const int bE = lane_bit(E), bO = lane_bit(O);
-            const int ke = mbcnt64(O, mbcnt64(E, gbase)) + bE;
-            kinfo[g] = ke | (bE << 16) | (bO << 17);
-            gbase += __popcll(E) + __popcll(O);
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < G2; ++g) kinfo[g] = 0;
-    }
-
     double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
     double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
     const __amdgpu_buffer_rsrc_t r_rot = tile_rsrc(rot_t, (n - s) * 8);
@@ -1147,7 +1335,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         } else {
 #pragma unroll 1
             for (int g = g0; g < G2; ++g) {
-                const int cg = __popcll(wm.get(2 * g)) + __popcll(wm.get(2 * g + 1));
+                const int cg = (int)((gcnt >> (8 * g)) & 0xffu);
                 if (m + cg > CAP) break;
                 m += cg;
                 g1 = g + 1;
@@ -1325,14 +1513,23 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         for (int q = lane; q < n_groups; q += kWave) acc += gs[(size_t)q * kGsumPitch];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) {
+        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
+        if (level == 1) {
+            // the fused level-0 launch could only accumulate the signal's own knot total (its tiles ran concurrently): it is
+            // complete now, in the buffer this launch is about to clear (the record-driven level 0 wrote the same number)
+            int a0 = 0;
+            for (int q = lane; q < n_groups; q += kWave) a0 += gc[(size_t)q * kGsumPitch];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a0 += __shfl_xor(a0, d);
+            if (lane == 0) st->m[0] = a0;
+        }
+        if (lane == 0 && !FUSE0) {
             // the baseline this level reads held a NaN: the reference counted its knots under the NaN rules (nan_rules)
             if (level >= 1 && ((st->nan_mask >> (level - 1)) & 1)) acc += st->c_delta[level - 1];
             st->m[level] = acc;
             // the pending baseline is not decomposable: launches from level + 1 on do nothing (this one completes)
             if (level >= 1 && acc < 2 && st->stop_level < 0) st->stop_level = level;
         }
-        int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
         for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
     }
 }

@@ -5,6 +5,7 @@ Device memory for the device-resident entry points is whatever the caller owns (
 hipMalloc'd buffers, ...) — only raw pointers cross the boundary.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -14,6 +15,7 @@ from ._lib import ITDError, MAX_ROWS
 STOP_NATURAL, STOP_TIMEOUT = 0, 1
 DETECT_KNOTS, DETECT_VALLEYS, DETECT_PEAKS = 0, 1, 2
 ITD_OK, ITD_ERR_INVALID_ARG, ITD_ERR_NONFINITE = 0, 1, 6
+LEVEL0_AUTO, LEVEL0_RECORDS, LEVEL0_FUSED = 0, 1, 2
 TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0 = 0, 1, 2, 3, 4
 
 
@@ -32,6 +34,9 @@ class Engine:
             raise ITDError(rc, "itd_engine_create(max_n=%d, max_batch=%d, device=%d)" % (max_n, max_batch, device))
         self._h = h
         self.max_n, self.max_batch, self.device = int(max_n), int(max_batch), int(device)
+        mode = os.environ.get("PYITD_LEVEL0_MODE")      # diagnostic override: run a whole test suite in one level-0 mode
+        if mode:
+            self.set_level0_mode(int(mode))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -79,6 +84,10 @@ class Engine:
     def set_nan_fallback(self, on):
         """No-op since ABI revision 2 (the extraction kernel follows the reference's NaN rules itself)."""
         self._check(self._L.itd_set_nan_fallback(self._h, 1 if on else 0))
+
+    def set_level0_mode(self, mode):
+        """LEVEL0_AUTO (fused level 0, record-driven repeat if the input is too smooth), LEVEL0_RECORDS, LEVEL0_FUSED."""
+        self._check(self._L.itd_set_level0_mode(self._h, int(mode)))
 
     def set_batch_chunk(self, signals_per_chunk):
         """Signals per launch sequence of a batched decomposition (0 = automatic, about 2^24 samples per chunk)."""

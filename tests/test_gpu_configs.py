@@ -321,3 +321,87 @@ def test_two_gpu_ranks_shard_and_gather_over_rccl(torch, oracle):
         ref = oracle.itd_lean(_batch_signal(b, 1 << 16), 5)
         assert got["n_rows"][b] == ref["rows"].shape[0]
         assert got["knot_counts"][b][: len(ref["knot_counts"])] == ref["knot_counts"].tolist()
+
+
+def _modes_agree(P, torch, oracle, x, m, expect_repeat=None):
+    """The three level-0 modes give bit-identical results; returns the rows of the automatic mode."""
+    from pyitd_amd.engine import LEVEL0_AUTO, LEVEL0_RECORDS
+    x = np.ascontiguousarray(x)
+    n = x.shape[0]
+    ref = oracle.itd(x, m)
+    out = {}
+    for mode in (LEVEL0_AUTO, LEVEL0_RECORDS):
+        eng = P.Engine(n, 1, 0)
+        eng.set_level0_mode(mode)
+        xd = torch.from_numpy(x).cuda()
+        rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        bases = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), bases.data_ptr(), None)
+        s = eng.summary(1)
+        nr, nb = int(s["n_rows"][0]), int(s["n_baselines"][0])
+        assert nr == ref["rows"].shape[0] and nb == ref["baselines"].shape[0], "mode %d" % mode
+        assert [int(v) for v in s["knot_counts"][0, 1:] if v >= 0] == ref["knot_counts"].tolist(), "mode %d" % mode
+        assert int(s["knot_counts"][0, 0]) == len(oracle.knots(np.asarray(x, dtype=np.float64))), "mode %d: knots of the input" % mode
+        assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "mode %d rows" % mode)
+        assert_bits_equal(bases[:nb].cpu().numpy(), ref["baselines"], "mode %d baselines" % mode)
+        out[mode] = rows[:nr].cpu().numpy()
+        eng.close()
+    return out[LEVEL0_AUTO]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_level0_on_smooth_signals(P, torch, oracle, dtype):
+    """The fused level-0 launch takes a tile's neighbouring knots from the 128 samples either side; smoother stretches
+    make it walk on through the signal (overlapping 512-sample windows).  Knot spacings from a few samples to ~3000."""
+    n = 200003
+    t = np.arange(n) / n
+    rng = np.random.default_rng(17)
+    cases = {
+        "extrema every ~60 samples": np.sin(2 * np.pi * 1700 * t),
+        "every ~300": np.sin(2 * np.pi * 333 * t) + 0.3 * t,
+        "every ~1500": np.sin(2 * np.pi * 67 * t) * (1 + t),
+        "every ~3000": np.sin(2 * np.pi * 33.3 * t + 0.4),
+        "chirp from dense to sparse": np.sin(2 * np.pi * (3000 * t - 2950 * t * t)),
+        "noise burst in a slow wave": np.sin(2 * np.pi * 40 * t) + np.where((t > 0.4) & (t < 0.41), 0.01 * rng.standard_normal(n), 0.0),
+        "plateaus (quantised slow wave)": np.round(np.sin(2 * np.pi * 90 * t) * 20) / 20,
+    }
+    for name, x in cases.items():
+        _modes_agree(P, torch, oracle, x.astype(dtype), 6)
+
+
+def test_fused_level0_beyond_its_reach_repeats_record_driven(P, torch, oracle):
+    """Knots further apart than the fused launch reaches (> ~4000 samples): itd_get_summary repeats the call through
+    k_scan0 + records; the engine's following decompositions start record-driven; a forced-fused engine reports it."""
+    from pyitd_amd.engine import LEVEL0_FUSED
+    n = 1 << 18
+    t = np.arange(n) / n
+    x = np.sin(2 * np.pi * 9 * t) + 0.2 * t * t          # an extremum every ~14 500 samples
+    _modes_agree(P, torch, oracle, x, 5)
+    mono = np.linspace(-1, 2, n) ** 3                      # no knots at all: the whole signal is one segment
+    _modes_agree(P, torch, oracle, mono, 3)
+    eng = P.Engine(n, 1, 0)
+    eng.set_level0_mode(LEVEL0_FUSED)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.empty((7, n), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    eng.decompose_dev(xd.data_ptr(), np.float64, n, 1, n, 5, rows.data_ptr(), None, None)
+    with pytest.raises(P.ITDError):
+        eng.summary(1)
+    eng.close()
+
+
+def test_fused_level0_float32_subnormals_and_huge_values(P, torch, oracle):
+    """The fused launch evaluates the predicate in float32 for float32 input: differences of subnormals must not be
+    flushed, and +-inf / 1e38 magnitudes behave like the reference's float64 differences of the widened values."""
+    rng = np.random.default_rng(23)
+    n = 70000
+    tiny = (rng.standard_normal(n) * 1e-42).astype(np.float32)          # float32 subnormals (spacing 1.4e-45)
+    assert np.count_nonzero(tiny) > n // 2 and np.abs(tiny).max() < 1.2e-38
+    _modes_agree(P, torch, oracle, tiny, 5)
+    huge = (rng.standard_normal(n) * 1e38).astype(np.float32)
+    huge[np.isinf(huge)] = np.float32(3e38)
+    _modes_agree(P, torch, oracle, huge, 4)
+    mixed = rng.standard_normal(n).astype(np.float32)
+    mixed[::7] = mixed[1::7][: len(mixed[::7])]                          # equal neighbours: plateaus of two
+    _modes_agree(P, torch, oracle, mixed, 6)
