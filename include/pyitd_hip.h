@@ -54,6 +54,8 @@ typedef enum itd_status {
 #define ITD_DETECT_KNOTS 0  /* union used by the extraction, ITD.py:87-98 */
 #define ITD_DETECT_VALLEYS 1 /* detect_peaks(x), ITD.py:33-76 (dx[i]>0 & dx[i-1]<=0) */
 #define ITD_DETECT_PEAKS 2   /* detect_peaks(-x) = matlab_detect_peaks(x), numba_accelerated_itd.py:17-59 */
+#define ITD_DETECT_CPP 3     /* itd.cpp:161-168: (x[i-1] < x[i] && x[i] >= x[i+1]) || (x[i-1] > x[i] && x[i] <= x[i+1]) */
+#define ITD_DETECT_ZERO_CROSS 4 /* find_extrema's test, itd_fourier_decomposition.py:23-27: sign change x[i] -> x[i+1] */
 
 typedef struct itd_engine itd_engine; /* opaque; not thread-safe: one engine per host thread/stream */
 
@@ -169,6 +171,30 @@ int itd_detect_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t 
  * All host pointers; x [n], extrema [m+2] int64, bk [m+2]. */
 int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host,
                              int64_t m, double *bk_host);
+
+/* ---- cubic-spline baseline variant with externally supplied knots ---------------------------
+ * itd_baseline_extract_fast(I, extrema_input, idx), itd_fourier_decomposition.py:49-122 — the Python twin of
+ * itd_baseline_extract(data, baseline, length, &idx, compute_extrema), itd.cpp:156-239.  Restated literally in float64,
+ * quirks included (knot values for k = 1..idx-2 only, K[idx-1] = 0, K[idx] = I[e[idx]], the sweep as written, natural ends,
+ * the segment idx-2 evaluated linearly).  Float results agree with the reference to rounding (the reference's numpy form
+ * uses libm pow for t**3, numba multiplies, the knot recurrences run here as scans): tests hold them to 1e-9 of the
+ * signal's scale; knot indices are exact.
+ *   extrema_dev   idx+1 knots (int32, device): e[0..idx-1] strictly increasing sample indices, e[idx] any sample index
+ *                 (find_extrema leaves 0 there); 2 <= idx <= n-1.  Invalid lists return ITD_ERR_INVALID_ARG.
+ *                 NULL = compute_extrema (itd.cpp:159-169): the knots are the samples with
+ *                 (x[i-1] < x[i] && x[i] >= x[i+1]) || (x[i-1] > x[i] && x[i] <= x[i+1]), e[idx] = 0 (the file's static
+ *                 array at first call); *idx_host receives their count; fewer than 2 leave baseline_dev untouched (:170).
+ *   the float32 form widens the signal first: itd.cpp's all-float32 arithmetic has no compilable reference to pin. */
+int itd_baseline_extract_cubic_f64(itd_engine *e, const double *x_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
+                                   double *baseline_dev, int64_t *idx_host, void *stream);
+int itd_baseline_extract_cubic_f32(itd_engine *e, const float *x_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
+                                   double *baseline_dev, int64_t *idx_host, void *stream);
+/* host form: extrema_host int64 [idx+1] or NULL (detect); extrema_out_host (optional, capacity n) receives detected knots */
+int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host,
+                                        int64_t idx, double *baseline_host, int64_t *idx_out, int64_t *extrema_out_host);
+/* find_extrema(signal), itd_fourier_decomposition.py:17-31: [0, the sign changes s[i] -> s[i+1], one extrapolated index],
+ * zero padded to n entries like the reference's numpy.zeros array; *idx_out = the reference's returned idx. */
+int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, int64_t *extrema_host, int64_t *idx_out);
 
 /* ---- introspection for benchmarks -------------------------------------------------------------
  * hipEvent pairs on the launch stream.  Extraction launches are dispatched with their own start/stop events

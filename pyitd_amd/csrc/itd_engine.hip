@@ -17,6 +17,7 @@
 
 #include "../../include/pyitd_hip.h"
 #include "itd_kernels.hpp"
+#include "itd_cubic.hpp"
 
 #ifndef ITD_TILE
 #define ITD_TILE 512
@@ -86,6 +87,10 @@ struct itd_engine {
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
     // host-convenience staging (grow only)
+    double *d_cub = nullptr; size_t cub_bytes = 0;        // cubic variant: K, h, u, b0, d, b (6 arrays of idx+2 doubles)
+    void *d_cub_aux = nullptr; size_t cub_aux_bytes = 0;  // cubic variant: workgroup maps + carries
+    int32_t *d_cub_e = nullptr; size_t cub_e_bytes = 0;   // cubic variant: the caller's knots narrowed to int32 (host form)
+    int32_t *d_flag = nullptr;                            // [1] device-side argument check
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
     double *d_io_bases = nullptr; size_t io_bases_bytes = 0;
@@ -370,6 +375,7 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     alloc((void **)&e->d_hrecs, 2 * (size_t)e->max_tiles * sizeof(TileRec));
     alloc((void **)&e->d_hgsum, 3 * (size_t)e->hgsum_third * sizeof(int32_t));
     alloc((void **)&e->d_hstate, sizeof(SigState));
+    alloc((void **)&e->d_flag, 64);
     const size_t st_b = B * sizeof(SigState);
     if (rc == hipSuccess) rc = hipHostMalloc((void **)&e->h_state, st_b);
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -391,6 +397,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
+    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_aux); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_flag);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -563,7 +570,7 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
 
 // level-0 knot scan of one device signal into the workspace of batch slot 0; optional ordered list in d_kidx
 template <typename Tin>
-int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, hipStream_t st)
+int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, hipStream_t st, int64_t tail_value = -1)
 {
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kWave);
@@ -574,7 +581,7 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
                                               e->d_hrecs, e->d_hgsum, e->d_hstate);
     if (compact)
         k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_hcounts, e->d_hgsum, n_tiles, n, e->d_kidx, e->max_n + 2,
-                                              e->d_total, e->d_hstate);
+                                              e->d_total, e->d_hstate, tail_value);
     HIP_TRY(e, hipGetLastError());
     return ITD_OK;
 }
@@ -623,7 +630,7 @@ template <typename Tin>
 int detect_dev(itd_engine *e, const Tin *x, int64_t n, int32_t mode, int32_t *idx, int64_t *count, hipStream_t st)
 {
     if (!e || !x || !count) return ITD_ERR_INVALID_ARG;
-    if (n < 3 || n > e->max_n || mode < 0 || mode > 2) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n || mode < 0 || mode > 4) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     int rc = scan_level0<Tin>(e, x, n, mode, true, st);
     if (rc) return rc;
@@ -768,6 +775,171 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
     return ITD_OK;
 }
 
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The cubic-spline baseline variant (itd_cubic.hpp): itd_baseline_extract_fast(I, extrema_input, idx),
+// itd_fourier_decomposition.py:49-122 = itd.cpp:156-239.  Single-level operator; synchronous like the other helpers.
+// ---------------------------------------------------------------------------------------------
+namespace {
+// x: n float64 samples on the device; ek: idx+1 knots (int32, device, validated); baseline: n float64 (device)
+int cubic_core(itd_engine *e, const double *x, int64_t n, const int32_t *ek, int64_t idx, double *baseline, hipStream_t st)
+{
+    const size_t L = (size_t)idx + 2;
+    int rc = grow(e, &e->d_cub, &e->cub_bytes, 6 * L * sizeof(double));
+    if (rc) return rc;
+    const int64_t count = idx - 1;                                   // elements of either recurrence
+    const int nblk = (int)((count + kScanBlockElems - 1) / kScanBlockElems);
+    rc = grow(e, &e->d_cub_aux, &e->cub_aux_bytes, (size_t)nblk * (sizeof(Affine) + sizeof(double)));
+    if (rc) return rc;
+    double *K = e->d_cub, *h = K + L, *u = h + L, *b0 = u + L, *d = b0 + L, *b = d + L;
+    Affine *maps = (Affine *)e->d_cub_aux;
+    double *carry = (double *)(maps + nblk);
+    k_cubic_knots<<<(unsigned)((idx + 1 + 255) / 256), 256, 0, st>>>(x, ek, idx, K, h);
+    k_cubic_rhs<<<(unsigned)((idx + 255) / 256), 256, 0, st>>>(K, h, idx, u, b0, d);
+    HIP_TRY(e, hipMemsetAsync(b, 0, L * sizeof(double), st));         // b[0] = 0 in front of the sweep; b[idx] stays 0
+    const Recur<true> rf{b0, u, d, idx};
+    k_recur_reduce<true><<<nblk, kScanThreads, 0, st>>>(rf, count, maps);
+    k_recur_carries<<<1, 64, 0, st>>>(maps, nblk, nullptr, carry);
+    k_recur_apply<true><<<nblk, kScanThreads, 0, st>>>(rf, count, carry, b);
+    const Recur<false> rb{b, u, d, idx};                              // back substitution, in place, from b[idx-1]
+    k_recur_reduce<false><<<nblk, kScanThreads, 0, st>>>(rb, count, maps);
+    k_recur_carries<<<1, 64, 0, st>>>(maps, nblk, b + (idx - 1), carry);
+    k_recur_apply<false><<<nblk, kScanThreads, 0, st>>>(rb, count, carry, b);
+    k_cubic_fix_ends<<<1, 1, 0, st>>>(b, idx);
+    k_cubic_eval<T><<<(unsigned)tiles_of(n), kWave, 0, st>>>(ek, K, b, h, idx, n, baseline);
+    HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
+}
+
+// knots of x by one of the cubic variant's predicates into d_kidx+1 (d_kidx[0] = 0 in front of them), *idx_out = their
+// count (find_extrema: including the leading 0 and the extrapolated tail, like the reference's return value)
+int cubic_detect(itd_engine *e, const double *x, int64_t n, int mode, int64_t *count, hipStream_t st)
+{
+    int rc = scan_level0<double>(e, x, n, mode, true, st, mode == (int)kCpp ? 0 : -1);
+    if (rc) return rc;
+    if (mode == (int)kZeroCross) k_zero_cross_tail<<<1, 1, 0, st>>>(e->d_kidx, e->d_total);
+    return fetch_total(e, st, count);
+}
+
+int cubic_dev(itd_engine *e, const double *x, int64_t n, const int32_t *extrema, int64_t idx, double *baseline,
+              int64_t *idx_out, hipStream_t st)
+{
+    if (!e || !x || !baseline) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    const int32_t *ek = extrema;
+    if (!extrema) {   // compute_extrema = true, itd.cpp:159-169; e[idx] = 0: the file's static array at first call
+        int64_t m = 0;
+        const int rc = cubic_detect(e, x, n, (int)kCpp, &m, st);
+        if (rc) return rc;
+        idx = m;
+        ek = e->d_kidx + 1;
+    } else {
+        if (idx < 2 || idx > n - 1) return ITD_ERR_INVALID_ARG;
+        HIP_TRY(e, hipMemsetAsync(e->d_flag, 0, sizeof(int32_t), st));
+        k_cubic_validate<<<(unsigned)((idx + 1 + 255) / 256), 256, 0, st>>>(extrema, idx, n, e->d_flag);
+        int32_t bad = 0;
+        HIP_TRY(e, hipMemcpyAsync(&bad, e->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        if (bad) return ITD_ERR_INVALID_ARG;
+    }
+    if (idx_out) *idx_out = idx;
+    if (idx < 2) return ITD_OK;        // itd.cpp:170-172: break early, the baseline is left untouched
+    const int rc = cubic_core(e, x, n, ek, idx, baseline, st);
+    if (rc) return rc;
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int itd_baseline_extract_cubic_f64(itd_engine *e, const double *x_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
+                                   double *baseline_dev, int64_t *idx_host, void *stream)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    return cubic_dev(e, x_dev, n, extrema_dev, idx, baseline_dev, idx_host, stream ? (hipStream_t)stream : e->own_stream);
+}
+
+int itd_baseline_extract_cubic_f32(itd_engine *e, const float *x_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
+                                   double *baseline_dev, int64_t *idx_host, void *stream)
+{
+    if (!e || !x_dev) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    k_widen_f32<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(x_dev, (double *)e->d_io_x, n);   // float64 arithmetic on the widened signal
+    return cubic_dev(e, (const double *)e->d_io_x, n, extrema_dev, idx, baseline_dev, idx_host, st);
+}
+
+int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host,
+                                        int64_t idx, double *baseline_host, int64_t *idx_out, int64_t *extrema_out_host)
+{
+    if (!e || !x_host || !baseline_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, (size_t)n * sizeof(double) * 2);   // baseline | widened knots
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    const int32_t *ek = nullptr;
+    if (extrema_host) {
+        if (idx < 2 || idx > n - 1) return ITD_ERR_INVALID_ARG;
+        rc = grow(e, &e->d_cub_e, &e->cub_e_bytes, (size_t)(idx + 1) * sizeof(int32_t));
+        if (rc) return rc;
+        int64_t *d_e64 = (int64_t *)(e->d_io_rows + n);
+        HIP_TRY(e, hipMemcpyAsync(d_e64, extrema_host, (size_t)(idx + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        // range check on the host copy first: narrowing to int32 must not wrap
+        for (int64_t k = 0; k <= idx; ++k)
+            if (extrema_host[k] < 0 || extrema_host[k] >= n) return ITD_ERR_INVALID_ARG;
+        k_narrow_idx<<<(unsigned)((idx + 1 + 255) / 256), 256, 0, st>>>(d_e64, e->d_cub_e, idx + 1);
+        ek = e->d_cub_e;
+    }
+    int64_t got = 0;
+    rc = cubic_dev(e, (const double *)e->d_io_x, n, ek, idx, e->d_io_rows, &got, st);
+    if (rc) return rc;
+    if (idx_out) *idx_out = got;
+    if (got >= 2) HIP_TRY(e, hipMemcpyAsync(baseline_host, e->d_io_rows, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (extrema_out_host && !extrema_host && got > 0) {
+        int64_t *d_e64 = (int64_t *)(e->d_io_rows + n);
+        k_widen_idx<<<(unsigned)((got + 255) / 256), 256, 0, st>>>(e->d_kidx + 1, d_e64, got);
+        HIP_TRY(e, hipMemcpyAsync(extrema_out_host, d_e64, (size_t)got * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
+}
+
+int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, int64_t *extrema_host, int64_t *idx_out)
+{
+    if (!e || !s_host || !extrema_host || !idx_out) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, (size_t)(n + 2) * sizeof(int64_t));
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    int64_t m = 0;
+    rc = cubic_detect(e, (const double *)e->d_io_x, n, (int)kZeroCross, &m, st);
+    if (rc) return rc;
+    // d_kidx = [0, crossings (m of them), extrapolated tail]: idx = m + 2 entries, the rest of the caller's array is zero
+    const int64_t idx = m + 2;
+    if (idx > n) return ITD_ERR_INVALID_ARG;   // the reference's own array would overflow (every interior sample a crossing)
+    int64_t *d_e64 = (int64_t *)e->d_io_rows;
+    k_widen_idx<<<(unsigned)((idx + 255) / 256), 256, 0, st>>>(e->d_kidx, d_e64, idx);
+    memset(extrema_host, 0, (size_t)n * sizeof(int64_t));
+    HIP_TRY(e, hipMemcpyAsync(extrema_host, d_e64, (size_t)idx * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    *idx_out = idx;
+    return ITD_OK;
+}
 
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
 {

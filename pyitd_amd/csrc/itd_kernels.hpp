@@ -134,7 +134,9 @@ __host__ __device__ constexpr int rec_count(unsigned long long p) { return (int)
 __host__ __device__ constexpr int rec_hpos(unsigned long long p, int k) { return (int)((p >> (11 + 10 * k)) & 0x3ffull); }   // k = 0..2
 __host__ __device__ constexpr int rec_tpos(unsigned long long p, int k) { return (int)((p >> (41 + 10 * k)) & 0x3ffull); }   // k = 0: second last, 1: last
 
-enum DetectMode : int { kKnots = 0, kValleys = 1, kPeaks = 2 };
+// kCpp: the knot predicate of itd.cpp:161-168 (strict on the left, non-strict on the right); kZeroCross: the sign changes
+// s[i] -> s[i+1] of find_extrema, itd_fourier_decomposition.py:23-27 (both feed the cubic variant, itd_cubic.hpp)
+enum DetectMode : int { kKnots = 0, kValleys = 1, kPeaks = 2, kCpp = 3, kZeroCross = 4 };
 
 // Tiles are grouped in runs of 64; every producer of a tile list adds its count to the group's sum (one
 // atomic per non-empty tile).  Each group sum sits on a 128-byte line of its own: device-scope atomics on
@@ -294,6 +296,8 @@ __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, i
         const bool valley = (vil > 0.0) && (vix <= 0.0);
         const bool peak = (vil < 0.0) && (vix >= 0.0);
         bool f = (mode == kKnots) ? (valley || peak) : (mode == kValleys ? valley : peak);
+        if (mode == kCpp) f = ((xm < x0) && (x0 >= xp)) || ((xm > x0) && (x0 <= xp));
+        if (mode == kZeroCross) f = ((x0 > 0.0) && (0.0 > xp)) || ((x0 < 0.0) && (0.0 < xp));
         // first and last sample are never knots (ITD.py:70-73), nothing beyond sample n-2: edge tiles only
         if (edge) f = f && (s + pos >= 1) && (s + pos <= n - 2);
         const unsigned long long mk = __ballot(f);
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
                                                    const int32_t *__restrict__ counts,
                                                    const int32_t *__restrict__ gsum_in, int n_tiles, int64_t n,
                                                    int32_t *__restrict__ kidx, int64_t kidx_stride,
-                                                   int32_t *__restrict__ total_out, const SigState *__restrict__ state)
+                                                   int32_t *__restrict__ total_out, const SigState *__restrict__ state,
+                                                   int64_t tail_value /* e[m+1]; < 0: n-1 (ITD.py:98) */)
 {
     const int sig = blockIdx.y;
     const int t = blockIdx.x;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
     if (lane == 0 && t == n_tiles - 1) {
         const int m = base + c;
         e[0] = 0;                    // ITD.py:96
-        e[m + 1] = (int32_t)(n - 1); // ITD.py:98
+        e[m + 1] = (int32_t)(tail_value < 0 ? n - 1 : tail_value); // ITD.py:98
         total_out[2 * sig] = m;
         total_out[2 * sig + 1] = state[sig].in_nan;   // set by k_detect, which has completed
     }

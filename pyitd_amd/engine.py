@@ -147,6 +147,35 @@ class Engine:
                                                      _np_ptr(bk)))
         return bk
 
+    # ---- cubic-spline baseline variant (include/pyitd_hip.h: itd_baseline_extract_cubic_*, itd_find_extrema_*) ----------
+    def find_extrema_host(self, signal):
+        """find_extrema (itd_fourier_decomposition.py:17-31): (extrema int64[n] zero padded, idx)."""
+        s = np.ascontiguousarray(signal, dtype=np.float64)
+        n = s.shape[0]
+        ext = np.zeros(n, np.int64)
+        idx = ctypes.c_int64(0)
+        self._check(self._L.itd_find_extrema_host_f64(self._h, _np_ptr(s), n, _np_ptr(ext), ctypes.byref(idx)))
+        return ext, int(idx.value)
+
+    def cubic_extract_host(self, x, extrema=None, idx=0):
+        """itd_baseline_extract_fast (itd_fourier_decomposition.py:49-122).  extrema=None: the knots are detected with
+        itd.cpp's predicate (itd.cpp:161-168).  Returns (baseline or None when fewer than 2 knots, knots int64, idx)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = x.shape[0]
+        base = np.empty(n)
+        got = ctypes.c_int64(0)
+        if extrema is None:
+            kn = np.zeros(n, np.int64)
+            self._check(self._L.itd_baseline_extract_cubic_host_f64(self._h, _np_ptr(x), n, None, 0, _np_ptr(base),
+                                                                    ctypes.byref(got), _np_ptr(kn)))
+            return (base if got.value >= 2 else None), kn, int(got.value)
+        e = np.ascontiguousarray(extrema, dtype=np.int64)
+        if e.shape[0] < idx + 1:
+            raise ValueError("extrema_input needs idx+1 entries")
+        self._check(self._L.itd_baseline_extract_cubic_host_f64(self._h, _np_ptr(x), n, _np_ptr(e), int(idx), _np_ptr(base),
+                                                                ctypes.byref(got), None))
+        return base, e, int(idx)
+
 
 class DeviceBuffer:
     """hipMalloc'd bytes on one GPU through the C ABI (itd_dev_alloc / itd_dev_copy / itd_dev_free): what the numpy

@@ -250,6 +250,63 @@ def itd_batch(x, max_iteration: int = 11, keep_baselines: bool = False, device=N
             d_bases.free()
 
 
+# ---- cubic-spline baseline variant with externally supplied knots: itd_fourier_decomposition.py / itd.cpp ------------------
+def generate_sine_wave(freq, sample_rate, duration):
+    """itd_fourier_decomposition.py:11-14 (host numpy: the knot positions depend on the sign of every sample, so the sine is
+    generated exactly as the reference generates it)."""
+    t = numpy.arange(0, duration, 1 / sample_rate)
+    return numpy.sin(2 * numpy.pi * freq * t)
+
+
+def find_extrema(signal, device=0):
+    """itd_fourier_decomposition.py:17-31 — (extrema int64[n], idx): 0, the sign changes signal[i] -> signal[i+1], one
+    extrapolated index; the rest of the array is zero like the reference's numpy.zeros."""
+    s = numpy.asarray(signal, dtype=numpy.float64)
+    if len(s) < 3:
+        raise ValueError("find_extrema needs at least 3 samples")
+    return _engine_for(len(s), device).find_extrema_host(s)
+
+
+def itd_baseline_extract_fast(I, extrema_input, idx, device=0):
+    """itd_fourier_decomposition.py:49-122 — natural-cubic baseline through the knot values at the caller's knots
+    (float64[n]).  The Python twin of itd.cpp:156-239 with compute_extrema = false."""
+    x = numpy.asarray(I, dtype=numpy.float64)
+    if len(x) < 3:
+        raise ValueError("itd_baseline_extract_fast needs at least 3 samples")
+    base, _, _ = _engine_for(len(x), device).cubic_extract_host(x, extrema_input, int(idx))
+    return base
+
+
+def itd_baseline_extract_cubic(x, device=0, want_knots=False):
+    """itd.cpp:156-239 with compute_extrema = true: knots by the file's own 3-point predicate (:161-168), then the same
+    spline.  Returns the baseline (the input itself, unchanged, when fewer than 2 knots exist — itd.cpp:170-172 leaves the
+    caller's buffer alone); with want_knots also the knot indices."""
+    x = numpy.asarray(x, dtype=numpy.float64)
+    if len(x) < 3:
+        raise ValueError("needs at least 3 samples")
+    base, kn, idx = _engine_for(len(x), device).cubic_extract_host(x)
+    out = x.copy() if base is None else base
+    return (out, kn[:idx].copy()) if want_knots else out
+
+
+def itd_sine_wrapper(signal, sample_rate, device=0):
+    """itd_fourier_decomposition.py:33-47 — peel frequency-governed bands: for each synthetic sine (descending
+    frequencies) the sine's zero crossings are the knots of one cubic baseline extraction."""
+    problem = numpy.array(signal, dtype=numpy.float64)
+    duration = len(problem) / sample_rate
+    frequencies = numpy.arange(2, sample_rate // 2 - 1, 96)[::-1]
+    products = []
+    for k in range(1, frequencies.size):
+        sine_wave = generate_sine_wave(frequencies[k], sample_rate, duration)
+        extrema, idx = find_extrema(sine_wave, device)
+        baseline = itd_baseline_extract_fast(problem, extrema, idx, device)
+        rotation = problem - baseline
+        products.append(rotation)
+        problem = problem - rotation
+    products.append(problem)
+    return products
+
+
 def itd(data, max_iteration: int = 22, device=0):
     """ITD_numba.py:100-136 — free-function driver (its default of 22 overruns the 22-row buffer upstream;
     the usable range is 0..20)."""
