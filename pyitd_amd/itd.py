@@ -273,6 +273,10 @@ def itd_baseline_extract_fast(I, extrema_input, idx, device=0):
     x = numpy.asarray(I, dtype=numpy.float64)
     if len(x) < 3:
         raise ValueError("itd_baseline_extract_fast needs at least 3 samples")
+    ext = numpy.asarray(extrema_input)
+    over = ext[: int(idx) + 1][ext[: int(idx) + 1] >= len(x)]
+    if over.size:   # find_extrema's extrapolated last knot can lie beyond the signal: the reference's numpy form raises here
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (int(over[0]), len(x)))
     base, _, _ = _engine_for(len(x), device).cubic_extract_host(x, extrema_input, int(idx))
     return base
 

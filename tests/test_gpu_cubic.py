@@ -60,14 +60,14 @@ def test_find_extrema_matches_oracle(P, oracle):
 
 
 def test_large_signal_many_knots_vs_oracle(P, oracle):
-    """2^21 samples with ~8e5 knots: the recurrences span hundreds of workgroups (reduce / carries / apply)."""
+    """2^21 samples with ~4e5 knots: the recurrences span hundreds of workgroups (reduce / carries / apply)."""
     rng = np.random.default_rng(31)
     n = 1 << 21
     x = np.cumsum(rng.standard_normal(n)) * 0.01 + np.sin(np.arange(n) / 50.0)
     e, idx = oracle.extrema_cpp(x)
     ref = oracle.itd_baseline_extract_fast(x, e, idx)
     base, knots = P.itd_baseline_extract_cubic(x, want_knots=True)
-    assert len(knots) == idx > 500000
+    assert len(knots) == idx > 300000
     np.testing.assert_array_equal(knots, e[:idx])
     _close(base, ref, float(np.max(np.abs(x))), "2^21 detect")
     # external knots: every 7th detected knot, the reference's own zero-terminated convention
@@ -81,8 +81,10 @@ def test_bad_knot_lists_are_rejected(P):
     x = np.sin(np.arange(3000.0) / 9)
     with pytest.raises(P.ITDError):
         P.itd_baseline_extract_fast(x, np.array([0, 10, 10, 50, 0]), 4)        # not strictly increasing
+    with pytest.raises(IndexError):
+        P.itd_baseline_extract_fast(x, np.array([0, 10, 20, 5000, 0]), 4)      # outside the signal (the reference's IndexError)
     with pytest.raises(P.ITDError):
-        P.itd_baseline_extract_fast(x, np.array([0, 10, 20, 5000, 0]), 4)      # outside the signal
+        P.itd_baseline_extract_fast(x, np.array([0, 10, 20, -5, 0]), 4)        # negative: python would wrap, the ABI refuses
     with pytest.raises(P.ITDError):
         P.itd_baseline_extract_fast(x, np.array([0, 0]), 1)                    # idx < 2
     flat = np.linspace(0, 1, 500)                                              # no knots: itd.cpp:170 leaves the buffer alone
@@ -93,12 +95,14 @@ def test_bad_knot_lists_are_rejected(P):
 def test_sine_wrapper_bands_sum_back(P, oracle):
     """itd_sine_wrapper (itd_fourier_decomposition.py:33-47) at a small sample rate: the bands sum back to the signal, and
     the first band equals the oracle's extraction with the same knots."""
-    sr, n = 1000, 2000
-    rng = np.random.default_rng(3)
+    sr, n = 600, 1801       # chosen so that every sine's extrapolated last knot lies inside the signal (elsewhere the reference
+    rng = np.random.default_rng(3)     # itself fails: IndexError in numpy, an out-of-bounds read under numba)
     sig = np.sin(2 * np.pi * 40 * np.arange(n) / sr) + 0.3 * rng.standard_normal(n)
     bands = P.itd_sine_wrapper(sig, sr)
     assert len(bands) == len(np.arange(2, sr // 2 - 1, 96))
     assert np.max(np.abs(np.sum(bands, axis=0) - sig)) < 1e-9
+    with pytest.raises(IndexError):       # the reference's own failure mode, mirrored
+        P.itd_sine_wrapper(sig[:1000], 500)
     f1 = np.arange(2, sr // 2 - 1, 96)[::-1][1]
     e, idx = oracle.find_extrema(P.generate_sine_wave(f1, sr, n / sr))
     ref = sig - oracle.itd_baseline_extract_fast(sig, e, idx)
