@@ -196,6 +196,16 @@ int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int
  * zero padded to n entries like the reference's numpy.zeros array; *idx_out = the reference's returned idx. */
 int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, int64_t *extrema_host, int64_t *idx_out);
 
+/* ---- instantaneous amplitude / phase / frequency of a proper rotation --------------------------
+ * The time-frequency-energy step the reference describes (README.md:13-21, 41-55) but does not implement; definitions of the
+ * paper it quotes (Frei & Osorio 2007, single-wave analysis): half waves between zero crossings, amplitude = the half wave's
+ * largest |x|, phase by arcsin(x / amplitude) placed in the wave's quadrant, frequency = forward phase difference / 2 pi in
+ * cycles per sample.  rot_dev: one row of the decomposition (or any oscillation about zero); any output may be NULL. */
+int itd_instantaneous_f64(itd_engine *e, const double *rot_dev, int64_t n, double *amp_dev, double *phase_dev, double *freq_dev,
+                          void *stream);
+int itd_instantaneous_host_f64(itd_engine *e, const double *rot_host, int64_t n, double *amp_host, double *phase_host,
+                               double *freq_host);
+
 /* ---- introspection for benchmarks -------------------------------------------------------------
  * hipEvent pairs on the launch stream.  Extraction launches are dispatched with their own start/stop events
  * (hipExtLaunchKernel: the events take the dispatch's own begin/end timestamps, so they agree with rocprofv3's kernel durations); the

@@ -9,10 +9,10 @@ behind a C ABI (include/pyitd_hip.h), and this host-side mirror of the reference
 from . import _lib
 from ._lib import ITDError, build
 from .engine import Engine
-from .itd import (ITD, baseline_knot_estimation, detect_knots, detect_peaks, find_extrema, generate_sine_wave, isin, itd,
+from .itd import (ITD, baseline_knot_estimation, detect_knots, detect_peaks, find_extrema, generate_sine_wave, instantaneous, isin, itd,
                   itd_baseline_extract, itd_baseline_extract_cubic, itd_baseline_extract_fast, itd_batch, itd_levels,
                   itd_sine_wrapper, matlab_detect_peaks, release_engines)
 
 __all__ = ["ITD", "ITDError", "Engine", "build", "itd", "itd_levels", "itd_batch", "itd_baseline_extract", "detect_peaks",
            "matlab_detect_peaks", "detect_knots", "baseline_knot_estimation", "isin", "find_extrema", "generate_sine_wave",
-           "itd_baseline_extract_fast", "itd_baseline_extract_cubic", "itd_sine_wrapper", "release_engines"]
+           "itd_baseline_extract_fast", "itd_baseline_extract_cubic", "itd_sine_wrapper", "release_engines", "instantaneous"]

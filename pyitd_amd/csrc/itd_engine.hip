@@ -18,6 +18,7 @@
 #include "../../include/pyitd_hip.h"
 #include "itd_kernels.hpp"
 #include "itd_cubic.hpp"
+#include "itd_tfe.hpp"
 
 #ifndef ITD_TILE
 #define ITD_TILE 512
@@ -938,6 +939,53 @@ int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, in
     HIP_TRY(e, hipMemcpyAsync(extrema_host, d_e64, (size_t)idx * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
     *idx_out = idx;
+    return ITD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Instantaneous amplitude / phase / frequency of a proper rotation (itd_tfe.hpp; README.md:13-21, 41-55).
+// ---------------------------------------------------------------------------------------------
+int itd_instantaneous_f64(itd_engine *e, const double *rot_dev, int64_t n, double *amp_dev, double *phase_dev, double *freq_dev,
+                          void *stream)
+{
+    if (!e || !rot_dev || (!amp_dev && !phase_dev && !freq_dev)) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    int64_t m = 0;
+    int rc = cubic_detect(e, rot_dev, n, (int)kZeroCross, &m, st);   // ordered zero crossings in d_kidx[1..m]
+    if (rc) return rc;
+    rc = grow(e, &e->d_cub, &e->cub_bytes, (size_t)(m + 2) * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long *amp_bits = (unsigned long long *)e->d_cub;
+    HIP_TRY(e, hipMemsetAsync(amp_bits, 0, (size_t)(m + 1) * sizeof(unsigned long long), st));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    k_tfe_amplitude<<<blocks, 256, 0, st>>>(rot_dev, n, e->d_kidx + 1, m, amp_bits);
+    k_tfe_phase<<<blocks, 256, 0, st>>>(rot_dev, n, e->d_kidx + 1, m, amp_bits, amp_dev, phase_dev, freq_dev);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
+}
+
+int itd_instantaneous_host_f64(itd_engine *e, const double *rot_host, int64_t n, double *amp_host, double *phase_host,
+                               double *freq_host)
+{
+    if (!e || !rot_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, 3 * (size_t)n * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, rot_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    double *d_a = e->d_io_rows, *d_p = d_a + n, *d_f = d_p + n;
+    rc = itd_instantaneous_f64(e, (const double *)e->d_io_x, n, d_a, d_p, d_f, st);
+    if (rc) return rc;
+    if (amp_host) HIP_TRY(e, hipMemcpyAsync(amp_host, d_a, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (phase_host) HIP_TRY(e, hipMemcpyAsync(phase_host, d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (freq_host) HIP_TRY(e, hipMemcpyAsync(freq_host, d_f, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
     return ITD_OK;
 }
 

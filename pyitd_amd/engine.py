@@ -176,6 +176,14 @@ class Engine:
                                                                 ctypes.byref(got), None))
         return base, e, int(idx)
 
+    def instantaneous_host(self, rotation):
+        """(amplitude, phase, frequency) of a proper rotation, float64[n] each (include/pyitd_hip.h: itd_instantaneous_*)."""
+        x = np.ascontiguousarray(rotation, dtype=np.float64)
+        n = x.shape[0]
+        a, p, f = np.empty(n), np.empty(n), np.empty(n)
+        self._check(self._L.itd_instantaneous_host_f64(self._h, _np_ptr(x), n, _np_ptr(a), _np_ptr(p), _np_ptr(f)))
+        return a, p, f
+
 
 class DeviceBuffer:
     """hipMalloc'd bytes on one GPU through the C ABI (itd_dev_alloc / itd_dev_copy / itd_dev_free): what the numpy

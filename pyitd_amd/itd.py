@@ -311,6 +311,16 @@ def itd_sine_wrapper(signal, sample_rate, device=0):
     return products
 
 
+def instantaneous(rotation, device=0):
+    """Instantaneous amplitude, phase (radians, 0..2 pi per wave) and frequency (cycles per sample) of a proper rotation —
+    the time-frequency-energy step README.md:13-21, 41-55 describes and the reference does not implement (definitions: Frei &
+    Osorio 2007, single-wave analysis; see pyitd_amd/csrc/itd_tfe.hpp).  Returns three float64[N] arrays."""
+    x = numpy.asarray(rotation, dtype=numpy.float64)
+    if x.ndim != 1 or len(x) < 3:
+        raise ValueError("expected a 1-D rotation with at least 3 samples")
+    return _engine_for(len(x), device).instantaneous_host(x)
+
+
 def itd(data, max_iteration: int = 22, device=0):
     """ITD_numba.py:100-136 — free-function driver (its default of 22 overruns the 22-row buffer upstream;
     the usable range is 0..20)."""
