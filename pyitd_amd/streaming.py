@@ -15,7 +15,8 @@ false), every numeric step of which runs on the GPU (pyitd_amd/csrc/itd_cubic.hp
     recipe's literal choice is margin = 1: "the last extrema in the first buffer to the first extrema in the last buffer";
     the operator pins the first and last knot value to the data there, as the recipe asks.  Because the operator never
     computes the knot value of its second-to-last knot (K[idx-1] stays 0, a quirk of the reference), two further extrema are
-    always taken behind the inner third so that the quirk's segments lie outside what is emitted);
+    always taken behind the inner third so that the quirk's segments lie outside what is emitted — its influence still
+    decays only by ~0.27 per knot, which is why the default margin is 8 extrema rather than the recipe's 1);
   * only the inner third is emitted.
 
 `push(block)` returns the baseline of the PREVIOUS block (latency: one block), or None while the buffer is filling;
