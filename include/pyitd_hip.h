@@ -196,6 +196,32 @@ int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int
  * zero padded to n entries like the reference's numpy.zeros array; *idx_out = the reference's returned idx. */
 int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, int64_t *extrema_host, int64_t *idx_out);
 
+/* ---- the FITPACK flavour of the baseline and its 2-D consumers -----------------------------
+ * itd_baseline_extract_modified(x), numba_accelerated_itd.py:182-211 (= itd_baseline_extract, siftED2D.ipynb cell 1; MEITD.py:
+ * 303-338 is the same operator without the early-out): knots = the tier-1 set, baseline knot values with odd-reflected ends
+ * (:196-206), the INTERPOLATING cubic B-spline through them — custom_splrep -> scipy.interpolate.splrep(x, y, k=3), whose
+ * default without weights is s = 0; SciPy's FITPACK curfit, restated in pyitd_amd/csrc/itd_fitpack.hpp and held bit for bit to
+ * scipy's splrep (tests/test_fitpack_host.py) — evaluated at every sample like numba_splev (:89-164, its equi_spaced interval
+ * formula included).  Batched: signal b at x_dev + b*x_stride, n samples each; one GPU thread per signal computes the
+ * coefficients (the sweep over the knots is serial), one thread per sample evaluates.
+ *   min_extrema   signals with fewer knots are returned unchanged (baseline = x): 10 for numba_accelerated_itd.py:188-190 and
+ *                 siftED2D, 0 for MEITD's form; fewer than 2 knots are always returned unchanged (splrep needs m > k)
+ *   rot_dev       optional: x - baseline (MEITD.py:335)
+ *   knots_host    optional [batch]: the knot count of every signal
+ * Returns ITD_ERR_NONFINITE if a signal holds a NaN.  Synchronous. */
+int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                                    int32_t min_extrema, double *baseline_dev, int64_t baseline_stride, double *rot_dev,
+                                    int64_t rot_stride, int32_t *knots_host, void *stream);
+int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
+                                         double *baseline_host, double *rot_host, int32_t *knots_host);
+/* crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols float64 (the ensemble
+ * members of retrieve_statistical_image_component go through in one call): the operator over every row, then over every
+ * column of that; over every column, then every row of that; the mean of the two.  Transposes and the mean run on the GPU. */
+int itd_crossways_f64(itd_engine *e, const double *img_dev, int32_t planes, int32_t rows, int32_t cols, int32_t min_extrema,
+                      double *out_dev, void *stream);
+int itd_crossways_host_f64(itd_engine *e, const double *img_host, int32_t planes, int32_t rows, int32_t cols, int32_t min_extrema,
+                           double *out_host);
+
 /* ---- instantaneous amplitude / phase / frequency of a proper rotation --------------------------
  * The time-frequency-energy step the reference describes (README.md:13-21, 41-55) but does not implement; definitions of the
  * paper it quotes (Frei & Osorio 2007, single-wave analysis): half waves between zero crossings, amplitude = the half wave's

@@ -217,6 +217,67 @@ def make_cubic_case(ref_cubic, name, I, extrema, idx, out_dir, knots_from):
     print("%-28s N=%-7d idx=%-6d knots from %s, finite=%s" % (name, I.shape[0], idx, knots_from, bool(np.isfinite(base).all())))
 
 
+def make_spline_cases(ref_dir, out_dir, radio):
+    """The FITPACK flavour of the baseline and its 2-D consumers, from the reference's own functions:
+    numba_accelerated_itd.itd_baseline_extract_modified (:182-211), MEITD.itd_baseline_extract (:303-338) and the functions
+    of siftED2D.ipynb cell 1 (exec'd like PyITD.ipynb's), all under the numba stand-in and with this image's real scipy —
+    the third-party dependency the reference calls (interpolate.splrep, numba_accelerated_itd.py:84)."""
+    import scipy
+    _install_numba_shim()
+    sys.path.insert(0, ref_dir)
+    try:
+        import numba_accelerated_itd as R
+        try:
+            import MEITD as M
+        except Exception as ex:           # noqa
+            print("MEITD.py not importable here:", ex)
+            M = None
+    finally:
+        sys.path.pop(0)
+    with open(os.path.join(ref_dir, "siftED2D.ipynb")) as f:
+        cell1 = "".join(json.load(f)["cells"][1]["source"])
+    ns = {}
+    exec(compile(cell1, "siftED2D.ipynb:cell1", "exec"), ns)
+    os.makedirs(out_dir, exist_ok=True)
+    rng = np.random.default_rng(777)
+    n = 512
+    rows = {
+        "pixels512": rng.integers(0, 256, n).astype(np.float64),
+        "walk2000": np.cumsum(rng.standard_normal(2000)),
+        "sines4096": sines_noise(4096, dtype=np.float64),
+        "radio8000": radio,
+        "quant600": np.round(rng.standard_normal(600) * 3),
+        "alternating100": ((-1.0) ** np.arange(100)) * (1 + rng.random(100)),      # every sample an extremum: equi_spaced
+        "few_extrema300": np.sin(np.linspace(0, 7 * np.pi, 300)),                   # 6 extrema < 10: returned unchanged
+        "monotone64": np.linspace(0, 1, 64) ** 2,
+        "exactly10_200": np.sin(np.linspace(0, 10.5 * np.pi, 200)),
+    }
+    for name, x in rows.items():
+        with np.errstate(all="ignore"):
+            base = np.array(R.itd_baseline_extract_modified(x.copy()))
+        rec = {"x": x, "baseline": base, "scipy_version": np.array(scipy.__version__)}
+        if M is not None:
+            try:
+                with np.errstate(all="ignore"):
+                    r, b = M.itd_baseline_extract(x.copy())
+                rec["meitd_rotation"], rec["meitd_baseline"] = np.array(r), np.array(b)
+            except Exception as ex:       # noqa
+                rec["meitd_error"] = np.array(type(ex).__name__)
+        np.savez_compressed(os.path.join(out_dir, "row_" + name + ".npz"), **rec)
+        print("%-28s N=%-5d unchanged=%s meitd=%s" % ("spline row_" + name, x.size, bool(base is not None and np.array_equal(base, x)),
+                                                     "meitd_baseline" in rec or str(rec.get("meitd_error"))))
+    img = rng.integers(0, 256, (48, 64)).astype(np.float64)
+    img[10:20] = np.round(np.linspace(0, 255, 64))[None, :]          # smooth rows: fewer than 10 extrema -> unchanged rows
+    with np.errstate(all="ignore"):
+        cw = np.array(ns["crossways_itd_baseline_extract"](img))
+    np.random.seed(20240)
+    with np.errstate(all="ignore"):
+        low = np.array(ns["retrieve_statistical_image_component"](img))
+    np.savez_compressed(os.path.join(out_dir, "image48x64.npz"), image=img, crossways=cw, lowpass=low, seed=np.int64(20240),
+                        scipy_version=np.array(scipy.__version__))
+    print("spline image48x64: crossways + ensemble low-pass (numpy.random.seed(20240))")
+
+
 def chirp(n, dtype=np.float32):
     t = np.arange(n, dtype=np.float64) / n
     return np.sin(2 * np.pi * (50 * t + 0.5 * (8000 - 50) * t * t)).astype(dtype)
@@ -311,6 +372,9 @@ def main():
                   ("cubic_detect_smooth2000", np.sin(np.linspace(0, 9 * np.pi, 2000)) + 0.1 * np.linspace(0, 1, 2000) ** 2)):
         e, idx = extrema_cpp(np.asarray(x, dtype=np.float64))
         make_cubic_case(cub, nm, x, e, idx, cdir, "itd.cpp:161-168 predicate")
+
+    # (8) the FITPACK flavour of the baseline and its 2-D consumers
+    make_spline_cases(args.ref, os.path.join(args.out, "spline"), radio)
 
 
 if __name__ == "__main__":

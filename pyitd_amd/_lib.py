@@ -10,7 +10,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"),
+HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"),
+           os.path.join(_HERE, "csrc", "itd_fitpack.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
 
 MAX_ROWS = 22
@@ -43,6 +44,10 @@ ABI = {
     "itd_baseline_extract_cubic_f32": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_baseline_extract_cubic_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_find_extrema_host_f64": (_INT, [_P, _P, _I64, _P, _P]),
+    "itd_baseline_extract_spline_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
+    "itd_baseline_extract_spline_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "itd_crossways_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "itd_crossways_host_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "itd_instantaneous_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P]),
     "itd_instantaneous_host_f64": (_INT, [_P, _P, _I64, _P, _P, _P]),
     "itd_set_nan_fallback": (_INT, [_P, _INT]),

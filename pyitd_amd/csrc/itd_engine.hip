@@ -19,6 +19,7 @@
 #include "itd_kernels.hpp"
 #include "itd_cubic.hpp"
 #include "itd_tfe.hpp"
+#include "itd_spline.hpp"
 
 #ifndef ITD_TILE
 #define ITD_TILE 512
@@ -92,6 +93,9 @@ struct itd_engine {
     void *d_cub_aux = nullptr; size_t cub_aux_bytes = 0;  // cubic variant: workgroup maps + carries
     int32_t *d_cub_e = nullptr; size_t cub_e_bytes = 0;   // cubic variant: the caller's knots narrowed to int32 (host form)
     int32_t *d_flag = nullptr;                            // [1] device-side argument check
+    void *d_sp = nullptr; size_t sp_bytes = 0;            // spline flavour (batched): lists, counts, records, group sums, states,
+                                                          // ordered knot lists, totals, fit arrays, metadata
+    double *d_sp2 = nullptr; size_t sp2_bytes = 0;        // 2-D consumers: three planes of scratch
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
     double *d_io_bases = nullptr; size_t io_bases_bytes = 0;
@@ -399,6 +403,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
     (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_aux); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_flag);
+    (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -939,6 +944,171 @@ int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, in
     HIP_TRY(e, hipMemcpyAsync(extrema_host, d_e64, (size_t)idx * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
     *idx_out = idx;
+    return ITD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The FITPACK flavour of the baseline, batched (itd_spline.hpp): itd_baseline_extract_modified,
+// numba_accelerated_itd.py:182-211 (= siftED2D.ipynb cell 1); MEITD.py:303-338 with min_extrema = 0.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+struct SplineWs {
+    int32_t *lists, *counts, *gsum, *kidx, *totals;
+    TileRec *recs;
+    SigState *state;
+    double *a, *c;
+    SplineMeta *meta;
+    int64_t kidx_stride, lda;
+    int n_tiles, n_groups;
+};
+int spline_workspace(itd_engine *e, int64_t n, int batch, SplineWs &w)
+{
+    w.n_tiles = (int)tiles_of(n);
+    w.n_groups = groups_of(w.n_tiles);
+    w.kidx_stride = n + 2;
+    w.lda = n + 3;                                   // m <= n + ... data sites: knots <= n - 2, m <= n; 1-based arrays
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t B = (size_t)batch, tiles = B * (size_t)w.n_tiles;
+    const size_t b_lists = al(tiles * T * sizeof(int32_t)), b_counts = al(tiles * sizeof(int32_t)), b_recs = al(tiles * sizeof(TileRec));
+    const size_t b_gsum = al(B * (size_t)w.n_groups * kGsumPitch * sizeof(int32_t)), b_state = al(B * sizeof(SigState));
+    const size_t b_kidx = al(B * (size_t)w.kidx_stride * sizeof(int32_t)), b_tot = al(B * 2 * sizeof(int32_t));
+    const size_t b_a = al(B * 4 * (size_t)w.lda * sizeof(double)), b_c = al(B * (size_t)w.lda * sizeof(double)), b_meta = al(B * sizeof(SplineMeta));
+    const int rc = grow(e, &e->d_sp, &e->sp_bytes, b_lists + b_counts + b_recs + b_gsum + b_state + b_kidx + b_tot + b_a + b_c + b_meta);
+    if (rc) return rc;
+    char *p = (char *)e->d_sp;
+    w.lists = (int32_t *)p; p += b_lists;
+    w.counts = (int32_t *)p; p += b_counts;
+    w.recs = (TileRec *)p; p += b_recs;
+    w.gsum = (int32_t *)p; p += b_gsum;
+    w.state = (SigState *)p; p += b_state;
+    w.kidx = (int32_t *)p; p += b_kidx;
+    w.totals = (int32_t *)p; p += b_tot;
+    w.a = (double *)p; p += b_a;
+    w.c = (double *)p; p += b_c;
+    w.meta = (SplineMeta *)p;
+    return ITD_OK;
+}
+
+// baseline (and optionally rotation) of `batch` contiguous-sample signals; all device pointers; asynchronous on st
+int spline_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_stride, int min_extrema, double *base,
+                   int64_t base_stride, double *rot, int64_t rot_stride, hipStream_t st, SplineWs &w)
+{
+    int rc = spline_workspace(e, n, batch, w);
+    if (rc) return rc;
+    const dim3 grid_t(w.n_tiles, batch), blk(kWave);
+    const int64_t ge = (int64_t)batch * w.n_groups * kGsumPitch;
+    k_init_state<<<(unsigned)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048), 256, 0, st>>>(w.state, batch, w.gsum, ge);
+    k_detect<double, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, w.n_tiles, (int)kKnots, w.lists, w.counts, w.recs, w.gsum, w.state);
+    k_compact<T><<<grid_t, blk, 0, st>>>(w.lists, w.counts, w.gsum, w.n_tiles, n, w.kidx, w.kidx_stride, w.totals, w.state, -1);
+    k_spline_fit<<<(batch + 63) / 64, 64, 0, st>>>(x, x_stride, n, batch, w.kidx, w.kidx_stride, w.totals, min_extrema, w.a, w.c, w.lda, w.meta);
+    k_spline_eval<<<dim3((unsigned)((n + 255) / 256), batch), 256, 0, st>>>(x, x_stride, n, batch, w.kidx, w.kidx_stride, w.c, w.meta, base,
+                                                                            base_stride, rot, rot_stride);
+    HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
+}
+
+// after spline_enqueue: synchronise, fetch the per-signal knot counts, report NaN input
+int spline_finish(itd_engine *e, int batch, const SplineWs &w, int32_t *knots_host, hipStream_t st)
+{
+    std::vector<int32_t> tot((size_t)batch * 2);
+    HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    bool nan_in = false;
+    for (int b = 0; b < batch; ++b) {
+        if (knots_host) knots_host[b] = tot[2 * (size_t)b];
+        nan_in = nan_in || tot[2 * (size_t)b + 1] != 0;
+    }
+    return nan_in ? ITD_ERR_NONFINITE : ITD_OK;
+}
+}  // namespace
+extern "C" {
+
+int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                                    int32_t min_extrema, double *baseline_dev, int64_t baseline_stride, double *rot_dev,
+                                    int64_t rot_stride, int32_t *knots_host, void *stream)
+{
+    if (!e || !x_dev || !baseline_dev) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n >= (int64_t)INT32_MAX - 8 || batch < 1 || min_extrema < 0) return ITD_ERR_INVALID_ARG;
+    if (batch > 1 && (x_stride < n || baseline_stride < n || (rot_dev && rot_stride < n))) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    SplineWs w;
+    const int rc = spline_enqueue(e, x_dev, n, batch, x_stride, min_extrema, baseline_dev, baseline_stride, rot_dev, rot_stride, st, w);
+    if (rc) return rc;
+    return spline_finish(e, batch, w, knots_host, st);
+}
+
+int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
+                                         double *baseline_host, double *rot_host, int32_t *knots_host)
+{
+    if (!e || !x_host || !baseline_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || batch < 1) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    const size_t cnt = (size_t)n * (size_t)batch;
+    int rc = grow(e, &e->d_sp2, &e->sp2_bytes, 3 * cnt * sizeof(double));
+    if (rc) return rc;
+    double *d_x = e->d_sp2, *d_b = d_x + cnt, *d_r = d_b + cnt;
+    HIP_TRY(e, hipMemcpyAsync(d_x, x_host, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = itd_baseline_extract_spline_f64(e, d_x, n, batch, n, min_extrema, d_b, n, rot_host ? d_r : nullptr, n, knots_host, st);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(baseline_host, d_b, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (rot_host) HIP_TRY(e, hipMemcpyAsync(rot_host, d_r, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
+}
+
+// crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols (device, contiguous):
+// rows then columns of the rows' result, columns then rows of the columns' result, averaged.
+int itd_crossways_f64(itd_engine *e, const double *img_dev, int32_t planes, int32_t rows, int32_t cols, int32_t min_extrema,
+                      double *out_dev, void *stream)
+{
+    if (!e || !img_dev || !out_dev || planes < 1 || rows < 3 || cols < 3) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    const size_t cnt = (size_t)planes * rows * cols;
+    int rc = grow(e, &e->d_sp2, &e->sp2_bytes, 3 * cnt * sizeof(double));
+    if (rc) return rc;
+    double *A = e->d_sp2, *Bq = A + cnt, *C = Bq + cnt;       // scratch planes
+    SplineWs w;
+    auto tr = [&](const double *in, int r, int c, double *out) {
+        k_transpose<<<dim3((c + 31) / 32, (r + 31) / 32, planes), 256, 0, st>>>(in, r, c, out);
+    };
+    auto ext = [&](const double *in, int sigs, int len, double *out) {   // every row of `sigs` x `len`
+        return spline_enqueue(e, in, len, sigs, len, min_extrema, out, len, nullptr, 0, st, w);
+    };
+    // lengthwise = rows(data); then its columns
+    if ((rc = ext(img_dev, planes * rows, cols, A))) return rc;             // A = lengthwise (rows done)
+    tr(A, rows, cols, Bq);                                                  // Bq = lengthwise^T  [cols][rows]
+    if ((rc = ext(Bq, planes * cols, rows, A))) return rc;                  // A = columns of lengthwise, transposed layout
+    tr(A, cols, rows, C);                                                   // C = lengthwise, final [rows][cols]
+    // crosswise = columns(data); then its rows
+    tr(img_dev, rows, cols, A);                                             // A = data^T
+    if ((rc = ext(A, planes * cols, rows, Bq))) return rc;                  // Bq = columns of data (transposed layout)
+    tr(Bq, cols, rows, A);                                                  // A = crosswise [rows][cols]
+    if ((rc = ext(A, planes * rows, cols, Bq))) return rc;                  // Bq = rows of crosswise
+    k_mean2<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(C, Bq, (int64_t)cnt, out_dev);
+    HIP_TRY(e, hipGetLastError());
+    // NaN input: the four detections' flags are gone but the last one's is representative enough for an error return
+    return spline_finish(e, planes * rows, w, nullptr, st);
+}
+
+int itd_crossways_host_f64(itd_engine *e, const double *img_host, int32_t planes, int32_t rows, int32_t cols, int32_t min_extrema,
+                           double *out_host)
+{
+    if (!e || !img_host || !out_host || planes < 1 || rows < 3 || cols < 3) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    const size_t cnt = (size_t)planes * rows * cols;
+    int rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, 2 * cnt * sizeof(double));
+    if (rc) return rc;
+    double *d_in = e->d_io_rows, *d_out = d_in + cnt;
+    HIP_TRY(e, hipMemcpyAsync(d_in, img_host, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = itd_crossways_f64(e, d_in, planes, rows, cols, min_extrema, d_out, st);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(out_host, d_out, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
     return ITD_OK;
 }
 

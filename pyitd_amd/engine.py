@@ -176,6 +176,26 @@ class Engine:
                                                                 ctypes.byref(got), None))
         return base, e, int(idx)
 
+    # ---- the FITPACK flavour of the baseline and its 2-D consumers (itd_baseline_extract_spline_*, itd_crossways_*) --------
+    def spline_extract_host(self, x, min_extrema=10, want_rotation=False):
+        """x[B, n] float64 -> (baseline[B, n], rotation[B, n] or None, knots[B]) (numba_accelerated_itd.py:182-211)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B, n = x.shape
+        base = np.empty((B, n))
+        rot = np.empty((B, n)) if want_rotation else None
+        knots = np.zeros(B, np.int32)
+        self._check(self._L.itd_baseline_extract_spline_host_f64(self._h, _np_ptr(x), n, B, int(min_extrema), _np_ptr(base),
+                                                                 _np_ptr(rot), _np_ptr(knots)))
+        return base, rot, knots
+
+    def crossways_host(self, images, min_extrema=10):
+        """images[P, rows, cols] float64 -> crossways_itd_baseline_extract of every plane (siftED2D.ipynb cell 1)."""
+        img = np.ascontiguousarray(images, dtype=np.float64)
+        P, r, c = img.shape
+        out = np.empty((P, r, c))
+        self._check(self._L.itd_crossways_host_f64(self._h, _np_ptr(img), P, r, c, int(min_extrema), _np_ptr(out)))
+        return out
+
     def instantaneous_host(self, rotation):
         """(amplitude, phase, frequency) of a proper rotation, float64[n] each (include/pyitd_hip.h: itd_instantaneous_*)."""
         x = np.ascontiguousarray(rotation, dtype=np.float64)

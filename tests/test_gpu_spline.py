@@ -1,0 +1,82 @@
+"""The FITPACK flavour of the baseline on the GPU (pyitd_amd/csrc/itd_spline.hpp + itd_fitpack.hpp) and its 2-D / ensemble
+consumers against the reference-generated vectors (tests/golden/spline) and the scipy-backed oracle.  Knot counts exact; the
+floats are expected bit for bit (the restated curfit reproduces scipy's splrep bit for bit on the host and the kernels perform
+the same operations in the same order) — asserted to 1e-12 of the signal's scale so that a last-bit libm difference between
+the GPU and the host cannot fail the suite; the number of exactly equal values is asserted separately."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from test_oracle_spline import row_cases
+
+pytestmark = pytest.mark.gpu
+SPLINE = os.path.join(GOLDEN, "spline")
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyitd_amd
+    return pyitd_amd
+
+
+@pytest.fixture(scope="module")
+def so():
+    from oracle import spline_oracle
+    return spline_oracle
+
+
+def _close(got, ref, what, tol=1e-12):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, what
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    err = float(np.max(np.abs(got - ref)))
+    assert err <= tol * scale, "%s: max |diff| %.3e (scale %.3e)" % (what, err, scale)
+    return float(np.mean(got.view(np.uint64) == ref.view(np.uint64)))
+
+
+@pytest.mark.parametrize("name", row_cases())
+def test_rows_match_reference_goldens(P, name):
+    g = np.load(os.path.join(SPLINE, name + ".npz"))
+    exact = _close(P.itd_baseline_extract_modified(g["x"]), g["baseline"], name)
+    assert exact > 0.99, "%s: only %.4f of the values are bit-identical" % (name, exact)
+    if "meitd_baseline" in g:
+        rot, base = P.itd_baseline_extract_spline(g["x"])
+        _close(base, g["meitd_baseline"], name + " (MEITD form)")
+        _close(rot, g["meitd_rotation"], name + " rotation")
+    else:
+        with pytest.raises(TypeError):
+            P.itd_baseline_extract_spline(g["x"])
+
+
+def test_crossways_and_ensemble_match_reference(P):
+    g = np.load(os.path.join(SPLINE, "image48x64.npz"))
+    _close(P.crossways_itd_baseline_extract(g["image"]), g["crossways"], "crossways")
+    np.random.seed(int(g["seed"]))                       # the reference draws its noise from numpy's global generator
+    _close(P.retrieve_statistical_image_component(g["image"]), g["lowpass"], "ensemble low-pass")
+    hl = P.totalextract2d(g["image"], verbose=False)
+    assert hl.shape == (2,) + g["image"].shape
+    assert np.max(np.abs(hl.sum(axis=0) - g["image"])) < 1e-9     # siftED2D.ipynb cell 4: the two parts sum back
+
+
+def test_batch_of_image_rows_vs_oracle(P, so):
+    """The reference's workload shape: hundreds of 512-sample rows in one call; mixed rows (noisy, smooth = unchanged,
+    alternating = equi-spaced knots)."""
+    rng = np.random.default_rng(5)
+    B, n = 300, 512
+    x = rng.integers(0, 256, (B, n)).astype(np.float64)
+    x[7] = np.linspace(0, 255, n)
+    x[8] = ((-1.0) ** np.arange(n)) * (1 + rng.random(n))
+    x[9] = np.round(100 * np.sin(np.arange(n) / 40.0))
+    got = P.itd_baseline_extract_rows(x)
+    for b in list(range(12)) + [100, 299]:
+        _close(got[b], so.baseline(x[b], 10), "row %d" % b)
+    assert np.array_equal(got[7], x[7])
+
+
+def test_long_signal(P, so):
+    """One long signal through the same operator (the coefficient sweep is serial per signal: slow but exact)."""
+    n = 1 << 17
+    x = np.cumsum(np.random.default_rng(6).standard_normal(n))
+    _close(P.itd_baseline_extract_modified(x), so.baseline(x, 10), "2^17 samples")
