@@ -266,6 +266,20 @@ def make_spline_cases(ref_dir, out_dir, radio):
         np.savez_compressed(os.path.join(out_dir, "row_" + name + ".npz"), **rec)
         print("%-28s N=%-5d unchanged=%s meitd=%s" % ("spline row_" + name, x.size, bool(base is not None and np.array_equal(base, x)),
                                                      "meitd_baseline" in rec or str(rec.get("meitd_error"))))
+    if M is not None:      # MEITD.py:395-549: the selection drivers on top of the operator
+        t = np.arange(3000)
+        sigs = {"two_tone_noise": np.sin(2 * np.pi * t / 37.0) + 0.6 * np.sin(2 * np.pi * t / 411.0) + 0.2 * rng.standard_normal(3000),
+                "walk": np.cumsum(rng.standard_normal(3000)) * 0.3,
+                "am": (1 + 0.5 * np.sin(t / 200.0)) * np.sin(t / 9.0) + 0.05 * t / 3000}
+        for name, x in sigs.items():
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
+                hi, lo, res = M.MEITD(x.copy())
+                xi = M.XITD(x.copy())
+                wpe = M.weighted_permutation_entropy(x, order=3, normalize=True)
+            np.savez_compressed(os.path.join(out_dir, "meitd_" + name + ".npz"), x=x, high=np.array(hi), low=np.array(lo),
+                                residual=np.array(res), xitd=np.array(xi), wpe=np.float64(wpe))
+            print("spline meitd_%-18s high %d low %d rows, XITD %d rows" % (name, len(hi), len(lo), len(xi)))
     img = rng.integers(0, 256, (48, 64)).astype(np.float64)
     img[10:20] = np.round(np.linspace(0, 255, 64))[None, :]          # smooth rows: fewer than 10 extrema -> unchanged rows
     with np.errstate(all="ignore"):

@@ -80,3 +80,18 @@ def test_long_signal(P, so):
     n = 1 << 17
     x = np.cumsum(np.random.default_rng(6).standard_normal(n))
     _close(P.itd_baseline_extract_modified(x), so.baseline(x, 10), "2^17 samples")
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(SPLINE) if f.startswith("meitd_")))
+def test_meitd_and_xitd_match_reference(P, name):
+    """MEITD / XITD (MEITD.py:395-549) end to end on the GPU operators against the reference's own run."""
+    from pyitd_amd import meitd
+    g = np.load(os.path.join(SPLINE, name + ".npz"))
+    hi, lo, res = meitd.MEITD(g["x"].copy())
+    assert hi.shape == g["high"].shape and lo.shape == g["low"].shape        # the same selection decisions
+    if hi.size:
+        _close(hi, g["high"], name + " high", 1e-10)
+    if lo.size:
+        _close(lo, g["low"], name + " low", 1e-10)
+    _close(res, g["residual"], name + " residual", 1e-10)
+    _close(meitd.XITD(g["x"].copy()), g["xitd"], name + " XITD", 1e-10)
