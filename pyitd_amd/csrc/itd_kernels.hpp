@@ -96,6 +96,9 @@ struct SigState {
                              // level 0 has to be repeated through k_scan0 + the record-driven launch
     int32_t fin_stopped;     // written by k_finalize only: the verdict after the last pending baseline's stop test
     int32_t fin_stop_level;  // (kept apart from stop_level, which k_finalize's own workgroups still read)
+    int32_t chain_stop;      // written by k_chain_finalize only (itd_chain.hpp): some pending baseline inside the run had < 2
+                             // knots, the one-launch chain's rows past that level are not the reference's: repeat level by level
+    int32_t pad_;
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 

@@ -31,3 +31,11 @@ def _built_artifacts():
     _lib.build()
     from oracle import cpu_oracle
     cpu_oracle.build()
+    # torch first: on this image torch's own HIP runtime refuses to start ("No HIP GPUs are available") once libpyitd_hip.so has
+    # initialised the system one, whereas the other order works — and some GPU tests hold their device buffers in torch tensors
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass

@@ -1,5 +1,7 @@
 """Device-resident entry points (torch tensors carry the HBM buffers; only raw pointers cross the C ABI):
 batches, strides, the ping-pong/keep-all baseline modes, full-size property checks."""
+import os
+
 import numpy as np
 import pytest
 
@@ -189,6 +191,8 @@ def test_kernel_timing_api(P, torch, oracle):
     # itd_set_kernel_timing / _stride / itd_get_kernel_timing: instrumented decompositions launch the extraction kernels with
     # their own events; results must not change and the tallies must count exactly the instrumented launches
     from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0
+    if os.environ.get("PYITD_CHAIN_MODE", "1") != "1":
+        pytest.skip("the launch classes counted here are the level-by-level engine's (the suite is being run through the chain)")
     n, m = 1 << 16, 5
     x = sines_noise(n, seed=2, dtype=np.float32)
     ref = oracle.itd(x, m)
