@@ -179,6 +179,9 @@ def run_rank(args):
         sp = stream.cuda_stream
         x_ptr, rows_ptr = x.data_ptr(), rows.data_ptr()
     eng = sb.engine
+    if args.chain and not stub:
+        from pyitd_amd.engine import CHAIN_ONLY
+        eng.set_chain_mode(CHAIN_ONLY)     # the whole decomposition as one persistent launch; a chain that cannot complete raises
 
     def sync():
         if not stub:
@@ -223,9 +226,9 @@ def run_rank(args):
     table = sb.gather(device=dev) if dist.is_initialized() else None
 
     if not sharded and not stub:
-        from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
+        from pyitd_amd.engine import TIME_CHAIN, TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
         timing = {k: eng.kernel_timing(t) for k, t in (("ext", TIME_EXTRACT), ("l0", TIME_EXTRACT_L0), ("fin", TIME_EXTRACT_FINAL),
-                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0))}
+                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0), ("chain", TIME_CHAIN))}
         eng.set_timing(0)
     else:
         timing = None
@@ -323,6 +326,20 @@ def run_rank(args):
                 "whole decomposition (188 B/sample)": frac(float(algorithmic_bytes_per_sample(LEVELS)), avg_us("dec")),
             },
         }
+    if timing is not None and args.chain:
+        # --chain: the dominant (only) kernel is k_chain.  Two figures: against the SURVEY's algorithmic bytes (188 B/sample: what
+        # the reference's level-by-level data flow moves) and against what this launch itself has to move (4 B read + 8 B per row)
+        ch_us = timing["chain"][0] / max(timing["chain"][1], 1) * 1e3
+        own_bytes = 4.0 + 8.0 * R
+        out["roofline"].update({
+            "kernel": "k_chain (one persistent launch: all %d levels, the tile stays in registers; opt-in, itd_set_chain_mode)" % (M + 2),
+            "achieved": round(float(algorithmic_bytes_per_sample(LEVELS)) * n / (ch_us * 1e-6) / 1e9, 1) if ch_us > 0 else 0.0,
+            "frac": round(float(algorithmic_bytes_per_sample(LEVELS)) * n / (ch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if ch_us > 0 else 0.0,
+            "avg_launch_us": round(ch_us, 2), "launches_timed": timing["chain"][1], "traffic": None, "traffic_source": None,
+            "own_bytes_per_sample": own_bytes,
+            "own_frac": round(own_bytes * n / (ch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if ch_us > 0 else 0.0,
+        })
+        out["config"]["launch_form"] = "chain"
     if world == 1 and not stub and not args.no_cpu_baseline:
         out.update(cpu_legs(x_host, n, M, summ, rows, args))
     print(json.dumps(out))
@@ -413,6 +430,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=LOG2N, help="N = 1: samples of the single signal (24); N > 1: samples per signal (20)")
     ap.add_argument("--batch", type=int, default=1024, help="N > 1: signals per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain", action="store_true", help="run the opt-in one-launch chain (itd_set_chain_mode) instead of one launch per level")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher only
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -710,10 +710,11 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                                                         (WANT_BASES && !fin) ? rem : 0, 8);
         unsigned long long *eg_next = endg + ((int64_t)(level + 1) * batch + sig) * 8;   // not touched by the last level
         bool odd_vals = false, own_nan = false;
+        constexpr bool kOnePass = CAP >= TW;   // every tile fits the by-rank arrays: no pass loop, no per-group pass tests
         int rb = 0, g0 = 0;
         while (g0 < G2) {
             int g1 = g0, m = 0;
-            if (c - rb <= CAP) {
+            if (kOnePass || c - rb <= CAP) {
                 g1 = G2;
                 m = c - rb;
             } else {
