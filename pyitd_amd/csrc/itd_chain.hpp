@@ -1,10 +1,12 @@
-// itd_chain.hpp — the whole level loop of a decomposition (ITD.itd, ITD.py:384-432) in ONE launch.
+// itd_chain.hpp — the whole level loop of a decomposition (ITD.itd, ITD.py:384-432) in ONE launch.  Opt-in
+// (itd_set_chain_mode): bit-exact with the level-by-level engine on the whole test suite, measured 15 % slower than it on the
+// benchmark signal because it is bound by instruction issue — kept as the working base of that direction.
 //
 // The level-by-level engine (itd_kernels.hpp) streams every level's input once: 8 B read + 16 B written per sample and
 // level, and it sits at the floor of that traffic.  The only bytes left to remove are the baseline's round trip between two
-// levels.  Here a wavefront keeps its 512-sample tile IN REGISTERS through all levels: level 0 reads the caller's signal
-// (the fused level-0 front end of k_extract), every level stores its rotation row (and the baseline row only if the caller
-// asked for the reference's `baselines` buffer), and the next level starts from the baseline still held in the registers:
+// levels.  Here a wavefront keeps its tile IN REGISTERS through all levels: level 0 reads the caller's signal (the fused
+// level-0 front end of k_extract), every level stores its rotation row (and the baseline row only if the caller asked for the
+// reference's `baselines` buffer), and the next level starts from the baseline still held in the registers:
 // 4 + 8 (L + 1) bytes per sample for L + 1 rows instead of 20 + 24 L.
 //
 // What a tile needs from its neighbours at level j — the two knots in front of it, the three behind it, the two samples
@@ -13,16 +15,19 @@
 //   * work is handed out by tickets (one returning atomic per tile), per XCD in chunks of 256 consecutive tiles, so a
 //     wavefront only ever waits for tiles whose tickets were drawn before or shortly after its own: running wavefronts
 //     hold a sliding window of the tile sequence, no co-residency of the whole grid is assumed;
-//   * a tile publishes the record of its new baseline as sixteen 8-byte {tag, dword} granules, each ONE agent-scope
-//     (sc1, write-through) store, and its knot count as one more; readers re-load granules with agent-scope (sc1) loads
-//     until every tag matches — the data is the flag, no fence and no ordering between stores is needed
-//     (cdna_hip_programming.md, Guideline 16, form R2).  The tag is the call's generation number, kept in device memory
-//     and advanced by the init kernel (replay-safe); every level has granule arrays of its own, so nothing is overwritten
-//     while a slower neighbour may still need it;
-//   * every spin is bounded (wall clock + a launch-wide give-up word): a tile whose halo knots lie beyond kChainWindows
-//     x 64 tiles, or a spin that outlasts its limit, sets ChainCtl::give_up, every wavefront leaves, and the engine repeats
-//     the call level by level (itd_get_summary), as it does when the stop rule `num_extrema < 2` (ITD.py:404) fires inside
-//     the requested levels: the chain runs all levels optimistically and k_chain_finalize checks the totals afterwards.
+//   * a tile publishes the record of its new baseline as sixteen 8-byte {tag, dword} granules, each ONE store, and its knot
+//     count as one more; readers re-load granules with agent-scope (sc1) loads until every tag matches — the data is the
+//     flag, no fence and no ordering between stores is needed (cdna_hip_programming.md, Guideline 16, form R2).  The tag is
+//     the call's generation number, kept in device memory and advanced by the init kernel (replay-safe); every level has
+//     granule arrays of its own, so nothing is overwritten while a slower neighbour may still need it; every array exists
+//     in a same-XCD (L2) and a write-through copy (gran_store2);
+//   * a wavefront holds two tiles: a level is attempted (one round of polls) and either runs to completion or leaves the tile
+//     untouched, and the wavefront turns to its other tile instead of spinning;
+//   * every wait is bounded (wall clock + a launch-wide give-up word): a tile whose halo knots lie beyond kChainWindows
+//     x 64 tiles, or a wavefront that cannot move for ITD_CHAIN_SPIN_US, sets ChainCtl::give_up, every wavefront leaves, and
+//     the engine repeats the call level by level (itd_get_summary), as it does when the stop rule `num_extrema < 2`
+//     (ITD.py:404) fires inside the requested levels: the chain runs all levels optimistically and k_chain_finalize checks
+//     the totals afterwards.
 // Arithmetic, association order, NaN rules: the code of k_extract, unchanged.
 #pragma once
 #include "itd_kernels.hpp"
@@ -58,12 +63,14 @@ struct ChainCtl {
 #define ITD_CHAIN_SPARSE 6       // a tile with fewer knots than this polls the count windows together with the four records
 #endif
 #ifndef ITD_CHAIN_ABL
-#define ITD_CHAIN_ABL 0          // timing-only ablations (results are wrong): 1 no rotation-row stores, 2 granules are taken as
-                                 // published whatever their tag (no waiting for the neighbours)
+#define ITD_CHAIN_ABL 0          // diagnostics: 1 no rotation-row stores (timing only, results wrong), 2 granules are taken as
+                                 // published whatever their tag (timing only), 4 every read from the write-through copy B
 #endif
 #ifndef ITD_CHAIN_CTX
 #define ITD_CHAIN_CTX 2          // tile contexts per wavefront (1: a wavefront spins on its one tile)
 #endif
+// ISA markers for tools/isa_regions.py (comments in the assembly; no instructions)
+#define CHAIN_MARK(n) asm volatile("; CHAIN_MARK " #n)
 #ifndef ITD_CHAIN_PROF
 #define ITD_CHAIN_PROF 0
 #endif
@@ -141,11 +148,6 @@ __device__ __forceinline__ bool chain_spin(ChainSpin &sp, ChainCtl *ctl)
     return true;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Nearest non-empty tiles of this level in direction DIR from tile t, enough of them to hold `need` knots (2 in front,
-// 3 behind): u[k] / c[k] = tile and knot count, in walking order.  Polls the tiles' count granules window by window; a
-// window is usable up to its first tile that has not published yet.  Returns the number of tiles found (the signal's end
-// may come first), or -1 to give up.
 // ---------------------------------------------------------------------------------------------
 // One 64-tile count window (lane l holds the count granule of tile base + DIR * l, out-of-range tiles as published and empty):
 // adds the window's non-empty tiles, nearest first, to the candidates until they hold `need` knots.  A window is usable up to
@@ -247,6 +249,7 @@ __device__ __forceinline__ int chain_publish(int lane, const double (&xr)[TW / 1
         gcount[g] = __popcll(E) + __popcll(O);
         total += gcount[g];
     }
+    CHAIN_MARK(31);
     if (lane == 0) {
         if (total) atomicAdd(gsum_slot, total);
         if (!count_only) gran_store2(cnt_g, copy, gen, (unsigned)total);
@@ -278,6 +281,7 @@ __device__ __forceinline__ int chain_publish(int lane, const double (&xr)[TW / 1
             gbase += gcount[g];
         }
     }
+    CHAIN_MARK(32);
     wave_sync();
     if (lane == 0) lrec->packed = rec_pack(total, s_pos[0], s_pos[1], s_pos[2], s_pos[3], s_pos[4]);
     wave_sync();
@@ -518,6 +522,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
         } else {
             // ---- level j >= 1: the input is the baseline in the registers, its knots the flag words chain_publish left; the
             //      neighbours' records of this level arrive as granules ------------------------------------------------------
+            CHAIN_MARK(10);
             own_c = own_total;
             const int64_t lv0 = (int64_t)level * lv_tiles + sig * n_tiles;   // this level's granules of the signal's tile 0
             const unsigned long long *cg = cntg + lv0;          // copy A; copy B = + gran_copy (records: 16 gran_copy)
@@ -537,7 +542,6 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
             // two 64-tile count windows are polled together with those four records, one round trip instead of two.
             const bool sparse = own_total < ITD_CHAIN_SPARSE;
             {
-                {
                     const unsigned long long g = inr ? gran_load(rg_of(uspec) + w16, gen) : ((unsigned long long)gen << 32);
                     unsigned long long gb = (unsigned long long)gen << 32, gf = gb;
                     if (sparse) {
@@ -593,8 +597,8 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                         ready = ok_b && ok_f;
                     }
                     if (!ready) return 0;
-                }
             }
+            CHAIN_MARK(11);
             s_rb[q4][w16] = specw;
             if (walk_b) {
                 ub0 = ub1 = ubx = -1; cb0 = cb1 = cbx = 0;
@@ -640,6 +644,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                 e2 = bits_d((unsigned)__builtin_amdgcn_readlane(lo, 4), (unsigned)__builtin_amdgcn_readlane(lo, 5));
                 e3 = bits_d((unsigned)__builtin_amdgcn_readlane(lo, 6), (unsigned)__builtin_amdgcn_readlane(lo, 7));
             }
+            CHAIN_MARK(12);
             wave_sync();
             if (lane < 5) {
                 int sl, sh, vw;
@@ -673,6 +678,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
             }
             if (lane < 2) s_bl[lane] = 0.0;
             wave_sync();
+            CHAIN_MARK(13);
             if (own_c > 0) {
                 int gbase = 0;
 #pragma unroll
@@ -690,6 +696,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                 for (int g = 0; g < G2; ++g) kinfo[g] = 0;
             }
         }
+        CHAIN_MARK(14);
         CHAIN_T(pt_front);
         CHAIN_ACC(level == 0 ? 2 : 3, pt_front - pt_lv0);   // whole front end of level 0 / of a later level
 #if ITD_CHAIN_PROF
@@ -727,6 +734,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                 }
             }
             const int nfp = min(3, (c - rb - m) + nf);
+            CHAIN_MARK(20);
             if (c > 0) {
 #pragma unroll
                 for (int g = 0; g < G2; ++g) {
@@ -758,6 +766,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                 }
             }
             wave_sync();
+            CHAIN_MARK(21);
             if (g1 < G2 && lane < 2) { s_hX[5 + lane] = s_X[m + lane]; s_hI[5 + lane] = s_gi[m + lane]; }
             // ---- knot values, ITD.py:100-110 ----
             for (int L = 1 + lane; L <= m + 3; L += kWave) {
@@ -773,6 +782,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                 s_B[L] = Bv;
             }
             wave_sync();
+            CHAIN_MARK(22);
             // ---- per-segment slope, ITD.py:115-116 ----
             for (int L = 1 + lane; L <= m + 2; L += kWave) {
                 const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
@@ -780,6 +790,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                 if (!endn) s_S[L] = sl;
             }
             wave_sync();
+            CHAIN_MARK(23);
             // ---- baseline at the two samples next to the tile (lane 0) ----
             if (lane == 0) {
                 if (g0 == 0 && t >= 1) {
@@ -792,6 +803,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                     s_bl[1] = s_B[L] + s_S[L] * (xhi - s_X[L]);
                 }
             }
+            CHAIN_MARK(24);
             // ---- baseline map + rotation, ITD.py:114-119; the baseline replaces the input in the registers ----
 #pragma unroll
             for (int g = 0; g < G2; ++g) {
@@ -840,6 +852,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
             g0 = g1;
             wave_sync();
         }
+        CHAIN_MARK(25);
         CHAIN_T(pt_map);
         CHAIN_ACC(4, pt_map - pt_front);   // passes + map + stores issued
         // ---- knots of the baseline just produced = the next level's input; the reference's NaN rules first where they apply ----
@@ -857,6 +870,7 @@ __global__ __launch_bounds__(kWave) void k_chain(const Tin *__restrict__ xin, in
                                           gsum + (int64_t)(level + 1) * gsum_level_pitch + grp, s_rec, s_pos, own);
         }
         wave_sync();
+        CHAIN_MARK(33);
         CHAIN_T(pt_pub);
         CHAIN_ACC(5, pt_pub - pt_map);   // scan + publish
     }

@@ -811,6 +811,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *base, in
     const int64_t lim = bytes_left < 0 ? 0 : (bytes_left > 0x7fffffffll ? 0x7fffffffll : bytes_left);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)lim, 0x00020000);
 }
+// the same with 32-bit arithmetic: `elems` elements of `elem_bytes` bytes (<= 0 elements: an empty descriptor, loads read 0)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc32(const void *base, int elems, unsigned elem_bytes)
+{
+    const unsigned e = elems < 0 ? 0u : (unsigned)elems;
+    const unsigned lim = e > 0x7fffffffu / elem_bytes ? 0x7fffffffu : e * elem_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)lim, 0x00020000);
+}
 template <bool NT>
 __device__ __forceinline__ void tile_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff, double &a, double &b)
 {
@@ -988,12 +995,12 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         const int lane = lane_id();
         if constexpr (FUSE0) {
             if (t < n_tiles) {
-                const int64_t s = (int64_t)t * TW;
+                const int si = t * TW, rem = (int)n - si;   // 32-bit: see the note at `si` below
                 // halo groups through descriptors of their own: an empty one (extent 0) reads zeros, so tile 0 / the last
                 // tiles need no branch
-                const __amdgpu_buffer_rsrc_t rl = tile_rsrc(x + (s >= 128 ? s - 128 : 0), s >= 128 ? 128 * (int64_t)sizeof(Tin) : 0);
-                const __amdgpu_buffer_rsrc_t rh = tile_rsrc(x + (s + TW < n ? s + TW : 0), s + TW < n ? (n - s - TW) * (int64_t)sizeof(Tin) : 0);
-                const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x + s, (n - s) * (int64_t)sizeof(Tin));
+                const __amdgpu_buffer_rsrc_t rl = tile_rsrc32(x + (si >= 128 ? si - 128 : 0), si >= 128 ? 128 : 0, sizeof(Tin));
+                const __amdgpu_buffer_rsrc_t rh = tile_rsrc32(x + (rem > TW ? si + TW : 0), rem > TW ? rem - TW : 0, sizeof(Tin));
+                const __amdgpu_buffer_rsrc_t rx = tile_rsrc32(x + si, rem, sizeof(Tin));
                 tile_load2<false>(rl, lane * 2 * (int)sizeof(Tin), 0, pre[k].hq[0][0], pre[k].hq[0][1]);
 #pragma unroll
                 for (int g = 0; g < G2; ++g)
@@ -1011,8 +1018,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             const int uspec = q4 == 0 ? t - 1 : q4 == 1 ? t + 1 : q4 == 2 ? t - 2 : t + 2;
             pre[k].specw = 0;
             if (uspec >= 0 && uspec < n_tiles && !(ITD_ABL_R & (2 | 32768))) pre[k].specw = reinterpret_cast<const int32_t *>(recs + uspec)[w16];
-            const int64_t s = (int64_t)t * TW;
-            const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x + s, (n - s) * (int64_t)sizeof(Tin));
+            const int si = t * TW;
+            const __amdgpu_buffer_rsrc_t rx = tile_rsrc32(x + si, (int)n - si, sizeof(Tin));
 #pragma unroll
             for (int g = 0; g < G2; ++g)
                 tile_load2<(ITD_NT & 4) != 0>(rx, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), pre[k].q[g][0], pre[k].q[g][1]);
@@ -1059,7 +1066,12 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int lane = lane_v;
     const int q4 = lane >> 4, w16 = lane & 15;
     const int64_t s = (int64_t)t * TW;
-    const bool full = (s + TW <= n);
+    // Sample arithmetic in 32 bits (n < 2^31 - 1: itd_engine.hip check_args), relative to the tile where it could overflow:
+    // gfx9 has no scalar 64-bit ordered compare, so an int64 `<` on these wave-uniform values becomes a vector compare, its
+    // result a lane mask, and everything that depends on it exec-masked vector code
+    const int ni = (int)n, si = t * TW;
+    const int rem = ni - si;            // samples of the signal from the tile's first on (>= 1)
+    const bool full = rem >= TW;
     int nb = 0, nf = 0, own_c = 0;   // real knots found in front (0..2) / behind (0..3); the tile's own knots
     // the tile's own knots, decoded once: kinfo[g] = ke | bitE << 16 | bitO << 17 with ke = knots of the tile at or before the
     // lane's even sample of group g; gcnt = the groups' knot counts, 8 bits each
@@ -1131,7 +1143,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 sh = 11 + 10 * j;
                 vw = kRecDwHval + 2 * j;
             }
-            int32_t idx = lane < 2 ? 0 : (int32_t)(n - 1);
+            int32_t idx = lane < 2 ? 0 : ni - 1;
             double val = lane < 2 ? e0 : e3;
             if (real) {
                 const unsigned long long pk = ((unsigned long long)(unsigned)s_rb[sl][1] << 32) | (unsigned)s_rb[sl][0];
@@ -1214,7 +1226,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
         // window = [s-128, s+TW+128): positions allowed to flag are the signal's 1 .. n-2 (ITD.py:70-73)
         unsigned long long E[G2 + 2], O[G2 + 2];
-        knot_masks<Tin, G2 + 2>(v, (int)max((int64_t)1, 129 - s), (int)min((int64_t)(TW + 255), n - 2 - s + 128), E, O);
+        knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O);
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
             const int bE = lane_bit(E[g + 1]), bO = lane_bit(O[g + 1]);
@@ -1230,7 +1242,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         nf = min(cR, 3);
         if (lane < 5) {   // defaults: the end knots e[0] = 0, e[m+1] = n-1 (ITD.py:96,98)
             s_hX[lane] = lane < 2 ? e0 : e3;
-            s_hI[lane] = lane < 2 ? 0 : (int32_t)(n - 1);
+            s_hI[lane] = lane < 2 ? 0 : ni - 1;
         }
         if (lane < 2) s_bl[lane] = 0.0;
         // the samples next to the tile, where the record-driven launch keeps them (s_rb[0] / s_rb[1] edge fields)
@@ -1241,7 +1253,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             const int bE = lane_bit(E[0]), bO = lane_bit(O[0]);
             const int re = mbcnt64(O[0], mbcnt64(E[0], 0));   // knots of the group before the even sample
             const int se = re - cL + 2, so = re + bE - cL + 2;
-            const int32_t pe = (int32_t)s - 128 + 2 * lane;
+            const int32_t pe = si - 128 + 2 * lane;
             if (bE && se >= 0) { s_hX[se] = (double)v[0][0]; s_hI[se] = pe; }
             if (bO && so >= 0) { s_hX[so] = (double)v[0][1]; s_hI[so] = pe + 1; }
         }
@@ -1249,25 +1261,26 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             const int bE = lane_bit(E[G2 + 1]), bO = lane_bit(O[G2 + 1]);
             const int re = mbcnt64(O[G2 + 1], mbcnt64(E[G2 + 1], 0));
             const int ro_ = re + bE;
-            const int32_t pe = (int32_t)s + TW + 2 * lane;
+            const int32_t pe = si + TW + 2 * lane;
             if (bE && re < 3) { s_hX[2 + re] = (double)v[G2 + 1][0]; s_hI[2 + re] = pe; }
             if (bO && ro_ < 3) { s_hX[2 + ro_] = (double)v[G2 + 1][1]; s_hI[2 + ro_] = pe + 1; }
         }
         wave_sync();
         // ---- a halo group with too few knots (smooth stretches): walk on through the signal.  Windows of 512 samples that
         //      overlap by two, so every position is an inner position of some window; wave-uniform, rare for noisy input ----
-        int64_t ql = s - 128;                  // front: first position not yet evaluated (everything above it is)
-        int64_t qr = s + TW + 127;             // rear: last position not yet evaluated
+        int ql = si - 128;                     // front: first position not yet evaluated (everything above it is)
+        unsigned qr = (unsigned)si + TW + 127; // rear: last position not yet evaluated (unsigned: may pass 2^31 at the far end)
+        const unsigned n1 = (unsigned)ni - 1u;
         bool fail = false;
-        if ((nb < 2 && ql > 0) || (nf < 3 && qr < n - 1)) {
+        if ((nb < 2 && ql > 0) || (nf < 3 && qr < n1)) {
             Tin w[4][2];
             unsigned long long WE[4], WO[4];
             for (int step = 0; nb < 2 && ql > 0 && step < kReach; ++step) {
-                const int64_t p0 = ql > 510 ? ql - 510 : 0;                 // window [p0, p0+512): inner positions p0+1 .. p0+510
-                const __amdgpu_buffer_rsrc_t rw = tile_rsrc(x + p0, (n - p0) * (int64_t)sizeof(Tin));
+                const int p0 = ql > 510 ? ql - 510 : 0;                     // window [p0, p0+512): inner positions p0+1 .. p0+510
+                const __amdgpu_buffer_rsrc_t rw = tile_rsrc32(x + p0, ni - p0, sizeof(Tin));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) tile_load2<false>(rw, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), w[g][0], w[g][1]);
-                knot_masks<Tin, 4>(w, (int)max((int64_t)1, 1 - p0), (int)(ql - p0), WE, WO);
+                knot_masks<Tin, 4>(w, max(1, 1 - p0), ql - p0, WE, WO);
                 for (int g = 3; g >= 0 && nb < 2; --g) {                     // nearest first: from the top
                     unsigned long long Eg = WE[g], Og = WO[g];
                     while ((Eg | Og) && nb < 2) {
@@ -1285,12 +1298,12 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 }
                 ql = p0;
             }
-            for (int step = 0; nf < 3 && qr < n - 1 && step < kReach; ++step) {
-                const int64_t p0 = qr - 1;                                   // inner positions qr .. qr+509
-                const __amdgpu_buffer_rsrc_t rw = tile_rsrc(x + p0, (n - p0) * (int64_t)sizeof(Tin));
+            for (int step = 0; nf < 3 && qr < n1 && step < kReach; ++step) {
+                const int p0 = (int)(qr - 1u);                               // inner positions qr .. qr+509 (p0 < n - 1: fits)
+                const __amdgpu_buffer_rsrc_t rw = tile_rsrc32(x + p0, ni - p0, sizeof(Tin));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) tile_load2<false>(rw, lane * 2 * (int)sizeof(Tin), g * 128 * (int)sizeof(Tin), w[g][0], w[g][1]);
-                knot_masks<Tin, 4>(w, 1, (int)min((int64_t)510, n - 2 - p0), WE, WO);
+                knot_masks<Tin, 4>(w, 1, min(510, ni - 2 - p0), WE, WO);
                 for (int g = 0; g < 4 && nf < 3; ++g) {
                     unsigned long long Eg = WE[g], Og = WO[g];
                     while ((Eg | Og) && nf < 3) {
@@ -1308,7 +1321,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 }
                 qr += 510;
             }
-            fail = (nb < 2 && ql > 0) || (nf < 3 && qr < n - 1);
+            fail = (nb < 2 && ql > 0) || (nf < 3 && qr < n1);
             wave_sync();
         }
         if (fail && lane == 0) atomicOr(&st->l0_fail, 1);   // the engine repeats level 0 through k_scan0 + the record-driven launch
@@ -1324,12 +1337,12 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int c = (ITD_ABL_R & 2048) ? 0 : own_c;
     double *rot_t = rot_out + (int64_t)sig * rot_stride + s;
     double *bas_t = FINAL ? nullptr : base_out + (int64_t)sig * base_stride + s;
-    const __amdgpu_buffer_rsrc_t r_rot = tile_rsrc(rot_t, (n - s) * 8);
-    const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc(FINAL ? rot_t : bas_t, FINAL ? 0 : (n - s) * 8);
-    const bool tail_tile = (s + TW >= n);   // holds sample n-1 (or runs past it)
-    const bool near_end = (s + TW >= n - 2);
-    const bool interior = full && !near_end && s != 0;   // no end-of-signal rule applies to any sample of the tile
-    const int nrem = (int)min((int64_t)(n - s), (int64_t)(TW + 2));   // samples of the signal from s on, clipped: p < nrem <=> s + p < n
+    const __amdgpu_buffer_rsrc_t r_rot = tile_rsrc32(rot_t, rem, 8);
+    const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc32(FINAL ? rot_t : bas_t, FINAL ? 0 : rem, 8);
+    const bool tail_tile = rem <= TW;       // holds sample n-1 (or runs past it)
+    const bool near_end = rem <= TW + 2;    // holds sample n-2 or later
+    const bool interior = full && !near_end && t != 0;   // no end-of-signal rule applies to any sample of the tile
+    const int nrem = min(rem, TW + 2);      // samples of the signal from s on, clipped: p < nrem <=> s + p < n
     bool odd_vals = false, own_nan = false;   // wave-uniform: the new baseline tile holds a NaN or an infinity / a NaN
     // s_hX[5], s_hX[6] / s_hI[5], s_hI[6]: the previous run's last two knots; s_bl[0], s_bl[1]: baseline at samples s-1, s+TW
 
@@ -1365,11 +1378,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 const int Lo = Le + bO;              // slot of the odd sample's knot: rank ke+bO-1
                 if (bE && (unsigned)(Le - 2) < (unsigned)(m + 3)) {
                     s_X[Le] = xr[g][0];
-                    s_gi[Le] = (int32_t)s + p;
+                    s_gi[Le] = si + p;
                 }
                 if (bO && (unsigned)(Lo - 2) < (unsigned)(m + 3)) {
                     s_X[Lo] = xr[g][1];
-                    s_gi[Lo] = (int32_t)s + p + 1;
+                    s_gi[Lo] = si + p + 1;
                 }
             }
         }
@@ -1413,13 +1426,12 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
       }
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
-            if (g0 == 0 && s >= 1) {   // sample s-1 = the last sample of tile t-1
+            if (g0 == 0 && t >= 1) {   // sample s-1 = the last sample of tile t-1
                 const double xlo = bits_d((unsigned)s_rb[0][kRecDwEdge + 2], (unsigned)s_rb[0][kRecDwEdge + 3]);
                 s_bl[0] = s_B[1] + s_S[1] * (xlo - s_X[1]);
             }
-            const int64_t i = s + TW;
-            if (g1 == G2 && i < n - 1) {
-                const int L = (nf >= 1 && s_hI[2] == (int32_t)i) ? m + 2 : 1 + m;   // sample s+TW is itself a knot
+            if (g1 == G2 && rem > TW + 1) {   // sample s+TW exists and is not the signal's last
+                const int L = (nf >= 1 && s_hI[2] == si + TW) ? m + 2 : 1 + m;   // sample s+TW is itself a knot
                 const double xhi = bits_d((unsigned)s_rb[1][kRecDwEdge], (unsigned)s_rb[1][kRecDwEdge + 1]);   // first sample of tile t+1
                 s_bl[1] = s_B[L] + s_S[L] * (xhi - s_X[L]);
             }
@@ -1483,8 +1495,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                     so = bo != bo ? inf : bo;
                 }
                 if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, se, so);
-                if (!FINAL && (near_end || s == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples (of the mutated array), ITD.py:101-102
-                    if (s == 0 && p == 0) { ends_next[0] = se; ends_next[1] = so; }
+                if (!FINAL && (near_end || t == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples (of the mutated array), ITD.py:101-102
+                    if (t == 0 && p == 0) { ends_next[0] = se; ends_next[1] = so; }
                     if (p == nrem - 2) { ends_next[2] = se; ends_next[3] = so; }
                     if (p + 1 == nrem - 2) ends_next[2] = so;
                     if (p == nrem - 1) ends_next[3] = se;
