@@ -166,6 +166,14 @@ int itd_decompose_host_f32(itd_engine *e, const float *x_host, int64_t n, int32_
                            double *rows_host, double *baselines_host, int32_t *n_rows, int32_t *n_baselines,
                            int32_t *stop_reason, int64_t *knot_counts);
 
+/* The reference keeps the baselines of the last run on the instance (ITD.py:413-414,423-424) but most callers only look at
+ * the returned rows: with itd_set_host_keep_baselines(e, 1) a host-form call with baselines_host == NULL still computes the
+ * baselines buffer and leaves it on the device (half the PCIe traffic of the call); itd_get_last_baselines_host copies its
+ * first n_baselines rows ([n_baselines][n] float64; n and n_baselines as the call reported them) out later — until the next
+ * host-form call on this engine, after which it returns ITD_ERR_NOT_RUN. */
+int itd_set_host_keep_baselines(itd_engine *e, int32_t enable);
+int itd_get_last_baselines_host(itd_engine *e, double *baselines_host, int64_t n, int32_t n_baselines);
+
 /* ---- single-level operators ---------------------------------------------------------------------
  * itd_baseline_extract (ITD.py:79-121): rotation/baseline of ONE extraction of a device signal.
  * knots_dev (optional, capacity n int32) receives the interior knot indices, *m_host their count. */

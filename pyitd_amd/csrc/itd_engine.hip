@@ -114,6 +114,8 @@ struct itd_engine {
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
     double *d_io_bases = nullptr; size_t io_bases_bytes = 0;
+    bool host_keep_bases = false;      // itd_set_host_keep_baselines: host-form calls leave their baselines in d_io_bases
+    int64_t kept_n = 0; int32_t kept_nb = -1;   // what itd_get_last_baselines_host can still deliver (-1: nothing)
     // last run
     bool ran = false;
     int32_t last_batch = 0, last_m = 0;
@@ -702,6 +704,26 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode)
     return ITD_OK;
 }
 
+int itd_set_host_keep_baselines(itd_engine *e, int32_t enable)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    e->host_keep_bases = enable != 0;
+    if (!enable) e->kept_nb = -1;
+    return ITD_OK;
+}
+
+int itd_get_last_baselines_host(itd_engine *e, double *baselines_host, int64_t n, int32_t n_baselines)
+{
+    if (!e || (!baselines_host && n_baselines > 0)) return ITD_ERR_INVALID_ARG;
+    if (e->kept_nb < 0) return ITD_ERR_NOT_RUN;
+    if (n != e->kept_n || n_baselines != e->kept_nb) return ITD_ERR_INVALID_ARG;
+    if (n_baselines == 0) return ITD_OK;
+    DevGuard g(e->device);
+    HIP_TRY(e, hipMemcpyAsync(baselines_host, e->d_io_bases, (size_t)n_baselines * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->own_stream));
+    HIP_TRY(e, hipStreamSynchronize(e->own_stream));
+    return ITD_OK;
+}
+
 int itd_set_chain_mode(itd_engine *e, int32_t mode)
 {
     if (!e || mode < ITD_CHAIN_AUTO || mode > ITD_CHAIN_ONLY) return ITD_ERR_INVALID_ARG;
@@ -754,13 +776,15 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
     if (rc) return rc;
     rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, R * (size_t)n * sizeof(double));
     if (rc) return rc;
-    if (bases_host) {
+    const bool dev_bases = bases_host || e->host_keep_bases;
+    e->kept_nb = -1;
+    if (dev_bases) {
         rc = grow(e, &e->d_io_bases, &e->io_bases_bytes, R * (size_t)n * sizeof(double));
         if (rc) return rc;
     }
     hipStream_t st = e->own_stream;
     HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(Tin), hipMemcpyHostToDevice, st));
-    rc = enqueue_any<Tin>(e, (const Tin *)e->d_io_x, n, 1, n, M, e->d_io_rows, bases_host ? e->d_io_bases : nullptr, st);
+    rc = enqueue_any<Tin>(e, (const Tin *)e->d_io_x, n, 1, n, M, e->d_io_rows, dev_bases ? e->d_io_bases : nullptr, st);
     if (rc) return rc;
     int32_t nr = 0, nb = 0, why = 0, nanlv = -1;
     int64_t kc[ITD_MAX_ROWS + 1];
@@ -774,6 +798,7 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
     if (n_baselines) *n_baselines = nb;
     if (stop_reason) *stop_reason = why;
     if (knot_counts) memcpy(knot_counts, kc, sizeof(kc));
+    if (dev_bases && nanlv == -1) { e->kept_n = n; e->kept_nb = nb; }
     return nanlv != -1 ? ITD_ERR_NONFINITE : ITD_OK;
 }
 

@@ -118,20 +118,33 @@ class Engine:
 
     # ---- numpy in -> numpy out ----------------------------------------------------------------
     def decompose_host(self, x, max_iteration, want_baselines=True):
+        """want_baselines: True = copy them back now; False = none; "lazy" = leave them on the device: the result carries
+        `n_baselines` and `fetch_baselines()`, valid until this engine's next host-form decomposition."""
         x = np.ascontiguousarray(x)
         if x.dtype != np.float32:
             x = np.ascontiguousarray(x, dtype=np.float64)
         n = x.shape[0]
         R = max_iteration + 2
         rows = np.empty((R, n), np.float64)
-        bases = np.zeros((R, n), np.float64) if want_baselines else None
+        lazy = want_baselines == "lazy"
+        self._check(self._L.itd_set_host_keep_baselines(self._h, 1 if lazy else 0))
+        bases = np.zeros((R, n), np.float64) if (want_baselines and not lazy) else None
         n_rows, n_b, stop = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
         kc = np.zeros(MAX_ROWS + 1, np.int64)
         f = self._L.itd_decompose_host_f32 if x.dtype == np.float32 else self._L.itd_decompose_host_f64
         rc = self._check(f(self._h, _np_ptr(x), n, max_iteration, _np_ptr(rows), _np_ptr(bases), ctypes.byref(n_rows),
                            ctypes.byref(n_b), ctypes.byref(stop), _np_ptr(kc)), allow=(ITD_ERR_NONFINITE,))
         out = {"rows": rows[: n_rows.value], "stop": stop.value, "knot_counts": kc, "nonfinite": rc == ITD_ERR_NONFINITE}
-        if want_baselines:
+        if lazy:
+            nb = n_b.value
+            out["n_baselines"] = nb
+
+            def fetch_baselines():
+                b = np.zeros((nb, n), np.float64)
+                self._check(self._L.itd_get_last_baselines_host(self._h, _np_ptr(b), n, nb))
+                return b
+            out["fetch_baselines"] = fetch_baselines
+        elif want_baselines:
             out["baselines"] = bases[: n_b.value]
         return out
 

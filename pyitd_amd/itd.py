@@ -15,6 +15,16 @@ from . import _lib
 from .engine import DETECT_KNOTS, DETECT_PEAKS, DETECT_VALLEYS, STOP_TIMEOUT, Engine
 
 _engines = {}
+_pending = None    # weak reference to the ITD instance whose baselines are still on the device (at most one per process)
+
+
+def _flush_pending():
+    """Bring the baselines of the last ITD().itd() call to the host before their device buffer is reused or freed."""
+    global _pending
+    inst = _pending() if _pending is not None else None
+    _pending = None
+    if inst is not None:
+        inst._fetch_baselines()
 
 
 _MAX_N = 2 ** 31 - 2     # the ABI's limit: int32 knot indices
@@ -29,6 +39,7 @@ def _engine_for(n, device=0):
         cap = 1 << max(12, int(n - 1).bit_length()) if eng is None else max(n, eng.max_n + eng.max_n // 2)
         cap = n if cap > _MAX_N else cap
         if eng is not None:
+            _flush_pending()
             eng.close()
         eng = Engine(cap, 1, device)
         _engines[key] = eng
@@ -36,6 +47,16 @@ def _engine_for(n, device=0):
 
 
 _batch_engines = {}
+_pending = None    # weak reference to the ITD instance whose baselines are still on the device (at most one per process)
+
+
+def _flush_pending():
+    """Bring the baselines of the last ITD().itd() call to the host before their device buffer is reused or freed."""
+    global _pending
+    inst = _pending() if _pending is not None else None
+    _pending = None
+    if inst is not None:
+        inst._fetch_baselines()
 
 
 def _batch_engine_for(n, batch, device=0):
@@ -53,6 +74,7 @@ def _batch_engine_for(n, batch, device=0):
 
 def release_engines():
     """Free every cached engine (their HBM workspaces)."""
+    _flush_pending()
     for cache in (_engines, _batch_engines):
         for eng in cache.values():
             eng.close()
@@ -129,7 +151,8 @@ class ITD:
         self.DTYPE = numpy.float64
         self.device = device
         self.rotations = None
-        self.baselines = None
+        self._baselines = None
+        self._fetch = None          # the last run's baselines are still on the device: fetched when first asked for
         self.knot_counts = None
         self.stop_reason = None
 
@@ -148,7 +171,9 @@ class ITD:
             # counter > max_iteration holds at once: the first pending pair is summed (ITD.py:418-422)
             raise ValueError("max_iteration must be >= 0")
         m = min(int(max_iteration), _lib.MAX_ITERATION)
-        res = _engine_for(n, self.device).decompose_host(x, m, want_baselines=True)
+        self._fetch = None          # this instance's previous baselines are being replaced: nothing to bring home
+        _flush_pending()            # another instance's may still sit in the engine's staging buffer: fetch those first
+        res = _engine_for(n, self.device).decompose_host(x, m, want_baselines="lazy")
         if res["nonfinite"]:
             # the reference would run detect_peaks' NaN branch on the INPUT and write +inf into the caller's array
             # (ITD.py:46-51); this build only follows NaNs that arise inside the decomposition
@@ -157,10 +182,34 @@ class ITD:
             # the reference's buffers hold 22 rows (ITD.py:384-385): row 22 does not exist
             raise IndexError("index 22 is out of bounds for axis 0 with size 22")
         self.rotations = res["rows"]
-        self.baselines = res["baselines"]
+        # the reference stores the baselines on the instance (ITD.py:413-414,423-424); here they stay on the GPU until somebody
+        # asks (`baselines`, get_baselines()) or the engine's staging buffer is needed again — half the PCIe traffic of a call
+        self._baselines = None
+        self._fetch = res["fetch_baselines"]
+        global _pending
+        import weakref
+        _pending = weakref.ref(self)
         self.knot_counts = res["knot_counts"]
         self.stop_reason = "timeout" if res["stop"] == STOP_TIMEOUT else "natural"
         return self.rotations
+
+    def _fetch_baselines(self):
+        if self._fetch is not None:
+            f, self._fetch = self._fetch, None
+            self._baselines = f()
+
+    @property
+    def baselines(self):
+        self._fetch_baselines()
+        return self._baselines
+
+    @baselines.setter
+    def baselines(self, value):
+        self._fetch = None
+        self._baselines = value
+
+    def __del__(self):
+        self._fetch = None
 
     def get_baselines(self):
         if self.baselines is None:

@@ -275,3 +275,31 @@ def test_knots_on_tile_boundaries(P, oracle, case):
             assert dec.stop_reason == ref["stop"] and rows.shape[0] == ref["rows"].shape[0]
             assert_bits_equal(rows, ref["rows"], "%s %s m=%d" % (case, np.dtype(dtype).name, m))
             assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
+
+
+def test_baselines_stay_on_the_device_until_asked_for(P, oracle):
+    """ITD.itd leaves the baselines on the GPU (half the PCIe traffic of a call); `baselines` / get_baselines() fetch them, and
+    nothing that reuses or frees the engine's staging buffer in between may lose them (ITD.py:413-414: the reference keeps them
+    on the instance)."""
+    rng = np.random.default_rng(77)
+    xa, xb = rng.standard_normal(5000), rng.standard_normal(7001).astype(np.float32)
+    ra, rb = oracle.itd(xa, 4), oracle.itd(xb, 6)
+    a, b = P.ITD(), P.ITD()
+    a.itd(xa, 4)
+    b.itd(xb, 6)                                    # a's baselines must have been brought home before b's run
+    assert_bits_equal(a.get_baselines(), ra["baselines"], "first instance, after a second one ran")
+    assert_bits_equal(b.baselines, rb["baselines"], "second instance, attribute form")
+    a.itd(xa, 4)
+    P.itd_baseline_extract(rng.standard_normal(300000))   # grows (replaces) the cached engine
+    assert_bits_equal(a.get_baselines(), ra["baselines"], "after the engine was replaced")
+    a.itd(xa, 4)
+    P.release_engines()
+    assert_bits_equal(a.get_baselines(), ra["baselines"], "after release_engines()")
+    c = P.ITD()
+    c.itd(xb, 6)
+    del c                                           # an instance that never asked: nothing to fetch, nothing to leak
+    a.itd(xa, 4)
+    assert_bits_equal(a.get_baselines(), ra["baselines"], "plain use")
+    a.baselines = None
+    with pytest.raises(ValueError):
+        a.get_baselines()
