@@ -10,11 +10,11 @@
 //   k_cubic_knots   knot values K[k] (:61-83) and spacings h[k] (:85-86), one thread per knot;
 //   k_cubic_rhs     u, the right-hand side b0 and the pivots d[i] = 2 - u[i] * v[i-1] (:88-96; d does not depend on the sweep);
 //   affine scans    the forward sweep  b[i] = (b0[i] - u[i] b[i-1]) / d[i]  (:93-98) and the back substitution
-//                   b[i] = b[i] - v[i] b[i+1]  (:100-101) are first-order linear recurrences: every thread composes the
-//                   affine map of its 16-element chunk, the maps are combined across the workgroup and across workgroups
-//                   (three launches: reduce, scan of the workgroup aggregates, apply), and each thread then re-evaluates its
-//                   chunk from its carry-in WITH THE REFERENCE'S OWN FORMULA — only the carry-ins see a different
-//                   association (|C| < 1: the composed maps contract);
+//                   b[i] = b[i] - v[i] b[i+1]  (:100-101) are first-order linear recurrences y -> a_i + c_i y: the maps are
+//                   composed in order by wave scans inside a workgroup and across workgroups (three launches: reduce, scan of
+//                   the workgroup aggregates, apply); every element is its inclusive map applied to the carry-in, so the
+//                   association differs from the reference's serial loop (|c_i| < 1: the composed maps contract, rounding
+//                   differences do not grow);
 //   k_cubic_eval    one wavefront per 512 samples: segment of each sample from a bitmap of the tile's knots (the j_lookup
 //                   loop, :107-111, is "number of knots e[1..idx-1] at or before the sample"), then the spline formula
 //                   (:113-120) with t*t*t where the reference has numpy's float64 ** 3 (libm pow; numba multiplies).
@@ -85,81 +85,91 @@ struct Recur {
         const double vi = (i == 0) ? 0.0 : 1 - u[i];
         return Affine{b0_or_bf[i], -vi};
     }
-    __device__ __forceinline__ double step(int64_t q, double prev) const   // the reference's own formula
-    {
-        const int64_t i = knot(q);
-        if (FWD) { double b = b0_or_bf[i] - u[i] * prev; return b / d[i]; }   // :95,98
-        const double vi = (i == 0) ? 0.0 : 1 - u[i];
-        return b0_or_bf[i] - vi * prev;                                      // :101
-    }
 };
 
-// workgroup-wide exclusive scan of the threads' chunk maps (identity where a thread has no elements); returns the map of
-// everything in the workgroup in front of the calling thread and, through `total`, the workgroup's aggregate
-__device__ __forceinline__ Affine block_exclusive(Affine mine, Affine *s_wave /* kScanThreads/64 */, Affine *total)
+// The scans run over consecutive elements in COALESCED rounds: a workgroup owns kScanBlockElems consecutive elements and walks
+// them in rounds of kScanThreads (thread t takes element round * kScanThreads + t: lane-contiguous loads and stores; the first
+// version gave every thread 16 consecutive elements, i.e. a 128-byte stride between lanes — every load instruction touched 64
+// cache lines and the launches ran at a twentieth of the memory rate).  Inside a round the maps are combined by an ordered
+// wave scan (shuffles), the four waves through LDS, the rounds through a running carry.
+__device__ __forceinline__ Affine wave_inclusive(Affine inc, int lane)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    Affine inc = mine;   // inclusive scan inside the wavefront
 #pragma unroll
     for (int dlt = 1; dlt < 64; dlt <<= 1) {
         const double pa = __shfl_up(inc.a, dlt), pc = __shfl_up(inc.c, dlt);
         if (lane >= dlt) inc = compose(inc, Affine{pa, pc});
     }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    Affine pre{0.0, 1.0};
-    for (int w = 0; w < wave; ++w) pre = compose(s_wave[w], pre);
-    Affine tot = pre;
-    for (int w = wave; w < kScanThreads / 64; ++w) tot = compose(s_wave[w], tot);
-    *total = tot;
-    // exclusive = everything in front of this thread: the waves in front, then the lanes in front
-    const double ea = __shfl_up(inc.a, 1), ec = __shfl_up(inc.c, 1);
-    Affine ex = lane == 0 ? Affine{0.0, 1.0} : Affine{ea, ec};
-    return compose(ex, pre);
+    return inc;
 }
 
+// reduce: the composed map of the workgroup's elements, in order
 template <bool FWD>
 __global__ __launch_bounds__(kScanThreads) void k_recur_reduce(Recur<FWD> r, int64_t count, Affine *__restrict__ block_maps)
 {
     __shared__ Affine s_wave[kScanThreads / 64];
-    const int64_t q0 = ((int64_t)blockIdx.x * kScanThreads + threadIdx.x) * kScanChunk;
-    Affine m{0.0, 1.0};
-    for (int k = 0; k < kScanChunk; ++k)
-        if (q0 + k < count) m = compose(r.map(q0 + k), m);
-    Affine tot;
-    (void)block_exclusive(m, s_wave, &tot);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kScanBlockElems;
+    Affine tot{0.0, 1.0};   // thread 0's copy is the one that counts
+    for (int round = 0; round < kScanChunk; ++round) {
+        const int64_t q = base + (int64_t)round * kScanThreads + threadIdx.x;
+        const Affine m = q < count ? r.map(q) : Affine{0.0, 1.0};
+        const Affine inc = wave_inclusive(m, lane);
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 0; w < kScanThreads / 64; ++w) tot = compose(s_wave[w], tot);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) block_maps[blockIdx.x] = tot;
 }
 
-// carry-in of every workgroup: y in front of its first element (one workgroup; the aggregates are few)
-__global__ void k_recur_carries(const Affine *__restrict__ block_maps, int n_blocks, const double *__restrict__ y_init /* nullptr: 0 */,
-                                double *__restrict__ carry)
+// carry-in of every workgroup: y in front of its first element.  One wavefront: lane l composes its run of consecutive
+// workgroup maps, the runs are scanned across the lanes, and every lane then walks its run from its own carry-in.
+__global__ __launch_bounds__(64) void k_recur_carries(const Affine *__restrict__ block_maps, int n_blocks,
+                                                      const double *__restrict__ y_init /* nullptr: 0 */, double *__restrict__ carry)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    double y = y_init ? *y_init : 0.0;
-    for (int b = 0; b < n_blocks; ++b) {
+    const int lane = threadIdx.x;
+    const int per = (n_blocks + 63) / 64;
+    const int b0 = lane * per, b1 = min(n_blocks, b0 + per);
+    Affine m{0.0, 1.0};
+    for (int b = b0; b < b1; ++b) m = compose(block_maps[b], m);
+    const Affine inc = wave_inclusive(m, lane);
+    const double ea = __shfl_up(inc.a, 1), ec = __shfl_up(inc.c, 1);
+    const Affine ex = lane == 0 ? Affine{0.0, 1.0} : Affine{ea, ec};
+    double y = ex.a + ex.c * (y_init ? *y_init : 0.0);
+    for (int b = b0; b < b1; ++b) {
         carry[b] = y;
         y = block_maps[b].a + block_maps[b].c * y;
     }
 }
 
+// apply: every element from the running carry through the inclusive maps of its round
 template <bool FWD>
 __global__ __launch_bounds__(kScanThreads) void k_recur_apply(Recur<FWD> r, int64_t count, const double *__restrict__ carry,
                                                                double *__restrict__ out)
 {
     __shared__ Affine s_wave[kScanThreads / 64];
-    const int64_t q0 = ((int64_t)blockIdx.x * kScanThreads + threadIdx.x) * kScanChunk;
-    Affine m{0.0, 1.0};
-    for (int k = 0; k < kScanChunk; ++k)
-        if (q0 + k < count) m = compose(r.map(q0 + k), m);
-    Affine tot;
-    const Affine ex = block_exclusive(m, s_wave, &tot);
-    double y = ex.a + ex.c * carry[blockIdx.x];
-    for (int k = 0; k < kScanChunk; ++k)
-        if (q0 + k < count) {
-            y = r.step(q0 + k, y);
-            out[r.knot(q0 + k)] = y;
-        }
+    __shared__ double s_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kScanBlockElems;
+    double y_in = carry[blockIdx.x];      // y in front of the round's first element
+    for (int round = 0; round < kScanChunk; ++round) {
+        const int64_t q = base + (int64_t)round * kScanThreads + threadIdx.x;
+        const Affine m = q < count ? r.map(q) : Affine{0.0, 1.0};
+        const Affine inc = wave_inclusive(m, lane);
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        Affine pre{0.0, 1.0};             // the waves of this round in front of mine
+        for (int w = 0; w < wave; ++w) pre = compose(s_wave[w], pre);
+        const double y_wave = pre.a + pre.c * y_in;          // y in front of my wave
+        const double y = inc.a + inc.c * y_wave;
+        if (q < count) out[r.knot(q)] = y;
+        if (threadIdx.x == kScanThreads - 1) s_y = y;       // the round's last element (identity maps carry it on)
+        __syncthreads();
+        y_in = s_y;
+    }
 }
 
 // b[0] = 0, b[idx-1] = 0 (:104-105), b[idx] = 0 (never written by the reference: zeros)

@@ -814,8 +814,9 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
     k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_hcounts,
                                               e->d_hrecs, e->d_hgsum, e->d_hstate);
     if (compact)
+        // (the second half of the helpers' count buffer receives every tile's knot base: the instantaneous-frequency step uses it)
         k_compact<T><<<grid_t, blk, 0, st>>>(e->d_lists, e->d_hcounts, e->d_hgsum, n_tiles, n, e->d_kidx, e->max_n + 2,
-                                              e->d_total, e->d_hstate, tail_value);
+                                              e->d_total, e->d_hstate, tail_value, e->d_hcounts + e->max_tiles);
     HIP_TRY(e, hipGetLastError());
     return ITD_OK;
 }
@@ -1357,9 +1358,11 @@ int itd_instantaneous_f64(itd_engine *e, const double *rot_dev, int64_t n, doubl
     if (rc) return rc;
     unsigned long long *amp_bits = (unsigned long long *)e->d_cub;
     HIP_TRY(e, hipMemsetAsync(amp_bits, 0, (size_t)(m + 1) * sizeof(unsigned long long), st));
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    k_tfe_amplitude<<<blocks, 256, 0, st>>>(rot_dev, n, e->d_kidx + 1, m, amp_bits);
-    k_tfe_phase<<<blocks, 256, 0, st>>>(rot_dev, n, e->d_kidx + 1, m, amp_bits, amp_dev, phase_dev, freq_dev);
+    static_assert(kTfeTile == T, "k_compact's per-tile bases are per T samples");
+    const unsigned blocks = (unsigned)tiles_of(n);
+    const int32_t *tile_base = e->d_hcounts + e->max_tiles;   // crossings in front of every tile (k_compact)
+    k_tfe_amplitude<<<blocks, 64, 0, st>>>(rot_dev, n, tile_base, amp_bits);
+    k_tfe_phase<<<blocks, 64, 0, st>>>(rot_dev, n, tile_base, amp_bits, amp_dev, phase_dev, freq_dev);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipStreamSynchronize(st));
     return ITD_OK;

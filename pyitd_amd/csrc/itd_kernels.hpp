@@ -445,7 +445,8 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
                                                    const int32_t *__restrict__ gsum_in, int n_tiles, int64_t n,
                                                    int32_t *__restrict__ kidx, int64_t kidx_stride,
                                                    int32_t *__restrict__ total_out, const SigState *__restrict__ state,
-                                                   int64_t tail_value /* e[m+1]; < 0: n-1 (ITD.py:98) */)
+                                                   int64_t tail_value /* e[m+1]; < 0: n-1 (ITD.py:98) */,
+                                                   int32_t *__restrict__ tile_base_out = nullptr /* optional [n_tiles]: knots in front of each tile */)
 {
     const int sig = blockIdx.y;
     const int t = blockIdx.x;
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     const int base = acc;
+    if (tile_base_out && lane == 0) tile_base_out[(size_t)sig * n_tiles + t] = base;
     int32_t *e = kidx + (size_t)sig * kidx_stride;
     const int32_t *src = lists + ((size_t)sig * n_tiles + t) * TW;
     for (int j = lane; j < c; j += kWave) e[1 + base + j] = src[j];
