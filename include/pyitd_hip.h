@@ -43,7 +43,7 @@ typedef enum itd_status {
     ITD_ERR_HIP = 3,           /* a HIP runtime call failed: see itd_last_error() */
     ITD_ERR_NOMEM = 4,         /* device or host allocation failed */
     ITD_ERR_NOT_RUN = 5,       /* results requested before a decomposition was enqueued */
-    ITD_ERR_NONFINITE = 6      /* the input signal contains a NaN, or a baseline went NaN while the NaN fallback was off */
+    ITD_ERR_NONFINITE = 6      /* the input signal contains a NaN and the operator / the engine's mode rejects such input */
 } itd_status;
 
 /* stop reasons of the level loop */
@@ -102,14 +102,26 @@ int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t bat
  *   knot_counts  [batch][ITD_MAX_ROWS+1]  knot_counts[j] = interior knots of the input of extraction j+1
  *                (j = 0: the signal itself; j >= 1: the number the reference prints at ITD.py:403);
  *                entries past the last evaluated level are -1
- *   nan_levels   [batch]      -1 = results follow the reference; -2 = the input signal itself contains a NaN
- *                (rejected, rows undefined)
+ *   nan_levels   [batch]      -1 = results follow the reference; -2 = the input signal itself contains a NaN and the engine
+ *                was told to reject such input (itd_set_nan_input_mode: rows undefined)
  * NaNs that arise inside a decomposition are followed exactly: a baseline acquires NaNs when the signal starts with a
  * plateau (ITD.py:115-116 divides by x[e_1]-x[0] = 0); the reference's stop test then counts knots under detect_peaks'
  * NaN rules (ITD.py:46-51,64-68) and overwrites NaN with +inf in place (ITD.py:50).  Since ABI revision 2 the extraction
  * kernel applies these rules itself, tile by tile, in the same launch (no re-run, no extra pass over the signal). */
 int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
                     int64_t *knot_counts, int32_t *nan_levels);
+/* NaN in the INPUT.  The reference runs it through detect_peaks' NaN branch at level 0 — NaN differences count as +inf, NaN
+ * samples and their neighbours cannot be peaks — and overwrites the NaNs of the caller's array with +inf (ITD.py:46-51, 64-68;
+ * there is no copy at ITD.py:41, 82, 389); everything after that sees the mutated array.
+ *   ITD_NAN_INPUT_FOLLOW (default)  the decomposition found a NaN in a signal: itd_get_summary repeats the call with a level 0
+ *                                   that follows those rules on a mutated float64 copy of the signal (inside the engine: x_dev is
+ *                                   never written); rows / baselines / knot counts are the reference's, bit for bit.  As with the
+ *                                   other repeats x_dev / rows_dev / baselines_dev must stay valid until itd_get_summary.
+ *   ITD_NAN_INPUT_REJECT            ABI revision 2's behaviour: nan_levels = -2, host forms return ITD_ERR_NONFINITE.
+ * The single-level operators (itd_detect_*, itd_baseline_extract_*, ...) always reject NaN input (ITD_ERR_NONFINITE). */
+#define ITD_NAN_INPUT_FOLLOW 0
+#define ITD_NAN_INPUT_REJECT 1
+int itd_set_nan_input_mode(itd_engine *e, int32_t mode);
 /* ABI revision 1 switched a NaN-faithful re-run on and off here; kept as a no-op (always faithful now) */
 int itd_set_nan_fallback(itd_engine *e, int enable);
 /* Level 0 of a decomposition (the caller's signal) finds its knots in one of two ways:

@@ -362,6 +362,24 @@ def main():
     case("edge_denormal", rng.standard_normal(512) * 1e-310, 5)
     case("edge_large", rng.standard_normal(512) * 1e300, 5)
     case("edge_int_valued", rng.integers(-3, 4, 4000).astype(np.float64), 9)
+    # (6b) NaN in the INPUT: detect_peaks' NaN branch at level 0 and the in-place NaN -> +inf mutation (ITD.py:46-51, 64-68);
+    #      a generator of their own, so that the cases above keep their draws
+    rng_n = np.random.default_rng(987)
+
+    def with_nan(x, at):
+        x = np.array(x, copy=True)
+        x[at] = np.nan
+        return x
+
+    base = np.sin(np.arange(3000) / 7.0) + 0.3 * rng_n.standard_normal(3000)
+    case("nanin_mid", with_nan(base[:1500], [700]), 5)
+    case("nanin_first_sample", with_nan(base[:600], [0]), 5)
+    case("nanin_second_sample", with_nan(base[:600], [1]), 5)
+    case("nanin_last_sample", with_nan(base[:600], [599]), 5)
+    case("nanin_tile_edges", with_nan(base, [5, 6, 300, 510, 511, 512, 1023, 1025, 1536, 2047, 2048]), 6)
+    case("nanin_run", with_nan(base[:2000], list(range(1000, 1010))), 4)
+    case("nanin_f32", with_nan(base[:2500].astype(np.float32), [3, 1234, 1235, 2400]), 7)
+    case("nanin_with_inf", with_nan(np.where(np.arange(1200) == 400, np.inf, base[:1200]), [800]), 4)
 
     # (7) cubic-spline baseline variant with externally supplied knots: the reference's
     #     itd_baseline_extract_fast fed (a) by its own find_extrema on synthetic sines, as itd_sine_wrapper does

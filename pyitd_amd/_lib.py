@@ -51,6 +51,7 @@ ABI = {
     "itd_instantaneous_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P]),
     "itd_instantaneous_host_f64": (_INT, [_P, _P, _I64, _P, _P, _P]),
     "itd_set_nan_fallback": (_INT, [_P, _INT]),
+    "itd_set_nan_input_mode": (_INT, [_P, _I32]),
     "itd_set_batch_chunk": (_INT, [_P, _I32]),
     "itd_set_level0_mode": (_INT, [_P, _I32]),
     "itd_set_host_keep_baselines": (_INT, [_P, _I32]),

@@ -37,7 +37,7 @@ constexpr int64_t kSlotPad = ITD_SLOT_PAD;   // elements (multiple of 2 keeps th
 static_assert(T % 128 == 0 && T / 64 <= kMaxGroups, "tile geometry: whole 8/16-byte loads per lane, <= 8 flag words per record");
 
 // per-signal state + the (padded) group sums of all three rotating buffers, one launch
-__global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsum_elems)
+__global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsum_elems, int keep_in_nan = 0)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < gsum_elems; i += (int64_t)gridDim.x * blockDim.x)
         gsum[i] = 0;
@@ -46,7 +46,7 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
     for (int j = 0; j < kMaxLevels; ++j) { st[b].m[j] = -1; st[b].c_delta[j] = 0; }
     st[b].stop_level = -1;
     st[b].nan_mask = 0;
-    st[b].in_nan = 0;
+    if (!keep_in_nan) st[b].in_nan = 0;   // the NaN-input repeat needs to know which signals hold one (k_nan_level0)
     st[b].l0_fail = 0;
     st[b].fin_stopped = 0;
     st[b].fin_stop_level = -1;
@@ -127,6 +127,8 @@ struct itd_engine {
     double *last_rows = nullptr, *last_bases = nullptr;
     bool last_fused = false;
     bool last_chain = false;
+    bool last_nan_input = false;       // the last run was the NaN-input repeat (k_nan_level0): its results follow the reference
+    int32_t nan_input_mode = ITD_NAN_INPUT_FOLLOW;   // itd_set_nan_input_mode
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;   // event pairs: [2k] start, [2k+1] stop
@@ -197,8 +199,12 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 
 template <typename Tin>
 int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M,
-                      double *rows, double *bases_user, hipStream_t st, bool fuse0)
+                      double *rows, double *bases_user, hipStream_t st, bool fuse0, bool nan_input = false)
 {
+    // nan_input: the caller's signal holds a NaN (found by the previous, rejected run of this call): level 0 the way the
+    // reference runs it — k_nan_level0 writes the mutated signal (NaN -> +inf, ITD.py:50) into the third baseline slot, which
+    // nothing touches before level 2, and the level-0 records; the record-driven level-0 extraction then reads that copy
+    if (nan_input) fuse0 = false;
     const int n_tiles = (int)tiles_of(n);
     const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
@@ -213,7 +219,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         // only the part of each buffer this batch/size uses needs clearing, but the buffers are small: clear all
         const int64_t ge = 3 * e->gsum_third;
         const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
-        k_init_state<<<gb, 256, 0, st>>>(e->d_state, batch, e->d_gsum, ge);
+        k_init_state<<<gb, 256, 0, st>>>(e->d_state, batch, e->d_gsum, ge, nan_input ? 1 : 0);
     }
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
@@ -230,7 +236,11 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *rows_c = rows + (int64_t)b0 * rows_stride;
         double *bases_c = bases_user ? bases_user + (int64_t)b0 * rows_stride : nullptr;
         double *pp_c = e->d_pp + (int64_t)b0 * 3 * e->pp_pitch;
-        if (!fuse0) {
+        double *xm_c = pp_c + 2 * e->pp_pitch;   // NaN-input repeat: the mutated signal, one per signal at the slots' stride
+        if (nan_input) {
+            k_nan_level0<Tin, T><<<dim3(n_tiles, nb), blk, 0, st>>>(xc, x_stride, n, n_tiles, xm_c, 3 * e->pp_pitch, cnt(0), rec(0),
+                                                                    gs(0), state);
+        } else if (!fuse0) {
             const int pair = time_slot(e, ITD_TIME_SCAN0);
             const Tin *a_x = xc; int64_t a_xs = x_stride, a_n = n; int a_nt = n_tiles;
             int32_t *a_c = cnt(0), *a_g = gs(0); TileRec *a_r = rec(0); SigState *a_st = state;
@@ -275,7 +285,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
     } while (0)
             if (j == 0) {   // never the last level: M >= 0
-                if (fuse0) ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, true);
+                if (nan_input) ITD_LAUNCH_EXTRACT(double, false, xm_c, 3 * e->pp_pitch, kRankCap0, false);
+                else if (fuse0) ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, true);
                 else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, false);
             } else {
                 if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap, false);
@@ -308,6 +319,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_bases = bases_user;
     e->last_fused = fuse0;
     e->last_chain = false;
+    e->last_nan_input = nan_input;
     return ITD_OK;
 }
 
@@ -408,6 +420,7 @@ int enqueue_chain(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t
     e->last_bases = bases_user;
     e->last_fused = false;
     e->last_chain = true;
+    e->last_nan_input = false;
     return ITD_OK;
 }
 
@@ -479,7 +492,7 @@ const char *itd_status_string(int s)
         case ITD_ERR_HIP: return "HIP runtime error";
         case ITD_ERR_NOMEM: return "out of memory";
         case ITD_ERR_NOT_RUN: return "no decomposition has been run";
-        case ITD_ERR_NONFINITE: return "non-finite values in a baseline";
+        case ITD_ERR_NONFINITE: return "NaN in the input (rejected by this operator / mode)";
         default: return "unknown status";
     }
 }
@@ -613,6 +626,26 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     if (e->last_chain)
         HIP_TRY(e, hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(ChainCtl), hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    auto any_nan_input = [&]() {
+        for (int b = 0; b < B; ++b) if (e->h_state[b].in_nan) return true;
+        return false;
+    };
+    auto repeat = [&](bool f0, bool nan_in) {   // the same call again, level by level
+        const int rc = e->last_x_f32
+            ? enqueue_decompose<float>(e, (const float *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0, nan_in)
+            : enqueue_decompose<double>(e, (const double *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0, nan_in);
+        if (rc) return rc;
+        HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+        HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+        return (int)ITD_OK;
+    };
+    if (!e->last_nan_input && e->nan_input_mode == ITD_NAN_INPUT_FOLLOW && any_nan_input()) {
+        // A signal of the call holds a NaN.  The reference runs such input through detect_peaks' NaN branch and overwrites the
+        // NaNs with +inf (ITD.py:46-51, 64-68); the launches so far evaluated plain rules.  Repeat the call with the level 0
+        // that follows the reference (k_nan_level0); SigState::in_nan stays set and tells it which signals are concerned.
+        const int rc = repeat(false, true);
+        if (rc) return rc;
+    } else
     if (e->last_chain) {
         // the one-launch chain is optimistic: it ran every requested level.  If the stop rule fired inside them (chain_stop),
         // a tile's halo knots lay beyond its walk / a spin outlasted its limit (give_up), or level 0 fell short of its reach
@@ -683,7 +716,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         if (stop_reason) stop_reason[b] = why;
         if (knot_counts)
             for (int j = 0; j <= ITD_MAX_ROWS; ++j) knot_counts[(size_t)b * (ITD_MAX_ROWS + 1) + j] = s.m[j];
-        if (nan_levels) nan_levels[b] = s.in_nan ? -2 : -1;
+        if (nan_levels) nan_levels[b] = (s.in_nan && !e->last_nan_input) ? -2 : -1;
     }
     return ITD_OK;
 }
@@ -701,6 +734,13 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode)
     if (!e || mode < ITD_LEVEL0_AUTO || mode > ITD_LEVEL0_FUSED) return ITD_ERR_INVALID_ARG;
     e->l0_mode = mode;
     e->l0_records_left = 0;
+    return ITD_OK;
+}
+
+int itd_set_nan_input_mode(itd_engine *e, int32_t mode)
+{
+    if (!e || (mode != ITD_NAN_INPUT_FOLLOW && mode != ITD_NAN_INPUT_REJECT)) return ITD_ERR_INVALID_ARG;
+    e->nan_input_mode = mode;
     return ITD_OK;
 }
 

@@ -310,6 +310,10 @@ __device__ __forceinline__ int scan_flags(Tile<TW> tile, int64_t s, int64_t n, i
     return total;
 }
 
+template <int TW>
+__device__ __forceinline__ int record_from_masks(Tile<TW> tile, int64_t s, const WaveMasks &wm, int total,
+                                                 int32_t *__restrict__ list, TileRec *__restrict__ rec, int32_t *rec_lds);
+
 // producer side (LDS tile: level-0 scan, NaN-faithful path, API helpers): the tile's record for the next launch and
 // (optionally) its ordered knot list.  The first three / last two knots are found with scalar bit scans of the
 // wave-uniform flag words, merging the even and odd word of each 128-sample group in sample order.
@@ -318,11 +322,19 @@ __device__ __forceinline__ int detect_tile(Tile<TW> tile, int64_t s, int64_t n, 
                                            int32_t *__restrict__ list, TileRec *__restrict__ rec,
                                            int32_t *rec_lds /* sizeof(TileRec) bytes of wave-private LDS, 16-byte aligned */)
 {
+    WaveMasks wm;
+    const int total = scan_flags<TW>(tile, s, n, mode, wm);
+    return record_from_masks<TW>(tile, s, wm, total, list, rec, rec_lds);
+}
+
+// the record (and optional ordered list) of a tile whose knot flag words are known (lane g holds word g)
+template <int TW>
+__device__ __forceinline__ int record_from_masks(Tile<TW> tile, int64_t s, const WaveMasks &wm, int total,
+                                                 int32_t *__restrict__ list, TileRec *__restrict__ rec, int32_t *rec_lds)
+{
     constexpr int G = TW / 64;
     static_assert(G <= kMaxGroups, "tile too wide for the record's flag words");
     const int lane = lane_id();
-    WaveMasks wm;
-    const int total = scan_flags<TW>(tile, s, n, mode, wm);
     int h0 = 0, h1 = 0, h2 = 0, t0 = 0, t1 = 0;
     if (total > 0) {
         int k = 0;
@@ -429,6 +441,79 @@ __global__ __launch_bounds__(kWave) void k_detect(const Tin *__restrict__ x, int
     const size_t slot = (size_t)sig * n_tiles + t;
     const int total = detect_tile<TW>(tile, s, n, mode, lists ? lists + slot * TW : nullptr, recs + slot, s_rec);
     if (lane_id() == 0) {
+        counts[slot] = total;
+        if (total) atomicAdd(&gsum_out[((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch], total);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_nan_level0: level 0 of a decomposition whose INPUT holds a NaN, the way the reference runs it (ITD.py:87-88 on top of
+// :44-68): idx_max = detect_peaks(x) takes the NaN branch — differences that are NaN count as +inf, NaN samples and their two
+// neighbours cannot be peaks, and x is overwritten in place, NaN -> +inf (:46-51, :64-68); idx_min = detect_peaks(-x) then sees a
+// NaN-free array (plain rules on the mutated values), and so does everything after it.  This launch writes the mutated signal
+// (float64) to `xm`, and the level-0 counts / records / group sums / end samples of the knot set
+//     valleys under the NaN rules on the original values  U  peaks under the plain rules on the mutated values;
+// the record-driven level-0 extraction then runs on `xm`.  The rules apply per signal, only if that signal holds a NaN
+// (SigState::in_nan, kept from the run that found it): a signal without one gets the plain knot set.  Rare path: LDS tile,
+// one wavefront per tile, like k_detect.
+// ---------------------------------------------------------------------------------------------
+template <typename Tin, int TW>
+__global__ __launch_bounds__(kWave) void k_nan_level0(const Tin *__restrict__ x, int64_t x_stride, int64_t n, int n_tiles,
+                                                      double *__restrict__ xm, int64_t xm_stride, int32_t *__restrict__ counts,
+                                                      TileRec *__restrict__ recs, int32_t *__restrict__ gsum_out,
+                                                      SigState *__restrict__ state)
+{
+    constexpr int G = TW / 64;
+    __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
+    __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
+    const int t = blockIdx.x, sig = blockIdx.y, lane = lane_id();
+    const int64_t s = (int64_t)t * TW;
+    const Tin *xs = x + (int64_t)sig * x_stride;
+    Tile<TW> tile{s_x};
+    TileRegs<Tin, TW> regs;
+    tile_fetch<Tin, TW>(regs, xs, n, s);
+    tile_commit<Tin, TW>(regs, xs, n, s, tile);
+    wave_sync();
+    const bool sig_nan = state[sig].in_nan != 0;
+    const double inf = __builtin_huge_val();
+    const bool edge = (s == 0) || (s + TW >= n - 1);
+    // valleys of the original values (detect_peaks(x), ITD.py:44-73)
+    WaveMasks vm;
+    int total = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const int pos = flag_pos(g, lane);
+        const double xa = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
+        double vil = xp - x0, vix = x0 - xa;
+        bool ok = true;
+        if (sig_nan) {
+            vil = vil != vil ? inf : vil;                         // :51
+            vix = vix != vix ? inf : vix;
+            ok = !(xa != xa || x0 != x0 || xp != xp);             // :64-68 (samples beyond the signal were staged as 0: never NaN)
+        }
+        bool f = (vil > 0.0) && (vix <= 0.0) && ok;               // :59
+        if (edge) f = f && (s + pos >= 1) && (s + pos <= n - 2);  // :70-73
+        vm.set(g, __ballot(f));
+    }
+    wave_sync();
+    // the mutation (:50), in the staged tile (its two halo samples included) and in the float64 copy the extraction reads
+    for (int k = lane - 1; k <= TW; k += kWave) {
+        double v = tile.at(k);
+        if (v != v) { v = inf; tile.at(k) = v; }
+        if (k >= 0 && k < TW && s + k < n) xm[(int64_t)sig * xm_stride + s + k] = v;
+    }
+    wave_sync();
+    if (s == 0 || s + TW >= n - 2) publish_ends<TW>(tile, s, n, state[sig].ends[0]);
+    // peaks of the mutated values (detect_peaks(-x): plain rules), merged with the valleys
+    WaveMasks wm;
+    (void)scan_flags<TW>(tile, s, n, (int)kPeaks, wm);
+    wm.lo |= vm.lo;
+    wm.hi |= vm.hi;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) total += __popcll(wm.get(g));
+    const size_t slot = (size_t)sig * n_tiles + t;
+    (void)record_from_masks<TW>(tile, s, wm, total, nullptr, recs + slot, s_rec);
+    if (lane == 0) {
         counts[slot] = total;
         if (total) atomicAdd(&gsum_out[((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch], total);
     }

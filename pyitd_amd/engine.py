@@ -18,6 +18,7 @@ ITD_OK, ITD_ERR_INVALID_ARG, ITD_ERR_NONFINITE = 0, 1, 6
 LEVEL0_AUTO, LEVEL0_RECORDS, LEVEL0_FUSED = 0, 1, 2
 TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0, TIME_CHAIN = 0, 1, 2, 3, 4, 5
 CHAIN_AUTO, CHAIN_OFF, CHAIN_ONLY = 0, 1, 2
+NAN_INPUT_FOLLOW, NAN_INPUT_REJECT = 0, 1
 
 
 def _np_ptr(a):
@@ -88,6 +89,10 @@ class Engine:
     def set_nan_fallback(self, on):
         """No-op since ABI revision 2 (the extraction kernel follows the reference's NaN rules itself)."""
         self._check(self._L.itd_set_nan_fallback(self._h, 1 if on else 0))
+
+    def set_nan_input_mode(self, mode):
+        """NAN_INPUT_FOLLOW (default: a NaN in the input is treated as the reference treats it, ITD.py:46-51) or NAN_INPUT_REJECT."""
+        self._check(self._L.itd_set_nan_input_mode(self._h, int(mode)))
 
     def set_level0_mode(self, mode):
         """LEVEL0_AUTO (fused level 0, record-driven repeat if the input is too smooth), LEVEL0_RECORDS, LEVEL0_FUSED."""

@@ -174,9 +174,7 @@ class ITD:
         self._fetch = None          # this instance's previous baselines are being replaced: nothing to bring home
         _flush_pending()            # another instance's may still sit in the engine's staging buffer: fetch those first
         res = _engine_for(n, self.device).decompose_host(x, m, want_baselines="lazy")
-        if res["nonfinite"]:
-            # the reference would run detect_peaks' NaN branch on the INPUT and write +inf into the caller's array
-            # (ITD.py:46-51); this build only follows NaNs that arise inside the decomposition
+        if res["nonfinite"]:    # only an engine switched to NAN_INPUT_REJECT gets here
             raise ValueError("the input signal contains NaN")
         if max_iteration > _lib.MAX_ITERATION and res["stop"] == STOP_TIMEOUT:
             # the reference's buffers hold 22 rows (ITD.py:384-385): row 22 does not exist

@@ -254,8 +254,7 @@ def test_single_level_helpers_reject_nan_input(P):
     for f in (P.detect_peaks, P.matlab_detect_peaks, P.detect_knots, P.itd_baseline_extract):
         with pytest.raises((ValueError, P.ITDError)):
             f(x)
-    with pytest.raises(ValueError):
-        P.ITD().itd(x)
+    assert P.ITD().itd(x, 3).shape[0] >= 1       # the decomposition itself follows the reference (test_nan_input_follows_the_reference)
 
 
 def test_stopped_signals_in_a_batch(P, torch, oracle):

@@ -53,16 +53,45 @@ def test_driver_matches_golden(P, name):
     assert kc[: len(want)] == want and len(kc) >= len(want)
 
 
-def test_nan_input_is_rejected(P):
-    x = np.sin(np.linspace(0, 30, 500))
-    x[100] = np.nan
-    with pytest.raises(ValueError):
-        P.ITD().itd(x, 3)
+def test_nan_input_follows_the_reference(P):
+    """NaN in the input: the reference runs detect_peaks' NaN branch at level 0 and overwrites the NaNs with +inf (ITD.py:46-51,
+    64-68); so does the engine, on a copy (the golden cases nanin_* pin that to the reference's own runs).  The caller's array is
+    not written.  An engine told to reject such input raises instead; the single-level operators always do."""
+    from oracle import cpu_oracle
+    from pyitd_amd.engine import Engine, NAN_INPUT_REJECT
+    rng = np.random.default_rng(3)
+    n = 70000                                   # many tiles; NaNs on and next to tile boundaries, at both ends, in a run
+    x = np.cumsum(rng.standard_normal(n)) * 0.05 + np.sin(np.arange(n) / 11.0)
+    for at in (0, 1, 511, 512, 513, 4095, 4096, 30000, 30001, 30002, n - 2, n - 1):
+        x[at] = np.nan
+    keep = x.copy()
+    ref = cpu_oracle.itd(x.copy(), 6)
+    d = P.ITD()
+    rows = d.itd(x, 6)
+    assert np.array_equal(np.isnan(x), np.isnan(keep)), "the caller's array must not be written"
+    assert_bits_equal(rows, ref["rows"], "NaN input rows")
+    assert_bits_equal(d.get_baselines(), ref["baselines"], "NaN input baselines")
+    kc = [int(v) for v in d.knot_counts if v >= 0]      # [0] = the signal's own knots; [j >= 1] = what the reference prints (ITD.py:403)
+    want = [int(v) for v in ref["knot_counts"]]
+    assert kc[1: 1 + len(want)] == want
+    # float32 input, and a batch in which only some signals hold a NaN
+    xs = np.stack([np.sin(np.arange(9000) / (5.0 + b)) + 0.2 * rng.standard_normal(9000) for b in range(6)]).astype(np.float32)
+    xs[1, 100] = np.nan
+    xs[4, [0, 8999]] = np.nan
+    out = P.itd_batch(xs, 5, keep_baselines=True)
+    for b in range(6):
+        r = cpu_oracle.itd(xs[b], 5)
+        assert_bits_equal(out["rows"][b, : out["n_rows"][b]], r["rows"], "batch signal %d" % b)
+        assert_bits_equal(out["baselines"][b, : out["n_baselines"][b]], r["baselines"], "batch signal %d baselines" % b)
+    eng = Engine(n, 1)
+    eng.set_nan_input_mode(NAN_INPUT_REJECT)
+    assert eng.decompose_host(x, 3)["nonfinite"]
+    eng.close()
+    with pytest.raises((ValueError, P.ITDError)):
+        P.detect_peaks(x)
     y = np.sin(np.linspace(0, 30, 500))
     y[200] = np.inf          # infinities follow the reference's plain rules (raw differences), then its NaN path
-    from oracle import cpu_oracle
     ref = cpu_oracle.itd(y, 4)
-    d = P.ITD()
     assert_bits_equal(d.itd(y, 4), ref["rows"], "inf input rows")
     assert_bits_equal(d.get_baselines(), ref["baselines"], "inf input baselines")
 

@@ -41,7 +41,7 @@ def test_oracle_is_clean_under_asan_and_ubsan():
         out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True,
                              timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
-        assert "clean 34" in out.stdout, out.stdout + out.stderr[-500:]
+        assert "clean 42" in out.stdout, out.stdout + out.stderr[-500:]
         assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-2000:]
     finally:
         p = os.path.join(ROOT, "oracle", "libitd_oracle_asan.so")
