@@ -118,7 +118,11 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
  *                                   never written); rows / baselines / knot counts are the reference's, bit for bit.  As with the
  *                                   other repeats x_dev / rows_dev / baselines_dev must stay valid until itd_get_summary.
  *   ITD_NAN_INPUT_REJECT            ABI revision 2's behaviour: nan_levels = -2, host forms return ITD_ERR_NONFINITE.
- * The single-level operators (itd_detect_*, itd_baseline_extract_*, ...) always reject NaN input (ITD_ERR_NONFINITE). */
+ * The reference's own single-level functions follow the same mode: itd_detect_* in the modes KNOTS / VALLEYS (detect_peaks) /
+ * PEAKS (matlab_detect_peaks: the NaN branch on the negated differences, numba_accelerated_itd.py:28-49) and
+ * itd_baseline_extract_* repeat their scan under the NaN rules when they find a NaN (the device forms only when they
+ * synchronise anyway, i.e. when m_host / count_host is given).  The cubic / spline / instantaneous operators, whose reference
+ * code has no NaN branch, reject NaN input (ITD_ERR_NONFINITE). */
 #define ITD_NAN_INPUT_FOLLOW 0
 #define ITD_NAN_INPUT_REJECT 1
 int itd_set_nan_input_mode(itd_engine *e, int32_t mode);
@@ -165,8 +169,7 @@ int itd_set_batch_chunk(itd_engine *e, int32_t signals_per_chunk);
 /* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
  * launch); to inspect them run itd_detect_* on the input or on a stored baseline row.  The single-level operators
  * below work in a workspace of their own: calling them between itd_decompose_* and itd_get_summary (on any stream)
- * does not disturb the decomposition.  They return ITD_ERR_NONFINITE for a signal that contains a NaN (the reference's
- * detect_peaks would take its NaN branch and write +inf into the caller's array, ITD.py:46-51). */
+ * does not disturb the decomposition.  A signal that contains a NaN: see itd_set_nan_input_mode. */
 
 /* ---- one-call host convenience (numpy in -> numpy out, what the reference's callers see) -------
  * Copies x to the GPU, decomposes, copies rows (and baselines if non-NULL) back.

@@ -381,6 +381,36 @@ def main():
     case("nanin_f32", with_nan(base[:2500].astype(np.float32), [3, 1234, 1235, 2400]), 7)
     case("nanin_with_inf", with_nan(np.where(np.arange(1200) == 400, np.inf, base[:1200]), [800]), 4)
 
+    # (6c) the single-level functions on NaN input: detect_peaks (ITD.py:33-76), matlab_detect_peaks
+    #      (numba_accelerated_itd.py:17-59: the NaN branch on the negated differences), itd_baseline_extract (ITD.py:79-121)
+    import importlib
+    sys.path.insert(0, args.ref)
+    try:
+        nai = importlib.import_module("numba_accelerated_itd")
+    finally:
+        sys.path.pop(0)
+    rng_h = np.random.default_rng(4711)
+    rec = {}
+    for c in range(12):
+        n = int(rng_h.integers(5, 2600)) if c else 1500
+        x = np.sin(np.arange(n) / 5.0) + 0.4 * rng_h.standard_normal(n)
+        at = rng_h.integers(0, n, int(rng_h.integers(1, 6)))
+        if c == 0:
+            at = np.array([0, 1, 511, 512, 513, 1023, 1024, 1498, 1499])
+        x[at] = np.nan
+        if c % 3 == 1:
+            x[int(at[0] + 2) % n] = np.inf
+        with np.errstate(all="ignore"):
+            rot, base = ns1["itd_baseline_extract"](x.copy())
+            rec["x_%d" % c] = x
+            rec["valleys_%d" % c] = np.asarray(ns1["detect_peaks"](x.copy()), dtype=np.int64)
+            rec["matlab_%d" % c] = np.asarray(nai.matlab_detect_peaks(x.copy()), dtype=np.int64)
+            rec["rot_%d" % c] = np.asarray(rot)
+            rec["base_%d" % c] = np.asarray(base)
+    rec["cases"] = np.int64(12)
+    np.savez_compressed(os.path.join(args.out, "helpers_nan_input.npz"), **rec)
+    print("helpers_nan_input       12 signals: detect_peaks / matlab_detect_peaks / itd_baseline_extract on NaN input")
+
     # (7) cubic-spline baseline variant with externally supplied knots: the reference's
     #     itd_baseline_extract_fast fed (a) by its own find_extrema on synthetic sines, as itd_sine_wrapper does
     #     (itd_fourier_decomposition.py:33-47), (b) by itd.cpp's knot predicate on the signal itself

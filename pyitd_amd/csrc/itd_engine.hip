@@ -274,12 +274,12 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 #define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE)                                                             \
     do {                                                                                                                   \
         const TIN *a_x = XIN; int64_t a_xs = XSTRIDE, a_n = n, a_rs = rows_stride, a_bs = base_stride;                     \
-        int a_nt = n_tiles, a_b = nb, a_lvl = j;                                                                           \
+        int a_nt = n_tiles, a_b = nb, a_lvl = j, a_keep = 0;                                                               \
         const int32_t *a_ci = cnt(j), *a_gi = gs(j); int32_t *a_co = cnt(j + 1), *a_go = gs(j + 1), *a_gc = gs(j + 2);      \
         const TileRec *a_ri = rec(j); TileRec *a_ro = rec(j + 1); double *a_rot = rot_out, *a_bas = base_out;              \
         SigState *a_st = state;                                                                                            \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
-                        &a_bas, &a_bs, &a_st, &a_lvl};                                                                     \
+                        &a_bas, &a_bs, &a_st, &a_lvl, &a_keep};                                                            \
         HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, kTilesPerWave, FUSE>), grid_x, \
                                       blk, args, 0, st, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                     \
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
@@ -843,14 +843,21 @@ int decompose_host(itd_engine *e, const Tin *x_host, int64_t n, int32_t M, doubl
 }
 
 // level-0 knot scan of one device signal into the workspace of batch slot 0; optional ordered list in d_kidx
+// nan_xm: the scanned signal holds a NaN (found by a first scan, SigState::in_nan kept): the knot set the reference's NaN
+// branch gives (k_nan_level0), and — if non-null — the mutated float64 copy of the signal
 template <typename Tin>
-int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, hipStream_t st, int64_t tail_value = -1)
+int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, hipStream_t st, int64_t tail_value = -1,
+                bool nan_follow = false, double *nan_xm = nullptr)
 {
     const int n_tiles = (int)tiles_of(n);
     const dim3 grid_t(n_tiles, 1), blk(kWave);
     // the helpers' own state, counts, records and group sums: a decomposition's workspace is never touched
     k_init_state<<<(unsigned)std::min<int64_t>((3 * e->hgsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_hstate, 1, e->d_hgsum,
-                                                                                                   3 * e->hgsum_third);
+                                                                                                   3 * e->hgsum_third, nan_follow ? 1 : 0);
+    if (nan_follow)
+        k_nan_level0<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, nan_xm, n, e->d_hcounts, e->d_hrecs, e->d_hgsum, e->d_hstate,
+                                                     mode, compact ? e->d_lists : nullptr);
+    else
     k_detect<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, mode, compact ? e->d_lists : nullptr, e->d_hcounts,
                                               e->d_hrecs, e->d_hgsum, e->d_hstate);
     if (compact)
@@ -863,18 +870,24 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
 
 // the knot total of the last helper scan; d_total[1] = the scanned signal held a NaN (the reference's detect_peaks would
 // take its NaN branch and write +inf into the caller's array: rejected, like NaN input of a decomposition)
-int fetch_total(itd_engine *e, hipStream_t st, int64_t *m_host)
+int fetch_total(itd_engine *e, hipStream_t st, int64_t *m_host, bool nan_is_error = true)
 {
     int32_t m32[2] = {0, 0};
     HIP_TRY(e, hipMemcpyAsync(m32, e->d_total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
     *m_host = m32[0];
-    return m32[1] ? ITD_ERR_NONFINITE : ITD_OK;
+    return (m32[1] && nan_is_error) ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
+// the three knot sets of the reference's own detect functions follow its NaN branch when the signal holds a NaN
+inline bool nan_follows(const itd_engine *e, int mode)
+{
+    return e->nan_input_mode == ITD_NAN_INPUT_FOLLOW && (mode == (int)kKnots || mode == (int)kValleys || mode == (int)kPeaks);
 }
 
 template <typename Tin>
 int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *base, int32_t *knots, int64_t *m_host,
-                hipStream_t st, bool want_sync)
+                hipStream_t st, bool want_sync, bool *took_nan_path = nullptr)
 {
     if (!e || !x || !rot || !base) return ITD_ERR_INVALID_ARG;
     if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
@@ -886,12 +899,30 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
     k_extract<Tin, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(x, n, n, n_tiles, 1, e->d_hcounts,
                                                       e->d_hcounts + e->max_tiles, e->d_hrecs, e->d_hrecs + e->max_tiles,
                                                       e->d_hgsum, e->d_hgsum + e->hgsum_third, e->d_hgsum + 2 * e->hgsum_third,
-                                                      rot, n, base, n, e->d_hstate, 0);
+                                                      rot, n, base, n, e->d_hstate, 0, 1);
     HIP_TRY(e, hipGetLastError());
     if (want_list) {
         int64_t m = 0;
-        rc = fetch_total(e, st, &m);
+        rc = fetch_total(e, st, &m, !nan_follows(e, (int)kKnots));
         if (rc) return rc;
+        int32_t has_nan = 0;
+        HIP_TRY(e, hipMemcpy(&has_nan, e->d_total + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (took_nan_path) *took_nan_path = has_nan != 0;
+        if (has_nan) {
+            // NaN in the signal: again, the way the reference runs it (ITD.py:87-88 over :46-51, 64-68): the mutated float64 copy
+            // goes into a staging buffer, the record-driven extraction reads that
+            rc = grow(e, &e->d_cub, &e->cub_bytes, (size_t)n * sizeof(double));
+            if (rc) return rc;
+            double *xm = e->d_cub;
+            rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st, -1, true, xm);
+            if (rc) return rc;
+            k_extract<double, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(
+                xm, n, n, n_tiles, 1, e->d_hcounts, e->d_hcounts + e->max_tiles, e->d_hrecs, e->d_hrecs + e->max_tiles, e->d_hgsum,
+                e->d_hgsum + e->hgsum_third, e->d_hgsum + 2 * e->hgsum_third, rot, n, base, n, e->d_hstate, 0, 1);
+            HIP_TRY(e, hipGetLastError());
+            rc = fetch_total(e, st, &m, false);
+            if (rc) return rc;
+        }
         if (m_host) *m_host = m;
         if (knots && m > 0) {
             HIP_TRY(e, hipMemcpyAsync(knots, e->d_kidx + 1, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToDevice, st));
@@ -909,8 +940,18 @@ int detect_dev(itd_engine *e, const Tin *x, int64_t n, int32_t mode, int32_t *id
     DevGuard g(e->device);
     int rc = scan_level0<Tin>(e, x, n, mode, true, st);
     if (rc) return rc;
-    rc = fetch_total(e, st, count);
+    rc = fetch_total(e, st, count, !nan_follows(e, mode));
     if (rc) return rc;
+    if (nan_follows(e, mode)) {
+        int32_t has_nan = 0;
+        HIP_TRY(e, hipMemcpy(&has_nan, e->d_total + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (has_nan) {   // the reference's NaN branch (ITD.py:46-51, 64-68; numba_accelerated_itd.py:28-49)
+            rc = scan_level0<Tin>(e, x, n, mode, true, st, -1, true, nullptr);
+            if (rc) return rc;
+            rc = fetch_total(e, st, count, false);
+            if (rc) return rc;
+        }
+    }
     if (idx && *count > 0) {
         HIP_TRY(e, hipMemcpyAsync(idx, e->d_kidx + 1, sizeof(int32_t) * (size_t)*count, hipMemcpyDeviceToDevice, st));
         HIP_TRY(e, hipStreamSynchronize(st));
@@ -969,7 +1010,8 @@ int itd_baseline_extract_host_f64(itd_engine *e, const double *x_host, int64_t n
     int64_t *d_k64 = (int64_t *)(d_bk + n + 2);
     HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
     int64_t m = 0;
-    rc = extract_dev<double>(e, (const double *)e->d_io_x, n, d_rot, d_base, nullptr, &m, st, true);
+    bool nan_path = false;
+    rc = extract_dev<double>(e, (const double *)e->d_io_x, n, d_rot, d_base, nullptr, &m, st, true, &nan_path);
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(rot_host, d_rot, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipMemcpyAsync(base_host, d_base, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -978,7 +1020,8 @@ int itd_baseline_extract_host_f64(itd_engine *e, const double *x_host, int64_t n
         HIP_TRY(e, hipMemcpyAsync(knots_host, d_k64, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     }
     if (bk_host) {
-        k_knot_values<double><<<(unsigned)((m + 2 + 255) / 256), 256, 0, st>>>((const double *)e->d_io_x, n, e->d_kidx, (int)m, d_bk);
+        // (a signal that holds NaNs: the knot values of the mutated copy, as the reference computes them after detect_peaks' write)
+        k_knot_values<double><<<(unsigned)((m + 2 + 255) / 256), 256, 0, st>>>(nan_path ? (const double *)e->d_cub : (const double *)e->d_io_x, n, e->d_kidx, (int)m, d_bk);
         HIP_TRY(e, hipMemcpyAsync(bk_host, d_bk, (size_t)(m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(e, hipStreamSynchronize(st));

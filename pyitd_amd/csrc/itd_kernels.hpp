@@ -456,12 +456,19 @@ __global__ __launch_bounds__(kWave) void k_detect(const Tin *__restrict__ x, int
 // the record-driven level-0 extraction then runs on `xm`.  The rules apply per signal, only if that signal holds a NaN
 // (SigState::in_nan, kept from the run that found it): a signal without one gets the plain knot set.  Rare path: LDS tile,
 // one wavefront per tile, like k_detect.
+// The single-level helpers use it too, with `lists` for the ordered compaction and one of
+//   kKnots    the extraction's set above (itd_baseline_extract, detect_knots);
+//   kValleys  detect_peaks(x) alone: the valleys under the NaN rules (ITD.py:33-76);
+//   kPeaks    matlab_detect_peaks(x) (numba_accelerated_itd.py:17-59): the same branch on the NEGATED differences
+//             (dx = -dx at :29, NaN -> +inf after it) — not detect_peaks(-x), which would see -NaN samples.
+// xm may be null when the mutated signal is not needed.
 // ---------------------------------------------------------------------------------------------
 template <typename Tin, int TW>
 __global__ __launch_bounds__(kWave) void k_nan_level0(const Tin *__restrict__ x, int64_t x_stride, int64_t n, int n_tiles,
                                                       double *__restrict__ xm, int64_t xm_stride, int32_t *__restrict__ counts,
                                                       TileRec *__restrict__ recs, int32_t *__restrict__ gsum_out,
-                                                      SigState *__restrict__ state)
+                                                      SigState *__restrict__ state, int mode = (int)kKnots,
+                                                      int32_t *__restrict__ lists = nullptr)
 {
     constexpr int G = TW / 64;
     __shared__ __attribute__((aligned(16))) double s_x[Tile<TW>::kSize];
@@ -485,6 +492,7 @@ __global__ __launch_bounds__(kWave) void k_nan_level0(const Tin *__restrict__ x,
         const int pos = flag_pos(g, lane);
         const double xa = tile.at(pos - 1), x0 = tile.at(pos), xp = tile.at(pos + 1);
         double vil = xp - x0, vix = x0 - xa;
+        if (mode == (int)kPeaks) { vil = -vil; vix = -vix; }      // numba_accelerated_itd.py:29
         bool ok = true;
         if (sig_nan) {
             vil = vil != vil ? inf : vil;                         // :51
@@ -500,19 +508,19 @@ __global__ __launch_bounds__(kWave) void k_nan_level0(const Tin *__restrict__ x,
     for (int k = lane - 1; k <= TW; k += kWave) {
         double v = tile.at(k);
         if (v != v) { v = inf; tile.at(k) = v; }
-        if (k >= 0 && k < TW && s + k < n) xm[(int64_t)sig * xm_stride + s + k] = v;
+        if (xm && k >= 0 && k < TW && s + k < n) xm[(int64_t)sig * xm_stride + s + k] = v;
     }
     wave_sync();
     if (s == 0 || s + TW >= n - 2) publish_ends<TW>(tile, s, n, state[sig].ends[0]);
     // peaks of the mutated values (detect_peaks(-x): plain rules), merged with the valleys
     WaveMasks wm;
-    (void)scan_flags<TW>(tile, s, n, (int)kPeaks, wm);
+    if (mode == (int)kKnots) (void)scan_flags<TW>(tile, s, n, (int)kPeaks, wm);
     wm.lo |= vm.lo;
     wm.hi |= vm.hi;
 #pragma unroll 1
     for (int g = 0; g < G; ++g) total += __popcll(wm.get(g));
     const size_t slot = (size_t)sig * n_tiles + t;
-    (void)record_from_masks<TW>(tile, s, wm, total, nullptr, recs + slot, s_rec);
+    (void)record_from_masks<TW>(tile, s, wm, total, lists ? lists + slot * TW : nullptr, recs + slot, s_rec);
     if (lane == 0) {
         counts[slot] = total;
         if (total) atomicAdd(&gsum_out[((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch], total);
@@ -1029,7 +1037,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                                                      int32_t *__restrict__ gsum_out, int32_t *__restrict__ gsum_clear,
                                                      double *__restrict__ rot_out, int64_t rot_stride,
                                                      double *__restrict__ base_out, int64_t base_stride,
-                                                     SigState *__restrict__ state, int level)
+                                                     SigState *__restrict__ state, int level,
+                                                     int keep_nan = 0 /* single-level helper: store the baseline as computed (the NaN -> +inf
+                                                                         write, ITD.py:50, belongs to the driver's stop test) */)
 {
     constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
@@ -1548,8 +1558,10 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 if (__builtin_expect(__any(nonfinite(be) || nonfinite(bo)), 0)) {   // rare: the stored baseline is the mutated one, ITD.py:50
                     odd_vals = true;
                     own_nan = own_nan || __any(__builtin_isunordered(be, bo));
-                    se = be != be ? inf : be;
-                    so = bo != bo ? inf : bo;
+                    if (!keep_nan) {
+                        se = be != be ? inf : be;
+                        so = bo != bo ? inf : bo;
+                    }
                 }
                 if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, se, so);
             }
@@ -1578,8 +1590,10 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 if (__builtin_expect(__any(nonfinite(be) || nonfinite(bo)), 0)) {   // rare: the stored baseline is the mutated one, ITD.py:50
                     odd_vals = true;
                     own_nan = own_nan || __any(__builtin_isunordered(be, bo));
-                    se = be != be ? inf : be;
-                    so = bo != bo ? inf : bo;
+                    if (!keep_nan) {
+                        se = be != be ? inf : be;
+                        so = bo != bo ? inf : bo;
+                    }
                 }
                 if constexpr (!FINAL) tile_store2<(ITD_NT & 2) != 0>(r_bas, p * 8, se, so);
                 if (!FINAL && (near_end || t == 0) && !(ITD_ABL_R & 16384)) {   // the next level's end samples (of the mutated array), ITD.py:101-102

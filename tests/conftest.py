@@ -15,7 +15,8 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "radio8000_input.npz")
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and f != "radio8000_input.npz" and not f.startswith("helpers_"))
 
 
 @pytest.fixture(scope="session")

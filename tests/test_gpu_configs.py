@@ -248,13 +248,33 @@ def test_helpers_do_not_disturb_a_decomposition_in_flight(P, torch, oracle):
     eng.close()
 
 
-def test_single_level_helpers_reject_nan_input(P):
-    x = np.sin(np.arange(5000.0) / 7)
-    x[1234] = np.nan
-    for f in (P.detect_peaks, P.matlab_detect_peaks, P.detect_knots, P.itd_baseline_extract):
-        with pytest.raises((ValueError, P.ITDError)):
-            f(x)
-    assert P.ITD().itd(x, 3).shape[0] >= 1       # the decomposition itself follows the reference (test_nan_input_follows_the_reference)
+def test_single_level_helpers_follow_the_reference_on_nan_input(P, oracle):
+    """detect_peaks / matlab_detect_peaks / detect_knots / itd_baseline_extract on NaN input: the reference's NaN branch
+    (ITD.py:46-51, 64-68; numba_accelerated_itd.py:28-49), pinned by its own outputs (helpers_nan_input.npz) and, on a longer
+    signal with NaNs on tile boundaries, by the oracle."""
+    from helpers import load_golden
+    g = load_golden("helpers_nan_input")
+    for c in range(int(g["cases"])):
+        x = g["x_%d" % c]
+        np.testing.assert_array_equal(P.detect_peaks(x.copy()), g["valleys_%d" % c])
+        np.testing.assert_array_equal(P.matlab_detect_peaks(x.copy()), g["matlab_%d" % c])
+        rot, base = P.itd_baseline_extract(x.copy())
+        assert_bits_equal(rot, g["rot_%d" % c], "rotation %d" % c)
+        assert_bits_equal(base, g["base_%d" % c], "baseline %d" % c)
+    rng = np.random.default_rng(8)
+    n = 40000
+    x = np.sin(np.arange(n) / 9.0) + 0.3 * rng.standard_normal(n)
+    x[[0, 511, 512, 513, 1024, 20000, 20001, n - 1]] = np.nan
+    keep = x.copy()
+    np.testing.assert_array_equal(P.detect_peaks(x), oracle.detect_peaks(x))
+    np.testing.assert_array_equal(P.matlab_detect_peaks(x), oracle.detect_peaks(x, matlab=True))
+    np.testing.assert_array_equal(P.detect_knots(x), oracle.knots(x))
+    rot, base = P.itd_baseline_extract(x)
+    r2, b2 = oracle.itd_baseline_extract(x)
+    assert_bits_equal(rot, r2, "rotation")
+    assert_bits_equal(base, b2, "baseline")
+    assert np.array_equal(np.isnan(x), np.isnan(keep)), "the caller's array must not be written"
+    assert P.ITD().itd(x, 3).shape[0] >= 1
 
 
 def test_stopped_signals_in_a_batch(P, torch, oracle):

@@ -112,3 +112,18 @@ def test_numba_restatement_matches_reference(name):
     res = numba_itd.itd(g["x"], int(g["max_iteration"]))
     assert res["stop"] == str(g["stop"]) and res["rows"].shape[0] == int(g["n_rows"])
     assert sha(res["rows"]) == str(g["rows_sha256"])
+
+
+def test_oracle_single_level_functions_on_nan_input():
+    """detect_peaks / matlab_detect_peaks / itd_baseline_extract on signals that hold NaNs (their NaN branch and the in-place
+    NaN -> +inf mutation): the oracle against the reference's own outputs (tests/golden/helpers_nan_input.npz, oracle/gen_golden.py)."""
+    from helpers import assert_bits_equal, load_golden
+    from oracle import cpu_oracle
+    g = load_golden("helpers_nan_input")
+    for c in range(int(g["cases"])):
+        x = g["x_%d" % c]
+        np.testing.assert_array_equal(cpu_oracle.detect_peaks(x), g["valleys_%d" % c])
+        np.testing.assert_array_equal(cpu_oracle.detect_peaks(x, matlab=True), g["matlab_%d" % c])
+        rot, base = cpu_oracle.itd_baseline_extract(x)
+        assert_bits_equal(rot, g["rot_%d" % c], "rotation %d" % c)
+        assert_bits_equal(base, g["base_%d" % c], "baseline %d" % c)

@@ -17,7 +17,7 @@ from helpers import load_golden, sha
 n = 0
 for f in sorted(glob.glob(os.path.join(%(root)r, "tests", "golden", "*.npz"))):
     name = os.path.basename(f)[:-4]
-    if name == "radio8000_input":
+    if name == "radio8000_input" or name.startswith("helpers_"):
         continue
     g = load_golden(name)
     r = cpu_oracle.itd(g["x"], int(g["max_iteration"]))
