@@ -219,3 +219,35 @@ def test_kernel_timing_api(P, torch, oracle):
     assert nr == ref["rows"].shape[0]
     assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "rows with instrumented launches")
     eng.close()
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_decomposition_is_graph_capturable(P, torch, oracle, chain):
+    """include/pyitd_hip.h: the decompose calls allocate nothing and synchronise nothing, so a caller can capture them in a HIP
+    graph; replays on new data in the same buffers give that data's decomposition (the chain's generation tag lives in device
+    memory and advances with every replay)."""
+    from pyitd_amd.engine import CHAIN_ONLY
+    n, M = 1 << 18, 5
+    eng = P.Engine(n, 1, 0)
+    if chain:
+        eng.set_chain_mode(CHAIN_ONLY)
+    x = torch.zeros(n, dtype=torch.float32, device="cuda")
+    rows = torch.zeros((M + 2, n), dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    x.copy_(torch.from_numpy(sines_noise(n, seed=1)))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):       # once outside the capture (the chain's workspace is allocated at its first call)
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, s.cuda_stream)
+    eng.summary(1)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    for seed in (2, 3):
+        xh = sines_noise(n, seed=seed)
+        x.copy_(torch.from_numpy(xh))
+        rows.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert_bits_equal(rows.cpu().numpy(), oracle.itd_lean(xh, M)["rows"], "graph replay, seed %d" % seed)
+    eng.close()
