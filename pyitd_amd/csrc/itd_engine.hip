@@ -227,7 +227,6 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int chunk = chunk_of(e, n, batch);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = std::min(chunk, batch - b0);   // signals b0 .. b0+nb-1: grid.y, every per-signal pointer offset by b0
-        const dim3 grid_x((n_tiles + kTilesPerWave - 1) / kTilesPerWave, nb);   // k_extract: kTilesPerWave consecutive tiles per wavefront
         auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b0 * n_groups * kGsumPitch; };
         auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
         auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
@@ -271,7 +270,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
             // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
             // begin / end timestamps (no marker packets in the stream: nothing is added to the timed region)
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE)                                                             \
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE) ITD_LAUNCH_EXTRACT_KT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE, kTilesPerWave)
+#define ITD_LAUNCH_EXTRACT_KT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE, KTW)                                                      \
     do {                                                                                                                   \
         const TIN *a_x = XIN; int64_t a_xs = XSTRIDE, a_n = n, a_rs = rows_stride, a_bs = base_stride;                     \
         int a_nt = n_tiles, a_b = nb, a_lvl = j, a_keep = 0;                                                               \
@@ -280,19 +280,21 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         SigState *a_st = state;                                                                                            \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
                         &a_bas, &a_bs, &a_st, &a_lvl, &a_keep};                                                            \
-        HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, kTilesPerWave, FUSE>), grid_x, \
+        HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, KTW, FUSE>),                    \
+                                      dim3((n_tiles + (KTW) - 1) / (KTW), nb),                                               \
                                       blk, args, 0, st, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                     \
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
     } while (0)
             if (j == 0) {   // never the last level: M >= 0
                 if (nan_input) ITD_LAUNCH_EXTRACT(double, false, xm_c, 3 * e->pp_pitch, kRankCap0, false);
-                else if (fuse0) ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, true);
+                else if (fuse0) ITD_LAUNCH_EXTRACT_KT(Tin, false, xc, x_stride, kRankCap0, true, kFuse0TilesPerWave);
                 else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, false);
             } else {
                 if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap, false);
                 else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap, false);
             }
 #undef ITD_LAUNCH_EXTRACT
+#undef ITD_LAUNCH_EXTRACT_KT
         }
         // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
         {

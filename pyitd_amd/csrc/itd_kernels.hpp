@@ -74,7 +74,11 @@ constexpr int kTilesPerWave = ITD_KT;
 #ifndef ITD_KT0
 #define ITD_KT0 1
 #endif
-constexpr int kScanTilesPerWave = ITD_KT0;   // tiles per wavefront of the level-0 scan (4 measured 30 us vs 26 us at 1: the scan is instruction bound)
+constexpr int kScanTilesPerWave = ITD_KT0;
+#ifndef ITD_KT_FUSE0
+#define ITD_KT_FUSE0 1
+#endif
+constexpr int kFuse0TilesPerWave = ITD_KT_FUSE0;   // tiles per wavefront of the fused level-0 launch (the second tile's loads fly during the first's work)   // tiles per wavefront of the level-0 scan (4 measured 30 us vs 26 us at 1: the scan is instruction bound)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 constexpr int kMaxLevels = 24;         // levels 0 .. max_iteration+2 (<= 22) + slack
 
@@ -1044,7 +1048,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
     static_assert(CAP >= 128, "a pass must be able to take one 128-sample group");
-    static_assert(!FUSE0 || (KT == 1 && !FINAL), "the fused level-0 launch: one tile per wavefront, never the last level");
+    static_assert(!FUSE0 || !FINAL, "the fused level-0 launch is never the last level");
     constexpr int RK = CAP + 8;
     __shared__ double s_X[RK];      // value of the level's input at knot slot L
     __shared__ double s_B[RK];      // knot value B_L
