@@ -162,9 +162,13 @@ int itd_get_chain_repeats(const itd_engine *e);
  * counts; itd_chain.hpp); all zero in the shipped build */
 int itd_debug_chain_prof(itd_engine *e, uint64_t *out16, int32_t reset);
 /* Batched decompositions run as launch sequences over chunks of `signals_per_chunk` signals, all levels of a chunk before
- * the next chunk (0 = automatic: about 2^24 samples per chunk, so a level's baseline is still in the 256 MiB Infinity
- * Cache when the next level reads it).  Results do not depend on the chunk size. */
+ * the next chunk (0 = automatic: about 2^24 samples in flight — per chunk over one stream, 3/4 of that per chunk over two —, so a
+ * level's baseline is still in the 256 MiB Infinity Cache when the next level reads it).  Results do not depend on the chunk size. */
 int itd_set_batch_chunk(itd_engine *e, int32_t signals_per_chunk);
+/* The chunks of a batch are independent: they rotate over `streams` streams (the caller's and streams - 1 of the engine's, forked
+ * from / joined to the caller's stream by events), so that one chunk's launch boundaries and tails overlap another's work.
+ * 1 .. 4; default 2 (with automatic chunks of about 1.2e7 samples: 32.5 ms against 35.9 ms over one stream for 1024 x 2^20). */
+int itd_set_batch_streams(itd_engine *e, int32_t streams);
 
 /* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
  * launch); to inspect them run itd_detect_* on the input or on a stored baseline row.  The single-level operators

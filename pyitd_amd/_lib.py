@@ -53,6 +53,7 @@ ABI = {
     "itd_set_nan_fallback": (_INT, [_P, _INT]),
     "itd_set_nan_input_mode": (_INT, [_P, _I32]),
     "itd_set_batch_chunk": (_INT, [_P, _I32]),
+    "itd_set_batch_streams": (_INT, [_P, _I32]),
     "itd_set_level0_mode": (_INT, [_P, _I32]),
     "itd_set_host_keep_baselines": (_INT, [_P, _I32]),
     "itd_get_last_baselines_host": (_INT, [_P, _P, _I64, _I32]),

@@ -100,6 +100,9 @@ struct itd_engine {
     int32_t last_give_up = 0;               // ChainCtl::give_up of the last chained call that had to be repeated
     int32_t chain_grid = 6144;              // workgroups (= wavefronts) of the chain launch: about the chip's residency              // how often itd_get_summary had to repeat a chained call level by level
     int32_t chunk = 0;             // signals per launch sequence of a batched decomposition (0 = automatic, see enqueue_decompose)
+    int32_t batch_streams = 2;     // chunks of a batch rotate over this many streams (itd_set_batch_streams): 1 .. kMaxBatchStreams
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // the others besides the caller's, created on demand
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
@@ -193,7 +196,10 @@ void time_end(itd_engine *e, int k, hipStream_t st)
 int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 {
     if (e->chunk > 0) return std::min<int32_t>(e->chunk, batch);
-    const int64_t c = std::max<int64_t>(1, ((int64_t)1 << 24) / n);
+    // one stream: 2^24 samples per chunk; two or more (the default): 3/4 of that per chunk — two chunks in flight, measured best
+    // on 1024 x 2^20 (chunks of 10-12 signals over 2 streams: 32.5 ms against 35.9 ms with 16 over one, profiles/r02/session2_batch_streams.txt)
+    const int64_t per = e->batch_streams > 1 ? ((int64_t)3 << 22) : ((int64_t)1 << 24);
+    const int64_t c = std::max<int64_t>(1, per / n);
     return (int)std::min<int64_t>(c, batch);
 }
 
@@ -225,7 +231,25 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
     const int chunk = chunk_of(e, n, batch);
-    for (int b0 = 0; b0 < batch; b0 += chunk) {
+    // chunks are independent (per-signal state, counts, records, group sums, slots): with two streams they alternate, so that one
+    // chunk's launch boundaries and tails overlap the other's work (fork after the init, join before the caller's stream goes on)
+    const int n_chunks = (batch + chunk - 1) / chunk;
+    const int S = std::min<int>(e->batch_streams, n_chunks);   // streams in use: the caller's and S - 1 of the engine's
+    if (S > 1) {
+        if (!e->ev_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+        for (int k = 0; k < S - 1; ++k) {
+            if (!e->aux_stream[k]) {
+                HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream[k], hipStreamNonBlocking));
+                HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
+            }
+            HIP_TRY(e, hipStreamWaitEvent(e->aux_stream[k], e->ev_fork, 0));
+        }
+    }
+    int chunk_no = 0;
+    for (int b0 = 0; b0 < batch; b0 += chunk, ++chunk_no) {
+        const int lane_s = chunk_no % S;
+        const hipStream_t cst = lane_s == 0 ? st : e->aux_stream[lane_s - 1];   // this chunk's stream
         const int nb = std::min(chunk, batch - b0);   // signals b0 .. b0+nb-1: grid.y, every per-signal pointer offset by b0
         auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b0 * n_groups * kGsumPitch; };
         auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
@@ -237,7 +261,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *pp_c = e->d_pp + (int64_t)b0 * 3 * e->pp_pitch;
         double *xm_c = pp_c + 2 * e->pp_pitch;   // NaN-input repeat: the mutated signal, one per signal at the slots' stride
         if (nan_input) {
-            k_nan_level0<Tin, T><<<dim3(n_tiles, nb), blk, 0, st>>>(xc, x_stride, n, n_tiles, xm_c, 3 * e->pp_pitch, cnt(0), rec(0),
+            k_nan_level0<Tin, T><<<dim3(n_tiles, nb), blk, 0, cst>>>(xc, x_stride, n, n_tiles, xm_c, 3 * e->pp_pitch, cnt(0), rec(0),
                                                                     gs(0), state);
         } else if (!fuse0) {
             const int pair = time_slot(e, ITD_TIME_SCAN0);
@@ -245,7 +269,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             int32_t *a_c = cnt(0), *a_g = gs(0); TileRec *a_r = rec(0); SigState *a_st = state;
             void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_c, &a_r, &a_g, &a_st};
             HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_scan0<Tin, T, kScanTilesPerWave>),
-                                          dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, nb), blk, args, 0, st,
+                                          dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, nb), blk, args, 0, cst,
                                           pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,
                                           pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
         }
@@ -282,7 +306,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                         &a_bas, &a_bs, &a_st, &a_lvl, &a_keep};                                                            \
         HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, KTW, FUSE>),                    \
                                       dim3((n_tiles + (KTW) - 1) / (KTW), nb),                                               \
-                                      blk, args, 0, st, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                     \
+                                      blk, args, 0, cst, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                    \
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
     } while (0)
             if (j == 0) {   // never the last level: M >= 0
@@ -300,12 +324,16 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         {
             const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
             if (bases_c)
-                k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, st>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
+                k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
                                                                        gs(M + 2), n_tiles, M + 2, state);
             else
-                k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, st>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
+                k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
                                                                        e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, state);
         }
+    }
+    for (int k = 0; k < S - 1; ++k) {
+        HIP_TRY(e, hipEventRecord(e->ev_join[k], e->aux_stream[k]));
+        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[k], 0));
     }
     time_end(e, span_pair, st);
     HIP_TRY(e, hipGetLastError());
@@ -563,6 +591,11 @@ void itd_engine_destroy(itd_engine *e)
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    for (int k = 0; k < 3; ++k) {
+        if (e->aux_stream[k]) { (void)hipStreamSynchronize(e->aux_stream[k]); (void)hipStreamDestroy(e->aux_stream[k]); }
+        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
 }
 
@@ -793,6 +826,13 @@ int itd_debug_chain_prof(itd_engine *e, uint64_t *out16, int32_t reset)
     for (int k = 0; k < 16; ++k) out16[k] = e->h_ctl->prof[k];
     if (!ITD_CHAIN_PROF) { out16[14] = e->h_ctl->gen; out16[15] = (uint64_t)(uint32_t)e->last_give_up; }
     if (reset) HIP_TRY(e, hipMemset(e->d_ctl->prof, 0, sizeof(e->h_ctl->prof)));
+    return ITD_OK;
+}
+
+int itd_set_batch_streams(itd_engine *e, int32_t streams)
+{
+    if (!e || streams < 1 || streams > 4) return ITD_ERR_INVALID_ARG;
+    e->batch_streams = streams;
     return ITD_OK;
 }
 

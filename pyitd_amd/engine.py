@@ -115,6 +115,10 @@ class Engine:
         """Signals per launch sequence of a batched decomposition (0 = automatic, about 2^24 samples per chunk)."""
         self._check(self._L.itd_set_batch_chunk(self._h, int(signals_per_chunk)))
 
+    def set_batch_streams(self, streams):
+        """1 or 2: the chunks of a batched decomposition alternate over that many streams."""
+        self._check(self._L.itd_set_batch_streams(self._h, int(streams)))
+
     def kernel_timing(self, which=TIME_EXTRACT):
         """(total ms, launches) of the recorded launches of class `which` (TIME_*)."""
         ms, cnt = ctypes.c_double(0), ctypes.c_int32(0)

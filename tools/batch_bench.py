@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--log2n", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--chunks", type=str, default="0,1024,8,16,32,64", help="chunk sizes to time (0 = automatic)")
+ap.add_argument("--streams", type=str, default="1", help="batch streams to time (1, 2 or 1,2)")
 ap.add_argument("--stream-pool", type=int, default=0, help="also time one-signal launches over this many streams/engines (0 = skip)")
 args = ap.parse_args()
 B, n, M = args.batch, 1 << args.log2n, 7
@@ -34,8 +35,9 @@ for b in (0, 7, 15, B - 1):
     got = rows[b, :nr].cpu().numpy()
     assert nr == ref["rows"].shape[0] and np.array_equal(got.view(np.uint64), ref["rows"].view(np.uint64)), b
 print("parity ok on signals 0, 7, 15, %d; rows per signal %s" % (B - 1, sorted(set(s["n_rows"].tolist()))))
-for chunk in [int(c) for c in args.chunks.split(",")]:
+for chunk, streams in [(int(c), int(k)) for k in args.streams.split(",") for c in args.chunks.split(",")]:
     eng.set_batch_chunk(chunk)
+    eng.set_batch_streams(streams)
     eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, M, rows.data_ptr(), None, None)
     eng.summary(B)
     torch.cuda.synchronize()
@@ -44,8 +46,8 @@ for chunk in [int(c) for c in args.chunks.split(",")]:
         eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, M, rows.data_ptr(), None, None)
     eng.summary(B)
     dt = (time.perf_counter() - t0) / args.steps
-    print("chunk %4d: batch %d x 2^%d, 8 levels: %.2f ms per batch decomposition = %.0f Msamples/s, %.0f GB/s algorithmic = %.3f of 8 TB/s" % (
-        chunk, B, args.log2n, dt * 1e3, B * n / dt / 1e6, 188.0 * B * n / dt / 1e9, 188.0 * B * n / dt / 8e12))
+    print("streams %d chunk %4d: batch %d x 2^%d, 8 levels: %.2f ms per batch decomposition = %.0f Msamples/s, %.0f GB/s algorithmic = %.3f of 8 TB/s" % (
+        streams, chunk, B, args.log2n, dt * 1e3, B * n / dt / 1e6, 188.0 * B * n / dt / 1e9, 188.0 * B * n / dt / 8e12))
 eng.set_batch_chunk(0)
 
 if args.stream_pool > 0:
