@@ -234,7 +234,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // chunks are independent (per-signal state, counts, records, group sums, slots): with two streams they alternate, so that one
     // chunk's launch boundaries and tails overlap the other's work (fork after the init, join before the caller's stream goes on)
     const int n_chunks = (batch + chunk - 1) / chunk;
-    const int S = std::min<int>(e->batch_streams, n_chunks);   // streams in use: the caller's and S - 1 of the engine's
+    // streams in use: the caller's and S - 1 of the engine's; signals too long for two of them to share the Infinity Cache
+    // (more than 3 * 2^22 samples each) keep to one stream
+    const int S = (e->chunk == 0 && (int64_t)chunk * n > ((int64_t)3 << 22)) ? 1 : std::min<int>(e->batch_streams, n_chunks);
     if (S > 1) {
         if (!e->ev_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(e, hipEventRecord(e->ev_fork, st));
