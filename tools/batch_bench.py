@@ -14,7 +14,7 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--log2n", type=int, default=20)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--chunks", type=str, default="0,1024,8,16,32,64", help="chunk sizes to time (0 = automatic)")
-ap.add_argument("--streams", type=str, default="1", help="batch streams to time (1, 2 or 1,2)")
+ap.add_argument("--streams", type=str, default="2", help="batch streams to time (the engine default is 2; e.g. 1,2 times both)")
 ap.add_argument("--stream-pool", type=int, default=0, help="also time one-signal launches over this many streams/engines (0 = skip)")
 args = ap.parse_args()
 B, n, M = args.batch, 1 << args.log2n, 7
