@@ -342,11 +342,42 @@ def run_rank(args):
         out["config"]["launch_form"] = "chain"
     if world == 1 and not stub and not args.no_cpu_baseline:
         out.update(cpu_legs(x_host, n, M, summ, rows, args))
+    if world == 1 and not stub and not args.no_extra and args.log2n == LOG2N and not args.chain:
+        # BASELINE configs[2] beside the headline (informational: what one rank of the N > 1 runs does): 1024 x 2^20 signals
+        try:
+            out["config3_batch"] = batch_leg(torch, dev)
+        except Exception as ex:  # noqa: BLE001 — never at the cost of the headline line
+            out["config3_batch"] = {"error": repr(ex)[:200]}
     print(json.dumps(out))
     sys.stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0
+
+
+def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
+    """BASELINE configs[2] on this GPU: batch x 2^log2n float32 signals (SURVEY 8d recipe), 8 levels, device resident."""
+    import pyitd_amd
+    n = 1 << log2n
+    x = batch_signals_device(torch, dev, 0, batch, n)
+    rows = torch.empty((batch, MAX_ITERATION + 2, n), dtype=torch.float64, device=dev)
+    eng = pyitd_amd.Engine(n, batch, dev.index or 0)
+    stream = torch.cuda.Stream(device=dev)
+    for _ in range(2):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
+    s = eng.summary(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
+    return {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
+            "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "hbm_algorithmic_GBps": round(alg, 1), "frac_of_peak_whole_decomposition": round(alg / HBM_PEAK_GBPS, 4),
+            "rows_per_signal": sorted(set(int(v) for v in s["n_rows"]))}
 
 
 def cpu_legs(x_host, n, M, summ, rows, args):
@@ -430,6 +461,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=LOG2N, help="N = 1: samples of the single signal (24); N > 1: samples per signal (20)")
     ap.add_argument("--batch", type=int, default=1024, help="N > 1: signals per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational BASELINE configs[2] leg (1024 x 2^20 signals)")
     ap.add_argument("--chain", action="store_true", help="run the opt-in one-launch chain (itd_set_chain_mode) instead of one launch per level")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher only
     args = ap.parse_args()

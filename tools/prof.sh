@@ -5,7 +5,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra "$@" > $out/bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 grep '^{' $out/bench.log | tail -1 > $out/bench.json
 python3 - "$out" <<'PY'
