@@ -251,3 +251,31 @@ def test_decomposition_is_graph_capturable(P, torch, oracle, chain):
         torch.cuda.synchronize()
         assert_bits_equal(rows.cpu().numpy(), oracle.itd_lean(xh, M)["rows"], "graph replay, seed %d" % seed)
     eng.close()
+
+
+def test_batch_streams_and_chunks_do_not_change_results(P, torch, oracle):
+    """The chunks of a batch rotate over 1 .. 4 streams (itd_set_batch_streams) in any chunk size: rows, baselines and summaries
+    are the same, with signals that stop at different levels (and one that holds a NaN) spread over the chunks."""
+    rng = np.random.default_rng(91)
+    B, n, M = 23, 6000, 6
+    xs = np.stack([sines_noise(n, seed=b, fscale=1 + b / 16) for b in range(B)]).astype(np.float64)
+    xs[4] = np.linspace(0, 1, n)                      # stops at once
+    xs[9] = np.sin(np.arange(n) / 900.0)              # stops after a few levels
+    xs[17, [0, 3000, 3001]] = np.nan                  # the NaN-input repeat runs over the same streams
+    refs = [oracle.itd(xs[b], M) for b in range(B)]
+    x = torch.from_numpy(xs).cuda()
+    eng = P.Engine(n, B, 0)
+    for streams, chunk in ((1, 0), (2, 1), (2, 5), (3, 4), (4, 2), (4, 23)):
+        eng.set_batch_streams(streams)
+        eng.set_batch_chunk(chunk)
+        rows = torch.full((B, M + 2, n), -7.0, dtype=torch.float64, device="cuda")
+        bases = torch.full((B, M + 2, n), -7.0, dtype=torch.float64, device="cuda")
+        eng.decompose_dev(x.data_ptr(), np.float64, n, B, n, M, rows.data_ptr(), bases.data_ptr(), None)
+        s = eng.summary(B)
+        for b in range(B):
+            nr, nb = int(s["n_rows"][b]), int(s["n_baselines"][b])
+            what = "streams %d chunk %d signal %d" % (streams, chunk, b)
+            assert nr == refs[b]["rows"].shape[0] and nb == refs[b]["baselines"].shape[0], what
+            assert_bits_equal(rows[b, :nr].cpu().numpy(), refs[b]["rows"], what + " rows")
+            assert_bits_equal(bases[b, :nb].cpu().numpy(), refs[b]["baselines"], what + " baselines")
+    eng.close()
