@@ -33,7 +33,8 @@ def _run(E, x, M, mode, want_baselines=True):
 
 @pytest.mark.parametrize("name", ["chirp65536_f32_m3", "sines131072_f32_m7", "sines16384_f64_m7", "radio_tiled_32768_f32_m9",
                                   "radio8000_m11", "edge_lead_plateau_nan", "edge_monotone", "edge_n3", "edge_noise_m0",
-                                  "edge_noise_f32_odd", "edge_staircase", "demo400_m11"])
+                                  "edge_noise_f32_odd", "edge_staircase", "demo400_m11", "edge_zigzag1024", "edge_noise_m20",
+                                  "nanin_tile_edges", "nanin_f32"])
 def test_chain_matches_golden(E, name):
     g = load_golden(name)
     out = _run(E, g["x"], int(g["max_iteration"]), E.CHAIN_AUTO)
@@ -41,8 +42,9 @@ def test_chain_matches_golden(E, name):
     assert sha(out["rows"]) == str(g["rows_sha256"]), "rows are not bit-identical to the reference"
     assert tuple(out["baselines"].shape) == tuple(g["baselines_shape"])
     assert sha(out["baselines"]) == str(g["baselines_sha256"])
-    if str(g["stop"]) != "timeout":   # the stop rule fired inside the requested levels: the chain had to be repeated level by level
-        assert out["repeats"] == 1
+    if str(g["stop"]) != "timeout" and not name.startswith("nanin_"):
+        assert out["repeats"] == 1    # the stop rule fired inside the requested levels: the chain had to be repeated level by level
+    # (NaN in the input: itd_get_summary goes straight to the NaN-faithful level-by-level repeat)
 
 
 def test_chain_alone_completes_a_long_signal(E, oracle):
