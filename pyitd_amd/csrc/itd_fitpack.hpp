@@ -460,23 +460,47 @@ ITD_HD double knot_t(const int32_t *e, int m, int i /* 1-based */)
     return (double)(i <= K1 ? e[0] : (i <= m ? e[i - 3] : e[m - 1]));
 }
 
-// a: 4 columns of (m+1) entries, z: (m+1) entries, all 1-based and interleaved with `stride`; on return z holds c(1..m)
+// a: 4 columns of (m+1) entries, z: (m+1) entries, all 1-based and interleaved with `stride`; on return z holds c(1..m).
+// The sweep touches only rows l-3 .. l of the triangle for the data point in knot interval l, and l never decreases: those four
+// rows (and their right-hand sides) live in a sliding window of locals (registers on the GPU: every index below is a compile-time
+// constant) and a row goes to memory once, when the window moves past it.  The back substitution keeps the three coefficients it
+// has just solved in locals as well.  Arithmetic and its order are fpcurf's (the first version walked `a` and `z` in memory: on the
+// GPU, where one thread sweeps one signal, every rotation was a dependent global-memory round trip).
 template <typename YF>
 ITD_HD void interp_fit(const int32_t *e, int m, YF y_of, double *a, double *z, int64_t stride, int64_t lda /* = m_max + 1 */)
 {
 #define SA_(i, j) a[(((int64_t)(j) - 1) * lda + (i)) * stride]
 #define SZ_(i) z[(int64_t)(i) * stride]
     const int nk1 = m;
-    for (int i = 1; i <= nk1; ++i) {
-        SZ_(i) = 0.0;
-        for (int j = 1; j <= K1; ++j) SA_(i, j) = 0.0;
+    double W[K1][K1], Z[K1];       // window row r <-> row l - 3 + r of the triangle: W[r][c] = a(row, c + 1), Z[r] = z(row)
+#pragma unroll
+    for (int r = 0; r < K1; ++r) {
+        Z[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < K1; ++c) W[r][c] = 0.0;
     }
     int l = K1;
     double h[8], tl[8];
     for (int it = 1; it <= m; ++it) {
         const double xi = (double)e[it - 1];
         double yi = y_of(it - 1);
-        while (!(xi < knot_t(e, m, l + 1) || l == nk1)) ++l;
+        while (!(xi < knot_t(e, m, l + 1) || l == nk1)) {
+            // the window moves on: its first row (l - 3) is final
+            const int row = l - 3;
+#pragma unroll
+            for (int c = 0; c < K1; ++c) SA_(row, c + 1) = W[0][c];
+            SZ_(row) = Z[0];
+#pragma unroll
+            for (int r = 0; r < K1 - 1; ++r) {
+                Z[r] = Z[r + 1];
+#pragma unroll
+                for (int c = 0; c < K1; ++c) W[r][c] = W[r + 1][c];
+            }
+            Z[K1 - 1] = 0.0;
+#pragma unroll
+            for (int c = 0; c < K1; ++c) W[K1 - 1][c] = 0.0;
+            ++l;
+        }
         // fpbspl with the knots t(l-2) .. t(l+3) in registers: tl[q] = t(l - 2 + q)
         for (int q = 0; q < 6; ++q) tl[q] = knot_t(e, m, l - 2 + q);
         {
@@ -494,39 +518,52 @@ ITD_HD void interp_fit(const int32_t *e, int m, YF y_of, double *a, double *z, i
                 }
             }
         }
-        int j = l - K1;
+        // rotate the new row (h(1..4) in columns l-3 .. l) into rows l-3 .. l: row l - 4 + i is window row i - 1
+#pragma unroll
         for (int i = 1; i <= K1; ++i) {
-            ++j;
             const double piv = h[i];
             if (piv == 0.0) continue;
-            double cs, sn, ww = SA_(j, 1);
+            double cs, sn, ww = W[i - 1][0];
             fpgivs(piv, ww, cs, sn);
-            SA_(j, 1) = ww;
-            double zj = SZ_(j);
+            W[i - 1][0] = ww;
+            double zj = Z[i - 1];
             fprota(cs, sn, yi, zj);
-            SZ_(j) = zj;
+            Z[i - 1] = zj;
             if (i == K1) break;
-            int i2 = 1;
+#pragma unroll
             for (int i1 = i + 1; i1 <= K1; ++i1) {
-                ++i2;
-                double aj = SA_(j, i2);
+                const int i2 = i1 - i + 1;
+                double aj = W[i - 1][i2 - 1];
                 fprota(cs, sn, h[i1], aj);
-                SA_(j, i2) = aj;
+                W[i - 1][i2 - 1] = aj;
             }
         }
     }
-    // fpback(a, z, nk1, k1, c): in place in z
-    SZ_(nk1) = SZ_(nk1) / SA_(nk1, 1);
+    // the window's rows l-3 .. l (= nk1-3 .. nk1 once every data point is in)
+#pragma unroll
+    for (int r = 0; r < K1; ++r) {
+        const int row = l - 3 + r;
+        if (row >= 1 && row <= nk1) {
+#pragma unroll
+            for (int c = 0; c < K1; ++c) SA_(row, c + 1) = W[r][c];
+            SZ_(row) = Z[r];
+        }
+    }
+    // fpback(a, z, nk1, k1, c): in place in z; z1, z2, z3 = c(i+1), c(i+2), c(i+3)
+    double z1 = SZ_(nk1) / SA_(nk1, 1), z2 = 0.0, z3 = 0.0;
+    SZ_(nk1) = z1;
     int i = nk1 - 1;
     for (int j = 2; j <= nk1; ++j) {
         double store = SZ_(i);
         const int i1 = (j <= K) ? j - 1 : K;
-        int mm = i;
-        for (int lq = 1; lq <= i1; ++lq) {
-            ++mm;
-            store = store - SZ_(mm) * SA_(i, lq + 1);
-        }
-        SZ_(i) = store / SA_(i, 1);
+        if (i1 >= 1) store = store - z1 * SA_(i, 2);
+        if (i1 >= 2) store = store - z2 * SA_(i, 3);
+        if (i1 >= 3) store = store - z3 * SA_(i, 4);
+        const double zi = store / SA_(i, 1);
+        SZ_(i) = zi;
+        z3 = z2;
+        z2 = z1;
+        z1 = zi;
         --i;
     }
 #undef SA_
