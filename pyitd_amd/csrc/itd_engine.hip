@@ -831,6 +831,15 @@ int itd_debug_chain_prof(itd_engine *e, uint64_t *out16, int32_t reset)
     return ITD_OK;
 }
 
+#if ITD_PROF
+// diagnostic build only (tools/level0_prof.py): where the fused level-0 launch's wavefronts leave their phase times
+extern "C" int itd_debug_prof_buffer(void *dev_buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(dev_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &p, sizeof(p)) == hipSuccess ? ITD_OK : ITD_ERR_HIP;
+}
+#endif
+
 int itd_set_batch_streams(itd_engine *e, int32_t streams)
 {
     if (!e || streams < 1 || streams > 4) return ITD_ERR_INVALID_ARG;

@@ -653,12 +653,73 @@ __device__ __forceinline__ float wave_dpp(float old, float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+// lane L of `old` replaced by a wave-uniform value (v_writelane_b32; the value comes from the scalar unit: no hazard to cover)
+template <int L>
+__device__ __forceinline__ unsigned write_lane(unsigned old, unsigned value)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(L));
+    return old;
+}
 // this lane's bit of a wave-uniform 64-bit mask: one v_cndmask with the mask as the select operand
 __device__ __forceinline__ int lane_bit(unsigned long long mask)
 {
     int r;
     asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));
     return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// knot_predicate: the knot rule (ITD.py:59 on x and on -x, raw differences) over NG consecutive 128-sample groups as mask
+// algebra.  Per group d0 = even - left, d1 = odd - even; the difference behind an odd sample is the next lane's d0 (the next
+// group's lane 0 for lane 63; `dlast` behind the last position, only lane 63's value is used).  A position with the difference
+// dp in front of it and dn behind it is a knot <=> (dn > 0 & dp <= 0) | (dn < 0 & dp >= 0).
+// Every compare leaves the vector unit as a 64-bit lane mask; "the next lane's" masks are those masks shifted by one bit on the
+// scalar unit, and while no difference is NaN (no NaN sample, no inf - inf: the common case, tested once per call)
+// d > 0 <=> !(d <= 0) and d < 0 <=> !(d >= 0), so four ordered compares and one unordered compare per group do instead of
+// eight ordered ones plus a DPP shift of the differences.  No exec-masked short circuits, no bool -> mask round trips.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NG>
+__device__ __forceinline__ void knot_predicate(const T (&d0)[NG], const T (&d1)[NG], T dlast,
+                                               unsigned long long (&E)[NG], unsigned long long (&O)[NG])
+{
+    using ull = unsigned long long;
+    constexpr ull kTop = 1ull << 63;
+    ull unord = __ballot(dlast != dlast) & kTop;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) unord |= __ballot(__builtin_isunordered(d0[g], d1[g]));
+    const ull plast = __ballot(dlast > (T)0) & kTop, nlast = __ballot(dlast < (T)0) & kTop;
+    // group by group, so that only two groups' masks are alive at a time (scalar registers are scarce in the callers)
+    if (__builtin_expect(unord == 0, 1)) {
+        ull le = __ballot(d0[0] <= (T)0), ge = __ballot(d0[0] >= (T)0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int gn = g + 1 < NG ? g + 1 : g;
+            const ull le_n = __ballot(d0[gn] <= (T)0), ge_n = __ballot(d0[gn] >= (T)0);   // (unused for the last group)
+            const ull p1 = __ballot(d1[g] > (T)0), n1 = __ballot(d1[g] < (T)0);
+            const ull p2 = (~le >> 1) | (g + 1 < NG ? ~le_n << 63 : plast);
+            const ull n2 = (~ge >> 1) | (g + 1 < NG ? ~ge_n << 63 : nlast);
+            E[g] = (p1 & le) | (n1 & ge);
+            O[g] = (p2 & ~p1) | (n2 & ~n1);
+            le = le_n;
+            ge = ge_n;
+        }
+    } else {   // some difference is NaN: all eight ordered compares
+        ull p0 = __ballot(d0[0] > (T)0), n0 = __ballot(d0[0] < (T)0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int gn = g + 1 < NG ? g + 1 : g;
+            const ull p0_n = __ballot(d0[gn] > (T)0), n0_n = __ballot(d0[gn] < (T)0);
+            const ull le0 = __ballot(d0[g] <= (T)0), ge0 = __ballot(d0[g] >= (T)0);
+            const ull p1 = __ballot(d1[g] > (T)0), n1 = __ballot(d1[g] < (T)0);
+            const ull le1 = __ballot(d1[g] <= (T)0), ge1 = __ballot(d1[g] >= (T)0);
+            const ull p2 = (p0 >> 1) | (g + 1 < NG ? p0_n << 63 : plast);
+            const ull n2 = (n0 >> 1) | (g + 1 < NG ? n0_n << 63 : nlast);
+            E[g] = (p1 & le0) | (n1 & ge0);
+            O[g] = (p2 & le1) | (n2 & ge1);
+            p0 = p0_n;
+            n0 = n0_n;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,39 +736,36 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
 {
     constexpr int G2 = TW / 128;
     const int lane = lane_id();
-    double d0[G2];
-#pragma unroll
-    for (int g = 0; g < G2 && !(ITD_ABL_R & 4096); ++g) {
-        const double fill = (g == 0) ? x_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
-        const double left = wave_dpp<0x138>(fill, xr[g][1]);
-        d0[g] = xr[g][0] - left;
-    }
-    const bool edge = (s == 0) || (nrem <= TW + 1);   // the tile holds sample 0, or sample n-2 or later
-    WaveMasks nm;
+    unsigned long long E[G2], O[G2];   // flag words of the even / odd positions of group g (record words 2g, 2g+1)
     int total = 0;
     int gcount[G2];
     if (ITD_ABL_R & 4096) {   // timing skeleton: no scan, a constant non-zero count so that no level stops
         total = 3;
 #pragma unroll
-        for (int g = 0; g < G2; ++g) gcount[g] = 0;
-    }
+        for (int g = 0; g < G2; ++g) { gcount[g] = 0; E[g] = O[g] = 0; }
+    } else {
+        double d0[G2], d1[G2];
 #pragma unroll
-    for (int g = 0; g < G2 && !(ITD_ABL_R & 4096); ++g) {
-        const double d1 = xr[g][1] - xr[g][0];
-        const double fill = (g == G2 - 1) ? (x_hi - xr[g][1]) : wave_dpp<0x134>(0.0, d0[g < G2 - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
-        const double d2 = wave_dpp<0x130>(fill, d0[g]);
-        bool fe = ((d1 > 0.0) && (d0[g] <= 0.0)) || ((d1 < 0.0) && (d0[g] >= 0.0));
-        bool fo = ((d2 > 0.0) && (d1 <= 0.0)) || ((d2 < 0.0) && (d1 >= 0.0));
-        if (edge) {   // first and last sample are never knots (ITD.py:70-73); nothing beyond sample n-2
-            const int p = 128 * g + 2 * lane;
-            fe = fe && (s > 0 || p >= 1) && (p <= nrem - 2);
-            fo = fo && (p + 1 <= nrem - 2);
+        for (int g = 0; g < G2; ++g) {
+            const double fill = (g == 0) ? x_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
+            const double left = wave_dpp<0x138>(fill, xr[g][1]);
+            d0[g] = xr[g][0] - left;
+            d1[g] = xr[g][1] - xr[g][0];
         }
-        const unsigned long long E = __ballot(fe), O = __ballot(fo);
-        nm.set(2 * g, E);
-        nm.set(2 * g + 1, O);
-        gcount[g] = __popcll(E) + __popcll(O);
-        total += gcount[g];
+        knot_predicate<double, G2>(d0, d1, x_hi - xr[G2 - 1][1], E, O);
+        if ((s == 0) || (nrem <= TW + 1)) {   // the tile holds sample 0, or sample n-2 or later: the first and the last sample are
+            const int lo = s > 0 ? 0 : 1, hi = nrem - 2;   // never knots (ITD.py:70-73), nothing beyond sample n-2
+#pragma unroll
+            for (int g = 0; g < G2; ++g) {   // even position 128 g + 2 l, odd position 128 g + 2 l + 1 within [lo, hi]
+                E[g] &= bit_range((lo - 128 * g + 1) >> 1, (hi - 128 * g) >> 1);
+                O[g] &= bit_range((lo - 128 * g) >> 1, (hi - 128 * g - 1) >> 1);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            gcount[g] = __popcll(E[g]) + __popcll(O[g]);
+            total += gcount[g];
+        }
     }
     // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
     if (lane == 0) {
@@ -726,9 +784,8 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
             if (gcount[g] > 0 && (gbase < 3 || gbase + gcount[g] > total - 2)) {
-                const unsigned long long E = nm.get(2 * g), O = nm.get(2 * g + 1);
-                const int bE = lane_bit(E), bO = lane_bit(O);
-                const int re = mbcnt64(O, mbcnt64(E, gbase));   // knots before the even sample
+                const int bE = lane_bit(E[g]), bO = lane_bit(O[g]);
+                const int re = mbcnt64(O[g], mbcnt64(E[g], gbase));   // knots before the even sample
                 const int ro_ = re + bE;                        // knots before the odd sample
                 const int pe = 128 * g + 2 * lane;
                 if (bE) {
@@ -742,7 +799,21 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
             }
             gbase += gcount[g];
         }
-        if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)nm.hi << 32) | nm.lo;   // lane j holds word j
+        unsigned flo = 0, fhi = 0;   // lane j < 2 * G2 gets word j (v_writelane from the scalar registers)
+        auto put = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < G2) {
+                flo = write_lane<2 * g>(flo, (unsigned)E[g]);
+                fhi = write_lane<2 * g>(fhi, (unsigned)(E[g] >> 32));
+                flo = write_lane<2 * g + 1>(flo, (unsigned)O[g]);
+                fhi = write_lane<2 * g + 1>(fhi, (unsigned)(O[g] >> 32));
+            }
+        };
+        put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{}); put(std::integral_constant<int, 2>{});
+        put(std::integral_constant<int, 3>{}); put(std::integral_constant<int, 4>{}); put(std::integral_constant<int, 5>{});
+        put(std::integral_constant<int, 6>{}); put(std::integral_constant<int, 7>{});
+        static_assert(G2 <= 8, "flag words per record");
+        if (lane < 2 * G2) lrec->flags[lane] = ((unsigned long long)fhi << 32) | flo;
     }
     wave_sync();
     if (lane == 0) lrec->packed = rec_pack(total, s_pos[0], s_pos[1], s_pos[2], s_pos[3], s_pos[4]);
@@ -766,27 +837,19 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
 template <typename T, int NG>
 __device__ __forceinline__ void knot_masks(const T (&v)[NG][2], int lo, int hi, unsigned long long (&E)[NG], unsigned long long (&O)[NG])
 {
-    (void)0;
-    T d0[NG];
+    T d0[NG], d1[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const T fill = (g == 0) ? v[0][0] : wave_dpp<0x13C>((T)0, v[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
         const T left = wave_dpp<0x138>(fill, v[g][1]);
         d0[g] = v[g][0] - left;
+        d1[g] = v[g][1] - v[g][0];
     }
-    const bool clip = lo > 1 || hi < 128 * NG - 2;
+    knot_predicate<T, NG>(d0, d1, (T)0, E, O);   // last window position: right neighbour unknown (a zero difference never flags)
+    E[0] &= ~1ull;                                // window position 0: left neighbour unknown
+    if (lo > 1 || hi < 128 * NG - 2) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const T d1 = v[g][1] - v[g][0];
-        const T fill = (g == NG - 1) ? (T)0 : wave_dpp<0x134>((T)0, d0[g < NG - 1 ? g + 1 : g]);   // lane 63 <- lane 0 of the next group
-        const T d2 = wave_dpp<0x130>(fill, d0[g]);
-        const bool fe = ((d1 > (T)0) && (d0[g] <= (T)0)) || ((d1 < (T)0) && (d0[g] >= (T)0));
-        const bool fo = ((d2 > (T)0) && (d1 <= (T)0)) || ((d2 < (T)0) && (d1 >= (T)0));
-        E[g] = __ballot(fe);
-        O[g] = __ballot(fo);
-        if (g == 0) E[g] &= ~1ull;                      // window position 0: left neighbour unknown
-        if (g == NG - 1) O[g] &= ~(1ull << 63);         // last window position: right neighbour unknown
-        if (clip) {   // wave-uniform lane ranges: even position 128 g + 2 l in [lo, hi], odd position 128 g + 2 l + 1 in [lo, hi]
+        for (int g = 0; g < NG; ++g) {   // wave-uniform lane ranges: even position 128 g + 2 l in [lo, hi], odd position 128 g + 2 l + 1 in [lo, hi]
             E[g] &= bit_range((lo - 128 * g + 1) >> 1, (hi - 128 * g) >> 1);
             O[g] &= bit_range((lo - 128 * g) >> 1, (hi - 128 * g - 1) >> 1);
         }
@@ -1030,6 +1093,22 @@ __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, in
 // finds too few away from the signal's ends it raises SigState::l0_fail — the engine then repeats the level-0 step with
 // k_scan0 + the record-driven launch (itd_engine.hip).  The signal is read once: the separate scan pass disappears.
 constexpr int kReach = 8;   // extension windows per side (510 new samples each)
+// ITD_PROF=1 (diagnostic build, tools/level0_prof.py): wall-clock of a wavefront's phases in the fused level-0 launch, s_memtime
+// at the phase boundaries accumulated in scalar registers, one 128-byte row per wavefront at the end (no atomics)
+#ifndef ITD_PROF
+#define ITD_PROF 0
+#endif
+#if ITD_PROF
+__device__ unsigned long long *g_prof_buf;   // [wavefronts][16]
+#define PROF_MARK(i)                                                   \
+    if constexpr (FUSE0) {                                             \
+        const unsigned long long now__ = __builtin_readcyclecounter(); \
+        pt##i += now__ - pt_last;                                      \
+        pt_last = now__;                                               \
+    }
+#else
+#define PROF_MARK(i)
+#endif
 template <typename Tin, int TW, bool FINAL, int CAP, int KT, bool FUSE0 = false>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
@@ -1062,6 +1141,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     int32_t *s_gi = reinterpret_cast<int32_t *>(s_S);
 
     const int sig = blockIdx.y;
+#if ITD_PROF
+    unsigned long long pt_last = __builtin_readcyclecounter(), pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0, pt5 = 0, pt6 = 0, pt7 = 0, pt8 = 0;
+    const unsigned long long pt_begin = pt_last;
+    const unsigned long long pt_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     SigState *st = state + sig;
     const Tin *x = xin + (int64_t)sig * x_stride;
     const size_t slot0 = (size_t)sig * n_tiles;
@@ -1156,6 +1240,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const double mn = (e2 + e3) / 2.0;     // numpy.mean(x[-2:]), ITD.py:102
     double *ends_next = st->ends[(level + 1) & 1];
     const double inf = __builtin_huge_val();
+    PROF_MARK(0)   // requests issued, the signal's end samples here
 
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -1328,6 +1413,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         // window = [s-128, s+TW+128): positions allowed to flag are the signal's 1 .. n-2 (ITD.py:70-73)
         unsigned long long E[G2 + 2], O[G2 + 2];
         knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O);
+        PROF_MARK(1)   // the tile has arrived; knot predicate on tile + halo groups
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
             const int bE = lane_bit(E[g + 1]), bO = lane_bit(O[g + 1]);
@@ -1426,6 +1512,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             wave_sync();
         }
         if (fail && lane == 0) atomicOr(&st->l0_fail, 1);   // the engine repeats level 0 through k_scan0 + the record-driven launch
+        PROF_MARK(2)   // ranks, halo knots
     }
     // ---- the tile itself, needed from here on ---------------------------------------------------------------------------
     double xr[G2][2];   // samples beyond the row were read as 0
@@ -1502,6 +1589,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             }
         }
         wave_sync();
+        PROF_MARK(3)   // knots by rank into LDS
         if (g1 < G2 && lane < 2) { s_hX[5 + lane] = s_X[m + lane]; s_hI[5 + lane] = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
         // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
         for (int L = 1 + lane; L <= m + 3; L += kWave) {
@@ -1517,6 +1605,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             s_B[L] = Bv;
         }
         wave_sync();
+        PROF_MARK(4)   // knot values
         // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 --------------------------------
         for (int L = 1 + lane; L <= m + 2; L += kWave) {
             const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
@@ -1524,6 +1613,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             if (!endn) s_S[L] = sl;
         }
         wave_sync();
+        PROF_MARK(5)   // slopes
       }
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------
         if (lane == 0) {
@@ -1611,6 +1701,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         rb += m;
         g0 = g1;
         wave_sync();
+        PROF_MARK(6)   // map + stores issued
     }
     // ---- knots of the baseline just produced = the next level's input, on registers.  A tile that holds (or borders on) a
     //      NaN or an infinity first goes through the reference's NaN rules: what they add to the plain count, and the
@@ -1628,6 +1719,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                                 counts_out, recs_out, gsum_out, s_rec, s_pos);
     }
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
+    PROF_MARK(7)   // next level's scan + record
   }
     if (blockIdx.x == 0 && !(ITD_ABL_R & 16384)) {
         // ---- tile 0's wavefront, after its own tile (kept off the path between the loads and their first use: a branch
@@ -1657,6 +1749,20 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
         for (int q = lane; q < n_groups; q += kWave) gc[(size_t)q * kGsumPitch] = 0;
     }
+#if ITD_PROF
+    if constexpr (FUSE0) {
+        PROF_MARK(8)
+        if (lane_id() == 0 && g_prof_buf) {
+            unsigned long long *o = g_prof_buf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+            o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = pt3; o[4] = pt4; o[5] = pt5; o[6] = pt6; o[7] = pt7; o[8] = pt8;
+            o[9] = pt_last - pt_begin; o[10] = pt_begin; o[11] = pt_last;
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[12] = xcc; o[13] = hwid;
+            o[14] = __builtin_amdgcn_s_memrealtime() - pt_rt0; o[15] = pt_rt0;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
