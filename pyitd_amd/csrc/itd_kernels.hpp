@@ -732,7 +732,9 @@ template <int TW, bool COUNT_ONLY = false>
 __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], double x_lo, double x_hi, int64_t s, int nrem,
                                             size_t slot, size_t gsum_index, int32_t *__restrict__ counts_out,
                                             TileRec *__restrict__ recs_out, int32_t *__restrict__ gsum_out,
-                                            int32_t *s_rec /* sizeof(TileRec) bytes, 16-byte aligned */, int32_t *s_pos /* 8 ints */)
+                                            int32_t *s_rec /* sizeof(TileRec) bytes, 16-byte aligned */, int32_t *s_pos /* 8 ints */,
+                                            int count_hi = 0 /* added to the int behind the group sum by the same (64-bit) atomic:
+                                                                the fused level-0 launch's own knot count, for m[0] */)
 {
     constexpr int G2 = TW / 128;
     const int lane = lane_id();
@@ -770,7 +772,9 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
     // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
     if (lane == 0) {
         if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
-        if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[gsum_index], total);
+        if (count_hi)   // the group sums are 128 bytes apart: element +1 is free, and 8-byte aligned with element 0
+            atomicAdd(reinterpret_cast<unsigned long long *>(&gsum_out[gsum_index]), ((unsigned long long)(unsigned)count_hi << 32) | (unsigned)total);
+        else if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[gsum_index], total);
     }
     if constexpr (COUNT_ONLY) return total;   // the "Out of time!" launch: only the stop test reads this level's knots
     // the record: first three / last two knots, written by their owner lanes (rank = knots before the sample); the tile's
@@ -1423,7 +1427,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             gcnt |= (unsigned)cg << (8 * g);
             own_c += cg;
         }
-        if (lane == 0 && own_c) atomicAdd(const_cast<int32_t *>(&gs[(size_t)(t / kTilesPerGroup) * kGsumPitch]), own_c);   // for m[0] only
         const int cL = __popcll(E[0]) + __popcll(O[0]), cR = __popcll(E[G2 + 1]) + __popcll(O[G2 + 1]);
         nb = min(cL, 2);
         nf = min(cR, 3);
@@ -1551,6 +1554,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             }
         }
         const int nfp = min(3, (c - rb - m) + nf);   // real knots behind the run
+        const bool has_ends = (rb == 0 && nb == 0) || nfp < 3;
+        const bool one_pass = g0 == 0 && g1 == G2;   // the run is the whole tile: every own knot has a slot
       if (ITD_ABL_R & 2048) {   // timing skeleton: one constant segment instead of the knot phases
         if (lane == 0) { s_B[1] = 1.0; s_S[1] = 0.5; s_X[1] = 0.25; }
         wave_sync();
@@ -1564,11 +1569,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 const int ke = ki & 0xffff, bE = (ki >> 16) & 1, bO = (ki >> 17) & 1;
                 const int Le = ke - rb + 1;          // slot of the even sample's knot (if it is one): rank ke-1
                 const int Lo = Le + bO;              // slot of the odd sample's knot: rank ke+bO-1
-                if (bE && (unsigned)(Le - 2) < (unsigned)(m + 3)) {
+                if (bE && (one_pass || (unsigned)(Le - 2) < (unsigned)(m + 3))) {
                     s_X[Le] = xr[g][0];
                     s_gi[Le] = si + p;
                 }
-                if (bO && (unsigned)(Lo - 2) < (unsigned)(m + 3)) {
+                if (bO && (one_pass || (unsigned)(Lo - 2) < (unsigned)(m + 3))) {
                     s_X[Lo] = xr[g][1];
                     s_gi[Lo] = si + p + 1;
                 }
@@ -1599,9 +1604,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             const double tt = frac * (x2 - x0);
             const double u = x0 + tt;
             double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
-            const bool end0 = (L == 1) && (rb == 0) && (nb == 0);             // e[0]   = sample 0
-            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // e[m+1] = sample n-1
-            Bv = end0 ? m0 : (endn ? mn : Bv);
+            if (has_ends) {   // wave-uniform: only next to the signal's ends is a slot of the pass one of the two end knots
+                const bool end0 = (L == 1) && (rb == 0) && (nb == 0);         // e[0]   = sample 0
+                const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);       // e[m+1] = sample n-1
+                Bv = end0 ? m0 : (endn ? mn : Bv);
+            }
             s_B[L] = Bv;
         }
         wave_sync();
@@ -1609,7 +1616,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 --------------------------------
         for (int L = 1 + lane; L <= m + 2; L += kWave) {
             const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
-            const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);           // sample n-1 starts no segment
+            const bool endn = has_ends && (L >= m + 2) && (L - (m + 2) >= nfp);   // sample n-1 starts no segment
             if (!endn) s_S[L] = sl;
         }
         wave_sync();
@@ -1716,7 +1723,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             }
         }
         scan_publish<TW, FINAL>(xr, x_lo, x_hi, s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
-                                counts_out, recs_out, gsum_out, s_rec, s_pos);
+                                counts_out, recs_out, gsum_out, s_rec, s_pos, FUSE0 ? own_c : 0);
     }
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
     PROF_MARK(7)   // next level's scan + record
@@ -1732,13 +1739,13 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
         int32_t *gc = gsum_clear + (size_t)sig * n_groups * kGsumPitch;
         if (level == 1) {
-            // the fused level-0 launch could only accumulate the signal's own knot total (its tiles ran concurrently): it is
-            // complete now, in the buffer this launch is about to clear (the record-driven level 0 wrote the same number)
+            // the fused level-0 launch could only accumulate the signal's own knot total (its tiles ran concurrently), in the ints
+            // behind the group sums this launch reads (scan_publish's count_hi): complete now.  A record-driven level 0 has set m[0].
             int a0 = 0;
-            for (int q = lane; q < n_groups; q += kWave) a0 += gc[(size_t)q * kGsumPitch];
+            for (int q = lane; q < n_groups; q += kWave) a0 += gs[(size_t)q * kGsumPitch + 1];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) a0 += __shfl_xor(a0, d);
-            if (lane == 0) st->m[0] = a0;
+            if (lane == 0 && st->m[0] < 0) st->m[0] = a0;
         }
         if (lane == 0 && !FUSE0) {
             // the baseline this level reads held a NaN: the reference counted its knots under the NaN rules (nan_rules)
