@@ -1561,6 +1561,30 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         wave_sync();
       } else {
         // own knots by rank (owner lanes), slots 0 .. m+4 of this pass
+        if (one_pass) {
+            // the common case: every own knot has a slot and every halo slot a halo knot.  No exec-masked regions: samples that
+            // are not knots write to a spare slot behind the pass's slots
+            constexpr int kSpare = RK - 1;
+            if (c > 0) {
+#pragma unroll
+                for (int g = 0; g < G2; ++g) {
+                    int p = 128 * g + 2 * lane, ki = kinfo[g];
+                    asm volatile("" : "+v"(p), "+v"(ki));
+                    const int Le = (ki & 0xffff) + 1;               // rb = 0: slot of the even sample's knot (rank ke-1)
+                    const int se = (ki & 0x10000) ? Le : kSpare;
+                    const int so = (ki & 0x20000) ? Le + 1 : kSpare;   // the odd sample's knot: rank ke
+                    s_X[se] = xr[g][0];
+                    s_gi[se] = si + p;
+                    s_X[so] = xr[g][1];
+                    s_gi[so] = si + p + 1;
+                }
+            }
+            if (lane < 5) {   // slots 0, 1 and m+2 .. m+4: the five knots around the tile
+                const int L = lane < 2 ? lane : m + lane;
+                s_X[L] = s_hX[lane];
+                s_gi[L] = s_hI[lane];
+            }
+        } else {
         if (c > 0) {
 #pragma unroll
             for (int g = 0; g < G2; ++g) {
@@ -1569,11 +1593,11 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 const int ke = ki & 0xffff, bE = (ki >> 16) & 1, bO = (ki >> 17) & 1;
                 const int Le = ke - rb + 1;          // slot of the even sample's knot (if it is one): rank ke-1
                 const int Lo = Le + bO;              // slot of the odd sample's knot: rank ke+bO-1
-                if (bE && (one_pass || (unsigned)(Le - 2) < (unsigned)(m + 3))) {
+                if (bE && (unsigned)(Le - 2) < (unsigned)(m + 3)) {
                     s_X[Le] = xr[g][0];
                     s_gi[Le] = si + p;
                 }
-                if (bO && (one_pass || (unsigned)(Lo - 2) < (unsigned)(m + 3))) {
+                if (bO && (unsigned)(Lo - 2) < (unsigned)(m + 3)) {
                     s_X[Lo] = xr[g][1];
                     s_gi[Lo] = si + p + 1;
                 }
@@ -1592,6 +1616,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 s_X[L] = s_hX[5 + lane];
                 s_gi[L] = s_hI[5 + lane];
             }
+        }
         }
         wave_sync();
         PROF_MARK(3)   // knots by rank into LDS
