@@ -43,14 +43,9 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
         gsum[i] = 0;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    for (int j = 0; j < kMaxLevels; ++j) { st[b].m[j] = -1; st[b].c_delta[j] = 0; }
-    st[b].stop_level = -1;
-    st[b].nan_mask = 0;
-    if (!keep_in_nan) st[b].in_nan = 0;   // the NaN-input repeat needs to know which signals hold one (k_nan_level0)
-    st[b].l0_fail = 0;
-    st[b].fin_stopped = 0;
-    st[b].fin_stop_level = -1;
-    st[b].chain_stop = 0;
+    const int in_nan = st[b].in_nan;
+    sig_state_reset(st + b);
+    if (keep_in_nan) st[b].in_nan = in_nan;   // the NaN-input repeat needs to know which signals hold one (k_nan_level0)
 }
 
 __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
@@ -71,14 +66,21 @@ struct itd_engine {
     int32_t *d_counts = nullptr;   // [2][batch][tiles]  knots per tile, double buffered by level parity
     TileRec *d_recs = nullptr;     // [2][batch][tiles]  head/tail knot records, double buffered by level parity
     int64_t tiles_half = 0;        // elements per counts/recs buffer
-    int32_t *d_gsum = nullptr;     // [3][batch][groups*pitch]: per-64-tile knot totals, rotating by level % 3
+    int32_t *d_gsum = nullptr;     // [2][3][batch][groups*pitch]: per-64-tile knot totals, rotating by level % 3; two sets (below)
     int64_t gsum_third = 0;        // elements per buffer
     int32_t *d_kidx = nullptr;     // [max_n + 2]  ordered knot indices for the API helpers (single signal)
     int32_t *d_total = nullptr;    // [1] knot total written by k_compact
     double *d_pp = nullptr;        // [batch][3][pp_pitch] rotating baselines (slot = level % 3)
     int64_t pp_pitch = 0;          // elements between consecutive slots: max_n + kSlotPad (breaks the power-of-two distance)
-    SigState *d_state = nullptr;   // [batch]
+    SigState *d_state = nullptr;   // [2][batch]
     SigState *h_state = nullptr;   // pinned
+    // Per-signal states and group sums exist twice.  A decomposition works on the set the previous one did not use, and its last
+    // launch (k_finalize) re-initialises the other set for the call after it: no initialising launch in front of a decomposition,
+    // and the summary of the last call stays readable.  dirty_*: the leading part of a set that may not be in its initial state
+    // (signals / group-sum elements per buffer); a call that finds its set dirty initialises it with a launch of its own.
+    int cur_set = 0;
+    int32_t dirty_sig[2] = {0, 0};
+    int64_t dirty_gs[2] = {0, 0};
     // workspace of the single-level helpers (itd_detect_*, itd_baseline_extract_*): one signal, apart from the
     // decomposition's, so a helper call never disturbs a decomposition that is still in flight or not yet summarised
     int32_t *d_hcounts = nullptr;  // [2][tiles]
@@ -221,12 +223,28 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // (~2 us per launch, measured), the whole-decomposition span two marker records (~5 us each)
     e->timing_now = e->timing && (e->timing_seq++ % e->timing_stride == 0);
     const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
-    {
-        // only the part of each buffer this batch/size uses needs clearing, but the buffers are small: clear all
-        const int64_t ge = 3 * e->gsum_third;
+    // the set of states / group sums this call works on: the one the previous call did not use (the NaN-input repeat: the same
+    // again, its states carry the in_nan flags), initialised by that call's k_finalize unless the bookkeeping says otherwise
+    const int set = nan_input ? e->cur_set : (e->cur_set ^ 1);
+    SigState *const set_state = e->d_state + (size_t)set * e->max_batch;
+    int32_t *const set_gsum = e->d_gsum + (size_t)set * 3 * e->gsum_third;
+    SigState *const other_state = e->d_state + (size_t)(set ^ 1) * e->max_batch;
+    int32_t *const other_gsum = e->d_gsum + (size_t)(set ^ 1) * 3 * e->gsum_third;
+    const int64_t gs_extent = (int64_t)batch * n_groups * kGsumPitch;
+    // a call that is being captured into a graph must be complete in itself (the graph may be replayed any number of times)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (nan_input || capturing || e->dirty_sig[set] > 0 || e->dirty_gs[set] > 0) {
+        const int64_t ge = 3 * e->gsum_third;   // the buffers are small: clear all of them
         const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
-        k_init_state<<<gb, 256, 0, st>>>(e->d_state, batch, e->d_gsum, ge, nan_input ? 1 : 0);
+        k_init_state<<<gb, 256, 0, st>>>(set_state, batch, set_gsum, ge, nan_input ? 1 : 0);
+        e->dirty_sig[set] = std::max(e->dirty_sig[set], batch);
+    } else {
+        e->dirty_sig[set] = batch;
     }
+    e->dirty_gs[set] = gs_extent;
+    e->cur_set = set;
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
@@ -253,10 +271,10 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         const int lane_s = chunk_no % S;
         const hipStream_t cst = lane_s == 0 ? st : e->aux_stream[lane_s - 1];   // this chunk's stream
         const int nb = std::min(chunk, batch - b0);   // signals b0 .. b0+nb-1: grid.y, every per-signal pointer offset by b0
-        auto gs = [&](int level) { return e->d_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b0 * n_groups * kGsumPitch; };
+        auto gs = [&](int level) { return set_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b0 * n_groups * kGsumPitch; };
         auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
         auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
-        SigState *state = e->d_state + b0;
+        SigState *state = set_state + b0;
         const Tin *xc = x + (int64_t)b0 * x_stride;
         double *rows_c = rows + (int64_t)b0 * rows_stride;
         double *bases_c = bases_user ? bases_user + (int64_t)b0 * rows_stride : nullptr;
@@ -325,17 +343,23 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
         {
             const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
+            int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
-                                                                       gs(M + 2), n_tiles, M + 2, state);
+                                                                       gs(M + 2), n_tiles, M + 2, state, other_state + b0, og, e->gsum_third);
             else
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
-                                                                       e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, state);
+                                                                       e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, state, other_state + b0, og, e->gsum_third);
         }
     }
     for (int k = 0; k < S - 1; ++k) {
         HIP_TRY(e, hipEventRecord(e->ev_join[k], e->aux_stream[k]));
         HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[k], 0));
+    }
+    // what this call's k_finalize launches leave initialised in the other set
+    if (!capturing && batch >= e->dirty_sig[set ^ 1] && gs_extent >= e->dirty_gs[set ^ 1]) {
+        e->dirty_sig[set ^ 1] = 0;
+        e->dirty_gs[set ^ 1] = 0;
     }
     time_end(e, span_pair, st);
     HIP_TRY(e, hipGetLastError());
@@ -413,6 +437,8 @@ int enqueue_chain(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t
         const int64_t ge = (int64_t)(n_levels + 1) * gpitch;
         const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
         k_chain_init<<<gb, 256, 0, st>>>(e->d_ctl, e->d_state, batch, e->d_cgsum, ge);
+        e->cur_set = 0;   // the chain keeps to set 0 of the states and initialises them itself
+        e->dirty_sig[0] = std::max(e->dirty_sig[0], batch);
     }
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
@@ -553,12 +579,14 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     alloc((void **)&e->d_lists, (size_t)e->max_tiles * T * sizeof(int32_t));   // API helpers only (one signal)
     alloc((void **)&e->d_counts, 2 * (size_t)e->tiles_half * sizeof(int32_t));
     alloc((void **)&e->d_recs, 2 * (size_t)e->tiles_half * sizeof(TileRec));
-    alloc((void **)&e->d_gsum, 3 * (size_t)e->gsum_third * sizeof(int32_t));
+    alloc((void **)&e->d_gsum, 2 * 3 * (size_t)e->gsum_third * sizeof(int32_t));
     alloc((void **)&e->d_kidx, (size_t)(max_n + 2) * sizeof(int32_t));
     alloc((void **)&e->d_total, 64);
     e->pp_pitch = max_n + kSlotPad;
     alloc((void **)&e->d_pp, B * 3 * (size_t)e->pp_pitch * sizeof(double));
-    alloc((void **)&e->d_state, B * sizeof(SigState));
+    alloc((void **)&e->d_state, 2 * B * sizeof(SigState));
+    e->dirty_sig[0] = e->dirty_sig[1] = max_batch;       // nothing is initialised yet
+    e->dirty_gs[0] = e->dirty_gs[1] = e->gsum_third;
     e->hgsum_third = (int64_t)max_groups * kGsumPitch;
     alloc((void **)&e->d_hcounts, 2 * (size_t)e->max_tiles * sizeof(int32_t));
     alloc((void **)&e->d_hrecs, 2 * (size_t)e->max_tiles * sizeof(TileRec));
@@ -659,7 +687,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     if (!e->ran) return ITD_ERR_NOT_RUN;
     DevGuard g(e->device);
     const int B = e->last_batch;
-    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
     if (e->last_chain)
         HIP_TRY(e, hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(ChainCtl), hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
@@ -672,7 +700,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
             ? enqueue_decompose<float>(e, (const float *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0, nan_in)
             : enqueue_decompose<double>(e, (const double *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0, nan_in);
         if (rc) return rc;
-        HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+        HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
         HIP_TRY(e, hipStreamSynchronize(e->last_stream));
         return (int)ITD_OK;
     };
@@ -711,7 +739,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                 ? enqueue_decompose<float>(e, (const float *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0)
                 : enqueue_decompose<double>(e, (const double *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0);
             if (rc) return rc;
-            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
             HIP_TRY(e, hipStreamSynchronize(e->last_stream));
         }
     }
@@ -731,7 +759,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                 ? enqueue_decompose<float>(e, (const float *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, false)
                 : enqueue_decompose<double>(e, (const double *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, false);
             if (rc) return rc;
-            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
             HIP_TRY(e, hipStreamSynchronize(e->last_stream));
         }
     }

@@ -1805,16 +1805,43 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
 // row when c = 0.  Every workgroup totals the last level's group sums itself (a few KB from L2) so that all of them
 // reach the same verdict without reading what workgroup 0 publishes.  grid = (blocks, batch), 256 threads.
 // ---------------------------------------------------------------------------------------------
+// a signal's state as a decomposition expects to find it (k_init_state, and k_finalize for the call after the next)
+__device__ __forceinline__ void sig_state_reset(SigState *st)
+{
+    for (int j = 0; j < kMaxLevels; ++j) { st->m[j] = -1; st->c_delta[j] = 0; }
+    st->stop_level = -1;
+    st->nan_mask = 0;
+    st->in_nan = 0;
+    st->l0_fail = 0;
+    st->fin_stopped = 0;
+    st->fin_stop_level = -1;
+    st->chain_stop = 0;
+}
+
 constexpr int kFinalizeThreads = 256;
 __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restrict__ rows, int64_t rows_stride,
                                                                int64_t n, const double *__restrict__ bases,
                                                                int64_t bases_stride, int64_t bases_row_pitch,
                                                                int bases_rotate, const int32_t *__restrict__ gsum_last,
                                                                int n_tiles, int level_last,
-                                                               SigState *__restrict__ state)
+                                                               SigState *__restrict__ state,
+                                                               SigState *__restrict__ other_state = nullptr,
+                                                               int32_t *__restrict__ other_gsum = nullptr, int64_t other_third = 0)
 {
     __shared__ int s_red[kFinalizeThreads / 64];
     const int sig = blockIdx.y;
+    // the other set of states / group sums (itd_engine.hip): left in its initial state for the decomposition after this one —
+    // the signal's state, and elements 0 and 1 (all that is ever written) of its group-sum slots in the three rotating buffers
+    if (other_state) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) sig_state_reset(other_state + sig);
+        const int n_groups = groups_of(n_tiles);
+        int32_t *og = other_gsum + (size_t)sig * n_groups * kGsumPitch;
+        for (int k = blockIdx.x * kFinalizeThreads + threadIdx.x; k < 3 * n_groups; k += gridDim.x * kFinalizeThreads) {
+            int32_t *slot = og + (size_t)(k / n_groups) * other_third + (size_t)(k % n_groups) * kGsumPitch;
+            slot[0] = 0;
+            slot[1] = 0;
+        }
+    }
     SigState *st = state + sig;
     int stop_level = st->stop_level;
     int stopped = stop_level >= 0;
