@@ -279,3 +279,63 @@ def test_batch_streams_and_chunks_do_not_change_results(P, torch, oracle):
             assert_bits_equal(rows[b, :nr].cpu().numpy(), refs[b]["rows"], what + " rows")
             assert_bits_equal(bases[b, :nb].cpu().numpy(), refs[b]["baselines"], what + " baselines")
     eng.close()
+
+
+def test_state_sets_survive_changing_geometry(P, torch, oracle):
+    """The engine keeps two sets of per-signal states / group sums; a call's last launch re-initialises the set the NEXT call will
+    use (no initialising launch per call).  Results must not depend on what ran before: batches and lengths that grow and shrink
+    on one engine, calls whose summary is never read, signals that stop early or hold a NaN, a graph replayed twice and plain
+    calls after it."""
+    rng = np.random.default_rng(4711)
+    Bmax, nmax, M = 12, 70000, 6
+    eng = P.Engine(nmax, Bmax, 0)
+
+    def make(B, n, special):
+        xs = np.stack([sines_noise(n, seed=int(rng.integers(0, 1 << 30)), fscale=1 + b / 8) for b in range(B)]).astype(np.float64)
+        if special and B > 2:
+            xs[1] = np.linspace(-1, 1, n)            # stops at once
+            xs[2, n // 2] = np.nan                   # NaN-input repeat (runs on the same set again)
+        return xs
+
+    def check(xs, read_summary=True):
+        B, n = xs.shape
+        x = torch.from_numpy(xs).cuda()
+        rows = torch.full((B, M + 2, n), -3.0, dtype=torch.float64, device="cuda")
+        eng.decompose_dev(x.data_ptr(), np.float64, n, B, n, M, rows.data_ptr(), None, None)
+        if not read_summary:
+            torch.cuda.synchronize()
+            return
+        s = eng.summary(B)
+        for b in range(B):
+            ref = oracle.itd(xs[b], M)
+            nr = int(s["n_rows"][b])
+            assert nr == ref["rows"].shape[0], "B %d n %d signal %d" % (B, n, b)
+            assert_bits_equal(rows[b, :nr].cpu().numpy(), ref["rows"], "B %d n %d signal %d" % (B, n, b))
+            kc = [int(v) for v in s["knot_counts"][b] if v >= 0]     # [0]: the signal's own knots; [j >= 1]: the stop test's counts
+            want = [int(v) for v in ref["knot_counts"]]
+            assert kc[1: 1 + len(want)] == want[: len(kc) - 1], "B %d n %d signal %d" % (B, n, b)
+
+    for B, n, special, read in ((12, 70000, True, True), (1, 513, False, True), (3, 20000, True, False), (12, 9000, False, False),
+                                (2, 70000, False, True), (12, 1025, True, True), (5, 40000, True, True), (1, 3, False, True),
+                                (12, 70000, False, True)):
+        check(make(B, n, special), read)
+
+    # a captured call is complete in itself: replayed twice, then plain calls of another geometry
+    n = 1 << 15
+    x = torch.zeros((2, n), dtype=torch.float64, device="cuda")
+    rows = torch.zeros((2, M + 2, n), dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        eng.decompose_dev(x.data_ptr(), np.float64, n, 2, n, M, rows.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    for seed in (5, 6):
+        xh = np.stack([sines_noise(n, seed=seed), sines_noise(n, seed=seed + 10, fscale=3.0)]).astype(np.float64)
+        x.copy_(torch.from_numpy(xh))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for b in range(2):
+            assert_bits_equal(rows[b].cpu().numpy(), oracle.itd_lean(xh[b], M)["rows"], "replay seed %d signal %d" % (seed, b))
+    check(make(7, 30000, True))
+    check(make(12, 70000, False))
+    eng.close()
