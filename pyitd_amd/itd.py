@@ -47,16 +47,6 @@ def _engine_for(n, device=0):
 
 
 _batch_engines = {}
-_pending = None    # weak reference to the ITD instance whose baselines are still on the device (at most one per process)
-
-
-def _flush_pending():
-    """Bring the baselines of the last ITD().itd() call to the host before their device buffer is reused or freed."""
-    global _pending
-    inst = _pending() if _pending is not None else None
-    _pending = None
-    if inst is not None:
-        inst._fetch_baselines()
 
 
 def _batch_engine_for(n, batch, device=0):
