@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -563,8 +564,13 @@ int copy_to_host(itd_engine *e, void *dst_host, const void *src_dev, size_t byte
         }
     const size_t n_chunks = (bytes + kPinBytes - 1) / kPinBytes;
     std::atomic<size_t> ready{0};                       // chunks whose DMA has completed
-    std::vector<std::atomic<int>> done(n_chunks);       // host threads that have finished with chunk k
-    for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    std::unique_ptr<std::atomic<int>[]> done(new (std::nothrow) std::atomic<int>[n_chunks]);   // host threads done with chunk k
+    if (!done) {
+        HIP_TRY(e, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        return ITD_OK;
+    }
+    for (size_t k = 0; k < n_chunks; ++k) done[k].store(0, std::memory_order_relaxed);
     std::atomic<bool> abort_copy{false};
     auto worker = [&](int tix) {
         for (size_t k = 0; k < n_chunks; ++k) {
@@ -580,8 +586,16 @@ int copy_to_host(itd_engine *e, void *dst_host, const void *src_dev, size_t byte
         }
     };
     std::vector<std::thread> pool;
-    pool.reserve(kCopyThreads);
-    for (int t = 0; t < kCopyThreads; ++t) pool.emplace_back(worker, t);
+    try {   // nothing may be thrown across the C ABI: without its host threads the copy takes the plain path
+        pool.reserve(kCopyThreads);
+        for (int t = 0; t < kCopyThreads; ++t) pool.emplace_back(worker, t);
+    } catch (...) {
+        abort_copy.store(true);
+        for (auto &t : pool) t.join();
+        HIP_TRY(e, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+        return ITD_OK;
+    }
     hipError_t rc = hipSuccess;
     for (size_t k = 0; k < n_chunks && rc == hipSuccess; ++k) {
         if (k >= 2)   // the bounce buffer is free again once every host thread has copied chunk k-2 out of it
