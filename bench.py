@@ -21,6 +21,8 @@ Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kern
 algorithmic B/sample, timed with the launches' own hipEvents on the launch stream inside the timed region) + the per-kernel
 fractions + "cpu_baseline" (the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1)
 and the other CPU legs SURVEY 8d lists (all host cores over independent signals, numpy restatement, numba restatement).
+At N = 1 the line also carries "config3_batch" (BASELINE configs[2], 1024 x 2^20 signals): that leg is timed BEFORE the headline's
+warmup, so the headline's short timed region starts on a GPU at its sustained clocks (--no-extra skips the leg).
 """
 import argparse
 import json
