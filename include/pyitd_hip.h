@@ -89,7 +89,10 @@ int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32
  * baselines_dev  optional [batch][max_iteration+2][n] float64: row j = baseline after extraction j+1
  *                (the reference's `baselines` buffer, ITD.py:385,429); NULL = keep only a ping-pong pair
  *                inside the engine (saves 8 B/sample/level of HBM capacity, same traffic).
- * Everything is enqueued on `stream` with no host synchronisation; call itd_get_summary afterwards. */
+ * Everything is enqueued on `stream` with no host synchronisation; call itd_get_summary afterwards.
+ * Calls of one engine must be ordered with respect to each other (the same stream, or synchronised by the caller): they share
+ * the engine's workspace, and a call's last launch leaves part of it initialised for the next call.  A call that is captured
+ * into a graph initialises what it needs itself, so the graph can be replayed any number of times. */
 int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batch, int64_t x_stride,
                       int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream);
 int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
