@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 3
+#define ITD_ABI_VERSION 4
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -221,6 +221,11 @@ int itd_detect_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t 
  * All host pointers; x [n], extrema [m+2] int64, bk [m+2]. */
 int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host,
                              int64_t m, double *bk_host);
+/* The same on device buffers, enqueued on `stream` (no synchronisation, no validation: the caller guarantees
+ * 0 <= extrema_dev[k] < n): x_dev [n] float64, extrema_dev [m+2] int32 (what itd_detect_* delivers, with the end knots
+ * 0 and n-1 around it), bk_dev [m+2] float64 of which bk_dev[1..m] are written. */
+int itd_knot_values_f64(itd_engine *e, const double *x_dev, int64_t n, const int32_t *extrema_dev, int64_t m,
+                        double *bk_dev, void *stream);
 
 /* ---- cubic-spline baseline variant with externally supplied knots ---------------------------
  * itd_baseline_extract_fast(I, extrema_input, idx), itd_fourier_decomposition.py:49-122 — the Python twin of

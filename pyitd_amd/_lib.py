@@ -16,7 +16,7 @@ HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -40,6 +40,7 @@ ABI = {
     "itd_detect_f32": (_INT, [_P, _P, _I64, _I32, _P, _P, _P]),
     "itd_detect_host_f64": (_INT, [_P, _P, _I64, _I32, _P, _P]),
     "itd_knot_values_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P]),
+    "itd_knot_values_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P]),
     "itd_baseline_extract_cubic_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_baseline_extract_cubic_f32": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_baseline_extract_cubic_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),

@@ -1251,6 +1251,18 @@ int itd_knot_values_host_f64(itd_engine *e, const double *x_host, int64_t n, con
     return ITD_OK;
 }
 
+int itd_knot_values_f64(itd_engine *e, const double *x_dev, int64_t n, const int32_t *extrema_dev, int64_t m, double *bk_dev,
+                        void *stream)
+{
+    if (!e || !x_dev || !extrema_dev || !bk_dev) return ITD_ERR_INVALID_ARG;
+    if (n < 2 || n >= (int64_t)INT32_MAX || m < 0 || m > n) return ITD_ERR_INVALID_ARG;
+    if (m == 0) return ITD_OK;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    k_knot_values<double><<<(unsigned)((m + 2 + 255) / 256), 256, 0, st>>>(x_dev, n, extrema_dev, (int)m, bk_dev, 1);
+    HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
+}
 
 }  // extern "C"
 

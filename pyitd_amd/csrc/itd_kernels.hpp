@@ -1883,10 +1883,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restric
 // knot values of an explicit knot list (host-facing single-level operator, ITD.py:100-110)
 template <typename Tin>
 __global__ void k_knot_values(const Tin *__restrict__ x, int64_t n, const int32_t *__restrict__ e, int m,
-                              double *__restrict__ bk)
+                              double *__restrict__ bk, int interior_only = 0 /* leave bk[0], bk[m+1] as the caller set them */)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > m + 1) return;
+    if (k > m + 1 || (interior_only && (k == 0 || k == m + 1))) return;
     double v;
     if (k == 0) v = ((double)x[0] + (double)x[1]) / 2.0;
     else if (k == m + 1) v = ((double)x[n - 2] + (double)x[n - 1]) / 2.0;

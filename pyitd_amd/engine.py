@@ -186,6 +186,11 @@ class Engine:
                                                      _np_ptr(bk)))
         return bk
 
+    def knot_values_dev(self, x_ptr, n, extrema_ptr, m, bk_ptr, stream=None):
+        """baseline_knot_estimation on device buffers (itd_knot_values_f64): x float64[n], extrema int32[m+2], bk float64[m+2]
+        (bk[1..m] are written); asynchronous on `stream`."""
+        self._check(self._L.itd_knot_values_f64(self._h, x_ptr, n, extrema_ptr, m, bk_ptr, stream))
+
     # ---- cubic-spline baseline variant (include/pyitd_hip.h: itd_baseline_extract_cubic_*, itd_find_extrema_*) ----------
     def find_extrema_host(self, signal):
         """find_extrema (itd_fourier_decomposition.py:17-31): (extrema int64[n] zero padded, idx)."""

@@ -339,3 +339,33 @@ def test_state_sets_survive_changing_geometry(P, torch, oracle):
     check(make(7, 30000, True))
     check(make(12, 70000, False))
     eng.close()
+
+
+def test_knot_values_on_device_buffers(P, torch, oracle):
+    """itd_knot_values_f64: baseline_knot_estimation (numba_accelerated_itd.py:167-178) on device buffers — the knots as
+    itd_detect_* delivers them (int32, on the device), asynchronous on the caller's stream; bk[0] and bk[m+1] stay the caller's."""
+    from pyitd_amd import engine as E
+    n = 50000
+    xh = sines_noise(n, seed=12).astype(np.float64)
+    eng = P.Engine(n, 1, 0)
+    x = torch.from_numpy(xh).cuda()
+    idx = torch.zeros(n + 2, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    import ctypes
+    m = ctypes.c_int64(0)
+    rc = eng._L.itd_detect_f64(eng._h, x.data_ptr(), n, E.DETECT_KNOTS, idx.data_ptr() + 4, ctypes.byref(m), s.cuda_stream)
+    assert rc == 0
+    m = int(m.value)
+    want_knots = oracle.knots(xh)
+    assert m == len(want_knots)
+    idx[0] = 0
+    idx[m + 1] = n - 1
+    bk = torch.full((m + 2,), -5.0, dtype=torch.float64, device="cuda")
+    eng.knot_values_dev(x.data_ptr(), n, idx.data_ptr(), m, bk.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    e = np.concatenate([[0], want_knots, [n - 1]]).astype(np.int64)
+    want = oracle.knot_values(xh, e)
+    got = bk.cpu().numpy()
+    assert got[0] == -5.0 and got[-1] == -5.0
+    assert_bits_equal(got[1:-1], want[1:-1], "knot values on device buffers")
+    eng.close()
