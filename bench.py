@@ -374,15 +374,18 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
     rows = torch.empty((batch, MAX_ITERATION + 2, n), dtype=torch.float64, device=dev)
     eng = pyitd_amd.Engine(n, batch, dev.index or 0)
     stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()   # the signals were synthesised on torch's stream, the engine runs on `stream`: without this the
+    #                            first call read rows not yet written (all-zero signals -> one row; the lines of rounds 1-2
+    #                            showed rows_per_signal [1, 9] for that reason; the timed calls were never affected)
     for _ in range(2):
         eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
-    s = eng.summary(batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    s = eng.summary(batch)     # of the last timed call
     alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
     return {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
             "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
