@@ -142,12 +142,15 @@ def run_rank(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo" if stub else "nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if (stub or args.rehearse_one_gpu) else "nccl", rank=rank, world_size=world)
     if stub:
         dev = torch.device("cpu")
     else:
+        if args.rehearse_one_gpu:
+            local_rank = 0   # rehearsal on a one-GPU box: every rank computes on cuda:0, the summaries travel over gloo
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    coll_dev = torch.device("cpu") if (stub or args.rehearse_one_gpu) else dev   # where the collectives' tensors live
 
     from pyitd_amd.distributed import ShardedBatch
 
@@ -228,7 +231,7 @@ def run_rank(args):
     elapsed = elapsed_local
     per_rank_ms = [elapsed_local / args.steps * 1e3]
     if dist.is_initialized():
-        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=coll_dev)
         parts = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(parts, tt)
         per_rank_ms = [float(p.item()) / args.steps * 1e3 for p in parts]
@@ -238,7 +241,7 @@ def run_rank(args):
         extra_keep[2].close()
         extra_keep = None
     # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal), all-gathered
-    table = sb.gather(device=dev) if dist.is_initialized() else None
+    table = sb.gather(device=coll_dev) if dist.is_initialized() else None
 
     if not sharded and not stub:
         from pyitd_amd.engine import TIME_CHAIN, TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
@@ -290,6 +293,8 @@ def run_rank(args):
         },
         "hbm_algorithmic_GBps": round(algorithmic_bytes_per_sample(LEVELS) * samples_per_step * args.steps / elapsed / 1e9, 1),
     }
+    if args.rehearse_one_gpu:
+        out["config"]["rehearsal"] = "all %d ranks shared cuda:0, summaries over gloo: a check of the sharded path, not a scaling measurement" % world
     if stub:
         out["config"]["stub"] = True
         out["config"]["table_signal_ids"] = [int(v) for v in table["knot_counts"][:, 0]] if table is not None else None
@@ -477,6 +482,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational BASELINE configs[2] leg (1024 x 2^20 signals)")
     ap.add_argument("--chain", action="store_true", help="run the opt-in one-launch chain (itd_set_chain_mode) instead of one launch per level")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 on a one-GPU box: all ranks compute on cuda:0 and gather over gloo (checks the sharded path end to end; "
+                         "the line says so and is not a scaling measurement)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher only
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -424,3 +424,26 @@ def test_fused_level0_float32_subnormals_and_huge_values(P, torch, oracle):
     mixed = rng.standard_normal(n).astype(np.float32)
     mixed[::7] = mixed[1::7][: len(mixed[::7])]                          # equal neighbours: plateaus of two
     _modes_agree(P, torch, oracle, mixed, 6)
+
+
+def test_bench_gpus_2_rehearsal_on_one_gpu(torch):
+    """`python bench.py --gpus 2` as the driver's plain form: the parent spawns two ranks which shard config 4's batch recipe,
+    decompose their shard on the GPU and all-gather the summaries.  On a one-GPU box both ranks share cuda:0 and the collective
+    runs over gloo (--rehearse-one-gpu); everything else is the code path of the multi-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--batch", "6",
+                        "--log2n", "16", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["signals_per_gpu"] == 6 and d["config"]["samples_per_signal"] == 1 << 16
+    assert d["config"]["signals_in_gathered_table"] == 12 and d["config"]["rows_all_ranks"] == [9]
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2 and "rehearsal" in d["config"]
