@@ -68,7 +68,8 @@ const char *itd_last_error(const itd_engine *e);
  * `max_n` samples per call.  Allocates the device workspace once (three rotating float64 baseline slots per signal =
  * 24 B per sample, 0.3 B per sample of per-tile records and counts, and one signal's worth of knot lists for the
  * single-level helpers).  No allocation happens
- * in the decompose calls (they are graph-capturable). */
+ * in the decompose calls (they are graph-capturable).  `max_batch` is bounded by memory only: a batch runs in chunks of
+ * at most 65535 signals (itd_set_batch_chunk); the batched FITPACK-flavour call takes at most 65535 signals per call. */
 int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t max_batch);
 void itd_engine_destroy(itd_engine *e);
 int64_t itd_engine_workspace_bytes(const itd_engine *e);

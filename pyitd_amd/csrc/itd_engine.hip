@@ -199,14 +199,15 @@ void time_end(itd_engine *e, int k, hipStream_t st)
 // signals per launch sequence of a batched decomposition.  All levels of a chunk run before the next chunk starts, so
 // the baseline a level writes (8 B per sample per signal) is still in the 256 MiB Infinity Cache when the next level reads it
 // — the state the single 2^24-sample signal is in.  Automatic: about 2^24 samples per chunk.
+constexpr int32_t kMaxGridY = 65535;   // HIP's limit on gridDim.y
 int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 {
-    if (e->chunk > 0) return std::min<int32_t>(e->chunk, batch);
+    if (e->chunk > 0) return std::min<int32_t>(std::min<int32_t>(e->chunk, kMaxGridY), batch);
     // one stream: 2^24 samples per chunk; two or more (the default): 3/4 of that per chunk — two chunks in flight, measured best
     // on 1024 x 2^20 (chunks of 10-12 signals over 2 streams: 32.5 ms against 35.9 ms with 16 over one, profiles/r02/session2_batch_streams.txt)
     const int64_t per = e->batch_streams > 1 ? ((int64_t)3 << 22) : ((int64_t)1 << 24);
     const int64_t c = std::max<int64_t>(1, per / n);
-    return (int)std::min<int64_t>(c, batch);
+    return (int)std::min<int64_t>(std::min<int64_t>(c, kMaxGridY), batch);   // a chunk's signals are the launches' grid.y
 }
 
 template <typename Tin>
@@ -520,7 +521,7 @@ int check_args(itd_engine *e, const void *x, int64_t n, int32_t batch, int64_t x
 {
     if (!e || !x || !rows) return ITD_ERR_INVALID_ARG;
     if (n < 3 || n > e->max_n || n >= (int64_t)INT32_MAX) return ITD_ERR_INVALID_ARG;  // N < 3: ITD.py:42-43 is garbage
-    if (batch < 1 || batch > e->max_batch || batch > 65535) return ITD_ERR_INVALID_ARG;
+    if (batch < 1 || batch > e->max_batch) return ITD_ERR_INVALID_ARG;   // any size: batches run in chunks of <= 65535 signals
     if (batch > 1 && x_stride < n) return ITD_ERR_INVALID_ARG;
     if (M < 0 || M > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;  // row M+1 must fit in 22 rows (ITD.py:384,421)
     return ITD_OK;
@@ -635,7 +636,7 @@ const char *itd_last_error(const itd_engine *e) { return e ? e->err : "null engi
 
 int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t max_batch)
 {
-    if (!out || max_n < 3 || max_batch < 1 || max_batch > 65535 || max_n >= (int64_t)INT32_MAX) return ITD_ERR_INVALID_ARG;
+    if (!out || max_n < 3 || max_batch < 1 || max_n >= (int64_t)INT32_MAX) return ITD_ERR_INVALID_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ITD_ERR_NO_DEVICE;
@@ -1511,7 +1512,7 @@ int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t 
                                     int64_t rot_stride, int32_t *knots_host, void *stream)
 {
     if (!e || !x_dev || !baseline_dev) return ITD_ERR_INVALID_ARG;
-    if (n < 3 || n >= (int64_t)INT32_MAX - 8 || batch < 1 || min_extrema < 0) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n >= (int64_t)INT32_MAX - 8 || batch < 1 || batch > 65535 /* grid.y of its launches */ || min_extrema < 0) return ITD_ERR_INVALID_ARG;
     if (batch > 1 && (x_stride < n || baseline_stride < n || (rot_dev && rot_stride < n))) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;

@@ -447,3 +447,24 @@ def test_bench_gpus_2_rehearsal_on_one_gpu(torch):
     assert d["config"]["signals_per_gpu"] == 6 and d["config"]["samples_per_signal"] == 1 << 16
     assert d["config"]["signals_in_gathered_table"] == 12 and d["config"]["rows_all_ranks"] == [9]
     assert len(d["config"]["per_rank_ms_per_step"]) == 2 and "rehearsal" in d["config"]
+
+
+def test_batch_larger_than_one_grid(P, torch, oracle):
+    """More signals than gridDim.y allows (65535): the batch runs in chunks, nothing about it is special for the caller."""
+    B, n, m = 70000, 200, 3
+    rng = np.random.default_rng(77)
+    x_host = np.cumsum(rng.standard_normal((B, n)), axis=1).astype(np.float32)
+    x = torch.from_numpy(x_host).cuda()
+    rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    eng = P.Engine(n, B, 0)
+    torch.cuda.synchronize()
+    eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
+    s = eng.summary(B)
+    check = sorted(set(list(range(0, 40)) + list(range(65500, 65600)) + list(range(B - 40, B)) + rng.choice(B, 300, replace=False).tolist()))
+    got = rows[check].cpu().numpy()
+    for k, b in enumerate(check):
+        ref = oracle.itd(x_host[b], m)
+        nr = int(s["n_rows"][b])
+        assert nr == ref["rows"].shape[0] and ("natural", "timeout")[int(s["stop"][b])] == ref["stop"], "signal %d" % b
+        assert_bits_equal(got[k, :nr], ref["rows"], "signal %d rows" % b)
+    eng.close()

@@ -1,0 +1,52 @@
+"""Batches of SHORT signals (the reference's own demo sizes: 400-sample chirp, 8000-sample audio clip, image rows) through the
+batched engine: ms per batch, Gsamples/s and the fraction of the HBM peak against the level-by-level algorithmic bytes.
+usage (GPU box): python tools/small_batch_bench.py [max_iteration]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pyitd_amd  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+SHAPES = [(60000, 256), (40000, 400), (16384, 1024), (4096, 4096), (2048, 8000), (1024, 16384), (256, 65536), (16, 1 << 20),
+          (1, 400), (1, 8000), (1, 65536)]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for B, n in SHAPES:
+        t = torch.arange(n, dtype=torch.float64) / 8000.0
+        x = (torch.sin(2 * np.pi * 110 * t)[None, :] + 0.5 * torch.sin(2 * np.pi * 440 * t + 1.3)[None, :]
+             + 0.05 * torch.randn((B, n), generator=g, dtype=torch.float64)).to(torch.float32).to(dev)
+        rows = torch.empty((B, M + 2, n), dtype=torch.float64, device=dev)
+        eng = pyitd_amd.Engine(n, B, 0)
+        if os.environ.get("SMALL_CHAIN"):
+            eng.set_chain_mode(int(os.environ["SMALL_CHAIN"]))   # 1: CHAIN_AUTO, 2: CHAIN_ONLY (pyitd_amd/engine.py)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, M, rows.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        steps = 20
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, M, rows.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        s = eng.summary(B)
+        if os.environ.get("SMALL_CHAIN"):
+            print("        chain repeats so far: %d" % eng.chain_repeats)
+        alg = (20 + 24 * M) * B * n / dt / 1e9
+        print("%6d x %7d: %8.3f ms  %7.2f Gsamples/s  %6.0f GB/s algorithmic = %.3f of peak   rows %s" % (
+            B, n, dt * 1e3, B * n / dt / 1e9, alg, alg / 8000.0, sorted(set(int(v) for v in s["n_rows"]))), flush=True)
+        eng.close()
+        del x, rows
+
+
+if __name__ == "__main__":
+    main()
