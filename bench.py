@@ -135,6 +135,9 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
 
+    # the GPU box gives a process a CPU quota (cgroup), not the host's 256 hardware threads: a pool of that many spinning
+    # intra-op threads gets the whole process throttled for tens of milliseconds (tools/stall_probe.py); nothing here needs them
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -347,7 +347,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         }
         // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
         {
-            const int fb = (int)std::min<int64_t>((n + kFinalizeThreads - 1) / kFinalizeThreads, 1024);
+            // blocks per signal: a thread of the row fix-up moves 8 samples (four 16-byte accesses) before the grid is widened
+            const int fb = (int)std::min<int64_t>(std::max<int64_t>((n + 8 * kFinalizeThreads - 1) / (8 * kFinalizeThreads), 1), 1024);
             int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,

@@ -17,6 +17,11 @@ SHAPES = [(60000, 256), (40000, 400), (16384, 1024), (4096, 4096), (2048, 8000),
 
 
 def main():
+    global SHAPES
+    if os.environ.get("SMALL_SHAPE"):   # e.g. SMALL_SHAPE=16384x1024 (one shape: for a rocprofv3 kernel trace)
+        b, n = os.environ["SMALL_SHAPE"].split("x")
+        SHAPES = [(int(b), int(n))]
+    torch.set_num_threads(8)   # the box's CPU share is a cgroup quota: hundreds of spinning pool threads get the process throttled
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1)
     for B, n in SHAPES:
