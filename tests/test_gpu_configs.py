@@ -468,3 +468,39 @@ def test_batch_larger_than_one_grid(P, torch, oracle):
         assert nr == ref["rows"].shape[0] and ("natural", "timeout")[int(s["stop"][b])] == ref["stop"], "signal %d" % b
         assert_bits_equal(got[k, :nr], ref["rows"], "signal %d rows" % b)
     eng.close()
+
+
+def test_engines_on_concurrent_host_threads(P, torch, oracle):
+    """SURVEY 8b threading: an engine is not thread-safe, but several engines — each with its own host thread and stream —
+    run concurrently on one GPU.  Four threads decompose different signals in loops (device form and host form mixed)."""
+    n, m, iters = 50000, 5, 12
+    rng = np.random.default_rng(99)
+    sigs = [np.cumsum(rng.standard_normal(n)).astype(np.float32) + (0.3 * rng.standard_normal(n)).astype(np.float32) for _ in range(8)]
+    refs = [oracle.itd(x, m) for x in sigs]
+    errors = []
+
+    def worker(k):
+        try:
+            eng = P.Engine(n, 1, 0)
+            stream = torch.cuda.Stream()
+            rows = torch.empty((m + 2, n), dtype=torch.float64, device="cuda")
+            xs = [torch.from_numpy(x).cuda() for x in sigs]
+            torch.cuda.synchronize()
+            for it in range(iters):
+                j = (k + 3 * it) % len(sigs)
+                if it % 3 == 2:
+                    res = eng.decompose_host(sigs[j], m, want_baselines=True)
+                    got, nr = res["rows"], res["rows"].shape[0]
+                else:
+                    eng.decompose_dev(xs[j].data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, stream.cuda_stream)
+                    nr = int(eng.summary(1)["n_rows"][0])
+                    got = rows[:nr].cpu().numpy()
+                if nr != refs[j]["rows"].shape[0] or not np.array_equal(canon_u64(got), canon_u64(refs[j]["rows"])):
+                    errors.append((k, it, j))
+            eng.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    with ThreadPoolExecutor(4) as ex:
+        list(ex.map(worker, range(4)))
+    assert not errors, errors[:5]
