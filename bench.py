@@ -349,6 +349,23 @@ def run_rank(args):
                 "whole decomposition (188 B/sample)": frac(float(algorithmic_bytes_per_sample(LEVELS)), avg_us("dec")),
             },
         }
+    if sharded and not stub:
+        # N > 1: every GPU runs its shard as chunks whose launches overlap on two streams, so a single launch's duration is not
+        # a rate; the figure is the whole decomposition's algorithmic bytes (188 B/sample) per GPU over the max-over-ranks time.
+        # The per-launch figure of the dominant kernel is the N = 1 line's.
+        per_gpu_gbps = algorithmic_bytes_per_sample(LEVELS) * float(n) * per_gpu * args.steps / elapsed / 1e9
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "whole decomposition per GPU: fused level-0 launch + %d x k_extract<double> + final launch + k_finalize per chunk "
+                      "(20 + 24 x %d B/sample); per-launch figure of k_extract<double>: see the N = 1 line" % (LEVELS - 1, LEVELS - 1),
+            "achieved": round(per_gpu_gbps, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(per_gpu_gbps / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "per_gpu": True,
+        }
+        out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only (the N = 1 line of the same build carries all four CPU legs)
     if timing is not None and args.chain:
         # --chain: the dominant (only) kernel is k_chain.  Two figures: against the SURVEY's algorithmic bytes (188 B/sample: what
         # the reference's level-by-level data flow moves) and against what this launch itself has to move (4 B read + 8 B per row)

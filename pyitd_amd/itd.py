@@ -76,7 +76,9 @@ def _as_signal(data):
     everything else becomes float64."""
     a = numpy.asarray(data)
     if a.ndim != 1:
-        a = a.reshape(-1)
+        # the reference's driver fails on anything but a 1-D signal: its buffers are [22, len(data)] and the first extraction's
+        # result does not broadcast into them (ITD.py:384-389: ValueError from numpy, a typing error under numba)
+        raise ValueError("expected a 1-D signal, got an array of shape %s (ITD.py:384-389 cannot broadcast it either)" % (a.shape,))
     if a.dtype != numpy.float32:
         a = numpy.asarray(a, dtype=numpy.float64)
     return numpy.ascontiguousarray(a)

@@ -126,6 +126,9 @@ def test_api_surface_and_errors(P):
         d.get_rotations()
     with pytest.raises(ValueError):
         d.itd(np.zeros(2))
+    for bad in (np.zeros((4, 50)), np.zeros((1, 50)), np.zeros((50, 1))):   # the reference's driver raises ValueError on these
+        with pytest.raises(ValueError):
+            d.itd(bad)
     x = np.sin(np.linspace(0, 40, 1000)) + np.random.default_rng(2).standard_normal(1000)
     rows = d(x, max_iterations=2)           # __call__ (ITD.py:189)
     assert rows.shape == (4, 1000) and d.get_rotations() is rows
