@@ -11,12 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_chain.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"),
-           os.path.join(_HERE, "csrc", "itd_fitpack.hpp"),
+           os.path.join(_HERE, "csrc", "itd_fitpack.hpp"), os.path.join(_HERE, "csrc", "itd_resident.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -61,6 +61,8 @@ ABI = {
     "itd_set_chain_mode": (_INT, [_P, _I32]),
     "itd_set_chain_grid": (_INT, [_P, _I32]),
     "itd_get_chain_repeats": (_INT, [_P]),
+    "itd_set_resident_mode": (_INT, [_P, _I32]),
+    "itd_get_resident_repeats": (_INT, [_P]),
     "itd_debug_chain_prof": (_INT, [_P, _P, _I32]),
     "itd_dev_alloc": (_INT, [_INT, _I64, ctypes.POINTER(_P)]),
     "itd_dev_free": (_INT, [_INT, _P]),

@@ -21,6 +21,7 @@
 #include "../../include/pyitd_hip.h"
 #include "itd_kernels.hpp"
 #include "itd_chain.hpp"
+#include "itd_resident.hpp"
 #include "itd_cubic.hpp"
 #include "itd_tfe.hpp"
 #include "itd_spline.hpp"
@@ -108,6 +109,10 @@ struct itd_engine {
     int32_t batch_streams = 2;     // chunks of a batch rotate over this many streams (itd_set_batch_streams): 1 .. kMaxBatchStreams
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // the others besides the caller's, created on demand
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int32_t resident_mode = ITD_RESIDENT_AUTO;   // short signals as one workgroup each, one launch (itd_set_resident_mode)
+    int32_t resident_off_left = 0;  // automatic mode: decompositions still to run level by level after a resident call met a non-finite value
+    int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
+    bool resident_attr[10] = {};   // hipFuncSetAttribute done per kernel instance
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
@@ -136,6 +141,7 @@ struct itd_engine {
     double *last_rows = nullptr, *last_bases = nullptr;
     bool last_fused = false;
     bool last_chain = false;
+    bool last_resident = false;        // the last run was the one-workgroup form (k_resident)
     bool last_nan_input = false;       // the last run was the NaN-input repeat (k_nan_level0): its results follow the reference
     int32_t nan_input_mode = ITD_NAN_INPUT_FOLLOW;   // itd_set_nan_input_mode
     // timing
@@ -381,6 +387,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_bases = bases_user;
     e->last_fused = fuse0;
     e->last_chain = false;
+    e->last_resident = false;
     e->last_nan_input = nan_input;
     return ITD_OK;
 }
@@ -484,6 +491,78 @@ int enqueue_chain(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t
     e->last_bases = bases_user;
     e->last_fused = false;
     e->last_chain = true;
+    e->last_resident = false;
+    e->last_nan_input = false;
+    return ITD_OK;
+}
+
+// Short signals (n <= kResidentMax): the whole decomposition as ONE launch, one workgroup per signal, the signal resident
+// in LDS (itd_resident.hpp).  Optimistic like the chain: the kernel handles finite data only and raises SigState::res_fail
+// otherwise; itd_get_summary then repeats the call level by level.  The kernel initialises the states it works on itself
+// and leaves the other set's states as k_finalize would (the group sums are not touched).
+bool want_resident(itd_engine *e, int64_t n)
+{
+    if (n > kResidentMax || e->resident_mode == ITD_RESIDENT_OFF) return false;
+    if (e->resident_mode == ITD_RESIDENT_ONLY) return true;
+    // an engine that was told how to run its level 0 / its launches, or that is being timed launch by launch, means the
+    // level-by-level form
+    if (e->l0_mode != ITD_LEVEL0_AUTO || e->chain_mode != ITD_CHAIN_OFF || e->timing) return false;
+    if (e->resident_off_left > 0) { --e->resident_off_left; return false; }
+    return true;
+}
+
+template <typename Tin>
+int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, double *rows,
+                     double *bases_user, hipStream_t st)
+{
+    const int64_t R = (int64_t)M + 2;
+    const int64_t rows_stride = R * n;
+    const int set = e->cur_set ^ 1;
+    SigState *const set_state = e->d_state + (size_t)set * e->max_batch;
+    SigState *const other_state = e->d_state + (size_t)(set ^ 1) * e->max_batch;
+    if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
+        HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
+                                    (size_t)n * sizeof(double), (size_t)batch, st));
+    const size_t lds = resident_lds_bytes((int)n);
+    // four samples per thread: 64 threads up to 256 samples ... 1024 threads up to 4096 (the per-thread sample loops are unrolled:
+    // 64 VGPRs at four samples, 85 at eight, 239 at sixteen — and the wider workgroups hide the phases' latencies better)
+    const int cls = n <= 256 ? 0 : n <= 512 ? 1 : n <= 1024 ? 2 : n <= 2048 ? 3 : 4;
+    const int inst = cls + (sizeof(Tin) == 4 ? 0 : 5);
+    const int threads = 64 << cls;
+    const void *fn = cls == 0 ? reinterpret_cast<const void *>(&k_resident<Tin, 64, 4>)
+                   : cls == 1 ? reinterpret_cast<const void *>(&k_resident<Tin, 128, 4>)
+                   : cls == 2 ? reinterpret_cast<const void *>(&k_resident<Tin, 256, 4>)
+                   : cls == 3 ? reinterpret_cast<const void *>(&k_resident<Tin, 512, 4>)
+                              : reinterpret_cast<const void *>(&k_resident<Tin, 1024, 4>);
+    if (!e->resident_attr[inst]) {   // more than 64 KB of dynamic LDS has to be asked for
+        HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(256 << cls)));
+        e->resident_attr[inst] = true;
+    }
+    const Tin *a_x = x; int64_t a_xs = x_stride, a_rs = rows_stride, a_bs = rows_stride;
+    int a_n = (int)n, a_m = M;
+    double *a_rows = rows, *a_bases = bases_user;
+    SigState *a_st = set_state, *a_ot = other_state;
+    void *args[] = {&a_x, &a_xs, &a_n, &a_m, &a_rows, &a_rs, &a_bases, &a_bs, &a_st, &a_ot};
+    HIP_TRY(e, hipLaunchKernel(fn, dim3((unsigned)batch), dim3((unsigned)threads), args, lds, st));
+    HIP_TRY(e, hipGetLastError());
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    e->dirty_sig[set] = std::max(e->dirty_sig[set], batch);
+    if (cap == hipStreamCaptureStatusNone && batch >= e->dirty_sig[set ^ 1]) e->dirty_sig[set ^ 1] = 0;
+    e->cur_set = set;
+    e->ran = true;
+    e->last_batch = batch;
+    e->last_m = M;
+    e->last_n = n;
+    e->last_stream = st;
+    e->last_x = x;
+    e->last_x_f32 = sizeof(Tin) == 4;
+    e->last_x_stride = x_stride;
+    e->last_rows = rows;
+    e->last_bases = bases_user;
+    e->last_fused = false;
+    e->last_chain = false;
+    e->last_resident = true;
     e->last_nan_input = false;
     return ITD_OK;
 }
@@ -503,6 +582,7 @@ int enqueue_any(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x
 {
     // the chain kernel works in 32-bit sample / tile arithmetic (itd_chain.hpp)
     static_assert(kChainTile >= T, "the granule arrays are sized for tiles of T samples");
+    if (want_resident(e, n)) return enqueue_resident<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
     const bool fits = n <= ((int64_t)1 << 31) - 65536 && (int64_t)batch * tiles_of(n) < ((int64_t)1 << 31) - 65536;
     if (fits && want_chain(e)) return enqueue_chain<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
     return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, want_fused(e));
@@ -783,6 +863,23 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         HIP_TRY(e, hipStreamSynchronize(e->last_stream));
         return (int)ITD_OK;
     };
+    if (e->last_resident) {
+        // the one-workgroup form handles finite data only: a NaN / infinity in the input or in a baseline (a leading or
+        // trailing plateau, ITD.py:115-116) raised res_fail.  Repeat the call level by level — those kernels carry the
+        // reference's NaN rules — and let the engine's next decompositions start that way: workloads tend to be homogeneous
+        bool redo = false;
+        for (int b = 0; b < B; ++b) redo = redo || e->h_state[b].res_fail;
+        if (redo) {
+            if (e->resident_mode == ITD_RESIDENT_ONLY) {
+                snprintf(e->err, sizeof(e->err), "resident form: a non-finite sample or baseline (ITD_RESIDENT_ONLY forbids the level-by-level repeat)");
+                return ITD_ERR_HIP;
+            }
+            ++e->resident_repeats;
+            e->resident_off_left = 16;
+            const int rc = repeat(want_fused(e), false);
+            if (rc) return rc;
+        }
+    }
     if (!e->last_nan_input && e->nan_input_mode == ITD_NAN_INPUT_FOLLOW && any_nan_input()) {
         // A signal of the call holds a NaN.  The reference runs such input through detect_peaks' NaN branch and overwrites the
         // NaNs with +inf (ITD.py:46-51, 64-68); the launches so far evaluated plain rules.  Repeat the call with the level 0
@@ -913,6 +1010,16 @@ int itd_set_chain_mode(itd_engine *e, int32_t mode)
     e->chain_off_left = 0;
     return ITD_OK;
 }
+
+int itd_set_resident_mode(itd_engine *e, int32_t mode)
+{
+    if (!e || mode < ITD_RESIDENT_AUTO || mode > ITD_RESIDENT_ONLY) return ITD_ERR_INVALID_ARG;
+    e->resident_mode = mode;
+    e->resident_off_left = 0;
+    return ITD_OK;
+}
+
+int itd_get_resident_repeats(const itd_engine *e) { return e ? e->resident_repeats : -1; }
 
 int itd_set_chain_grid(itd_engine *e, int32_t workgroups)
 {

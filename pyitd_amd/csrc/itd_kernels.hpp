@@ -102,7 +102,8 @@ struct SigState {
     int32_t fin_stop_level;  // (kept apart from stop_level, which k_finalize's own workgroups still read)
     int32_t chain_stop;      // written by k_chain_finalize only (itd_chain.hpp): some pending baseline inside the run had < 2
                              // knots, the one-launch chain's rows past that level are not the reference's: repeat level by level
-    int32_t pad_;
+    int32_t res_fail;        // written by k_resident only (itd_resident.hpp): the one-workgroup form met a non-finite sample (it
+                             // handles finite data only): the call is repeated through the level-by-level engine
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
@@ -1816,6 +1817,7 @@ __device__ __forceinline__ void sig_state_reset(SigState *st)
     st->fin_stopped = 0;
     st->fin_stop_level = -1;
     st->chain_stop = 0;
+    st->res_fail = 0;
 }
 
 constexpr int kFinalizeThreads = 256;

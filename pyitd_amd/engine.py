@@ -19,6 +19,7 @@ LEVEL0_AUTO, LEVEL0_RECORDS, LEVEL0_FUSED = 0, 1, 2
 TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0, TIME_CHAIN = 0, 1, 2, 3, 4, 5
 CHAIN_AUTO, CHAIN_OFF, CHAIN_ONLY = 0, 1, 2
 NAN_INPUT_FOLLOW, NAN_INPUT_REJECT = 0, 1
+RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY = 0, 1, 2
 
 
 def _np_ptr(a):
@@ -42,6 +43,9 @@ class Engine:
         mode = os.environ.get("PYITD_CHAIN_MODE")       # the same for the launch form (CHAIN_AUTO / CHAIN_OFF / CHAIN_ONLY)
         if mode:
             self.set_chain_mode(int(mode))
+        mode = os.environ.get("PYITD_RESIDENT_MODE")    # and for the one-workgroup form of short signals (RESIDENT_*)
+        if mode:
+            self.set_resident_mode(int(mode))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -102,6 +106,16 @@ class Engine:
         """CHAIN_AUTO (one persistent launch for the whole decomposition, level-by-level repeat when the stop rule fires inside
         the requested levels or the knots are too sparse), CHAIN_OFF (one launch per level), CHAIN_ONLY (never repeat)."""
         self._check(self._L.itd_set_chain_mode(self._h, int(mode)))
+
+    def set_resident_mode(self, mode):
+        """RESIDENT_AUTO (signals of <= 4096 samples run as one workgroup each in one launch, the signal resident in LDS; a call
+        that meets a non-finite value is repeated level by level), RESIDENT_OFF, RESIDENT_ONLY (never repeat)."""
+        self._check(self._L.itd_set_resident_mode(self._h, int(mode)))
+
+    @property
+    def resident_repeats(self):
+        """Resident calls of this engine that itd_get_summary had to repeat level by level so far."""
+        return self._L.itd_get_resident_repeats(self._h)
 
     def set_chain_grid(self, workgroups):
         self._check(self._L.itd_set_chain_grid(self._h, int(workgroups)))

@@ -1,0 +1,188 @@
+"""The resident form of short signals (itd_set_resident_mode, pyitd_amd/csrc/itd_resident.hpp): one launch, one workgroup
+per signal, the signal in LDS through the whole driver loop (ITD.py:384-432).  Checked bit for bit against the CPU oracle
+and, summary entry for summary entry, against the level-by-level engine; the level-by-level repeat of calls that meet a
+non-finite value (leading plateaus -> the reference's NaN branch) included."""
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal, fuzz_signal, load_golden, sines_noise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyitd_amd
+    return pyitd_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cpu_oracle
+    cpu_oracle.lib()
+    return cpu_oracle
+
+
+def _run(P, torch, x_np, m, mode, keep=True):
+    from pyitd_amd.engine import LEVEL0_AUTO
+    B, n = x_np.shape
+    xd = torch.from_numpy(x_np).cuda()
+    rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    bases = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda") if keep else None
+    eng = P.Engine(n, B, 0)
+    eng.set_level0_mode(LEVEL0_AUTO)     # whatever PYITD_LEVEL0_MODE says: the resident form needs the automatic mode
+    eng.set_resident_mode(mode)
+    torch.cuda.synchronize()
+    eng.decompose_dev(xd.data_ptr(), x_np.dtype, n, B, n, m, rows.data_ptr(), bases.data_ptr() if keep else None, None)
+    s = eng.summary(B)
+    repeats = eng.resident_repeats
+    out = rows.cpu().numpy(), (bases.cpu().numpy() if keep else None), s, repeats
+    eng.close()
+    return out
+
+
+def _check_against_oracle(oracle, x, m, rows, bases, s, what):
+    for b in range(x.shape[0]):
+        ref = oracle.itd(x[b], m)
+        nr, nb = int(s["n_rows"][b]), int(s["n_baselines"][b])
+        assert nr == ref["rows"].shape[0] and nb == ref["baselines"].shape[0], "%s signal %d: %d rows / %d baselines" % (what, b, nr, nb)
+        assert ("natural", "timeout")[int(s["stop"][b])] == ref["stop"]
+        assert_bits_equal(rows[b, :nr], ref["rows"], "%s signal %d rows" % (what, b))
+        if bases is not None:
+            assert_bits_equal(bases[b, :nb], ref["baselines"], "%s signal %d baselines" % (what, b))
+        kc = [int(v) for v in s["knot_counts"][b] if v >= 0]
+        want = [int(v) for v in ref["knot_counts"]]
+        assert kc[1: 1 + len(want)] == want, "%s signal %d knot counts" % (what, b)
+
+
+FINITE_KINDS = (0, 1, 3, 4, 6, 7)     # fuzz families without plateaus at the signal's ends
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 63, 64, 65, 127, 129, 400, 511, 512, 513, 1000, 1024, 1025, 2047, 2049, 3000, 4095, 4096])
+def test_resident_is_bit_exact_at_every_length(P, torch, oracle, n):
+    from pyitd_amd.engine import RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY
+    rng = np.random.default_rng(1000 + n)
+    for dtype, m in ((np.float64, 7), (np.float32, 3), (np.float64, 0), (np.float32, 20)):
+        x = np.stack([fuzz_signal(rng, FINITE_KINDS[b % len(FINITE_KINDS)], n) for b in range(12)])
+        if dtype == np.float32:
+            x = np.clip(x, -3e38, 3e38)
+        x = x.astype(dtype)
+        x[5] = np.linspace(-1, 1, n)                       # monotone: stops at once with one all-zero row
+        x[7] = np.sin(np.linspace(0, 3.0, n)) + 0.01       # one extremum
+        rows, bases, s, rep = _run(P, torch, x, m, RESIDENT_AUTO)
+        _check_against_oracle(oracle, x, m, rows, bases, s, "n=%d %s m=%d" % (n, np.dtype(dtype).name, m))
+        # the level-by-level engine reports the same summary, entry for entry (knot counts incl. the unevaluated -1 slots)
+        rows2, bases2, s2, _ = _run(P, torch, x, m, RESIDENT_OFF)
+        for key in ("n_rows", "n_baselines", "stop", "nan_levels", "knot_counts"):
+            assert np.array_equal(s[key], s2[key]), key
+        for b in range(x.shape[0]):
+            assert_bits_equal(rows[b, : s["n_rows"][b]], rows2[b, : s["n_rows"][b]], "vs level-by-level, signal %d" % b)
+    if n >= 64:
+        # noise and random walks have no plateaus: the resident form completes on its own (RESIDENT_ONLY would refuse otherwise)
+        x = np.stack([fuzz_signal(rng, b % 2, n) for b in range(6)])
+        rows, bases, s, rep = _run(P, torch, x, 7, RESIDENT_ONLY)
+        assert rep == 0
+        _check_against_oracle(oracle, x, 7, rows, bases, s, "n=%d resident only" % n)
+
+
+def test_resident_goldens(P, torch, oracle):
+    """Every reference-generated golden vector short enough for the resident form, through the drop-in class (automatic mode)."""
+    import os
+    from conftest import golden_cases
+    seen = 0
+    for name in golden_cases():
+        g = load_golden(name)
+        if "x" not in g.files or "rows" not in g.files or g["x"].ndim != 1 or g["x"].shape[0] > 4096:
+            continue
+        x, m = g["x"], int(g["max_iteration"])
+        if not np.isfinite(x).all():
+            continue
+        d = P.ITD()
+        rows = d.itd(x, m)
+        assert_bits_equal(rows, g["rows"], name)
+        seen += 1
+    assert seen >= 3 or os.environ.get("PYITD_RESIDENT_MODE") == "1"
+
+
+def test_non_finite_values_repeat_level_by_level(P, torch, oracle):
+    """A leading plateau makes the first baseline NaN (0/0, ITD.py:115-116) and the reference continues under detect_peaks' NaN
+    rules; NaN / infinity in the input likewise.  The resident kernel raises res_fail, itd_get_summary repeats the call level by
+    level; results follow the reference, and the engine's next decompositions start level by level."""
+    from pyitd_amd.engine import RESIDENT_AUTO, RESIDENT_ONLY
+    n, m = 3000, 9
+    rng = np.random.default_rng(77)
+    x = np.stack([sines_noise(n, seed=b, fscale=20.0 + b, dtype=np.float64) for b in range(8)])
+    x[1, :40] = 0.0                 # silence at the head
+    x[3, -25:] = 0.5                # trailing plateau
+    x[5, 1500] = np.nan             # NaN in the input
+    x[6, 100] = np.inf
+    rows, bases, s, rep = _run(P, torch, x, m, RESIDENT_AUTO)
+    assert rep == 1
+    _check_against_oracle(oracle, x, m, rows, bases, s, "repeat")
+    # RESIDENT_ONLY refuses instead
+    with pytest.raises(P.ITDError):
+        _run(P, torch, x, m, RESIDENT_ONLY)
+    # one engine: resident call, failing call (repeat), then level by level for a while — results stay exact throughout
+    eng = P.Engine(n, 8, 0)
+    eng.set_resident_mode(RESIDENT_AUTO)
+    clean = np.stack([sines_noise(n, seed=40 + b, fscale=30.0, dtype=np.float64) for b in range(8)])
+    for k, sig in enumerate((clean, x, clean, clean)):
+        xd = torch.from_numpy(sig).cuda()
+        r = torch.full((8, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), np.float64, n, 8, n, m, r.data_ptr(), None, None)
+        sm = eng.summary(8)
+        _check_against_oracle(oracle, sig, m, r.cpu().numpy(), None, sm, "sequence step %d" % k)
+    assert eng.resident_repeats == 1
+    eng.close()
+
+
+def test_resident_large_batches_and_mixed_stops(P, torch, oracle):
+    """70 000 signals of 256 samples in one launch (one workgroup each); signals of a batch stop at different levels."""
+    from pyitd_amd.engine import RESIDENT_ONLY
+    B, n, m = 70000, 256, 7
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, n)).astype(np.float32)
+    t = np.linspace(0, 1, n, dtype=np.float32)
+    x[::7] = np.sin(2 * np.pi * 2.5 * t)[None] + 0.001 * x[::7]     # smoother ones: earlier natural stops
+    rows, _, s, rep = _run(P, torch, x, m, RESIDENT_ONLY, keep=False)
+    assert rep == 0 and len(set(s["n_rows"].tolist())) >= 3
+    pick = np.concatenate([np.arange(0, 64), rng.choice(B, 192, replace=False), [B - 1]])
+    for b in pick:
+        ref = oracle.itd(x[b], m)
+        nr = int(s["n_rows"][b])
+        assert nr == ref["rows"].shape[0]
+        assert_bits_equal(rows[b, :nr], ref["rows"], "signal %d" % b)
+    # reconstruction for all of them: the valid rows sum back to the input
+    ok = 0
+    for b0 in range(0, B, 10000):
+        blk = rows[b0:b0 + 10000]
+        nr = s["n_rows"][b0:b0 + 10000]
+        mask = np.arange(m + 2)[None, :, None] < nr[:, None, None]
+        rec = np.where(mask, blk, 0.0).sum(axis=1)
+        ok = max(ok, float(np.abs(rec - x[b0:b0 + 10000].astype(np.float64)).max()))
+    assert ok < 1e-12
+
+
+def test_resident_fuzz_slice(P, torch, oracle):
+    """Fixed-seed fuzz: random lengths 3 .. 4096, random max_iteration, all signal families (plateau families go through the
+    level-by-level repeat), float32 and float64."""
+    from pyitd_amd.engine import RESIDENT_AUTO
+    rng = np.random.default_rng(20261004)
+    for case in range(60):
+        n = int(rng.integers(3, 4097)) if case % 3 else int(rng.choice([3, 64, 512, 513, 4096]))
+        m = int(rng.integers(0, 21))
+        B = int(rng.integers(1, 9))
+        dtype = np.float32 if case % 2 else np.float64
+        x = np.stack([fuzz_signal(rng, int(rng.integers(0, 8)), n) for _ in range(B)]).astype(dtype)
+        if not np.isfinite(x).all():          # float32 overflow of the extreme-magnitude family
+            x = np.nan_to_num(x, nan=0.0, posinf=3e38, neginf=-3e38).astype(dtype)
+        rows, bases, s, _ = _run(P, torch, x, m, RESIDENT_AUTO)
+        _check_against_oracle(oracle, x, m, rows, bases, s, "fuzz case %d (n=%d m=%d B=%d)" % (case, n, m, B))
