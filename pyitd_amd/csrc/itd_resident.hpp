@@ -7,17 +7,17 @@
 // sample), every result row is written once (8 B per sample and row), nothing else touches HBM, and a batch of short
 // signals is one launch with one workgroup per signal.
 //
-// Per level (all phases separated by workgroup barriers; a 64-thread workgroup's barriers are free):
+// Per level, four workgroup barriers (a 64-thread workgroup's barriers are free):
 //   scan    knot predicate of detect_peaks(x) U detect_peaks(-x) (ITD.py:44-59, 87-98) per sample, one __ballot word per
-//           64 samples; exclusive prefix of the words' popcounts (one wavefront)
+//           64 samples; every wavefront totals the words itself (exclusive prefix of their popcounts)
 //   knots   ordered knot list by rank: index e_k and value x[e_k]; e_0 = 0, e_{m+1} = n-1 (ITD.py:93-98)
-//   values  B_k in the reference's association (ITD.py:100-110), then the segment slopes (ITD.py:115-116)
+//   values  B_k in the reference's association (ITD.py:100-110) and the segment slopes (ITD.py:115-116) in one phase
 //   map     baseline = B_k + slope_k * (x - x[e_k]) with k = knots at or before the sample (ITD.py:114-117),
 //           baseline[n-1] = 0 (ITD.py:112: never written); the baseline replaces the signal in LDS, the thread keeps the
-//           level's input in registers
-//   verdict the stop test of the pending baseline is the next level's scan (ITD.py:400-404): < 2 knots -> row c =
-//           baselines[c-1] (zeros at c = 0, ITD.py:404-416); c > max_iteration -> row c = rotation + baseline
-//           (ITD.py:418-426); otherwise row c = rotation = x - baseline (ITD.py:119, 428-432)
+//           level's input in registers; rotation = x - baseline (ITD.py:119) leaves for row c at once
+//   verdict the stop test of the pending baseline is the next level's scan (ITD.py:400-404): < 2 knots -> row c is
+//           rewritten with baselines[c-1] (zeros at c = 0, ITD.py:404-416); c > max_iteration -> row c = rotation +
+//           baseline (ITD.py:418-426); otherwise the baseline becomes the next extraction's input (ITD.py:428-432)
 //
 // The kernel handles FINITE data only.  A NaN or infinity in the input or in any baseline (0/0 on a leading or trailing
 // plateau, ITD.py:115-116) raises SigState::res_fail and the workgroup leaves; itd_get_summary then repeats the call
@@ -29,6 +29,12 @@
 
 #pragma clang fp contract(off)
 
+// timing-only ablations of k_resident (results are wrong by construction): 1 no knot values / slopes, 2 no prefix over the
+// words, 4 no state resets, 8 no row / baseline stores, 16 no knot list, 32 no by-rank reads in the map, 64 never stop naturally
+// (every build that is compared with another needs it: the level count must not depend on the values), 128 no scan loads
+#ifndef ITD_RES_ABL
+#define ITD_RES_ABL 0
+#endif
 namespace itd {
 
 constexpr int kResidentMax = 4096;        // samples: 34 B of LDS per sample, 160 KB per workgroup on gfx950
@@ -59,8 +65,7 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
     double *Bk = Xk + np2;                                       // knot value B_k
     double *Sk = Bk + np2;                                       // slope of the segment that starts at knot k
     unsigned long long *bal = reinterpret_cast<unsigned long long *>(Sk + np2);   // knot flags, one word per 64 samples
-    int *pre = reinterpret_cast<int *>(bal + Q);                 // knots in front of word q; pre[Q] = all
-    int *ctl = pre + Q + 1;                                      // [0]: a non-finite sample was seen
+    int *ctl = reinterpret_cast<int *>(bal + Q) + Q + 1;         // [0]: a non-finite sample was seen
     unsigned short *ek = reinterpret_cast<unsigned short *>(ctl + 3);   // by rank: the knots' sample indices
 
     SigState *st = state + sig;
@@ -70,18 +75,24 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
     const double inf = __builtin_huge_val();
 
     if (tid == 0) {
-        sig_state_reset(st);
-        if (other_state) sig_state_reset(other_state + sig);   // the engine's other set, as k_finalize leaves it
+        if (!(ITD_RES_ABL & 4)) {
+            sig_state_reset(st);
+            if (other_state) sig_state_reset(other_state + sig);   // the engine's other set, as k_finalize leaves it
+        }
         ctl[0] = 0;
     }
 
     // the thread's samples: word q = wave + W j, sample 64 q + lane — consecutive lanes, consecutive samples (coalesced
-    // rows, conflict-free LDS); xr[] = the input of the extraction in flight
-    double xr[SPT];
+    // rows, conflict-free LDS).  In registers: xr[] the input of the extraction in flight, xb[] its baseline, and per word
+    // (wave-uniform) the knot flags of the level's input and the number of knots in front of the word
+    double xr[SPT], xb[SPT];
+    unsigned long long bm[SPT];
+    int pr[SPT];
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
         const int q = wave + W * j, i = q * 64 + lane;
         xr[j] = 0.0;
+        xb[j] = 0.0;
         if (q < Q) {
             if (i < n) xr[j] = (double)x[i];
             xs[i] = xr[j];
@@ -89,47 +100,56 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
     }
     __syncthreads();
 
-    // knot flags of the signal in xs (interior samples 1 .. n-2, ITD.py:70-73) + their exclusive prefix by word; returns
-    // the knot total; ctl[0] is raised if a sample is not finite
-    auto scan = [&]() -> int {
+    // Knot flags of the signal in xs (cur[] = the thread's own samples of it; interior samples 1 .. n-2, ITD.py:70-73) into
+    // bm[], the words' exclusive prefix into pr[]; returns the knot total.  One barrier: every wavefront totals the words
+    // itself.  ctl[0] is raised if a sample is not finite.
+    auto scan = [&](const double (&cur)[SPT]) -> int {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int q = wave + W * j, i = q * 64 + lane;
+            bm[j] = 0;
             if (q < Q) {
                 bool f = false, bad = false;
                 if (i < n) {
-                    const double c = xs[i];
+                    const double c = cur[j];
                     bad = !(__builtin_fabs(c) < inf);
                     if (i >= 1 && i <= n - 2) {
-                        const double d0 = c - xs[i - 1], d1 = xs[i + 1] - c;   // dx[i-1], dx[i] (ITD.py:44)
+                        const double d0 = c - ((ITD_RES_ABL & 128) ? 0.5 : xs[i - 1]), d1 = ((ITD_RES_ABL & 128) ? 0.25 : xs[i + 1]) - c;   // dx[i-1], dx[i] (ITD.py:44)
                         f = (d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0);   // valley of x or of -x (ITD.py:59, 87-88)
                     }
                 }
-                const unsigned long long bm = __ballot(f);
+                bm[j] = __ballot(f);
                 const unsigned long long bb = __ballot(bad);
                 if (lane == 0) {
-                    bal[q] = bm;
+                    bal[q] = bm[j];
                     if (bb) ctl[0] = 1;
                 }
             }
         }
         __syncthreads();
-        if (wave == 0) {
-            const int c = lane < Q ? __popcll(bal[lane]) : 0;
-            int inc = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += t;
-            }
-            if (lane < Q) pre[lane] = inc - c;
-            if (lane == 63) pre[Q] = inc;
+        const int cnt = lane < Q ? __popcll(bal[lane]) : 0;
+        // inclusive prefix over the 64 lanes on the DPP path (no LDS round trips): Hillis-Steele inside the rows of 16 lanes
+        // (row_shr 1, 2, 4, 8: a lane without a source inside its row keeps the 0 it is given), then row 0's / rows 0-1's
+        // totals into the rows behind them (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3)
+        int inc = cnt;
+        if (!(ITD_RES_ABL & 2)) {
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);
         }
-        __syncthreads();
-        return pre[Q];
+        const int excl = inc - cnt;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int q = wave + W * j;
+            pr[j] = q < Q ? __builtin_amdgcn_readlane(excl, q) : 0;
+        }
+        return __builtin_amdgcn_readlane(inc, 63);
     };
 
-    int m = scan();
+    int m = scan(xr);
     if (tid == 0) st->m[0] = m;
     if (ctl[0]) {
         if (tid == 0) st->res_fail = 1;
@@ -141,13 +161,10 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int q = wave + W * j, i = q * 64 + lane;
-            if (q < Q) {
-                const unsigned long long bm = bal[q];
-                if ((bm >> lane) & 1ull) {
-                    const int k = pre[q] + __popcll(bm & ((1ull << lane) - 1ull)) + 1;
-                    ek[k] = (unsigned short)i;
-                    Xk[k] = xr[j];
-                }
+            if (q < Q && ((bm[j] >> lane) & 1ull) && !(ITD_RES_ABL & 16)) {
+                const int k = pr[j] + __popcll(bm[j] & ((1ull << lane) - 1ull)) + 1;
+                ek[k] = (unsigned short)i;
+                Xk[k] = xr[j];
             }
         }
         if (tid == 0) {
@@ -157,46 +174,60 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
             Xk[m + 1] = xs[n - 1];
         }
         __syncthreads();
-        // ---- knot values (ITD.py:100-110) --------------------------------------------------------------------------
-        for (int k = tid; k <= m + 1; k += TH) {
-            double v;
-            if (k == 0) v = (xs[0] + xs[1]) / 2.0;                   // numpy.mean(x[:2])
-            else if (k == m + 1) v = (xs[n - 2] + xs[n - 1]) / 2.0;   // numpy.mean(x[-2:])
-            else {
-                const int e0 = ek[k - 1], e1 = ek[k], e2 = ek[k + 1];
-                const double x0 = Xk[k - 1], x1 = Xk[k], x2 = Xk[k + 1];
-                const double frac = (double)(e1 - e0) / (double)(e2 - e0);
-                const double t = frac * (x2 - x0);
-                const double u = x0 + t;
-                v = 0.5 * u + 0.5 * x1;
+        // ---- knot values (ITD.py:100-110) and slopes (ITD.py:115-116; 0/0 on an end segment is the reference's NaN: the
+        //      next scan catches it).  A wavefront takes 64 consecutive knots and the 63 segments between them — B_{k+1} comes
+        //      from the next lane — so consecutive chunks overlap by one knot and no barrier separates values from slopes ------
+        for (int cidx = wave; 63 * cidx <= m + 1 && !(ITD_RES_ABL & 1); cidx += W) {
+            const int k = 63 * cidx + lane;
+            double v = 0.0, x0 = 0.0, xp1 = 0.0;
+            if (k <= m + 1) {
+                x0 = Xk[k];
+                if (k == 0) {
+                    v = (xs[0] + xs[1]) / 2.0;                   // numpy.mean(x[:2])
+                    xp1 = Xk[1];
+                } else if (k == m + 1) {
+                    v = (xs[n - 2] + xs[n - 1]) / 2.0;           // numpy.mean(x[-2:])
+                } else {
+                    const int e0 = ek[k - 1], e1 = ek[k], e2 = ek[k + 1];
+                    const double xm1 = Xk[k - 1];
+                    xp1 = Xk[k + 1];
+                    const double frac = (double)(e1 - e0) / (double)(e2 - e0);
+                    const double t = frac * (xp1 - xm1);
+                    const double u = xm1 + t;
+                    v = 0.5 * u + 0.5 * x0;
+                }
+                Bk[k] = v;
             }
-            Bk[k] = v;
+            const double vn = __shfl_down(v, 1, 64);
+            if (lane < 63 && k <= m) Sk[k] = (vn - v) / (xp1 - x0);
         }
         __syncthreads();
-        // ---- slopes (ITD.py:115-116; 0/0 on an end segment is the reference's NaN: caught by the next scan) ------------
-        for (int k = tid; k <= m; k += TH) Sk[k] = (Bk[k + 1] - Bk[k]) / (Xk[k + 1] - Xk[k]);
-        __syncthreads();
-        // ---- map (ITD.py:112-117): the baseline replaces the signal in LDS ------------------------------------------
+        // ---- map (ITD.py:112-117): the baseline replaces the signal in LDS; rotation = x - baseline (ITD.py:119) leaves at
+        //      once unless this is the extraction behind the last requested one (its row is never the rotation) -----------
+        double *row = rows_s + (int64_t)c * n;
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int q = wave + W * j, i = q * 64 + lane;
             if (q < Q && i < n) {
-                const int k = pre[q] + __popcll(bal[q] & ((2ull << lane) - 1ull));   // knots at or before the sample
-                const double b = (i == n - 1) ? 0.0 : Bk[k] + Sk[k] * (xr[j] - Xk[k]);
+                const int k = pr[j] + __popcll(bm[j] & ((2ull << lane) - 1ull));   // knots at or before the sample
+                const double b = (ITD_RES_ABL & 32) ? xr[j] * 0.75 + k : (i == n - 1) ? 0.0 : Bk[k] + Sk[k] * (xr[j] - Xk[k]);
+                xb[j] = b;
                 xs[i] = b;
-                if (bases_s && c <= M) bases_s[(int64_t)c * n + i] = b;
+                if (c <= M && !(ITD_RES_ABL & 8)) {
+                    row[i] = xr[j] - b;
+                    if (bases_s) bases_s[(int64_t)c * n + i] = b;
+                }
             }
         }
         __syncthreads();
         // ---- the pending baseline's stop test = the next level's scan (ITD.py:400-404) -------------------------------
-        m = scan();
+        m = scan(xb);
         if (tid == 0) st->m[c + 1] = m;
-        if (ctl[0]) {
+        if (ctl[0] && !(ITD_RES_ABL & 64)) {
             if (tid == 0) st->res_fail = 1;
             return;
         }
-        double *row = rows_s + (int64_t)c * n;
-        if (m < 2) {            // "No more decompositions possible": row c = baselines[c-1], the zero row at c = 0
+        if (m < 2 && !(ITD_RES_ABL & 64)) {            // "No more decompositions possible": row c = baselines[c-1], the zero row at c = 0
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave + W * j, i = q * 64 + lane;
@@ -209,27 +240,19 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
             }
             return;
         }
-        if (c > M) {            // "Out of time!": row c = rotation + baseline
+        if (c > M) {            // "Out of time!": row c = rotation + baseline (ITD.py:418-426)
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave + W * j, i = q * 64 + lane;
                 if (q < Q && i < n) {
-                    const double b = xs[i];
-                    const double r = xr[j] - b;
-                    row[i] = r + b;
+                    const double r = xr[j] - xb[j];
+                    row[i] = r + xb[j];
                 }
             }
             return;             // fin_stopped stays 0
         }
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) {   // row c = rotation; the baseline is the next extraction's input
-            const int q = wave + W * j, i = q * 64 + lane;
-            if (q < Q && i < n) {
-                const double b = xs[i];
-                row[i] = xr[j] - b;
-                xr[j] = b;
-            }
-        }
+        for (int j = 0; j < SPT; ++j) xr[j] = xb[j];   // the baseline is the next extraction's input (ITD.py:428-432)
     }
 }
 

@@ -312,6 +312,12 @@ def _rank_main(rank, world, port, q):
         rows = torch.empty((sb.n_local, m + 2, n), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
         sb.decompose(x.data_ptr(), np.float32, n, rows.data_ptr())
+        # what bench.py's ranks do around the timed region, on RCCL: barrier, the all-gather of the per-rank times, the table
+        dist.barrier()
+        tt = torch.tensor([1.0 + rank], dtype=torch.float64, device=torch.device("cuda", rank))
+        parts = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        assert [float(p.item()) for p in parts] == [1.0 + r for r in range(world)]
         table = sb.gather(device=torch.device("cuda", rank))
         if rank == 0:
             q.put({k: v.tolist() for k, v in table.items()})
@@ -336,6 +342,29 @@ def test_two_gpu_ranks_shard_and_gather_over_rccl(torch, oracle):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    for b in range(7):
+        ref = oracle.itd_lean(_batch_signal(b, 1 << 16), 5)
+        assert got["n_rows"][b] == ref["rows"].shape[0]
+        assert got["knot_counts"][b][: len(ref["knot_counts"])] == ref["knot_counts"].tolist()
+
+
+def test_one_rank_over_rccl(torch, oracle):
+    """The RCCL leg of the sharded path on the one-GPU box: a process group of ONE rank with backend "nccl" (= RCCL) runs the same
+    rank function as the two-GPU test — engine on its shard, barrier, all-gather of the times and of the summary table on device
+    tensors.  (Two ranks cannot share a GPU under RCCL; the two-rank logic runs over gloo in tests/test_distributed_cpu.py and in the
+    --rehearse-one-gpu run of bench.py.)"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rank_main, args=(0, 1, port, q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
     for b in range(7):
         ref = oracle.itd_lean(_batch_signal(b, 1 << 16), 5)
         assert got["n_rows"][b] == ref["rows"].shape[0]

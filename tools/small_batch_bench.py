@@ -22,8 +22,7 @@ if os.environ.get("SMALL_RESIDENT_SHAPES"):   # the sizes around the resident fo
 def main():
     global SHAPES
     if os.environ.get("SMALL_SHAPE"):   # e.g. SMALL_SHAPE=16384x1024 (one shape: for a rocprofv3 kernel trace)
-        b, n = os.environ["SMALL_SHAPE"].split("x")
-        SHAPES = [(int(b), int(n))]
+        SHAPES = [tuple(int(v) for v in item.split("x")) for item in os.environ["SMALL_SHAPE"].split(",")]
     torch.set_num_threads(8)   # the box's CPU share is a cgroup quota: hundreds of spinning pool threads get the process throttled
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1)
