@@ -2,7 +2,9 @@
 usage (GPU box): python tools/fuzz_parity.py [cases] [seed]          single signals through ITD.itd
                  python tools/fuzz_parity.py batch [cases] [seed]    random batches through itd_batch (grid.y = signal)
 A third of the inputs get NaNs sprinkled in (the reference's NaN branch at level 0), some an infinity.  PYITD_CHAIN_MODE=0 in
-the environment runs everything through the one-launch chain, PYITD_LEVEL0_MODE=1 through the record-driven level 0."""
+the environment runs everything through the one-launch chain, PYITD_LEVEL0_MODE=1 through the record-driven level 0.
+FUZZ_MAX_N=4096 folds every length into 3 .. 4096 (the resident form's range), FUZZ_NO_NAN=1 leaves the inputs as drawn (a NaN input
+sends the engine's next 16 decompositions level by level: without them nearly every case runs resident; PYITD_RESIDENT_MODE=1 = none)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +16,11 @@ argv = sys.argv[2:] if batch_mode else sys.argv[1:]
 cases = int(argv[0]) if len(argv) > 0 else 200
 rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
 cpu_oracle.lib()
+MAX_N = int(os.environ.get("FUZZ_MAX_N", "0"))
+
+
+def fold(n):
+    return 3 + (n - 3) % (MAX_N - 2) if MAX_N and n > MAX_N else n
 
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -23,6 +30,8 @@ from helpers import fuzz_signal
 def make(kind, n):
     x = fuzz_signal(rng, kind, n)
     r = rng.random()
+    if os.environ.get("FUZZ_NO_NAN"):
+        r = 1.0
     if r < 0.33 and np.all(np.isfinite(x)):          # NaNs in the input: singles, runs, at the ends, on tile boundaries
         k = int(rng.integers(1, 7))
         at = rng.integers(0, n, k)
@@ -44,7 +53,7 @@ if batch_mode:
     t0 = time.time()
     for c in range(cases):
         B = int(rng.integers(1, 40))
-        n = int(rng.choice([3, 17, 511, 512, 513, 4095, 4096, 4097, int(rng.integers(3, 40000))]))
+        n = fold(int(rng.choice([3, 17, 511, 512, 513, 4095, 4096, 4097, int(rng.integers(3, 40000))])))
         m = int(rng.integers(0, 9))
         dtype = np.float32 if rng.random() < 0.5 else np.float64
         x = np.stack([make(int(rng.integers(0, 7)), n) for _ in range(B)]).astype(dtype)
@@ -69,7 +78,7 @@ bad = 0
 t0 = time.time()
 for c in range(cases):
     kind = int(rng.integers(0, 8))
-    n = int(rng.choice([3, 4, 5, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 4097, int(rng.integers(3, 70000)), int(rng.integers(3, 300000))]))
+    n = fold(int(rng.choice([3, 4, 5, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 4097, int(rng.integers(3, 70000)), int(rng.integers(3, 300000))])))
     m = int(rng.integers(0, 12))
     dtype = np.float32 if rng.random() < 0.5 and kind != 7 else np.float64
     x = make(kind, n).astype(dtype)
