@@ -145,7 +145,7 @@ def run_rank(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo" if (stub or args.rehearse_one_gpu) else "nccl", rank=rank, world_size=world)
+    coll_backend = "gloo" if (stub or (args.rehearse_one_gpu and not args.try_rccl) or world == 1) else "nccl"
     if stub:
         dev = torch.device("cpu")
     else:
@@ -153,7 +153,30 @@ def run_rank(args):
             local_rank = 0   # rehearsal on a one-GPU box: every rank computes on cuda:0, the summaries travel over gloo
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    coll_dev = torch.device("cpu") if (stub or args.rehearse_one_gpu) else dev   # where the collectives' tensors live
+    if world > 1:
+        if coll_backend == "nccl":
+            # RCCL carries the path's only collectives (barrier, all-gather of times and summaries).  If it cannot come up on this
+            # node (every rank sees the same environment), the control plane falls back to gloo on host tensors and the line says
+            # so: the data path has no collective either way, so the measurement is the same
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("RCCL all_reduce probe returned %r" % probe.item())
+            except Exception as ex:  # noqa: BLE001
+                sys.stderr.write("bench.py rank %d: RCCL unavailable (%r): summaries over gloo\n" % (rank, ex))
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                coll_backend = "gloo (fallback: RCCL did not come up: %s)" % repr(ex)[:120]
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = dev if coll_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
 
     from pyitd_amd.distributed import ShardedBatch
 
@@ -290,6 +313,7 @@ def run_rank(args):
             "knots_per_level": [int(v) for v in summ["knot_counts"][0] if v >= 0],
             "sharding": "contiguous ranges of independent signals per GPU (ShardedBatch), no data-path collective; "
                         "all-gather of the per-signal summaries only",
+            "collective_backend": None if world == 1 else ("nccl (RCCL)" if coll_backend == "nccl" else coll_backend),
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "rows_all_ranks": None if table is None else sorted(set(int(v) for v in table["n_rows"])),
             "signals_in_gathered_table": None if table is None else int(len(table["n_rows"])),
@@ -502,6 +526,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational BASELINE configs[2] leg (1024 x 2^20 signals)")
     ap.add_argument("--chain", action="store_true", help="run the opt-in one-launch chain (itd_set_chain_mode) instead of one launch per level")
+    ap.add_argument("--try-rccl", action="store_true",
+                    help="with --rehearse-one-gpu: ask for RCCL first all the same (two ranks on one GPU: it refuses, which exercises "
+                         "the fallback of the control plane to gloo)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 on a one-GPU box: all ranks compute on cuda:0 and gather over gloo (checks the sharded path end to end; "
                          "the line says so and is not a scaling measurement)")
