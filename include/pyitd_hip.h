@@ -162,14 +162,14 @@ int itd_set_chain_mode(itd_engine *e, int32_t mode);
 int itd_set_chain_grid(itd_engine *e, int32_t workgroups);
 /* how many chained calls of this engine itd_get_summary has had to repeat level by level so far */
 int itd_get_chain_repeats(const itd_engine *e);
-/* Short signals (n <= 4096 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays
+/* Short signals (n <= 8192 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays
  * in LDS through all levels of the driver loop (ITD.py:384-432): the signal is read once and every result row written once
  * (4 + 8 rows bytes per sample; the level-by-level form is launch bound there: 10 dependent launches).  It handles finite data
  * only; a NaN / infinity in the input or in a baseline (a leading or trailing plateau, ITD.py:115-116) makes itd_get_summary
  * repeat the call level by level before it returns (x_dev / rows_dev / baselines_dev must stay valid until then, as before), and
  * the engine's next 16 decompositions start level by level.  Rows past n_rows are not written in this form.
- * ITD_RESIDENT_AUTO (default): resident for n <= 4096 unless the engine was given a level-0 mode, a chain mode or kernel timing;
- * ITD_RESIDENT_OFF: never; ITD_RESIDENT_ONLY: always for n <= 4096, never repeat (itd_get_summary fails with ITD_ERR_HIP
+ * ITD_RESIDENT_AUTO (default): resident for n <= 8192 unless the engine was given a level-0 mode, a chain mode or kernel timing;
+ * ITD_RESIDENT_OFF: never; ITD_RESIDENT_ONLY: always for n <= 8192, never repeat (itd_get_summary fails with ITD_ERR_HIP
  * instead; tests, benchmarks).  Results are identical in every mode. */
 #define ITD_RESIDENT_AUTO 0
 #define ITD_RESIDENT_OFF 1
@@ -177,6 +177,10 @@ int itd_get_chain_repeats(const itd_engine *e);
 int itd_set_resident_mode(itd_engine *e, int32_t mode);
 /* how many resident calls of this engine itd_get_summary has had to repeat level by level so far */
 int itd_get_resident_repeats(const itd_engine *e);
+/* The resident form holds a window of `segments` consecutive knot-to-knot segments of a level in LDS at a time; a level with more
+ * knots takes several passes.  0 = automatic (0.4 knots per sample: one pass for ordinary signals), otherwise >= 8 (cut to what
+ * fits the LDS).  Results do not depend on it (tests run tiny windows to exercise the passes). */
+int itd_set_resident_window(itd_engine *e, int32_t segments);
 /* diagnostic builds only (-DITD_CHAIN_PROF=1): 16 counters summed over the chain's wavefronts (100 MHz ticks per phase, event
  * counts; itd_chain.hpp); all zero in the shipped build */
 int itd_debug_chain_prof(itd_engine *e, uint64_t *out16, int32_t reset);

@@ -63,6 +63,7 @@ ABI = {
     "itd_get_chain_repeats": (_INT, [_P]),
     "itd_set_resident_mode": (_INT, [_P, _I32]),
     "itd_get_resident_repeats": (_INT, [_P]),
+    "itd_set_resident_window": (_INT, [_P, _I32]),
     "itd_debug_chain_prof": (_INT, [_P, _P, _I32]),
     "itd_dev_alloc": (_INT, [_INT, _I64, ctypes.POINTER(_P)]),
     "itd_dev_free": (_INT, [_INT, _P]),

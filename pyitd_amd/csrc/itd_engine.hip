@@ -112,7 +112,8 @@ struct itd_engine {
     int32_t resident_mode = ITD_RESIDENT_AUTO;   // short signals as one workgroup each, one launch (itd_set_resident_mode)
     int32_t resident_off_left = 0;  // automatic mode: decompositions still to run level by level after a resident call met a non-finite value
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
-    bool resident_attr[10] = {};   // hipFuncSetAttribute done per kernel instance
+    bool resident_attr[12] = {};
+    int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
@@ -523,26 +524,31 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
     if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
         HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
                                     (size_t)n * sizeof(double), (size_t)batch, st));
-    const size_t lds = resident_lds_bytes((int)n);
-    // four samples per thread: 64 threads up to 256 samples ... 1024 threads up to 4096 (the per-thread sample loops are unrolled:
-    // 64 VGPRs at four samples, 85 at eight, 239 at sixteen — and the wider workgroups hide the phases' latencies better)
-    const int cls = n <= 256 ? 0 : n <= 512 ? 1 : n <= 1024 ? 2 : n <= 2048 ? 3 : 4;
-    const int inst = cls + (sizeof(Tin) == 4 ? 0 : 5);
-    const int threads = 64 << cls;
+    // the window of by-rank knot slots: automatic (0.4 knots per sample) or what the engine was told, cut to what fits the LDS
+    int cw = e->resident_window > 0 ? e->resident_window : resident_auto_window((int)n);
+    cw = std::min(cw, resident_pad((int)n));
+    while (resident_lds_bytes((int)n, cw) > kResidentLdsMax) cw -= 64;
+    const size_t lds = resident_lds_bytes((int)n, cw);
+    // four samples per thread: 64 threads up to 256 samples ... 1024 threads up to 4096, eight per thread up to 8192 (the
+    // per-thread sample loops are unrolled over registers; the wider workgroups hide the phases' latencies better)
+    const int cls = n <= 256 ? 0 : n <= 512 ? 1 : n <= 1024 ? 2 : n <= 2048 ? 3 : n <= 4096 ? 4 : 5;
+    const int inst = cls + (sizeof(Tin) == 4 ? 0 : 6);
+    const int threads = cls == 5 ? 1024 : 64 << cls;
     const void *fn = cls == 0 ? reinterpret_cast<const void *>(&k_resident<Tin, 64, 4>)
                    : cls == 1 ? reinterpret_cast<const void *>(&k_resident<Tin, 128, 4>)
                    : cls == 2 ? reinterpret_cast<const void *>(&k_resident<Tin, 256, 4>)
                    : cls == 3 ? reinterpret_cast<const void *>(&k_resident<Tin, 512, 4>)
-                              : reinterpret_cast<const void *>(&k_resident<Tin, 1024, 4>);
+                   : cls == 4 ? reinterpret_cast<const void *>(&k_resident<Tin, 1024, 4>)
+                              : reinterpret_cast<const void *>(&k_resident<Tin, 1024, 8>);
     if (!e->resident_attr[inst]) {   // more than 64 KB of dynamic LDS has to be asked for
-        HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(256 << cls)));
+        HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResidentLdsMax));
         e->resident_attr[inst] = true;
     }
     const Tin *a_x = x; int64_t a_xs = x_stride, a_rs = rows_stride, a_bs = rows_stride;
-    int a_n = (int)n, a_m = M;
+    int a_n = (int)n, a_m = M, a_cw = cw;
     double *a_rows = rows, *a_bases = bases_user;
     SigState *a_st = set_state, *a_ot = other_state;
-    void *args[] = {&a_x, &a_xs, &a_n, &a_m, &a_rows, &a_rs, &a_bases, &a_bs, &a_st, &a_ot};
+    void *args[] = {&a_x, &a_xs, &a_n, &a_m, &a_cw, &a_rows, &a_rs, &a_bases, &a_bs, &a_st, &a_ot};
     HIP_TRY(e, hipLaunchKernel(fn, dim3((unsigned)batch), dim3((unsigned)threads), args, lds, st));
     HIP_TRY(e, hipGetLastError());
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1020,6 +1026,13 @@ int itd_set_resident_mode(itd_engine *e, int32_t mode)
 }
 
 int itd_get_resident_repeats(const itd_engine *e) { return e ? e->resident_repeats : -1; }
+
+int itd_set_resident_window(itd_engine *e, int32_t segments)
+{
+    if (!e || segments < 0 || (segments > 0 && segments < 8)) return ITD_ERR_INVALID_ARG;
+    e->resident_window = segments;
+    return ITD_OK;
+}
 
 int itd_set_chain_grid(itd_engine *e, int32_t workgroups)
 {

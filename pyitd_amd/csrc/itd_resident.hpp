@@ -35,38 +35,58 @@
 #ifndef ITD_RES_ABL
 #define ITD_RES_ABL 0
 #endif
+// wavefronts per SIMD the four-samples-per-thread instances are compiled for (8: 64 VGPRs)
+#ifndef ITD_RES_MINW
+#define ITD_RES_MINW 8
+#endif
 namespace itd {
 
-constexpr int kResidentMax = 4096;        // samples: 34 B of LDS per sample, 160 KB per workgroup on gfx950
+constexpr int kResidentMax = 8192;        // samples: the signal (8 B per sample) + a window of by-rank knot arrays in 160 KB of LDS
 
-// dynamic LDS of a workgroup that holds an n-sample signal: the signal, three by-rank knot arrays (value, B, slope), the
-// knots' indices (16 bit), one ballot word and one prefix per 64 samples, three control words
+// The by-rank knot arrays hold a WINDOW of `cw` consecutive segments (+ the knots either side that their knot values need); a
+// level with more knots than that takes several passes over its ranks (knot list, values, map per pass).  The automatic window
+// is 0.4 knots per sample: one pass for every level of ordinary signals (sines + noise: 0.40 / 0.12 / 0.04 ... knots per
+// sample), two for the first level of white noise (0.67) — and 18 instead of 34 B of LDS per sample, i.e. about twice the
+// workgroups per CU, which is what a latency-bound launch is short of.
 __host__ __device__ constexpr int resident_pad(int n) { return (n + 63) & ~63; }
-__host__ __device__ constexpr size_t resident_lds_bytes(int n)
+__host__ __device__ constexpr int resident_auto_window(int n)
 {
-    return (size_t)resident_pad(n) * (4 * 8 + 2) + (size_t)(resident_pad(n) / 64) * 12 + 16 + 8;
+    return resident_pad(n) * 2 / 5 < 64 ? 64 : resident_pad(n) * 2 / 5;
 }
+// dynamic LDS: the signal, three by-rank arrays of cw + 3 doubles (value, B, slope), the knots' 16-bit indices, one ballot word
+// per 64 samples, the level's four end samples, control words
+__host__ __device__ constexpr int resident_cap(int cw) { return (cw + 4 + 3) & ~3; }   // by-rank slots of a window of cw segments
+__host__ __device__ constexpr size_t resident_lds_bytes(int n, int cw)
+{
+    return (size_t)resident_pad(n) * 8 + (size_t)resident_cap(cw) * (3 * 8 + 2) + (size_t)(resident_pad(n) / 64) * 12 + 4 * 8 + 16 + 8;
+}
+constexpr size_t kResidentLdsMax = 160 * 1024;
 
 template <typename Tin, int TH, int SPT>
-__global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, int64_t x_stride, int n, int M,
+__global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(const Tin *__restrict__ xin, int64_t x_stride, int n, int M, int cw,
                                                    double *__restrict__ rows, int64_t rows_stride,
                                                    double *__restrict__ bases, int64_t bases_stride,
                                                    SigState *__restrict__ state, SigState *__restrict__ other_state)
 {
     static_assert(TH % 64 == 0 && TH * SPT <= kResidentMax, "geometry");
     constexpr int W = TH / 64;
+    constexpr int WPL = (TH * SPT / 64 + 63) / 64;   // ballot words a lane totals in the prefix (1 up to 4096 samples, 2 up to 8192)
+    static_assert(WPL == 1 || WPL == 2, "prefix geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int sig = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int np2 = resident_pad(n), Q = np2 >> 6;
+    const int cap = resident_cap(cw);                            // by-rank slots (slot 0 = the knot in front of the window)
     double *xs = reinterpret_cast<double *>(lds_raw);          // the level's input; after the map: its baseline
-    double *Xk = xs + np2;                                       // by rank: value of the level's input at knot k
-    double *Bk = Xk + np2;                                       // knot value B_k
-    double *Sk = Bk + np2;                                       // slope of the segment that starts at knot k
-    unsigned long long *bal = reinterpret_cast<unsigned long long *>(Sk + np2);   // knot flags, one word per 64 samples
-    int *ctl = reinterpret_cast<int *>(bal + Q) + Q + 1;         // [0]: a non-finite sample was seen
-    unsigned short *ek = reinterpret_cast<unsigned short *>(ctl + 3);   // by rank: the knots' sample indices
+    double *Xk = xs + np2;                                       // by slot: value of the level's input at the knot
+    double *Bk = Xk + cap;                                       // knot value B_k
+    double *Sk = Bk + cap;                                       // slope of the segment that starts at the knot
+    double *ends = Sk + cap;                                     // x[0], x[1], x[n-2], x[n-1] of the level's input (ITD.py:101-102)
+    unsigned long long *bal = reinterpret_cast<unsigned long long *>(ends + 4);   // knot flags, one word per 64 samples
+    int *pre = reinterpret_cast<int *>(bal + Q);                 // knots in front of word q (written and read by the word's wavefront)
+    int *ctl = pre + Q;                                          // [0]: a non-finite sample was seen
+    unsigned short *ek = reinterpret_cast<unsigned short *>(ctl + 4);   // by slot: the knots' sample indices
 
     SigState *st = state + sig;
     const Tin *x = xin + (int64_t)sig * x_stride;
@@ -83,16 +103,14 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
     }
 
     // the thread's samples: word q = wave + W j, sample 64 q + lane — consecutive lanes, consecutive samples (coalesced
-    // rows, conflict-free LDS).  In registers: xr[] the input of the extraction in flight, xb[] its baseline, and per word
-    // (wave-uniform) the knot flags of the level's input and the number of knots in front of the word
-    double xr[SPT], xb[SPT];
-    unsigned long long bm[SPT];
-    int pr[SPT];
+    // rows, conflict-free LDS).  Registers hold only xr[], the input of the extraction in flight: the words' knot flags and
+    // prefixes live in LDS (bal[], pre[]), the baseline in xs — 64 VGPRs, so that the CU's wavefront slots, not registers,
+    // bound the workgroups per CU once the rank window has cut the LDS per sample
+    double xr[SPT];
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
         const int q = wave + W * j, i = q * 64 + lane;
         xr[j] = 0.0;
-        xb[j] = 0.0;
         if (q < Q) {
             if (i < n) xr[j] = (double)x[i];
             xs[i] = xr[j];
@@ -100,37 +118,44 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
     }
     __syncthreads();
 
-    // Knot flags of the signal in xs (cur[] = the thread's own samples of it; interior samples 1 .. n-2, ITD.py:70-73) into
-    // bm[], the words' exclusive prefix into pr[]; returns the knot total.  One barrier: every wavefront totals the words
-    // itself.  ctl[0] is raised if a sample is not finite.
-    auto scan = [&](const double (&cur)[SPT]) -> int {
+    // Knot flags of the signal in xs (interior samples 1 .. n-2, ITD.py:70-73) into bal[], the exclusive prefix of the
+    // wavefront's own words into pre[]; returns the knot total.  One barrier: every wavefront totals the words itself.
+    // ctl[0] is raised if a sample is not finite; thread 0 leaves the level's four end samples in ends[].
+    auto scan = [&]() -> int {
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int q = wave + W * j, i = q * 64 + lane;
-            bm[j] = 0;
             if (q < Q) {
                 bool f = false, bad = false;
                 if (i < n) {
-                    const double c = cur[j];
+                    const double c = xs[i];
                     bad = !(__builtin_fabs(c) < inf);
                     if (i >= 1 && i <= n - 2) {
                         const double d0 = c - ((ITD_RES_ABL & 128) ? 0.5 : xs[i - 1]), d1 = ((ITD_RES_ABL & 128) ? 0.25 : xs[i + 1]) - c;   // dx[i-1], dx[i] (ITD.py:44)
                         f = (d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0);   // valley of x or of -x (ITD.py:59, 87-88)
                     }
                 }
-                bm[j] = __ballot(f);
+                const unsigned long long bw = __ballot(f);
                 const unsigned long long bb = __ballot(bad);
                 if (lane == 0) {
-                    bal[q] = bm[j];
+                    bal[q] = bw;
                     if (bb) ctl[0] = 1;
                 }
             }
         }
+        if (tid == 0) {
+            ends[0] = xs[0];
+            ends[1] = xs[1];
+            ends[2] = xs[n - 2];
+            ends[3] = xs[n - 1];
+        }
         __syncthreads();
-        const int cnt = lane < Q ? __popcll(bal[lane]) : 0;
         // inclusive prefix over the 64 lanes on the DPP path (no LDS round trips): Hillis-Steele inside the rows of 16 lanes
         // (row_shr 1, 2, 4, 8: a lane without a source inside its row keeps the 0 it is given), then row 0's / rows 0-1's
-        // totals into the rows behind them (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3)
+        // totals into the rows behind them (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3).  A lane totals WPL words.
+        const int c0 = WPL * lane < Q ? __popcll(bal[WPL * lane]) : 0;
+        const int c1 = (WPL == 2 && 2 * lane + 1 < Q) ? __popcll(bal[2 * lane + 1]) : 0;
+        const int cnt = c0 + c1;
         int inc = cnt;
         if (!(ITD_RES_ABL & 2)) {
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);
@@ -140,16 +165,15 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);
         }
+        // the prefixes of the wavefront's own words (nobody else reads them: no barrier)
         const int excl = inc - cnt;
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int q = wave + W * j;
-            pr[j] = q < Q ? __builtin_amdgcn_readlane(excl, q) : 0;
-        }
+        const int w0 = WPL * lane;
+        if (w0 < Q && (w0 % W) == wave) pre[w0] = excl;
+        if (WPL == 2 && w0 + 1 < Q && ((w0 + 1) % W) == wave) pre[w0 + 1] = excl + c0;
         return __builtin_amdgcn_readlane(inc, 63);
     };
 
-    int m = scan(xr);
+    int m = scan();
     if (tid == 0) st->m[0] = m;
     if (ctl[0]) {
         if (tid == 0) st->res_fail = 1;
@@ -157,71 +181,91 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
     }
 
     for (int c = 0;; ++c) {
-        // ---- ordered knot list of the level's input (knots by rank 1 .. m, the two ends at 0 and m+1) ----------------
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int q = wave + W * j, i = q * 64 + lane;
-            if (q < Q && ((bm[j] >> lane) & 1ull) && !(ITD_RES_ABL & 16)) {
-                const int k = pr[j] + __popcll(bm[j] & ((1ull << lane) - 1ull)) + 1;
-                ek[k] = (unsigned short)i;
-                Xk[k] = xr[j];
-            }
-        }
-        if (tid == 0) {
-            ek[0] = 0;                       // ITD.py:96
-            Xk[0] = xs[0];
-            ek[m + 1] = (unsigned short)(n - 1);   // ITD.py:98
-            Xk[m + 1] = xs[n - 1];
-        }
-        __syncthreads();
-        // ---- knot values (ITD.py:100-110) and slopes (ITD.py:115-116; 0/0 on an end segment is the reference's NaN: the
-        //      next scan catches it).  A wavefront takes 64 consecutive knots and the 63 segments between them — B_{k+1} comes
-        //      from the next lane — so consecutive chunks overlap by one knot and no barrier separates values from slopes ------
-        for (int cidx = wave; 63 * cidx <= m + 1 && !(ITD_RES_ABL & 1); cidx += W) {
-            const int k = 63 * cidx + lane;
-            double v = 0.0, x0 = 0.0, xp1 = 0.0;
-            if (k <= m + 1) {
-                x0 = Xk[k];
-                if (k == 0) {
-                    v = (xs[0] + xs[1]) / 2.0;                   // numpy.mean(x[:2])
-                    xp1 = Xk[1];
-                } else if (k == m + 1) {
-                    v = (xs[n - 2] + xs[n - 1]) / 2.0;           // numpy.mean(x[-2:])
-                } else {
-                    const int e0 = ek[k - 1], e1 = ek[k], e2 = ek[k + 1];
-                    const double xm1 = Xk[k - 1];
-                    xp1 = Xk[k + 1];
-                    const double frac = (double)(e1 - e0) / (double)(e2 - e0);
-                    const double t = frac * (xp1 - xm1);
-                    const double u = xm1 + t;
-                    v = 0.5 * u + 0.5 * x0;
-                }
-                Bk[k] = v;
-            }
-            const double vn = __shfl_down(v, 1, 64);
-            if (lane < 63 && k <= m) Sk[k] = (vn - v) / (xp1 - x0);
-        }
-        __syncthreads();
-        // ---- map (ITD.py:112-117): the baseline replaces the signal in LDS; rotation = x - baseline (ITD.py:119) leaves at
-        //      once unless this is the extraction behind the last requested one (its row is never the rotation) -----------
         double *row = rows_s + (int64_t)c * n;
+        // ---- passes over the level's ranks: segments k0 .. kend-1 (segment k = samples e_k <= i < e_{k+1}); the window's
+        //      slots hold the knots k0-1 .. kend+1, slot = k - k0 + 1 -------------------------------------------------------
+        for (int k0 = 0; k0 <= m; k0 += cw) {
+            const int kend = k0 + cw < m + 1 ? k0 + cw : m + 1;
+            // nothing derived from the lane / wavefront index is carried across the passes (registers)
+            int lane_p = lane, wave_p = wave;
+            asm volatile("" : "+v"(lane_p), "+s"(wave_p));
+            // -- ordered knot list (knots by rank 1 .. m; the two ends are knots 0 and m+1, ITD.py:93-98)
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int q = wave + W * j, i = q * 64 + lane;
-            if (q < Q && i < n) {
-                const int k = pr[j] + __popcll(bm[j] & ((2ull << lane) - 1ull));   // knots at or before the sample
-                const double b = (ITD_RES_ABL & 32) ? xr[j] * 0.75 + k : (i == n - 1) ? 0.0 : Bk[k] + Sk[k] * (xr[j] - Xk[k]);
-                xb[j] = b;
-                xs[i] = b;
-                if (c <= M && !(ITD_RES_ABL & 8)) {
-                    row[i] = xr[j] - b;
-                    if (bases_s) bases_s[(int64_t)c * n + i] = b;
+            for (int j = 0; j < SPT; ++j) {
+                const int q = wave_p + W * j, i = q * 64 + lane_p;
+                if (q < Q && !(ITD_RES_ABL & 16)) {
+                    const unsigned long long bw = bal[q];
+                    if ((bw >> lane_p) & 1ull) {
+                        const int k = pre[q] + __popcll(bw & ((1ull << lane_p) - 1ull)) + 1;
+                        if (k >= k0 - 1 && k <= kend + 1) {
+                            ek[k - k0 + 1] = (unsigned short)i;
+                            Xk[k - k0 + 1] = xr[j];
+                        }
+                    }
                 }
             }
+            if (tid == 0) {
+                if (k0 <= 1) {                   // knot 0: ITD.py:96
+                    ek[1 - k0] = 0;
+                    Xk[1 - k0] = ends[0];
+                }
+                if (kend + 1 >= m + 1) {         // knot m+1: ITD.py:98
+                    ek[m + 1 - k0 + 1] = (unsigned short)(n - 1);
+                    Xk[m + 1 - k0 + 1] = ends[3];
+                }
+            }
+            __syncthreads();
+            // -- knot values (ITD.py:100-110) and slopes (ITD.py:115-116; 0/0 on an end segment is the reference's NaN: the
+            //    next scan catches it).  A wavefront takes 64 consecutive knots and the 63 segments between them — B_{k+1} comes
+            //    from the next lane — so consecutive chunks overlap by one knot and no barrier separates values from slopes
+            for (int cidx = wave_p; k0 + 63 * cidx <= kend && !(ITD_RES_ABL & 1); cidx += W) {
+                const int k = k0 + 63 * cidx + lane_p, sl = k - k0 + 1;
+                double v = 0.0, x0 = 0.0, xp1 = 0.0;
+                if (k <= kend) {
+                    x0 = Xk[sl];
+                    if (k == 0) {
+                        v = (ends[0] + ends[1]) / 2.0;               // numpy.mean(x[:2])
+                        xp1 = Xk[sl + 1];
+                    } else if (k == m + 1) {
+                        v = (ends[2] + ends[3]) / 2.0;               // numpy.mean(x[-2:])
+                    } else {
+                        const int e0 = ek[sl - 1], e1 = ek[sl], e2 = ek[sl + 1];
+                        const double xm1 = Xk[sl - 1];
+                        xp1 = Xk[sl + 1];
+                        const double frac = (double)(e1 - e0) / (double)(e2 - e0);
+                        const double t = frac * (xp1 - xm1);
+                        const double u = xm1 + t;
+                        v = 0.5 * u + 0.5 * x0;
+                    }
+                    Bk[sl] = v;
+                }
+                const double vn = __shfl_down(v, 1, 64);
+                if (lane_p < 63 && k < kend) Sk[sl] = (vn - v) / (xp1 - x0);
+            }
+            __syncthreads();
+            // -- map (ITD.py:112-117) of the samples whose segment lies in the window: the baseline replaces the signal in LDS;
+            //    rotation = x - baseline (ITD.py:119) leaves at once unless this is the extraction behind the last requested
+            //    one (its row is never the rotation)
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int q = wave_p + W * j, i = q * 64 + lane_p;
+                if (q < Q && i < n) {
+                    const int k = pre[q] + __popcll(bal[q] & ((2ull << lane_p) - 1ull));   // knots at or before the sample
+                    if (k >= k0 && k < kend) {
+                        const int sl = k - k0 + 1;
+                        const double b = (ITD_RES_ABL & 32) ? xr[j] * 0.75 + k : (i == n - 1) ? 0.0 : Bk[sl] + Sk[sl] * (xr[j] - Xk[sl]);
+                        xs[i] = b;
+                        if (c <= M && !(ITD_RES_ABL & 8)) {
+                            row[i] = xr[j] - b;
+                            if (bases_s) bases_s[(int64_t)c * n + i] = b;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- the pending baseline's stop test = the next level's scan (ITD.py:400-404) -------------------------------
-        m = scan(xb);
+        m = scan();
         if (tid == 0) st->m[c + 1] = m;
         if (ctl[0] && !(ITD_RES_ABL & 64)) {
             if (tid == 0) st->res_fail = 1;
@@ -245,14 +289,18 @@ __global__ __launch_bounds__(TH) void k_resident(const Tin *__restrict__ xin, in
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave + W * j, i = q * 64 + lane;
                 if (q < Q && i < n) {
-                    const double r = xr[j] - xb[j];
-                    row[i] = r + xb[j];
+                    const double b = xs[i];
+                    const double r = xr[j] - b;
+                    row[i] = r + b;
                 }
             }
             return;             // fin_stopped stays 0
         }
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) xr[j] = xb[j];   // the baseline is the next extraction's input (ITD.py:428-432)
+        for (int j = 0; j < SPT; ++j) {   // the baseline is the next extraction's input (ITD.py:428-432)
+            const int q = wave + W * j, i = q * 64 + lane;
+            if (q < Q && i < n) xr[j] = xs[i];
+        }
     }
 }
 

@@ -108,9 +108,13 @@ class Engine:
         self._check(self._L.itd_set_chain_mode(self._h, int(mode)))
 
     def set_resident_mode(self, mode):
-        """RESIDENT_AUTO (signals of <= 4096 samples run as one workgroup each in one launch, the signal resident in LDS; a call
+        """RESIDENT_AUTO (signals of <= 8192 samples run as one workgroup each in one launch, the signal resident in LDS; a call
         that meets a non-finite value is repeated level by level), RESIDENT_OFF, RESIDENT_ONLY (never repeat)."""
         self._check(self._L.itd_set_resident_mode(self._h, int(mode)))
+
+    def set_resident_window(self, segments):
+        """Knot-to-knot segments of a level the resident form holds in LDS per pass (0 = automatic); results do not depend on it."""
+        self._check(self._L.itd_set_resident_window(self._h, int(segments)))
 
     @property
     def resident_repeats(self):

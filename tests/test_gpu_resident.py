@@ -30,7 +30,7 @@ def oracle():
     return cpu_oracle
 
 
-def _run(P, torch, x_np, m, mode, keep=True):
+def _run(P, torch, x_np, m, mode, keep=True, window=0):
     from pyitd_amd.engine import LEVEL0_AUTO
     B, n = x_np.shape
     xd = torch.from_numpy(x_np).cuda()
@@ -39,6 +39,7 @@ def _run(P, torch, x_np, m, mode, keep=True):
     eng = P.Engine(n, B, 0)
     eng.set_level0_mode(LEVEL0_AUTO)     # whatever PYITD_LEVEL0_MODE says: the resident form needs the automatic mode
     eng.set_resident_mode(mode)
+    eng.set_resident_window(window)
     torch.cuda.synchronize()
     eng.decompose_dev(xd.data_ptr(), x_np.dtype, n, B, n, m, rows.data_ptr(), bases.data_ptr() if keep else None, None)
     s = eng.summary(B)
@@ -65,7 +66,8 @@ def _check_against_oracle(oracle, x, m, rows, bases, s, what):
 FINITE_KINDS = (0, 1, 3, 4, 6, 7)     # fuzz families without plateaus at the signal's ends
 
 
-@pytest.mark.parametrize("n", [3, 4, 5, 7, 63, 64, 65, 127, 129, 400, 511, 512, 513, 1000, 1024, 1025, 2047, 2049, 3000, 4095, 4096])
+@pytest.mark.parametrize("n", [3, 4, 5, 7, 63, 64, 65, 127, 129, 400, 511, 512, 513, 1000, 1024, 1025, 2047, 2049, 3000, 4095, 4096,
+                               4097, 5000, 8000, 8191, 8192])
 def test_resident_is_bit_exact_at_every_length(P, torch, oracle, n):
     from pyitd_amd.engine import RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY
     rng = np.random.default_rng(1000 + n)
@@ -92,6 +94,20 @@ def test_resident_is_bit_exact_at_every_length(P, torch, oracle, n):
         _check_against_oracle(oracle, x, 7, rows, bases, s, "n=%d resident only" % n)
 
 
+@pytest.mark.parametrize("n,window", [(300, 8), (300, 64), (2000, 8), (2000, 100), (2000, 1000), (4096, 64), (8000, 8), (8000, 500), (8192, 3000)])
+def test_results_do_not_depend_on_the_rank_window(P, torch, oracle, n, window):
+    """The by-rank knot arrays hold a window of consecutive segments; a level with more knots takes several passes (knot list,
+    values, map per pass).  Tiny windows force many passes on every level — alternating signals have n - 2 knots."""
+    from pyitd_amd.engine import RESIDENT_ONLY
+    rng = np.random.default_rng(n + window)
+    x = np.stack([fuzz_signal(rng, k, n) for k in (0, 1, 4, 6, 0, 1)])
+    for dtype, m in ((np.float64, 5), (np.float32, 2)):
+        xd = x.astype(dtype)
+        rows, bases, s, rep = _run(P, torch, xd, m, RESIDENT_ONLY, window=window)
+        assert rep == 0
+        _check_against_oracle(oracle, xd, m, rows, bases, s, "n=%d window=%d %s" % (n, window, np.dtype(dtype).name))
+
+
 def test_resident_goldens(P, torch, oracle):
     """Every reference-generated golden vector short enough for the resident form, through the drop-in class (automatic mode)."""
     import os
@@ -99,7 +115,7 @@ def test_resident_goldens(P, torch, oracle):
     seen = 0
     for name in golden_cases():
         g = load_golden(name)
-        if "x" not in g.files or "rows" not in g.files or g["x"].ndim != 1 or g["x"].shape[0] > 4096:
+        if "x" not in g.files or "rows" not in g.files or g["x"].ndim != 1 or g["x"].shape[0] > 8192:
             continue
         x, m = g["x"], int(g["max_iteration"])
         if not np.isfinite(x).all():
@@ -172,12 +188,12 @@ def test_resident_large_batches_and_mixed_stops(P, torch, oracle):
 
 
 def test_resident_fuzz_slice(P, torch, oracle):
-    """Fixed-seed fuzz: random lengths 3 .. 4096, random max_iteration, all signal families (plateau families go through the
+    """Fixed-seed fuzz: random lengths 3 .. 8192, random max_iteration, all signal families (plateau families go through the
     level-by-level repeat), float32 and float64."""
     from pyitd_amd.engine import RESIDENT_AUTO
     rng = np.random.default_rng(20261004)
     for case in range(60):
-        n = int(rng.integers(3, 4097)) if case % 3 else int(rng.choice([3, 64, 512, 513, 4096]))
+        n = int(rng.integers(3, 8193)) if case % 3 else int(rng.choice([3, 64, 512, 513, 4096, 4097, 8192]))
         m = int(rng.integers(0, 21))
         B = int(rng.integers(1, 9))
         dtype = np.float32 if case % 2 else np.float64

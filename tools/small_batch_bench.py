@@ -15,8 +15,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 SHAPES = [(60000, 256), (40000, 400), (16384, 1024), (4096, 4096), (2048, 8000), (1024, 16384), (256, 65536), (16, 1 << 20),
           (1, 400), (1, 8000), (1, 65536)]
 if os.environ.get("SMALL_RESIDENT_SHAPES"):   # the sizes around the resident form's classes (pyitd_amd/csrc/itd_resident.hpp)
-    SHAPES = [(60000, 256), (32768, 512), (16384, 1024), (8192, 2048), (4096, 4096), (256, 1024), (64, 4096), (8, 4096),
-              (1, 256), (1, 512), (1, 1024), (1, 2048), (1, 4096)]
+    SHAPES = [(60000, 256), (32768, 512), (16384, 1024), (8192, 2048), (4096, 4096), (2048, 8000), (256, 1024), (64, 4096), (8, 4096),
+              (1, 256), (1, 512), (1, 1024), (1, 2048), (1, 4096), (1, 8000)]
 
 
 def main():
