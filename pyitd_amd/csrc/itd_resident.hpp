@@ -1,13 +1,14 @@
 // itd_resident.hpp — the WHOLE decomposition of a short signal in ONE launch, the signal resident in LDS.
 //
 // The level-by-level engine (itd_kernels.hpp) streams a level's input from HBM and is launch bound below ~2^16 samples
-// (10 dependent launches, ~6.5 us each) and traffic bound at 20 + 24 B per sample and level.  A signal of n <= 4096
-// samples fits into one workgroup's LDS together with its knot arrays, so ONE workgroup runs the reference's driver loop
+// (10 dependent launches, ~6.5 us each) and traffic bound at 20 + 24 B per sample and level.  A signal of n <= 8192
+// samples fits into one workgroup's LDS together with a window of its knot arrays, so ONE workgroup runs the reference's driver loop
 // (ITD.itd, ITD.py:384-432) for it from the first extraction to the stop rule: the signal is read once (4 or 8 B per
 // sample), every result row is written once (8 B per sample and row), nothing else touches HBM, and a batch of short
 // signals is one launch with one workgroup per signal.
 //
-// Per level, four workgroup barriers (a 64-thread workgroup's barriers are free):
+// Per level, one workgroup barrier for the scan and three per pass over the level's ranks (one pass unless the level has more
+// knots than the window holds; a 64-thread workgroup's barriers are free):
 //   scan    knot predicate of detect_peaks(x) U detect_peaks(-x) (ITD.py:44-59, 87-98) per sample, one __ballot word per
 //           64 samples; every wavefront totals the words itself (exclusive prefix of their popcounts)
 //   knots   ordered knot list by rank: index e_k and value x[e_k]; e_0 = 0, e_{m+1} = n-1 (ITD.py:93-98)
