@@ -22,7 +22,9 @@ algorithmic B/sample, timed with the launches' own hipEvents on the launch strea
 fractions + "cpu_baseline" (the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1)
 and the other CPU legs SURVEY 8d lists (all host cores over independent signals, numpy restatement, numba restatement).
 At N = 1 the line also carries "config3_batch" (BASELINE configs[2], 1024 x 2^20 signals): that leg is timed BEFORE the headline's
-warmup, so the headline's short timed region starts on a GPU at its sustained clocks (--no-extra skips the leg).
+warmup, so the headline's short timed region starts on a GPU at its sustained clocks (--no-extra skips the leg),
+and "short_signal_batches" (4096 x 4096 and 60 000 x 256 samples through the resident form and level by level, DESIGN.md section 11;
+timed after the headline, skipped by --no-extra as well).
 """
 import argparse
 import json
@@ -408,6 +410,10 @@ def run_rank(args):
         out.update(cpu_legs(x_host, n, M, summ, rows, args))
     if extra is not None:
         out["config3_batch"] = extra
+        try:
+            out["short_signal_batches"] = short_signal_leg(torch, dev)
+        except Exception as ex:  # noqa: BLE001 — informational, never at the cost of the line
+            out["short_signal_batches"] = {"error": repr(ex)[:200]}
     print(json.dumps(out))
     sys.stdout.flush()
     if dist.is_initialized():
@@ -441,6 +447,44 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
             "hbm_algorithmic_GBps": round(alg, 1), "frac_of_peak_whole_decomposition": round(alg / HBM_PEAK_GBPS, 4),
             "rows_per_signal": sorted(set(int(v) for v in s["n_rows"])),
             "order": "timed before the headline's warmup; its buffers are released after the headline's timed region"}, (x, rows, eng)
+
+
+def short_signal_leg(torch, dev, steps=10):
+    """Batches of SHORT signals (2^24 samples in all) through the resident form (one launch, one workgroup per signal, the signal in
+    LDS: pyitd_amd/csrc/itd_resident.hpp) and through the level-by-level engine — informational, timed after the headline."""
+    import pyitd_amd
+    from pyitd_amd.engine import RESIDENT_AUTO, RESIDENT_OFF
+    out = []
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for batch, n in ((4096, 4096), (60000, 256)):
+        t = torch.arange(n, dtype=torch.float64) / 8000.0
+        x = (torch.sin(2 * np.pi * 110 * t)[None, :] + 0.5 * torch.sin(2 * np.pi * 440 * t + 1.3)[None, :]
+             + 0.05 * torch.randn((batch, n), generator=g, dtype=torch.float64)).to(torch.float32).to(dev)
+        rows = torch.empty((batch, MAX_ITERATION + 2, n), dtype=torch.float64, device=dev)
+        eng = pyitd_amd.Engine(n, batch, dev.index or 0)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        item = {"signals": batch, "samples_per_signal": n}
+        for key, mode in (("resident_ms", RESIDENT_AUTO), ("level_by_level_ms", RESIDENT_OFF)):
+            eng.set_resident_mode(mode)
+            for _ in range(3):
+                eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
+            torch.cuda.synchronize()
+            item[key] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+            if mode == RESIDENT_AUTO:
+                s = eng.summary(batch)
+                item["rows_per_signal"] = sorted(set(int(v) for v in s["n_rows"]))
+                item["resident_repeats"] = eng.resident_repeats
+        item["resident_Msamples_per_s"] = round(batch * n / item["resident_ms"] / 1e3, 1)
+        out.append(item)
+        eng.close()
+        del x, rows
+    return {"workload": "float32 sines + noise, max_iteration=%d, device resident, %d timed calls per figure" % (MAX_ITERATION, steps),
+            "batches": out}
 
 
 def cpu_legs(x_host, n, M, summ, rows, args):
