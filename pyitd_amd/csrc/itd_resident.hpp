@@ -63,6 +63,22 @@ __host__ __device__ constexpr size_t resident_lds_bytes(int n, int cw)
 }
 constexpr size_t kResidentLdsMax = 160 * 1024;
 
+// 8-byte row stores / input loads through raw buffer descriptors (base = the row, extent = n samples): the lanes of the last,
+// partly filled 64-sample word need no guard — what lies beyond the row is not written and reads as 0
+__device__ __forceinline__ void res_store(__amdgpu_buffer_rsrc_t r, int i, double v)
+{
+    using U2 = unsigned __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2, v), r, i * 8, 0, kBufNT);   // result rows are never read again
+}
+__device__ __forceinline__ double res_load(__amdgpu_buffer_rsrc_t r, int i, const double *)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, i * 8, 0, 0));
+}
+__device__ __forceinline__ double res_load(__amdgpu_buffer_rsrc_t r, int i, const float *)
+{
+    return (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, i * 4, 0, 0));
+}
+
 template <typename Tin, int TH, int SPT>
 __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(const Tin *__restrict__ xin, int64_t x_stride, int n, int M, int cw,
                                                    double *__restrict__ rows, int64_t rows_stride,
@@ -107,14 +123,18 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
     // rows, conflict-free LDS).  Registers hold only xr[], the input of the extraction in flight: the words' knot flags and
     // prefixes live in LDS (bal[], pre[]), the baseline in xs — 64 VGPRs, so that the CU's wavefront slots, not registers,
     // bound the workgroups per CU once the rank window has cut the LDS per sample
+    // Samples of the padding (n .. np2-1) are 0 in registers and LDS throughout: they flag nothing and are never stored.
     double xr[SPT];
+    {
+        const __amdgpu_buffer_rsrc_t rx = tile_rsrc(x, (int64_t)n * (int64_t)sizeof(Tin));
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-        const int q = wave + W * j, i = q * 64 + lane;
-        xr[j] = 0.0;
-        if (q < Q) {
-            if (i < n) xr[j] = (double)x[i];
-            xs[i] = xr[j];
+        for (int j = 0; j < SPT; ++j) {
+            const int q = wave + W * j, i = q * 64 + lane;
+            xr[j] = 0.0;
+            if (q < Q) {
+                xr[j] = res_load(rx, i, x);
+                xs[i] = xr[j];
+            }
         }
     }
     __syncthreads();
@@ -127,15 +147,12 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
         for (int j = 0; j < SPT; ++j) {
             const int q = wave + W * j, i = q * 64 + lane;
             if (q < Q) {
-                bool f = false, bad = false;
-                if (i < n) {
-                    const double c = xs[i];
-                    bad = !(__builtin_fabs(c) < inf);
-                    if (i >= 1 && i <= n - 2) {
-                        const double d0 = c - ((ITD_RES_ABL & 128) ? 0.5 : xs[i - 1]), d1 = ((ITD_RES_ABL & 128) ? 0.25 : xs[i + 1]) - c;   // dx[i-1], dx[i] (ITD.py:44)
-                        f = (d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0);   // valley of x or of -x (ITD.py:59, 87-88)
-                    }
-                }
+                const double c = xs[i];
+                const bool bad = !(__builtin_fabs(c) < inf);
+                // dx[i-1], dx[i] (ITD.py:44); the reads next to the signal's ends stay inside xs (word 0 starts at sample 0, the
+                // padding ends the last word) and only interior samples can flag
+                const double d0 = c - ((ITD_RES_ABL & 128) ? 0.5 : xs[i > 0 ? i - 1 : 0]), d1 = ((ITD_RES_ABL & 128) ? 0.25 : xs[i < np2 - 1 ? i + 1 : i]) - c;
+                const bool f = ((d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0)) && i >= 1 && i <= n - 2;   // valley of x or of -x (ITD.py:59, 87-88)
                 const unsigned long long bw = __ballot(f);
                 const unsigned long long bb = __ballot(bad);
                 if (lane == 0) {
@@ -182,7 +199,8 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
     }
 
     for (int c = 0;; ++c) {
-        double *row = rows_s + (int64_t)c * n;
+        const __amdgpu_buffer_rsrc_t r_row = tile_rsrc(rows_s + (int64_t)c * n, (int64_t)n * 8);
+        const __amdgpu_buffer_rsrc_t r_base = tile_rsrc(bases_s ? bases_s + (int64_t)(c <= M ? c : 0) * n : nullptr, bases_s ? (int64_t)n * 8 : 0);
         // ---- passes over the level's ranks: segments k0 .. kend-1 (segment k = samples e_k <= i < e_{k+1}); the window's
         //      slots hold the knots k0-1 .. kend+1, slot = k - k0 + 1 -------------------------------------------------------
         for (int k0 = 0; k0 <= m; k0 += cw) {
@@ -250,15 +268,15 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave_p + W * j, i = q * 64 + lane_p;
-                if (q < Q && i < n) {
+                if (q < Q) {
                     const int k = pre[q] + __popcll(bal[q] & ((2ull << lane_p) - 1ull));   // knots at or before the sample
                     if (k >= k0 && k < kend) {
                         const int sl = k - k0 + 1;
-                        const double b = (ITD_RES_ABL & 32) ? xr[j] * 0.75 + k : (i == n - 1) ? 0.0 : Bk[sl] + Sk[sl] * (xr[j] - Xk[sl]);
+                        const double b = (ITD_RES_ABL & 32) ? xr[j] * 0.75 + k : (i >= n - 1) ? 0.0 : Bk[sl] + Sk[sl] * (xr[j] - Xk[sl]);
                         xs[i] = b;
                         if (c <= M && !(ITD_RES_ABL & 8)) {
-                            row[i] = xr[j] - b;
-                            if (bases_s) bases_s[(int64_t)c * n + i] = b;
+                            res_store(r_row, i, xr[j] - b);
+                            if (bases_s) res_store(r_base, i, b);
                         }
                     }
                 }
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave + W * j, i = q * 64 + lane;
-                if (q < Q && i < n) row[i] = c == 0 ? 0.0 : xr[j];
+                if (q < Q) res_store(r_row, i, c == 0 ? 0.0 : xr[j]);
             }
             if (tid == 0) {
                 st->stop_level = c + 1;
@@ -289,10 +307,10 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave + W * j, i = q * 64 + lane;
-                if (q < Q && i < n) {
+                if (q < Q) {
                     const double b = xs[i];
                     const double r = xr[j] - b;
-                    row[i] = r + b;
+                    res_store(r_row, i, r + b);
                 }
             }
             return;             // fin_stopped stays 0
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {   // the baseline is the next extraction's input (ITD.py:428-432)
             const int q = wave + W * j, i = q * 64 + lane;
-            if (q < Q && i < n) xr[j] = xs[i];
+            if (q < Q) xr[j] = xs[i];
         }
     }
 }

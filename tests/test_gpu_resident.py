@@ -202,3 +202,31 @@ def test_resident_fuzz_slice(P, torch, oracle):
             x = np.nan_to_num(x, nan=0.0, posinf=3e38, neginf=-3e38).astype(dtype)
         rows, bases, s, _ = _run(P, torch, x, m, RESIDENT_AUTO)
         _check_against_oracle(oracle, x, m, rows, bases, s, "fuzz case %d (n=%d m=%d B=%d)" % (case, n, m, B))
+
+
+def test_resident_call_is_graph_capturable(P, torch, oracle):
+    """The resident launch is complete in itself (the kernel initialises the states it works on): captured into a hipGraph — also
+    as the engine's very first call — and replayed on new data it gives the reference's rows."""
+    from pyitd_amd.engine import RESIDENT_ONLY
+    B, n, m = 4, 3000, 6
+    x_np = np.stack([sines_noise(n, seed=b, fscale=15.0 + b) for b in range(B)])
+    x = torch.from_numpy(x_np).cuda()
+    rows = torch.zeros((B, m + 2, n), dtype=torch.float64, device="cuda")
+    eng = P.Engine(n, B, 0)
+    eng.set_resident_mode(RESIDENT_ONLY)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for seed in (11, 12):
+        y_np = np.stack([sines_noise(n, seed=seed + b, fscale=9.0 + b) for b in range(B)])
+        x.copy_(torch.from_numpy(y_np))
+        rows.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        s = eng.summary(B)
+        _check_against_oracle(oracle, y_np, m, rows.cpu().numpy(), None, s, "graph replay seed %d" % seed)
+    eng.close()
