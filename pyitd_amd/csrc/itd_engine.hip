@@ -501,6 +501,7 @@ int enqueue_chain(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t
 // in LDS (itd_resident.hpp).  Optimistic like the chain: the kernel handles finite data only and raises SigState::res_fail
 // otherwise; itd_get_summary then repeats the call level by level.  The kernel initialises the states it works on itself
 // and leaves the other set's states as k_finalize would (the group sums are not touched).
+bool want_fused(itd_engine *e);
 bool want_resident(itd_engine *e, int64_t n)
 {
     if (n > kResidentMax || e->resident_mode == ITD_RESIDENT_OFF) return false;
@@ -541,7 +542,13 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
                    : cls == 4 ? reinterpret_cast<const void *>(&k_resident<Tin, 1024, 4>)
                               : reinterpret_cast<const void *>(&k_resident<Tin, 1024, 8>);
     if (!e->resident_attr[inst]) {   // more than 64 KB of dynamic LDS has to be asked for
-        HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResidentLdsMax));
+        const hipError_t arc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResidentLdsMax);
+        if (arc != hipSuccess) {     // a device / runtime that does not grant it: this engine runs level by level from now on
+            (void)hipGetLastError();
+            if (e->resident_mode == ITD_RESIDENT_ONLY) return fail_hip(e, arc, "hipFuncSetAttribute(k_resident, MaxDynamicSharedMemorySize)");
+            e->resident_mode = ITD_RESIDENT_OFF;
+            return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, want_fused(e));
+        }
         e->resident_attr[inst] = true;
     }
     const Tin *a_x = x; int64_t a_xs = x_stride, a_rs = rows_stride, a_bs = rows_stride;

@@ -59,7 +59,7 @@ __host__ __device__ constexpr int resident_auto_window(int n)
 __host__ __device__ constexpr int resident_cap(int cw) { return (cw + 4 + 3) & ~3; }   // by-rank slots of a window of cw segments
 __host__ __device__ constexpr size_t resident_lds_bytes(int n, int cw)
 {
-    return (size_t)resident_pad(n) * 8 + (size_t)resident_cap(cw) * (3 * 8 + 2) + (size_t)(resident_pad(n) / 64) * 12 + 4 * 8 + 16 + 8;
+    return (size_t)resident_pad(n) * 8 + (size_t)resident_cap(cw) * (3 * 8 + 2) + (size_t)(resident_pad(n) / 64) * 12 + 4 * 8 + 32 + 8;
 }
 constexpr size_t kResidentLdsMax = 160 * 1024;
 
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
     double *ends = Sk + cap;                                     // x[0], x[1], x[n-2], x[n-1] of the level's input (ITD.py:101-102)
     unsigned long long *bal = reinterpret_cast<unsigned long long *>(ends + 4);   // knot flags, one word per 64 samples
     int *pre = reinterpret_cast<int *>(bal + Q);                 // knots in front of word q (written and read by the word's wavefront)
-    int *ctl = pre + Q;                                          // [0]: a non-finite sample was seen
-    unsigned short *ek = reinterpret_cast<unsigned short *>(ctl + 4);   // by slot: the knots' sample indices
+    int *ctl = pre + Q;                                          // two sets (by scan parity) of: -, a NaN was seen, the NaN branch's two counts
+    unsigned short *ek = reinterpret_cast<unsigned short *>(ctl + 8);   // by slot: the knots' sample indices
 
     SigState *st = state + sig;
     const Tin *x = xin + (int64_t)sig * x_stride;
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
             sig_state_reset(st);
             if (other_state) sig_state_reset(other_state + sig);   // the engine's other set, as k_finalize leaves it
         }
-        ctl[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ctl[k] = 0;
     }
 
     // the thread's samples: word q = wave + W j, sample 64 q + lane — consecutive lanes, consecutive samples (coalesced
@@ -140,34 +141,95 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
     __syncthreads();
 
     // Knot flags of the signal in xs (interior samples 1 .. n-2, ITD.py:70-73) into bal[], the exclusive prefix of the
-    // wavefront's own words into pre[]; returns the knot total.  One barrier: every wavefront totals the words itself.
-    // ctl[0] is raised if a sample is not finite; thread 0 leaves the level's four end samples in ends[].
-    auto scan = [&]() -> int {
+    // wavefront's own words into pre[]; returns the number of flags (the knots of the next extraction) and leaves in m_stop
+    // what the reference's stop test counts (ITD.py:400-402).  The two differ only if the array holds a NaN — a baseline does
+    // after a leading / trailing plateau (0/0 at ITD.py:115-116): detect_peaks(b) then takes its NaN branch (NaN differences
+    // count as +inf, NaN samples and their neighbours are no peaks, ITD.py:46-51, 64-68) and OVERWRITES the NaNs with +inf in
+    // place (:50; no copy at :41), detect_peaks(-b) and the next extraction see the mutated array (plain rules: no NaN left;
+    // infinities just flow through the IEEE arithmetic).  `input`: the caller's signal — a NaN there follows other rules
+    // (the knots themselves come from the NaN branch): returns -1 and the caller leaves with res_fail.
+    // One barrier (four if a NaN was seen); every wavefront totals the words itself.
+    int m_stop = 0, n_scans = 0;
+    auto scan = [&](bool input, __amdgpu_buffer_rsrc_t r_mut, bool store_mut) -> int {
+        int *cs = ctl + 4 * (n_scans & 1), *co = ctl + 4 * ((n_scans & 1) ^ 1);   // this scan's counters, the previous scan's
+        ++n_scans;
+        if (tid == 0) co[1] = co[2] = co[3] = 0;   // last read before the barriers of the phases in between
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int q = wave + W * j, i = q * 64 + lane;
             if (q < Q) {
                 const double c = xs[i];
-                const bool bad = !(__builtin_fabs(c) < inf);
                 // dx[i-1], dx[i] (ITD.py:44); the reads next to the signal's ends stay inside xs (word 0 starts at sample 0, the
                 // padding ends the last word) and only interior samples can flag
                 const double d0 = c - ((ITD_RES_ABL & 128) ? 0.5 : xs[i > 0 ? i - 1 : 0]), d1 = ((ITD_RES_ABL & 128) ? 0.25 : xs[i < np2 - 1 ? i + 1 : i]) - c;
                 const bool f = ((d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0)) && i >= 1 && i <= n - 2;   // valley of x or of -x (ITD.py:59, 87-88)
                 const unsigned long long bw = __ballot(f);
-                const unsigned long long bb = __ballot(bad);
+                const unsigned long long bb = __ballot(c != c);
                 if (lane == 0) {
                     bal[q] = bw;
-                    if (bb) ctl[0] = 1;
+                    if (bb) cs[1] = 1;
                 }
             }
         }
-        if (tid == 0) {
+        __syncthreads();
+        const bool has_nan = cs[1] != 0;
+        if (has_nan) {
+            if (input) return -1;
+            // detect_peaks(b), NaN branch, on the array as it is (ITD.py:44-68): valleys among the samples whose three values are
+            // no NaN; a difference that is NaN all the same (inf - inf) counts as +inf
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int q = wave + W * j, i = q * 64 + lane;
+                if (q < Q) {
+                    const double a = xs[i > 0 ? i - 1 : 0], c = xs[i], b = xs[i < np2 - 1 ? i + 1 : i];
+                    double vil = b - c, vix = c - a;
+                    if (vil != vil) vil = inf;
+                    if (vix != vix) vix = inf;
+                    const bool ok = vil > 0.0 && vix <= 0.0 && a == a && c == c && b == b && i >= 1 && i <= n - 2;
+                    acc += __popcll(__ballot(ok));
+                }
+            }
+            if (lane == 0 && acc) atomicAdd(&cs[2], acc);
+            __syncthreads();
+            // the mutation (ITD.py:50), also in the stored baseline row: baselines[counter] is copied after it (ITD.py:429)
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int q = wave + W * j, i = q * 64 + lane;
+                if (q < Q) {
+                    const double c = xs[i];
+                    if (c != c) {
+                        xs[i] = inf;
+                        if (store_mut) res_store(r_mut, i, inf);
+                    }
+                }
+            }
+            __syncthreads();
+            // detect_peaks(-b) on the mutated array, plain rules (ITD.py:401) — and the flags of the next extraction
+            acc = 0;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int q = wave + W * j, i = q * 64 + lane;
+                if (q < Q) {
+                    const double c = xs[i];
+                    const double d0 = c - xs[i > 0 ? i - 1 : 0], d1 = xs[i < np2 - 1 ? i + 1 : i] - c;
+                    const bool inner = i >= 1 && i <= n - 2;
+                    const bool pk = d1 < 0.0 && d0 >= 0.0 && inner;
+                    const bool f = ((d1 > 0.0 && d0 <= 0.0) || pk) && inner;
+                    const unsigned long long bw = __ballot(f);
+                    acc += __popcll(__ballot(pk));
+                    if (lane == 0) bal[q] = bw;
+                }
+            }
+            if (lane == 0 && acc) atomicAdd(&cs[3], acc);
+            __syncthreads();
+        }
+        if (tid == 0) {   // read by this thread (knot list) and, behind the knot list's barrier, by everybody (knot values)
             ends[0] = xs[0];
             ends[1] = xs[1];
             ends[2] = xs[n - 2];
             ends[3] = xs[n - 1];
         }
-        __syncthreads();
         // inclusive prefix over the 64 lanes on the DPP path (no LDS round trips): Hillis-Steele inside the rows of 16 lanes
         // (row_shr 1, 2, 4, 8: a lane without a source inside its row keeps the 0 it is given), then row 0's / rows 0-1's
         // totals into the rows behind them (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3).  A lane totals WPL words.
@@ -188,15 +250,18 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
         const int w0 = WPL * lane;
         if (w0 < Q && (w0 % W) == wave) pre[w0] = excl;
         if (WPL == 2 && w0 + 1 < Q && ((w0 + 1) % W) == wave) pre[w0 + 1] = excl + c0;
-        return __builtin_amdgcn_readlane(inc, 63);
+        const int total = __builtin_amdgcn_readlane(inc, 63);
+        m_stop = has_nan ? cs[2] + cs[3] : total;
+        return total;
     };
 
-    int m = scan();
-    if (tid == 0) st->m[0] = m;
-    if (ctl[0]) {
+    const __amdgpu_buffer_rsrc_t r_none = tile_rsrc(nullptr, 0);
+    int m = scan(true, r_none, false);
+    if (m < 0) {   // a NaN in the caller's signal
         if (tid == 0) st->res_fail = 1;
         return;
     }
+    if (tid == 0) st->m[0] = m;
 
     for (int c = 0;; ++c) {
         const __amdgpu_buffer_rsrc_t r_row = tile_rsrc(rows_s + (int64_t)c * n, (int64_t)n * 8);
@@ -284,13 +349,9 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
             __syncthreads();
         }
         // ---- the pending baseline's stop test = the next level's scan (ITD.py:400-404) -------------------------------
-        m = scan();
-        if (tid == 0) st->m[c + 1] = m;
-        if (ctl[0] && !(ITD_RES_ABL & 64)) {
-            if (tid == 0) st->res_fail = 1;
-            return;
-        }
-        if (m < 2 && !(ITD_RES_ABL & 64)) {            // "No more decompositions possible": row c = baselines[c-1], the zero row at c = 0
+        m = scan(false, r_base, bases_s && c <= M);
+        if (tid == 0) st->m[c + 1] = m_stop;
+        if (m_stop < 2 && !(ITD_RES_ABL & 64)) {            // "No more decompositions possible": row c = baselines[c-1], the zero row at c = 0
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
                 const int q = wave + W * j, i = q * 64 + lane;

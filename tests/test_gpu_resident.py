@@ -128,9 +128,9 @@ def test_resident_goldens(P, torch, oracle):
 
 
 def test_non_finite_values_repeat_level_by_level(P, torch, oracle):
-    """A leading plateau makes the first baseline NaN (0/0, ITD.py:115-116) and the reference continues under detect_peaks' NaN
-    rules; NaN / infinity in the input likewise.  The resident kernel raises res_fail, itd_get_summary repeats the call level by
-    level; results follow the reference, and the engine's next decompositions start level by level."""
+    """A NaN in the caller's signal follows rules of its own (the knots themselves come from detect_peaks' NaN branch,
+    ITD.py:46-51, 87-88): the resident kernel raises res_fail, itd_get_summary repeats the call level by level; results follow the
+    reference, and the engine's next decompositions start level by level.  (Plateaus and infinities are handled in the kernel.)"""
     from pyitd_amd.engine import RESIDENT_AUTO, RESIDENT_ONLY
     n, m = 3000, 9
     rng = np.random.default_rng(77)
@@ -158,6 +158,33 @@ def test_non_finite_values_repeat_level_by_level(P, torch, oracle):
         _check_against_oracle(oracle, sig, m, r.cpu().numpy(), None, sm, "sequence step %d" % k)
     assert eng.resident_repeats == 1
     eng.close()
+
+
+@pytest.mark.parametrize("n", [200, 1500, 4096, 8000])
+def test_plateaus_follow_the_nan_rules_inside_the_resident_kernel(P, torch, oracle, n):
+    """A leading / trailing plateau makes a baseline NaN (0/0, ITD.py:115-116); the reference's stop test then runs detect_peaks
+    through its NaN branch, overwrites the NaNs with +inf in place (ITD.py:46-51, 64-68, 400-404) and decomposes the mutated
+    baseline on.  The resident kernel does the same in LDS — no repeat (RESIDENT_ONLY), bit-exact rows, baselines, knot counts.
+    Infinite samples in the input are plain data (no NaN branch)."""
+    from pyitd_amd.engine import RESIDENT_ONLY
+    rng = np.random.default_rng(500 + n)
+    x = np.stack([sines_noise(n, seed=b, fscale=25.0 + 3 * b, dtype=np.float64) for b in range(10)])
+    x[0, : max(2, n // 50)] = 0.0                     # digital silence at the head
+    x[1, -max(2, n // 40):] = 0.25                    # trailing plateau
+    x[2, :3] = x[2, 3]                                # the shortest leading plateau that matters
+    x[3, : n // 3] = 0.0
+    x[3, -n // 5:] = 0.0                              # both ends
+    x[4] = np.round(x[4] * 4) / 4                     # quantised: plateaus everywhere, usually at the ends too
+    x[5, n // 2] = np.inf
+    x[6, 1] = -np.inf
+    x[7] = fuzz_signal(rng, 5, n)                     # bursts between long constant stretches
+    x[8] = fuzz_signal(rng, 2, n)
+    for dtype, m in ((np.float64, 9), (np.float32, 4)):
+        xd = x.astype(dtype)
+        for window in (0, 8):
+            rows, bases, s, rep = _run(P, torch, xd, m, RESIDENT_ONLY, window=window)
+            assert rep == 0
+            _check_against_oracle(oracle, xd, m, rows, bases, s, "plateaus n=%d %s window=%d" % (n, np.dtype(dtype).name, window))
 
 
 def test_resident_large_batches_and_mixed_stops(P, torch, oracle):
