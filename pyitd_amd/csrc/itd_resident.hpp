@@ -20,9 +20,10 @@
 //           rewritten with baselines[c-1] (zeros at c = 0, ITD.py:404-416); c > max_iteration -> row c = rotation +
 //           baseline (ITD.py:418-426); otherwise the baseline becomes the next extraction's input (ITD.py:428-432)
 //
-// The kernel handles FINITE data only.  A NaN or infinity in the input or in any baseline (0/0 on a leading or trailing
-// plateau, ITD.py:115-116) raises SigState::res_fail and the workgroup leaves; itd_get_summary then repeats the call
-// through the level-by-level engine, whose kernels carry the reference's NaN rules (nan_rules, k_nan_level0).
+// Baselines that go NaN (0/0 on a leading or trailing plateau, ITD.py:115-116) follow the reference's NaN rules right here
+// (scan: the NaN branch of detect_peaks, the in-place NaN -> +inf write, ITD.py:46-51, 64-68); infinities are plain data.
+// Only a NaN in the CALLER'S signal raises SigState::res_fail and makes the workgroup leave; itd_get_summary then repeats
+// the call through the level-by-level engine (k_nan_level0).
 //
 // Arithmetic: binary64, the reference's association, no contraction, IEEE division — bit-identical to k_extract.
 #pragma once

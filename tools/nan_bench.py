@@ -2,7 +2,8 @@
 the first baseline goes NaN, ITD.py:115-116, and the stop test counts under detect_peaks' NaN rules, ITD.py:46-51,64-68).
   (1) one 2^22-sample signal with 0.5 s (at 48 kHz) of leading zeros vs the same signal without them;
   (2) a 64-signal batch of 2^20 samples where half of the signals start with silence vs a batch where none does.
-Both are checked bit-exactly against the CPU oracle on a sample, then timed."""
+  (3) a batch of 4096 x 4096-sample signals (the resident form) where every other signal starts with silence.
+All are checked bit-exactly against the CPU oracle on a sample, then timed."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,4 +58,12 @@ rng = np.random.default_rng(0)
 for b in range(0, B, 2):
     xs[b, : int(rng.integers(100, 48000))] = 0.0
 t_sil = run("batch 64 x 2^20, every other signal starts with silence", xs, [0, 1, 2])
+print("  ratio %.3f" % (t_sil / t_plain))
+B, n = 4096, 4096
+xb = np.stack([sines_noise(n, seed=b % 64, fscale=1.0 + b / 4096.0) for b in range(B)])
+t_plain = run("batch 4096 x 4096 (resident), no silence", xb, [0, 1, 4095])
+xs = xb.copy()
+for b in range(0, B, 2):
+    xs[b, : int(rng.integers(2, 1500))] = 0.0
+t_sil = run("batch 4096 x 4096 (resident), every other signal starts with silence", xs, [0, 1, 2, 4094])
 print("  ratio %.3f" % (t_sil / t_plain))
