@@ -552,10 +552,10 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
         e->resident_attr[inst] = true;
     }
     const Tin *a_x = x; int64_t a_xs = x_stride, a_rs = rows_stride, a_bs = rows_stride;
-    int a_n = (int)n, a_m = M, a_cw = cw;
+    int a_n = (int)n, a_m = M, a_cw = cw, a_nf = e->nan_input_mode == ITD_NAN_INPUT_FOLLOW ? 1 : 0;
     double *a_rows = rows, *a_bases = bases_user;
     SigState *a_st = set_state, *a_ot = other_state;
-    void *args[] = {&a_x, &a_xs, &a_n, &a_m, &a_cw, &a_rows, &a_rs, &a_bases, &a_bs, &a_st, &a_ot};
+    void *args[] = {&a_x, &a_xs, &a_n, &a_m, &a_cw, &a_nf, &a_rows, &a_rs, &a_bases, &a_bs, &a_st, &a_ot};
     HIP_TRY(e, hipLaunchKernel(fn, dim3((unsigned)batch), dim3((unsigned)threads), args, lds, st));
     HIP_TRY(e, hipGetLastError());
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

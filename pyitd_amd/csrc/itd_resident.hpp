@@ -82,6 +82,7 @@ __device__ __forceinline__ double res_load(__amdgpu_buffer_rsrc_t r, int i, cons
 
 template <typename Tin, int TH, int SPT>
 __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(const Tin *__restrict__ xin, int64_t x_stride, int n, int M, int cw,
+                                                   int nan_follow /* a NaN in the caller's signal: 1 = the reference's rules (below), 0 = leave (res_fail) */,
                                                    double *__restrict__ rows, int64_t rows_stride,
                                                    double *__restrict__ bases, int64_t bases_stride,
                                                    SigState *__restrict__ state, SigState *__restrict__ other_state)
@@ -147,8 +148,9 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
     // after a leading / trailing plateau (0/0 at ITD.py:115-116): detect_peaks(b) then takes its NaN branch (NaN differences
     // count as +inf, NaN samples and their neighbours are no peaks, ITD.py:46-51, 64-68) and OVERWRITES the NaNs with +inf in
     // place (:50; no copy at :41), detect_peaks(-b) and the next extraction see the mutated array (plain rules: no NaN left;
-    // infinities just flow through the IEEE arithmetic).  `input`: the caller's signal — a NaN there follows other rules
-    // (the knots themselves come from the NaN branch): returns -1 and the caller leaves with res_fail.
+    // infinities just flow through the IEEE arithmetic).  `input`: the caller's signal — there the first extraction's knots
+    // themselves are detect_peaks(x) under the NaN branch + detect_peaks(-x) of the mutated array (ITD.py:87-95), and the
+    // extraction works on the mutated values (the caller's array is not written); without nan_follow: returns -1.
     // One barrier (four if a NaN was seen); every wavefront totals the words itself.
     int m_stop = 0, n_scans = 0;
     auto scan = [&](bool input, __amdgpu_buffer_rsrc_t r_mut, bool store_mut) -> int {
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
         __syncthreads();
         const bool has_nan = cs[1] != 0;
         if (has_nan) {
-            if (input) return -1;
+            if (input && !nan_follow) return -1;
             // detect_peaks(b), NaN branch, on the array as it is (ITD.py:44-68): valleys among the samples whose three values are
             // no NaN; a difference that is NaN all the same (inf - inf) counts as +inf
             int acc = 0;
@@ -188,7 +190,9 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
                     if (vil != vil) vil = inf;
                     if (vix != vix) vix = inf;
                     const bool ok = vil > 0.0 && vix <= 0.0 && a == a && c == c && b == b && i >= 1 && i <= n - 2;
-                    acc += __popcll(__ballot(ok));
+                    const unsigned long long okw = __ballot(ok);
+                    acc += __popcll(okw);
+                    if (input && lane == 0) bal[q] = okw;   // the caller's signal: these ARE the valleys of its knot list (ITD.py:87)
                 }
             }
             if (lane == 0 && acc) atomicAdd(&cs[2], acc);
@@ -217,9 +221,11 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
                     const bool inner = i >= 1 && i <= n - 2;
                     const bool pk = d1 < 0.0 && d0 >= 0.0 && inner;
                     const bool f = ((d1 > 0.0 && d0 <= 0.0) || pk) && inner;
-                    const unsigned long long bw = __ballot(f);
-                    acc += __popcll(__ballot(pk));
-                    if (lane == 0) bal[q] = bw;
+                    const unsigned long long bw = __ballot(f), pw = __ballot(pk);
+                    acc += __popcll(pw);
+                    // a baseline: the next extraction finds its knots on the mutated array, plain rules; the caller's signal:
+                    // valleys from the NaN branch (above) + peaks of the mutated array (ITD.py:87-95)
+                    if (lane == 0) bal[q] = input ? (bal[q] | pw) : bw;
                 }
             }
             if (lane == 0 && acc) atomicAdd(&cs[3], acc);
@@ -258,11 +264,16 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
 
     const __amdgpu_buffer_rsrc_t r_none = tile_rsrc(nullptr, 0);
     int m = scan(true, r_none, false);
-    if (m < 0) {   // a NaN in the caller's signal
+    if (m < 0) {   // a NaN in the caller's signal and the engine was told to reject it: the level-by-level engine reports it
         if (tid == 0) st->res_fail = 1;
         return;
     }
     if (tid == 0) st->m[0] = m;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {   // the mutated values, if the scan met a NaN
+        const int q = wave + W * j, i = q * 64 + lane;
+        if (q < Q) xr[j] = xs[i];
+    }
 
     for (int c = 0;; ++c) {
         const __amdgpu_buffer_rsrc_t r_row = tile_rsrc(rows_s + (int64_t)c * n, (int64_t)n * 8);

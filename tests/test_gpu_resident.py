@@ -127,36 +127,52 @@ def test_resident_goldens(P, torch, oracle):
     assert seen >= 3 or os.environ.get("PYITD_RESIDENT_MODE") == "1"
 
 
-def test_non_finite_values_repeat_level_by_level(P, torch, oracle):
-    """A NaN in the caller's signal follows rules of its own (the knots themselves come from detect_peaks' NaN branch,
-    ITD.py:46-51, 87-88): the resident kernel raises res_fail, itd_get_summary repeats the call level by level; results follow the
-    reference, and the engine's next decompositions start level by level.  (Plateaus and infinities are handled in the kernel.)"""
-    from pyitd_amd.engine import RESIDENT_AUTO, RESIDENT_ONLY
+def test_nan_in_the_input_follows_the_reference_inside_the_resident_kernel(P, torch, oracle):
+    """A NaN in the caller's signal: the reference's first extraction takes its knots from detect_peaks' NaN branch on x (valleys
+    away from the NaNs; the NaNs become +inf in place) and detect_peaks(-x) of the mutated array (ITD.py:46-51, 87-95), and
+    decomposes the mutated values.  The resident kernel does that in LDS (RESIDENT_ONLY: no repeat); an engine told to reject NaN
+    input leaves the kernel instead and the level-by-level engine reports the signal (nan_levels = -2)."""
+    from pyitd_amd.engine import NAN_INPUT_REJECT, RESIDENT_AUTO, RESIDENT_ONLY
     n, m = 3000, 9
-    rng = np.random.default_rng(77)
-    x = np.stack([sines_noise(n, seed=b, fscale=20.0 + b, dtype=np.float64) for b in range(8)])
-    x[1, :40] = 0.0                 # silence at the head
-    x[3, -25:] = 0.5                # trailing plateau
-    x[5, 1500] = np.nan             # NaN in the input
-    x[6, 100] = np.inf
-    rows, bases, s, rep = _run(P, torch, x, m, RESIDENT_AUTO)
-    assert rep == 1
-    _check_against_oracle(oracle, x, m, rows, bases, s, "repeat")
-    # RESIDENT_ONLY refuses instead
-    with pytest.raises(P.ITDError):
-        _run(P, torch, x, m, RESIDENT_ONLY)
-    # one engine: resident call, failing call (repeat), then level by level for a while — results stay exact throughout
-    eng = P.Engine(n, 8, 0)
+    x = np.stack([sines_noise(n, seed=b, fscale=20.0 + b, dtype=np.float64) for b in range(10)])
+    x[1, 1500] = np.nan
+    x[2, [0, n - 1]] = np.nan                 # at the ends
+    x[3, 63:66] = np.nan                      # a run across a word boundary
+    x[4, [511, 512, 1023, 1024, 2047]] = np.nan
+    x[5, 700] = np.nan
+    x[5, 701] = np.inf                        # next to an infinity
+    x[6, 100] = np.inf                        # infinity alone: plain data
+    x[7, :40] = 0.0
+    x[7, 900] = np.nan                        # NaN input and a leading plateau
+    x[8, 1::2] = np.nan                       # every other sample
+    for dtype in (np.float64, np.float32):
+        xd = x.astype(dtype)
+        keep = xd.copy()
+        for window in (0, 16):
+            rows, bases, s, rep = _run(P, torch, xd, m, RESIDENT_ONLY, window=window)
+            assert rep == 0 and (s["nan_levels"] == -1).all()
+            _check_against_oracle(oracle, xd, m, rows, bases, s, "NaN input %s window=%d" % (np.dtype(dtype).name, window))
+        assert np.array_equal(np.isnan(xd), np.isnan(keep))
+    # rejected instead when the engine says so: the kernel leaves, the level-by-level engine flags the signals
+    B = x.shape[0]
+    xd = torch.from_numpy(x).cuda()
+    r = torch.zeros((B, m + 2, n), dtype=torch.float64, device="cuda")
+    eng = P.Engine(n, B, 0)
     eng.set_resident_mode(RESIDENT_AUTO)
-    clean = np.stack([sines_noise(n, seed=40 + b, fscale=30.0, dtype=np.float64) for b in range(8)])
-    for k, sig in enumerate((clean, x, clean, clean)):
-        xd = torch.from_numpy(sig).cuda()
-        r = torch.full((8, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()
-        eng.decompose_dev(xd.data_ptr(), np.float64, n, 8, n, m, r.data_ptr(), None, None)
-        sm = eng.summary(8)
-        _check_against_oracle(oracle, sig, m, r.cpu().numpy(), None, sm, "sequence step %d" % k)
+    eng.set_nan_input_mode(NAN_INPUT_REJECT)
+    torch.cuda.synchronize()
+    eng.decompose_dev(xd.data_ptr(), np.float64, n, B, n, m, r.data_ptr(), None, None)
+    sm = eng.summary(B)
     assert eng.resident_repeats == 1
+    assert sm["nan_levels"].tolist() == [-1, -2, -2, -2, -2, -2, -1, -2, -2, -1]
+    eng.close()
+    eng = P.Engine(n, B, 0)
+    eng.set_resident_mode(RESIDENT_ONLY)
+    eng.set_nan_input_mode(NAN_INPUT_REJECT)
+    torch.cuda.synchronize()
+    eng.decompose_dev(xd.data_ptr(), np.float64, n, B, n, m, r.data_ptr(), None, None)
+    with pytest.raises(P.ITDError):
+        eng.summary(B)
     eng.close()
 
 
