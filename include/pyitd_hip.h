@@ -165,9 +165,10 @@ int itd_get_chain_repeats(const itd_engine *e);
 /* Short signals (n <= 8192 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays
  * in LDS through all levels of the driver loop (ITD.py:384-432): the signal is read once and every result row written once
  * (4 + 8 rows bytes per sample; the level-by-level form is launch bound there: 10 dependent launches).  Baselines that go NaN
- * (a leading or trailing plateau, ITD.py:115-116) follow the reference's NaN rules inside the kernel; only a NaN in the caller's
- * signal makes itd_get_summary repeat the call level by level before it returns (x_dev / rows_dev / baselines_dev must stay valid
- * until then, as before), and the engine's next 16 decompositions start level by level.  Rows past n_rows are not written in this form.
+ * (a leading or trailing plateau, ITD.py:115-116) and NaNs in the caller's signal follow the reference's NaN rules inside the kernel;
+ * only under ITD_NAN_INPUT_REJECT does a NaN input make itd_get_summary repeat the call level by level before it returns (x_dev /
+ * rows_dev / baselines_dev must stay valid until then, as before; the engine's next 16 decompositions then start level by level).
+ * Rows past n_rows are not written in this form.
  * ITD_RESIDENT_AUTO (default): resident for n <= 8192 unless the engine was given a level-0 mode, a chain mode or kernel timing;
  * ITD_RESIDENT_OFF: never; ITD_RESIDENT_ONLY: always for n <= 8192, never repeat (itd_get_summary fails with ITD_ERR_HIP
  * instead; tests, benchmarks).  Results are identical in every mode. */

@@ -22,8 +22,8 @@
 //
 // Baselines that go NaN (0/0 on a leading or trailing plateau, ITD.py:115-116) follow the reference's NaN rules right here
 // (scan: the NaN branch of detect_peaks, the in-place NaN -> +inf write, ITD.py:46-51, 64-68); infinities are plain data.
-// Only a NaN in the CALLER'S signal raises SigState::res_fail and makes the workgroup leave; itd_get_summary then repeats
-// the call through the level-by-level engine (k_nan_level0).
+// A NaN in the CALLER'S signal follows them as well (its knots: NaN-branch valleys + peaks of the mutated array, ITD.py:87-95);
+// only an engine told to reject NaN input gets SigState::res_fail: itd_get_summary then repeats the call level by level.
 //
 // Arithmetic: binary64, the reference's association, no contraction, IEEE division — bit-identical to k_extract.
 #pragma once
