@@ -134,7 +134,7 @@ def test_nan_in_the_input_follows_the_reference_inside_the_resident_kernel(P, to
     away from the NaNs; the NaNs become +inf in place) and detect_peaks(-x) of the mutated array (ITD.py:46-51, 87-95), and
     decomposes the mutated values.  The resident kernel does that in LDS (RESIDENT_ONLY: no repeat); an engine told to reject NaN
     input leaves the kernel instead and the level-by-level engine reports the signal (nan_levels = -2)."""
-    from pyitd_amd.engine import CHAIN_OFF, LEVEL0_AUTO, NAN_INPUT_REJECT, RESIDENT_AUTO, RESIDENT_ONLY
+    from pyitd_amd.engine import CHAIN_OFF, LEVEL0_AUTO, NAN_INPUT_REJECT, RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY
     n, m = 3000, 9
     x = np.stack([sines_noise(n, seed=b, fscale=20.0 + b, dtype=np.float64) for b in range(10)])
     x[1, 1500] = np.nan
@@ -155,6 +155,12 @@ def test_nan_in_the_input_follows_the_reference_inside_the_resident_kernel(P, to
             assert rep == 0 and (s["nan_levels"] == -1).all()
             _check_against_oracle(oracle, xd, m, rows, bases, s, "NaN input %s window=%d" % (np.dtype(dtype).name, window))
         assert np.array_equal(np.isnan(xd), np.isnan(keep))
+        # the level-by-level engine (k_nan_level0 in front of a record-driven level 0) reports the same summary, entry for entry
+        _, _, s2, _ = _run(P, torch, xd, m, RESIDENT_OFF)
+        for key in ("n_rows", "n_baselines", "stop", "nan_levels", "knot_counts"):
+            assert np.array_equal(s[key], s2[key]), key
+        for b in range(xd.shape[0]):
+            assert int(s["knot_counts"][b, 0]) == len(oracle.knots(xd[b].astype(np.float64)))
     # rejected instead when the engine says so: the kernel leaves, the level-by-level engine flags the signals
     B = x.shape[0]
     xd = torch.from_numpy(x).cuda()
