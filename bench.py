@@ -479,6 +479,10 @@ def short_signal_leg(torch, dev, steps=10):
                 s = eng.summary(batch)
                 item["rows_per_signal"] = sorted(set(int(v) for v in s["n_rows"]))
                 item["resident_repeats"] = eng.resident_repeats
+                # the resident launch reads the signal once and writes every row once (PMC: profiles/r02/session6_resident_rocprof.txt)
+                alg = (4.0 * batch * n + 8.0 * n * float(s["n_rows"].sum())) / (item[key] * 1e-3) / 1e9
+                item["resident_hbm_algorithmic_GBps"] = round(alg, 1)
+                item["resident_frac_of_peak"] = round(alg / HBM_PEAK_GBPS, 4)
         item["resident_Msamples_per_s"] = round(batch * n / item["resident_ms"] / 1e3, 1)
         out.append(item)
         eng.close()
