@@ -113,11 +113,23 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
     double *bases_s = bases ? bases + (int64_t)sig * bases_stride : nullptr;
     const double inf = __builtin_huge_val();
 
-    if (tid == 0) {
-        if (!(ITD_RES_ABL & 4)) {
-            sig_state_reset(st);
-            if (other_state) sig_state_reset(other_state + sig);   // the engine's other set, as k_finalize leaves it
+    // the signal's state as a decomposition expects to find it (sig_state_reset, spread over the first wavefront's lanes) — and
+    // the engine's other set, as k_finalize leaves it for the call after this one
+    if (tid < kMaxLevels && !(ITD_RES_ABL & 4)) {
+        SigState *const os = other_state ? other_state + sig : nullptr;
+        st->m[tid] = -1;
+        st->c_delta[tid] = 0;
+        if (os) { os->m[tid] = -1; os->c_delta[tid] = 0; }
+        if (tid == 0) {
+            st->stop_level = -1; st->nan_mask = 0; st->in_nan = 0; st->l0_fail = 0;
+            st->fin_stopped = 0; st->fin_stop_level = -1; st->chain_stop = 0; st->res_fail = 0;
+            if (os) {
+                os->stop_level = -1; os->nan_mask = 0; os->in_nan = 0; os->l0_fail = 0;
+                os->fin_stopped = 0; os->fin_stop_level = -1; os->chain_stop = 0; os->res_fail = 0;
+            }
         }
+    }
+    if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) ctl[k] = 0;
     }
