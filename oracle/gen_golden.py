@@ -292,6 +292,52 @@ def make_spline_cases(ref_dir, out_dir, radio):
     print("spline image48x64: crossways + ensemble low-pass (numpy.random.seed(20240))")
 
 
+def make_stream_cases(cub, ns1, out_dir, radio):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import stream_oracle as so
+    os.makedirs(out_dir, exist_ok=True)
+
+    def ref_fast(W, sel, idx):
+        with np.errstate(all="ignore"):
+            return np.asarray(cub.itd_baseline_extract_fast(np.array(W, dtype=np.float64), np.array(sel, dtype=np.int64), int(idx)))
+
+    def ref_extract(W):
+        with np.errstate(all="ignore"):
+            r, b = ns1["itd_baseline_extract"](np.array(W, dtype=np.float64))
+        return np.asarray(r), np.asarray(b)
+
+    rng = np.random.default_rng(31044)
+    t = np.arange(8 * 1024)
+    chans = np.stack([np.cumsum(rng.standard_normal(t.size)) * 0.05 + np.sin(t / 40.0),
+                      np.sin(t / 17.0) + 0.3 * rng.standard_normal(t.size),
+                      np.round(3 * np.sin(t / 90.0) + rng.standard_normal(t.size)) / 2.0])
+    smooth = np.sin(2 * np.pi * t[:4096] / 1500.0) + 0.2 * np.sin(2 * np.pi * t[:4096] / 333.0)   # few extrema per block
+    cases = [("walk_L1024_m8", chans[0], 1024, 8, False), ("walk_L1024_m1", chans[0], 1024, 1, False),
+             ("radio_L2000_m8", radio, 2000, 8, False), ("radio_L500_m3", radio, 500, 3, False),
+             ("smooth_L512_m8", smooth, 512, 8, False), ("oneblock_L1024_m8", chans[1][:1024], 1024, 8, False),
+             ("twoblocks_L512_m2", chans[1][:1024], 512, 2, False),
+             ("chan3_shared_L1024_m8", chans, 1024, 8, True), ("chan3_own_L2048_m4", chans, 2048, 4, False)]
+    for name, x, L, margin, shared in cases:
+        base = so.blockwise_cubic(ref_fast, extrema_cpp, x, L, margin, shared)
+        np.savez_compressed(os.path.join(out_dir, "cubic_" + name + ".npz"), x=x, block=np.int64(L), margin=np.int64(margin),
+                            shared_knots=np.int64(shared), baseline=base)
+        print("stream cubic_%-24s shape %s L=%d margin=%d shared=%d finite=%s" % (name, np.shape(x), L, margin, shared,
+                                                                                  bool(np.isfinite(base).all())))
+    lead = np.concatenate([np.zeros(300), chans[1][:3796]])        # a leading plateau: 0/0 on the first window's end segment
+    for name, x, L in (("walk_L1024", chans[0], 1024), ("radio_L1000", radio, 1000), ("smooth_L512", smooth, 512),
+                       ("quant3_L512", chans, 512), ("oneblock_L2048", chans[1][:2048], 2048), ("leadzeros_L1024", lead, 1024)):
+        rot, base = so.blockwise_linear(ref_extract, x, L)
+        np.savez_compressed(os.path.join(out_dir, "linear_" + name + ".npz"), x=x, block=np.int64(L), rotation=rot, baseline=base)
+        print("stream linear_%-23s shape %s L=%d" % (name, np.shape(x), L))
+    # retained extrema along channels without blocks (itd.cpp:40-44): the knots of channel 0, every channel evaluated on them
+    for name, x in (("chan3_8192", chans), ("radio4", np.stack([radio, radio[::-1], np.roll(radio, 123) * 0.5, radio ** 3]))):
+        e, idx = extrema_cpp(np.asarray(x[0], dtype=np.float64))
+        bases = np.stack([ref_fast(x[c], e[: idx + 1], idx) for c in range(x.shape[0])])
+        np.savez_compressed(os.path.join(out_dir, "channels_" + name + ".npz"), x=x, extrema=e[: idx + 1].astype(np.int64),
+                            idx=np.int64(idx), baselines=bases)
+        print("stream channels_%-21s shape %s idx=%d" % (name, x.shape, idx))
+
+
 def chirp(n, dtype=np.float32):
     t = np.arange(n, dtype=np.float64) / n
     return np.sin(2 * np.pi * (50 * t + 0.5 * (8000 - 50) * t * t)).astype(dtype)
@@ -437,6 +483,11 @@ def main():
 
     # (8) the FITPACK flavour of the baseline and its 2-D consumers
     make_spline_cases(args.ref, os.path.join(args.out, "spline"), radio)
+
+    # (9) block-wise operation and retained extrema along several channels (itd.cpp:31-44).  The recipe has
+    #     no upstream code: oracle/stream_oracle.py states it once over operators that are passed in — here the REFERENCE's own
+    #     itd_baseline_extract_fast (itd_fourier_decomposition.py:49-122) and itd_baseline_extract (ITD.py:79-121).
+    make_stream_cases(cub, ns1, os.path.join(args.out, "stream"), radio)
 
 
 if __name__ == "__main__":
