@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 5
+#define ITD_ABI_VERSION 6
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -76,7 +76,8 @@ int64_t itd_engine_workspace_bytes(const itd_engine *e);
 int itd_engine_device(const itd_engine *e);
 
 /* Plain device-memory helpers for bindings that own no GPU allocator (the numpy path of pyitd_amd.itd_batch, the C
- * client of tests/c_client): hipMalloc / hipFree / synchronous hipMemcpy on `device_id`.  to_device: 1 = host -> device,
+ * client of tests/c_client): hipMalloc / hipFree / synchronous hipMemcpy on `device_id`, ordered against all work on the
+ * device (itd_dev_copy synchronises the device first: the engines' own streams are non-blocking).  to_device: 1 = host -> device,
  * 0 = device -> host.  Callers that already hold device buffers (torch tensors, their own hipMalloc) never need these. */
 int itd_dev_alloc(int device_id, int64_t bytes, void **out);
 int itd_dev_free(int device_id, void *p);
@@ -307,6 +308,75 @@ int itd_instantaneous_f64(itd_engine *e, const double *rot_dev, int64_t n, doubl
                           void *stream);
 int itd_instantaneous_host_f64(itd_engine *e, const double *rot_host, int64_t n, double *amp_host, double *phase_host,
                                double *freq_host);
+
+/* ---- batched single-level operators (ABI revision 6): asynchronous on `stream`, no host synchronisation, graph-capturable ---
+ * The reference applies its single-level functions row by row (siftED2D.ipynb cell 1: itd_baseline_extract over the rows of an
+ * image under numba.prange) and along channels (itd.cpp:40-44).  Signal b starts at x_dev + b * x_stride.  These calls work in
+ * workspaces of their own (grown on demand: the first call of a size allocates), apart from the decomposition's.
+ *
+ * itd_baseline_extract_batch_f64: itd_baseline_extract (ITD.py:79-121) of every signal: rot_dev / base_dev [batch] rows of n.
+ *   info_dev (optional) [batch]: the signal's interior knot count; -1 - count if the signal holds a NaN — its rows then follow
+ *   the plain rules, not detect_peaks' NaN branch (ITD.py:46-51): run that signal through itd_baseline_extract_* .
+ * itd_detect_batch_f64: the knots of every signal by predicate `mode` (ITD_DETECT_*): idx_dev (optional) [batch] lists at
+ *   idx_stride >= n - 2 (the knots alone, ascending); info_dev (optional) as above.  idx_dev == NULL: counts only (no list is
+ *   built).  batch <= 65535.
+ * itd_baseline_extract_cubic_batch_f64: itd_baseline_extract_fast (itd_fourier_decomposition.py:49-122) of every signal.
+ *   extrema_dev: idx + 1 knots as in itd_baseline_extract_cubic_f64 — ONE list for every signal (extrema_stride = 0: "retain the
+ *   extrema and reuse them ... along multiple channels", itd.cpp:40-44) or one per signal (extrema_stride >= idx + 1);
+ *   NULL = every signal's own knots by itd.cpp:159-169.  A signal with fewer than 2 knots or an invalid list keeps its
+ *   baseline row untouched.  info_dev (optional) [batch]: the idx used; -1 = invalid list, -2 = NaN in the signal.  batch <= 65535. */
+int itd_baseline_extract_batch_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride, double *rot_dev,
+                                   int64_t rot_stride, double *base_dev, int64_t base_stride, int32_t *info_dev, void *stream);
+int itd_detect_batch_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride, int32_t mode, int32_t *idx_dev,
+                         int64_t idx_stride, int32_t *info_dev, void *stream);
+int itd_baseline_extract_cubic_batch_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                                         const int32_t *extrema_dev, int64_t extrema_stride, int64_t idx, double *baseline_dev,
+                                         int64_t baseline_stride, int32_t *info_dev, void *stream);
+
+/* ---- block-wise (streaming) operation for unbounded signals (ABI revision 6) ------------------------------
+ * The recipe of the comment at itd.cpp:31-38 — "use a circular buffer with modulous tracking to rotate the samples / re-assess
+ * extrema in the entire buffer every iteration / use from the last extrema in the first buffer to the first extrema in the last
+ * buffer / set the first and last baseline knots manually to said values / update the j array / compute only the baseline[i]
+ * array for the inner third of the buffer overall / rotate buffers, rinse and repeat" — and itd.cpp:40-44's retained extrema
+ * along channels.  There is no reference code for it; oracle/stream_oracle.py states the recipe the tests hold this to.
+ *
+ * A stream keeps the last three blocks of `channels` channels in a device-resident ring.  A push stores one block of every
+ * channel and, from the second push on, emits the baseline (and rotation) of the PREVIOUS block — latency one block; flush
+ * emits the last block and empties the stream.  Window = the previous, the emitted and the next block (two blocks at either
+ * end of the stream, one if the stream holds a single block).
+ *   ITD_STREAM_CUBIC   itd_baseline_extract_fast (itd_fourier_decomposition.py:49-122) on the window's extrema (itd.cpp:161-168)
+ *                      from `margin` extrema in front of the emitted block to margin + 2 behind it (the recipe's literal
+ *                      choice is margin 1; the two extra keep the operator's uncomputed second-to-last knot value, K[idx-1]
+ *                      = 0, outside the block); the first and last knot value are the data there (itd.cpp:35).  Fewer than 4
+ *                      such extrema: the block is emitted unchanged (itd.cpp:170-172).  shared_knots: the extrema of channel
+ *                      0's window serve every channel (itd.cpp:40-44).
+ *   ITD_STREAM_LINEAR  itd_baseline_extract (ITD.py:79-121) on the window, every channel on its own knots.  The operator is
+ *                      local (two knots either side of a sample), so wherever the blocks hold a few knots the emitted stream is
+ *                      bit-identical to the whole-signal operator's rows.
+ * Ring, knot detection, knot selection and the operator all run on the device: a device-form push / flush enqueues its
+ * launches on `stream` and returns (no host synchronisation; `*emitted` is known from the block count alone); the host forms
+ * copy through pinned staging and synchronise once per call.  A NaN in a window makes the host forms return
+ * ITD_ERR_NONFINITE (the block is emitted under plain comparison rules); the device forms record it for itd_stream_status. */
+typedef struct itd_stream itd_stream;   /* opaque; not thread-safe */
+#define ITD_STREAM_CUBIC 0
+#define ITD_STREAM_LINEAR 1
+int itd_stream_create(itd_stream **out, int device_id, int64_t block /* samples, >= 8 */, int32_t channels, int32_t kind,
+                      int32_t margin /* cubic: >= 1 */, int32_t shared_knots);
+void itd_stream_destroy(itd_stream *s);
+int itd_stream_reset(itd_stream *s);            /* forget the blocks held and the recorded status */
+int64_t itd_stream_blocks(const itd_stream *s); /* blocks held since create / reset / flush */
+const char *itd_stream_last_error(const itd_stream *s);
+/* block_dev [channels] rows of `block` samples at in_stride; baseline_dev / rot_dev (optional) likewise, written when
+ * *emitted = 1 (every push but the first; every flush of a non-empty stream) */
+int itd_stream_push_f64(itd_stream *s, const double *block_dev, int64_t in_stride, double *baseline_dev, int64_t baseline_stride,
+                        double *rot_dev, int64_t rot_stride, int32_t *emitted, void *stream);
+int itd_stream_flush_f64(itd_stream *s, double *baseline_dev, int64_t baseline_stride, double *rot_dev, int64_t rot_stride,
+                         int32_t *emitted, void *stream);
+/* host forms: contiguous [channels][block] arrays; rot_host optional */
+int itd_stream_push_host_f64(itd_stream *s, const double *block_host, double *baseline_host, double *rot_host, int32_t *emitted);
+int itd_stream_flush_host_f64(itd_stream *s, double *baseline_host, double *rot_host, int32_t *emitted);
+/* synchronises the device; *status = 0, or 2 if some window since create / reset held a NaN */
+int itd_stream_status(itd_stream *s, int32_t *status);
 
 /* ---- introspection for benchmarks -------------------------------------------------------------
  * hipEvent pairs on the launch stream.  Extraction launches are dispatched with their own start/stop events

@@ -10,13 +10,13 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_chain.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"),
+HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_chain.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_stream.hpp"), os.path.join(_HERE, "csrc", "itd_engine_batch.inc"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"),
            os.path.join(_HERE, "csrc", "itd_fitpack.hpp"), os.path.join(_HERE, "csrc", "itd_resident.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -51,6 +51,19 @@ ABI = {
     "itd_crossways_host_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "itd_instantaneous_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P]),
     "itd_instantaneous_host_f64": (_INT, [_P, _P, _I64, _P, _P, _P]),
+    "itd_baseline_extract_batch_f64": (_INT, [_P, _P, _I64, _I32, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "itd_detect_batch_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _P]),
+    "itd_baseline_extract_cubic_batch_f64": (_INT, [_P, _P, _I64, _I32, _I64, _P, _I64, _I64, _P, _I64, _P, _P]),
+    "itd_stream_create": (_INT, [ctypes.POINTER(_P), _INT, _I64, _I32, _I32, _I32, _I32]),
+    "itd_stream_destroy": (None, [_P]),
+    "itd_stream_reset": (_INT, [_P]),
+    "itd_stream_blocks": (_I64, [_P]),
+    "itd_stream_last_error": (ctypes.c_char_p, [_P]),
+    "itd_stream_push_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "itd_stream_flush_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P]),
+    "itd_stream_push_host_f64": (_INT, [_P, _P, _P, _P, _P]),
+    "itd_stream_flush_host_f64": (_INT, [_P, _P, _P, _P]),
+    "itd_stream_status": (_INT, [_P, _P]),
     "itd_set_nan_fallback": (_INT, [_P, _INT]),
     "itd_set_nan_input_mode": (_INT, [_P, _I32]),
     "itd_set_batch_chunk": (_INT, [_P, _I32]),

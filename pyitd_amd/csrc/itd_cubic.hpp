@@ -6,19 +6,26 @@
 // itd_fourier_decomposition.py:17-31) and itd.cpp's own 3-point predicate (itd.cpp:161-168).
 //
 // The reference is three serial loops over the knots (knot values, the "Thomas" sweep as written, the back substitution)
-// and one over the samples.  Here:
-//   k_cubic_knots   knot values K[k] (:61-83) and spacings h[k] (:85-86), one thread per knot;
-//   k_cubic_rhs     u, the right-hand side b0 and the pivots d[i] = 2 - u[i] * v[i-1] (:88-96; d does not depend on the sweep);
-//   affine scans    the forward sweep  b[i] = (b0[i] - u[i] b[i-1]) / d[i]  (:93-98) and the back substitution
-//                   b[i] = b[i] - v[i] b[i+1]  (:100-101) are first-order linear recurrences y -> a_i + c_i y: the maps are
-//                   composed in order by wave scans inside a workgroup and across workgroups (three launches: reduce, scan of
-//                   the workgroup aggregates, apply); every element is its inclusive map applied to the carry-in, so the
-//                   association differs from the reference's serial loop (|c_i| < 1: the composed maps contract, rounding
-//                   differences do not grow);
+// and one over the samples.  Here everything is driven by a per-signal CubicJob in DEVICE memory (which knots, how many,
+// valid or not), so no knot count ever crosses to the host in the middle of a call, the launches are batched over signals /
+// channels (grid.y; one knot list for all of them or one each: itd.cpp:40-44 "retain the extrema ... along multiple channels")
+// and a call can be captured into a graph:
+//   k_cubic_sweep<true>   knot values K[k] (:61-83), the right-hand side and pivots (:88-96) computed on the fly, and the
+//                         forward sweep  b[i] = (b0[i] - u[i] b[i-1]) / d[i]  (:93-98);
+//   k_cubic_sweep<false>  the back substitution  b[i] = b[i] - v[i] b[i+1]  (:100-101), natural ends (:104-105).
+//       Both are first-order linear recurrences y -> a_i + c_i y.  A workgroup owns 4096 consecutive elements and walks them in
+//       coalesced rounds of 256: the maps of a round are composed in order by wave scans (shuffles), across the four waves through
+//       LDS, across rounds by a running carry.  ACROSS workgroups nothing is exchanged: a workgroup starts kWarm = 256 elements
+//       early from y = 0.  That is exact to far below rounding because the maps contract — forward |c_i c_{i+1}| <= 1/2 for
+//       every pair (c_i = u_i / (2 - u_i v_{i-1}) <= u_i / (2 - u_i), c_{i+1} <= 1 / (1 + u_i)), so 256 elements damp the
+//       unknown start value by 2^-128; backward c_i = v_i = h_i / (h_{i-1} + h_i) with integer spacings below 2^31, whose
+//       product over 256 elements is below 1e-70.  (The first version ran reduce / carries / apply launches per direction over
+//       six intermediate arrays: 198 of its 528 us at 2^24 samples.)
 //   k_cubic_eval    one wavefront per 512 samples: segment of each sample from a bitmap of the tile's knots (the j_lookup
 //                   loop, :107-111, is "number of knots e[1..idx-1] at or before the sample"), then the spline formula
 //                   (:113-120) with t*t*t where the reference has numpy's float64 ** 3 (libm pow; numba multiplies).
-// Float parity is therefore a tolerance, not bit equality (tests: 1e-9 of the signal's scale); knot indices are exact.
+// The association of the sweeps differs from the reference's serial loops, so float parity is a tolerance, not bit equality
+// (tests: 1e-9 of the signal's scale, measured ~4e-16); knot indices are exact.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,40 +34,53 @@
 
 namespace itd {
 
-// ---- knot values and spacings ----------------------------------------------------------------------------------------
-// e: idx+1 knots (int32, device); K: idx+1 values; h: idx spacings.  K[idx-1] = 0 (never computed by the reference).
-__global__ void k_cubic_knots(const double *__restrict__ I, const int32_t *__restrict__ e, int64_t idx, double *__restrict__ K,
-                              double *__restrict__ h)
+// What one signal's spline is built on.  Written on the device: by k_cubic_jobs (a caller's list / the detected knots) or by
+// the block-wise stream's knot selection (itd_stream.hpp).
+struct CubicJob {
+    int32_t first;    // the signal's knots are list[first .. first + idx] (idx + 1 entries, the reference's extrema_input)
+    int32_t idx;      // the reference's idx
+    int32_t valid;    // 0: nothing is built; k_cubic_eval leaves the baseline untouched (itd.cpp:170-172) or copies the signal
+    int32_t status;   // 0 ok, 1 = the caller's list is not strictly increasing / not inside the signal, 2 = NaN in the signal
+};
+
+struct CubicArgs {
+    const double *x; int64_t x_stride;        // signals
+    int64_t n;
+    const int32_t *e; int64_t e_stride;       // knot lists (e_stride = 0: one list for every signal)
+    const CubicJob *jobs; int job_stride;     // 0: one job for every signal (shared knots), 1: one each
+    double *K, *bf, *b; int64_t a_stride;     // per-signal knot arrays: values, forward sweep, final second derivatives
+};
+
+constexpr int kScanThreads = 256, kScanRounds = 16, kScanBlockElems = kScanRounds * kScanThreads, kWarm = kScanThreads;
+
+// ---- jobs -------------------------------------------------------------------------------------------------------------
+// mode 0: the caller's list (idx given; validated by k_cubic_validate afterwards); mode 1: the detected knots of signal b,
+// totals[2b] of them behind a leading slot (k_compact), totals[2b+1] = the signal holds a NaN
+__global__ void k_cubic_jobs(CubicJob *__restrict__ jobs, int n_jobs, int mode, int64_t idx, const int32_t *__restrict__ totals)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_jobs) return;
+    CubicJob j;
+    if (mode == 0) { j.first = 0; j.idx = (int32_t)idx; j.valid = idx >= 2; j.status = 0; }
+    else {
+        j.first = 1;
+        j.idx = totals[2 * b];
+        j.status = totals[2 * b + 1] ? 2 : 0;
+        j.valid = j.idx >= 2 && j.status == 0;      // itd.cpp:170-172: fewer than 2 knots, break early
+    }
+    jobs[b] = j;
+}
+
+// knots handed in by the caller: e[0..idx-1] strictly increasing and inside the signal, e[idx] inside the signal
+__global__ void k_cubic_validate(const int32_t *__restrict__ e, int64_t e_stride, int64_t idx, int64_t n, CubicJob *__restrict__ jobs)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > idx) return;
-    double v;
-    if (k == 0 || k == idx) v = I[e[k]];                      // :83
-    else if (k == idx - 1) v = 0.0;                           // the loop at :61 stops at idx-2
-    else {
-        const int32_t ep = e[k - 1], ec = e[k], en = e[k + 1];
-        const double ap = I[ep], ac = I[ec], an = I[en];
-        const double weight = (double)(ec - ep) / (double)(en - ep);                 // :77
-        v = 0.5 * (ap + weight * (an - ap)) + (1 - 0.5) * ac;                          // :80
-    }
-    K[k] = v;
-    if (k < idx) h[k] = (double)(e[k + 1] - e[k]);                                     // :86
-}
-
-// ---- u, b0, d for i = 1 .. idx-1 (:88-96); entry 0 of each array is 0 like the reference's zeros ----------------------
-__global__ void k_cubic_rhs(const double *__restrict__ K, const double *__restrict__ h, int64_t idx, double *__restrict__ u,
-                            double *__restrict__ b0, double *__restrict__ d)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= idx) return;
-    if (i == 0) { u[0] = 0.0; b0[0] = 0.0; d[0] = 0.0; return; }
-    const double hm = h[i - 1], hi = h[i];
-    const double ui = hm / (hm + hi);                                                   // :89
-    double vm = 0.0;                                                                    // v[0] = 0
-    if (i >= 2) { const double hmm = h[i - 2]; vm = 1 - hmm / (hmm + hm); }            // v[i-1] = 1 - u[i-1], :90
-    u[i] = ui;
-    b0[i] = 6 * ((K[i + 1] - K[i]) / hi - (K[i] - K[i - 1]) / hm) / (hm + hi);          // :91
-    d[i] = 2 - ui * vm;                                                                 // :94,96 (original u and v)
+    const int32_t *el = e + (int64_t)blockIdx.y * e_stride;
+    const int64_t v = el[k];
+    bool ok = v >= 0 && v < n;
+    if (k >= 1 && k < idx) ok = ok && v > (int64_t)el[k - 1];
+    if (!ok) { jobs[blockIdx.y].valid = 0; jobs[blockIdx.y].status = 1; }
 }
 
 // ---- first-order linear recurrences  y[i] = f_i(y[i-1])  with affine f_i -----------------------------------------------
@@ -69,29 +89,6 @@ __device__ __forceinline__ Affine compose(Affine later, Affine earlier)   // lat
 {
     return Affine{later.a + later.c * earlier.a, later.c * earlier.c};
 }
-constexpr int kScanChunk = 16, kScanThreads = 256, kScanBlockElems = kScanChunk * kScanThreads;
-
-// FWD: element q (q = 0 .. count-1) is knot i = 1 + q:  y = (b0[i] - u[i] * y_prev) / d[i]
-// BWD: element q is knot i = idx-2-q (running downwards):  y = bf[i] - v[i] * y_prev,  v[i] = 1 - u[i]
-template <bool FWD>
-struct Recur {
-    const double *b0_or_bf, *u, *d;
-    int64_t idx;
-    __device__ __forceinline__ int64_t knot(int64_t q) const { return FWD ? 1 + q : idx - 2 - q; }
-    __device__ __forceinline__ Affine map(int64_t q) const
-    {
-        const int64_t i = knot(q);
-        if (FWD) { const double di = d[i]; return Affine{b0_or_bf[i] / di, -(u[i] / di)}; }
-        const double vi = (i == 0) ? 0.0 : 1 - u[i];
-        return Affine{b0_or_bf[i], -vi};
-    }
-};
-
-// The scans run over consecutive elements in COALESCED rounds: a workgroup owns kScanBlockElems consecutive elements and walks
-// them in rounds of kScanThreads (thread t takes element round * kScanThreads + t: lane-contiguous loads and stores; the first
-// version gave every thread 16 consecutive elements, i.e. a 128-byte stride between lanes — every load instruction touched 64
-// cache lines and the launches ran at a twentieth of the memory rate).  Inside a round the maps are combined by an ordered
-// wave scan (shuffles), the four waves through LDS, the rounds through a running carry.
 __device__ __forceinline__ Affine wave_inclusive(Affine inc, int lane)
 {
 #pragma unroll
@@ -102,62 +99,73 @@ __device__ __forceinline__ Affine wave_inclusive(Affine inc, int lane)
     return inc;
 }
 
-// reduce: the composed map of the workgroup's elements, in order
-template <bool FWD>
-__global__ __launch_bounds__(kScanThreads) void k_recur_reduce(Recur<FWD> r, int64_t count, Affine *__restrict__ block_maps)
+// knot value K[k] (:61-83): the end values are the data, K[idx-1] = 0 (the loop at :61 stops at idx-2)
+__device__ __forceinline__ double cubic_knot_value(const double *__restrict__ I, const int32_t *__restrict__ e, int k, int idx)
 {
-    __shared__ Affine s_wave[kScanThreads / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kScanBlockElems;
-    Affine tot{0.0, 1.0};   // thread 0's copy is the one that counts
-    for (int round = 0; round < kScanChunk; ++round) {
-        const int64_t q = base + (int64_t)round * kScanThreads + threadIdx.x;
-        const Affine m = q < count ? r.map(q) : Affine{0.0, 1.0};
-        const Affine inc = wave_inclusive(m, lane);
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int w = 0; w < kScanThreads / 64; ++w) tot = compose(s_wave[w], tot);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) block_maps[blockIdx.x] = tot;
+    if (k == 0 || k == idx) return I[e[k]];                  // :83
+    if (k == idx - 1) return 0.0;
+    const int32_t ep = e[k - 1], ec = e[k], en = e[k + 1];
+    const double ap = I[ep], ac = I[ec], an = I[en];
+    const double weight = (double)(ec - ep) / (double)(en - ep);                 // :77
+    return 0.5 * (ap + weight * (an - ap)) + (1 - 0.5) * ac;                      // :80
 }
 
-// carry-in of every workgroup: y in front of its first element.  One wavefront: lane l composes its run of consecutive
-// workgroup maps, the runs are scanned across the lanes, and every lane then walks its run from its own carry-in.
-__global__ __launch_bounds__(64) void k_recur_carries(const Affine *__restrict__ block_maps, int n_blocks,
-                                                      const double *__restrict__ y_init /* nullptr: 0 */, double *__restrict__ carry)
-{
-    const int lane = threadIdx.x;
-    const int per = (n_blocks + 63) / 64;
-    const int b0 = lane * per, b1 = min(n_blocks, b0 + per);
-    Affine m{0.0, 1.0};
-    for (int b = b0; b < b1; ++b) m = compose(block_maps[b], m);
-    const Affine inc = wave_inclusive(m, lane);
-    const double ea = __shfl_up(inc.a, 1), ec = __shfl_up(inc.c, 1);
-    const Affine ex = lane == 0 ? Affine{0.0, 1.0} : Affine{ea, ec};
-    double y = ex.a + ex.c * (y_init ? *y_init : 0.0);
-    for (int b = b0; b < b1; ++b) {
-        carry[b] = y;
-        y = block_maps[b].a + block_maps[b].c * y;
-    }
-}
-
-// apply: every element from the running carry through the inclusive maps of its round
+// FWD: element q (q = 0 .. idx-2) is knot i = 1 + q:  y = (b0[i] - u[i] * y_prev) / d[i], y in front of knot 1 = b[0] = 0
+// BWD: element q is knot i = idx-2-q (running downwards):  y = bf[i] - v[i] * y_prev, v[i] = 1 - u[i]; y in front = bf[idx-1]
 template <bool FWD>
-__global__ __launch_bounds__(kScanThreads) void k_recur_apply(Recur<FWD> r, int64_t count, const double *__restrict__ carry,
-                                                               double *__restrict__ out)
+__global__ __launch_bounds__(kScanThreads) void k_cubic_sweep(CubicArgs A)
 {
     __shared__ Affine s_wave[kScanThreads / 64];
     __shared__ double s_y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kScanBlockElems;
-    double y_in = carry[blockIdx.x];      // y in front of the round's first element
-    for (int round = 0; round < kScanChunk; ++round) {
-        const int64_t q = base + (int64_t)round * kScanThreads + threadIdx.x;
-        const Affine m = q < count ? r.map(q) : Affine{0.0, 1.0};
+    __shared__ double s_K[kScanThreads + 2];
+    const int sig = blockIdx.y;
+    const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
+    if (!job.valid) return;
+    const int idx = job.idx, count = idx - 1;
+    const int base = blockIdx.x * kScanBlockElems;
+    if (base >= count) return;
+    const int32_t *e = A.e + (int64_t)sig * A.e_stride + job.first;
+    const double *I = A.x + (int64_t)sig * A.x_stride;
+    double *K = A.K + (int64_t)sig * A.a_stride, *bf = A.bf + (int64_t)sig * A.a_stride, *bo = A.b + (int64_t)sig * A.a_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r_first = base >= kWarm ? -1 : 0;        // one warm-up round in front of the workgroup's own elements
+    double y_in = 0.0;                                  // FWD at the very front: b[0] = 0
+    if (!FWD && r_first == 0) y_in = bf[idx - 1];       // BWD at the very front: the forward sweep's last value
+    for (int round = r_first; round < kScanRounds; ++round) {
+        const int q0 = base + round * kScanThreads;     // uniform
+        if (q0 >= count) break;
+        const int q = q0 + tid;
+        Affine m{0.0, 1.0};
+        if (FWD) {
+            // knot values of the round's knots 1+q0 .. 1+q0+255 and the two next to them, through LDS
+            const int i = 1 + q;
+            if (i <= idx) s_K[tid + 1] = cubic_knot_value(I, e, i, idx);
+            if (tid == 0) s_K[0] = cubic_knot_value(I, e, q0, idx);
+            if (tid == 1 && q0 + kScanThreads + 1 <= idx) s_K[kScanThreads + 1] = cubic_knot_value(I, e, q0 + kScanThreads + 1, idx);
+            __syncthreads();
+            if (q < count) {
+                const double Km = s_K[tid], Kc = s_K[tid + 1], Kp = s_K[tid + 2];
+                const double hm = (double)(e[i] - e[i - 1]), hi = (double)(e[i + 1] - e[i]);           // :86
+                const double ui = hm / (hm + hi);                                                       // :89
+                double vm = 0.0;                                                                        // v[0] = 0
+                if (i >= 2) { const double hmm = (double)(e[i - 1] - e[i - 2]); vm = 1 - hmm / (hmm + hm); }   // :90
+                const double b0 = 6 * ((Kp - Kc) / hi - (Kc - Km) / hm) / (hm + hi);                    // :91
+                const double di = 2 - ui * vm;                                                          // :94,96 (original u and v)
+                m = Affine{b0 / di, -(ui / di)};
+                if (round >= 0) {
+                    K[i] = Kc;
+                    if (q == 0) K[0] = Km;
+                    if (q == count - 1) K[idx] = Kp;
+                }
+            }
+        } else if (q < count) {
+            const int i = idx - 2 - q;
+            m = Affine{0.0, 0.0};                                                   // i = 0: v[0] = 0 and b[0] is forced to 0 (:104)
+            if (i >= 1) {
+                const double hm = (double)(e[i] - e[i - 1]), hi = (double)(e[i + 1] - e[i]);
+                m = Affine{bf[i], -(1 - hm / (hm + hi))};                           // v[i] = 1 - u[i], :90, :101
+            }
+        }
         const Affine inc = wave_inclusive(m, lane);
         if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
@@ -165,39 +173,53 @@ __global__ __launch_bounds__(kScanThreads) void k_recur_apply(Recur<FWD> r, int6
         for (int w = 0; w < wave; ++w) pre = compose(s_wave[w], pre);
         const double y_wave = pre.a + pre.c * y_in;          // y in front of my wave
         const double y = inc.a + inc.c * y_wave;
-        if (q < count) out[r.knot(q)] = y;
-        if (threadIdx.x == kScanThreads - 1) s_y = y;       // the round's last element (identity maps carry it on)
+        if (q < count && round >= 0) {
+            if (FWD) bf[1 + q] = y;
+            else { const int i = idx - 2 - q; bo[i] = i == 0 ? 0.0 : y; }           // :104 b[0] = 0
+        }
+        if (tid == kScanThreads - 1) s_y = y;                // the round's last element (identity maps carry it on)
         __syncthreads();
         y_in = s_y;
     }
+    if (!FWD && base == 0 && tid == 0) { bo[idx - 1] = 0.0; bo[idx] = 0.0; }   // :105; b[idx] is the reference's untouched zero
 }
 
-// b[0] = 0, b[idx-1] = 0 (:104-105), b[idx] = 0 (never written by the reference: zeros)
-__global__ void k_cubic_fix_ends(double *__restrict__ b, int64_t idx)
-{
-    b[0] = 0.0;
-    b[idx - 1] = 0.0;
-    b[idx] = 0.0;
-}
-
-// ---- evaluation: one wavefront per TW samples ------------------------------------------------------------------------
+// ---- evaluation: one wavefront per TW samples of [lo, hi) ------------------------------------------------------------
 // j(i) = number of k in [1, idx-1] with e[k] <= i (the j_lookup loop :107-111 for increasing knots), t = (i - e[j]) / h[j].
+// out holds the samples lo .. hi-1 of every signal (out[sig * out_stride + i - lo]); a signal without a valid job is left
+// untouched (itd.cpp:170-172) or, with copy_invalid, copied (the block-wise recipe: "the block is its own baseline").
 template <int TW>
-__global__ __launch_bounds__(64) void k_cubic_eval(const int32_t *__restrict__ e, const double *__restrict__ K,
-                                                   const double *__restrict__ b, const double *__restrict__ h, int64_t idx,
-                                                   int64_t n, double *__restrict__ baseline)
+__global__ __launch_bounds__(64) void k_cubic_eval(CubicArgs A, int64_t lo, int64_t hi, double *__restrict__ out, int64_t out_stride,
+                                                   int copy_invalid, double *__restrict__ rot = nullptr, int64_t rot_stride = 0)
 {
     static_assert(TW == 512, "8 bitmap words of 64 positions");
     __shared__ unsigned long long s_bits[TW / 64];
     const int lane = threadIdx.x;
-    const int64_t s = (int64_t)blockIdx.x * TW;
-    // j0 = number of knots e[1..idx-1] strictly in front of the tile (<= s-1): lower bound of s, wave-uniform
-    int64_t lo = 1, hi = idx;           // first k in [1, idx) with e[k] >= s
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (e[mid] < s) lo = mid + 1; else hi = mid;
+    const int sig = blockIdx.y;
+    const int64_t s = lo + (int64_t)blockIdx.x * TW;
+    const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
+    double *o = out + (int64_t)sig * out_stride - lo;
+    double *ro = rot ? rot + (int64_t)sig * rot_stride - lo : nullptr;     // optional: signal - baseline
+    const double *xs = A.x + (int64_t)sig * A.x_stride;
+    if (!job.valid) {
+        if (copy_invalid)
+            for (int p = lane; p < TW; p += 64)
+                if (s + p < hi) {
+                    o[s + p] = xs[s + p];
+                    if (ro) ro[s + p] = 0.0;
+                }
+        return;
     }
-    const int64_t kfirst = lo;          // knots kfirst, kfirst+1, ... lie at or behind s
+    const int64_t idx = job.idx;
+    const int32_t *e = A.e + (int64_t)sig * A.e_stride + job.first;
+    const double *K = A.K + (int64_t)sig * A.a_stride, *b = A.b + (int64_t)sig * A.a_stride;
+    // j0 = number of knots e[1..idx-1] strictly in front of the tile (<= s-1): lower bound of s, wave-uniform
+    int64_t l = 1, h = idx;             // first k in [1, idx) with e[k] >= s
+    while (l < h) {
+        const int64_t mid = (l + h) >> 1;
+        if (e[mid] < s) l = mid + 1; else h = mid;
+    }
+    const int64_t kfirst = l;           // knots kfirst, kfirst+1, ... lie at or behind s
     if (lane < TW / 64) s_bits[lane] = 0ull;
     __syncthreads();
     for (int64_t k = kfirst + lane; k < idx; k += 64) {     // at most TW of them fall into the tile
@@ -220,11 +242,12 @@ __global__ __launch_bounds__(64) void k_cubic_eval(const int32_t *__restrict__ e
     for (int q = 0; q < TW / 64; ++q) {
         const int p = q * 64 + lane;
         const int64_t i = s + p;
-        if (i >= n) continue;
+        if (i >= hi) continue;
         const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
         const int64_t j = pre[q] + __popcll(w[q] & upto);        // knots at or before the sample
-        const double hj = h[j];
-        const double t = (double)(i - (int64_t)e[j]) / hj;                          // :115
+        const int32_t ej = e[j];
+        const double hj = (double)(e[j + 1] - ej);                                  // :86
+        const double t = (double)(i - (int64_t)ej) / hj;                            // :115
         const double Kj = K[j], Kn = K[j + 1];
         double v;
         if (j == idx - 2) {
@@ -235,19 +258,9 @@ __global__ __launch_bounds__(64) void k_cubic_eval(const int32_t *__restrict__ e
             const double c2 = hj * hj / 6 * (t * t * t - t) * b[j + 1];
             v = ((omt * Kj + t * Kn) + c1) + c2;
         }
-        baseline[i] = v;
+        o[i] = v;
+        if (ro) ro[i] = xs[i] - v;
     }
-}
-
-// knots handed in by the caller: e[0..idx-1] strictly increasing and inside the signal, e[idx] inside the signal
-__global__ void k_cubic_validate(const int32_t *__restrict__ e, int64_t idx, int64_t n, int32_t *__restrict__ bad)
-{
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > idx) return;
-    const int64_t v = e[k];
-    bool ok = v >= 0 && v < n;
-    if (k >= 1 && k < idx) ok = ok && v > (int64_t)e[k - 1];
-    if (!ok) *bad = 1;
 }
 
 // find_extrema's tail (itd_fourier_decomposition.py:29-30): e[m+1] = 2 e[m] - e[m-1]; python's e[-1] (= 0) when m = 0

@@ -23,6 +23,7 @@
 #include "itd_chain.hpp"
 #include "itd_resident.hpp"
 #include "itd_cubic.hpp"
+#include "itd_stream.hpp"
 #include "itd_tfe.hpp"
 #include "itd_spline.hpp"
 
@@ -118,10 +119,12 @@ struct itd_engine {
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
     // host-convenience staging (grow only)
-    double *d_cub = nullptr; size_t cub_bytes = 0;        // cubic variant: K, h, u, b0, d, b (6 arrays of idx+2 doubles)
-    void *d_cub_aux = nullptr; size_t cub_aux_bytes = 0;  // cubic variant: workgroup maps + carries
+    void *d_cub = nullptr; size_t cub_bytes = 0;          // cubic variant: per-signal jobs + K, bf, b (3 arrays of idx+2 doubles each);
+                                                          // also staging of the NaN-input helper path and the instantaneous step
     int32_t *d_cub_e = nullptr; size_t cub_e_bytes = 0;   // cubic variant: the caller's knots narrowed to int32 (host form)
     int32_t *d_flag = nullptr;                            // [1] device-side argument check
+    void *d_dw = nullptr; size_t dw_bytes = 0;            // batched knot detection (DetectWs): cubic batch, detect batch, streams
+    void *d_bw = nullptr; size_t bw_bytes = 0;            // batched single-level tier-1 extraction (BatchWs)
     void *d_sp = nullptr; size_t sp_bytes = 0;            // spline flavour (batched): lists, counts, records, group sums, states,
                                                           // ordered knot lists, totals, fit arrays, metadata
     double *d_sp2 = nullptr; size_t sp2_bytes = 0;        // 2-D consumers: three planes of scratch
@@ -785,7 +788,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
-    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_aux); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_flag);
+    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_flag);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
     (void)hipFree(e->d_cntg); (void)hipFree(e->d_recg); (void)hipFree(e->d_endg); (void)hipFree(e->d_cgsum); (void)hipFree(e->d_ctl);
     if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -827,6 +830,10 @@ int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32
 {
     if (!dst || !src || bytes < 0) return ITD_ERR_INVALID_ARG;
     DevGuard g(device_id);
+    // Ordered against EVERYTHING on the device, whatever stream it was enqueued on: the engines' own streams are non-blocking
+    // (no implicit ordering with the null stream this copy uses), and a caller of this plain helper expects "after what I
+    // launched, before what I launch next"
+    if (hipDeviceSynchronize() != hipSuccess) return ITD_ERR_HIP;
     return hipMemcpy(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess
                ? ITD_OK : ITD_ERR_HIP;
 }
@@ -1200,7 +1207,7 @@ int extract_dev(itd_engine *e, const Tin *x, int64_t n, double *rot, double *bas
             // goes into a staging buffer, the record-driven extraction reads that
             rc = grow(e, &e->d_cub, &e->cub_bytes, (size_t)n * sizeof(double));
             if (rc) return rc;
-            double *xm = e->d_cub;
+            double *xm = (double *)e->d_cub;
             rc = scan_level0<Tin>(e, x, n, (int)kKnots, want_list, st, -1, true, xm);
             if (rc) return rc;
             k_extract<double, T, false, kRankCap0, kTilesPerWave><<<dim3((n_tiles + kTilesPerWave - 1) / kTilesPerWave), kWave, 0, st>>>(
@@ -1400,33 +1407,98 @@ int itd_knot_values_f64(itd_engine *e, const double *x_dev, int64_t n, const int
 // itd_fourier_decomposition.py:49-122 = itd.cpp:156-239.  Single-level operator; synchronous like the other helpers.
 // ---------------------------------------------------------------------------------------------
 namespace {
-// x: n float64 samples on the device; ek: idx+1 knots (int32, device, validated); baseline: n float64 (device)
-int cubic_core(itd_engine *e, const double *x, int64_t n, const int32_t *ek, int64_t idx, double *baseline, hipStream_t st)
+// Batched knot detection into a workspace of its own (grow-only): per-tile lists, counts, records, group sums, per-signal
+// states, the ordered knot lists kidx[b] = [lead slot, knots, tail] and totals[b] = {knot count, the signal holds a NaN}.
+struct DetectWs {
+    int32_t *lists, *counts, *gsum, *kidx, *totals;
+    TileRec *recs;
+    SigState *state;
+    int64_t kidx_stride;
+    int n_tiles, n_groups;
+};
+int detect_workspace(itd_engine *e, int64_t n, int batch, DetectWs &w)
 {
-    const size_t L = (size_t)idx + 2;
-    int rc = grow(e, &e->d_cub, &e->cub_bytes, 6 * L * sizeof(double));
+    w.n_tiles = (int)tiles_of(n);
+    w.n_groups = groups_of(w.n_tiles);
+    w.kidx_stride = n + 2;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t B = (size_t)batch, tiles = B * (size_t)w.n_tiles;
+    const size_t b_lists = al(tiles * T * sizeof(int32_t)), b_counts = al(tiles * sizeof(int32_t)), b_recs = al(tiles * sizeof(TileRec));
+    const size_t b_gsum = al(B * (size_t)w.n_groups * kGsumPitch * sizeof(int32_t)), b_state = al(B * sizeof(SigState));
+    const size_t b_kidx = al(B * (size_t)w.kidx_stride * sizeof(int32_t)), b_tot = al(B * 2 * sizeof(int32_t));
+    const int rc = grow(e, &e->d_dw, &e->dw_bytes, b_lists + b_counts + b_recs + b_gsum + b_state + b_kidx + b_tot);
     if (rc) return rc;
-    const int64_t count = idx - 1;                                   // elements of either recurrence
-    const int nblk = (int)((count + kScanBlockElems - 1) / kScanBlockElems);
-    rc = grow(e, &e->d_cub_aux, &e->cub_aux_bytes, (size_t)nblk * (sizeof(Affine) + sizeof(double)));
+    char *p = (char *)e->d_dw;
+    w.lists = (int32_t *)p; p += b_lists;
+    w.counts = (int32_t *)p; p += b_counts;
+    w.recs = (TileRec *)p; p += b_recs;
+    w.gsum = (int32_t *)p; p += b_gsum;
+    w.state = (SigState *)p; p += b_state;
+    w.kidx = (int32_t *)p; p += b_kidx;
+    w.totals = (int32_t *)p;
+    return ITD_OK;
+}
+// knots of `batch` signals (batch <= 65535: grid.y) by predicate `mode`, ordered, no host synchronisation.  kidx_out = NULL: into
+// the workspace's lists with a leading slot (what the cubic kernels and the stream's selection read); else the caller's
+// [batch][kidx_out_stride] array without one (itd_detect_batch_*)
+int detect_enqueue(itd_engine *e, const double *x, int64_t x_stride, int64_t n, int batch, int mode, int64_t tail_value,
+                   hipStream_t st, DetectWs &w, int32_t *kidx_out = nullptr, int64_t kidx_out_stride = 0, bool want_lists = true)
+{
+    int rc = detect_workspace(e, n, batch, w);
     if (rc) return rc;
-    double *K = e->d_cub, *h = K + L, *u = h + L, *b0 = u + L, *d = b0 + L, *b = d + L;
-    Affine *maps = (Affine *)e->d_cub_aux;
-    double *carry = (double *)(maps + nblk);
-    k_cubic_knots<<<(unsigned)((idx + 1 + 255) / 256), 256, 0, st>>>(x, ek, idx, K, h);
-    k_cubic_rhs<<<(unsigned)((idx + 255) / 256), 256, 0, st>>>(K, h, idx, u, b0, d);
-    HIP_TRY(e, hipMemsetAsync(b, 0, L * sizeof(double), st));         // b[0] = 0 in front of the sweep; b[idx] stays 0
-    const Recur<true> rf{b0, u, d, idx};
-    k_recur_reduce<true><<<nblk, kScanThreads, 0, st>>>(rf, count, maps);
-    k_recur_carries<<<1, 64, 0, st>>>(maps, nblk, nullptr, carry);
-    k_recur_apply<true><<<nblk, kScanThreads, 0, st>>>(rf, count, carry, b);
-    const Recur<false> rb{b, u, d, idx};                              // back substitution, in place, from b[idx-1]
-    k_recur_reduce<false><<<nblk, kScanThreads, 0, st>>>(rb, count, maps);
-    k_recur_carries<<<1, 64, 0, st>>>(maps, nblk, b + (idx - 1), carry);
-    k_recur_apply<false><<<nblk, kScanThreads, 0, st>>>(rb, count, carry, b);
-    k_cubic_fix_ends<<<1, 1, 0, st>>>(b, idx);
-    k_cubic_eval<T><<<(unsigned)tiles_of(n), kWave, 0, st>>>(ek, K, b, h, idx, n, baseline);
+    const dim3 grid_t(w.n_tiles, batch), blk(kWave);
+    const int64_t ge = (int64_t)batch * w.n_groups * kGsumPitch;
+    k_init_state<<<(unsigned)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048), 256, 0, st>>>(w.state, batch, w.gsum, ge);
+    k_detect<double, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, w.n_tiles, mode, want_lists ? w.lists : nullptr, w.counts, w.recs, w.gsum, w.state);
+    if (want_lists)
+        k_compact<T><<<grid_t, blk, 0, st>>>(w.lists, w.counts, w.gsum, w.n_tiles, n, kidx_out ? kidx_out : w.kidx,
+                                              kidx_out ? kidx_out_stride : w.kidx_stride, w.totals, w.state, tail_value, nullptr, kidx_out ? 0 : 1);
+    else
+        k_batch_totals<<<(batch + 3) / 4, 256, 0, st>>>(w.gsum, w.n_groups, batch, w.state, w.totals);
     HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
+}
+
+// The cubic operator over `batch` signals, asynchronous on st.  extrema = NULL: every signal's own knots (itd.cpp:159-169);
+// else the caller's list(s) of idx + 1 entries (e_stride = 0: one list for every signal, itd.cpp:40-44).  *jobs_out: the
+// per-signal jobs on the device (idx used, valid, status) for callers that synchronise afterwards.
+int cubic_batch(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_stride, const int32_t *extrema, int64_t e_stride,
+                int64_t idx, double *baseline, int64_t b_stride, hipStream_t st, const CubicJob **jobs_out, int *n_jobs_out)
+{
+    const int64_t L = (extrema ? idx : n) + 2;                        // entries per knot array
+    const size_t jobs_b = (((size_t)batch * sizeof(CubicJob)) + 255) & ~(size_t)255;
+    int rc = grow(e, &e->d_cub, &e->cub_bytes, jobs_b + 3 * (size_t)batch * (size_t)L * sizeof(double));
+    if (rc) return rc;
+    CubicJob *jobs = (CubicJob *)e->d_cub;
+    double *arr = (double *)((char *)e->d_cub + jobs_b);
+    CubicArgs A;
+    A.x = x; A.x_stride = x_stride; A.n = n;
+    A.K = arr; A.bf = arr + (size_t)batch * L; A.b = arr + 2 * (size_t)batch * L; A.a_stride = L;
+    A.jobs = jobs;
+    int n_jobs;
+    int64_t max_count;
+    if (!extrema) {
+        DetectWs w;
+        rc = detect_enqueue(e, x, x_stride, n, batch, (int)kCpp, 0 /* e[idx] = 0: the file's static array at first call */, st, w);
+        if (rc) return rc;
+        n_jobs = batch;
+        k_cubic_jobs<<<(batch + 255) / 256, 256, 0, st>>>(jobs, batch, 1, 0, w.totals);
+        A.e = w.kidx; A.e_stride = w.kidx_stride; A.job_stride = 1;
+        max_count = n;
+    } else {
+        n_jobs = e_stride ? batch : 1;
+        k_cubic_jobs<<<(n_jobs + 255) / 256, 256, 0, st>>>(jobs, n_jobs, 0, idx, nullptr);
+        k_cubic_validate<<<dim3((unsigned)((idx + 1 + 255) / 256), n_jobs), 256, 0, st>>>(extrema, e_stride, idx, n, jobs);
+        A.e = extrema; A.e_stride = e_stride; A.job_stride = e_stride ? 1 : 0;
+        max_count = idx - 1;
+    }
+    const unsigned nblk = (unsigned)std::max<int64_t>(1, (max_count + kScanBlockElems - 1) / kScanBlockElems);
+    k_cubic_sweep<true><<<dim3(nblk, batch), kScanThreads, 0, st>>>(A);
+    k_cubic_sweep<false><<<dim3(nblk, batch), kScanThreads, 0, st>>>(A);
+    k_cubic_eval<T><<<dim3((unsigned)tiles_of(n), batch), kWave, 0, st>>>(A, 0, n, baseline, b_stride, 0);
+    HIP_TRY(e, hipGetLastError());
+    if (jobs_out) *jobs_out = jobs;
+    if (n_jobs_out) *n_jobs_out = n_jobs;
     return ITD_OK;
 }
 
@@ -1440,33 +1512,29 @@ int cubic_detect(itd_engine *e, const double *x, int64_t n, int mode, int64_t *c
     return fetch_total(e, st, count);
 }
 
+// one signal, synchronous: ONE host synchronisation, at the end (the job: knot count, validity)
 int cubic_dev(itd_engine *e, const double *x, int64_t n, const int32_t *extrema, int64_t idx, double *baseline,
-              int64_t *idx_out, hipStream_t st)
+              int64_t *idx_out, hipStream_t st, const int32_t **knots_dev_out = nullptr)
 {
     if (!e || !x || !baseline) return ITD_ERR_INVALID_ARG;
     if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    if (extrema && (idx < 2 || idx > n - 1)) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
-    const int32_t *ek = extrema;
-    if (!extrema) {   // compute_extrema = true, itd.cpp:159-169; e[idx] = 0: the file's static array at first call
-        int64_t m = 0;
-        const int rc = cubic_detect(e, x, n, (int)kCpp, &m, st);
-        if (rc) return rc;
-        idx = m;
-        ek = e->d_kidx + 1;
-    } else {
-        if (idx < 2 || idx > n - 1) return ITD_ERR_INVALID_ARG;
-        HIP_TRY(e, hipMemsetAsync(e->d_flag, 0, sizeof(int32_t), st));
-        k_cubic_validate<<<(unsigned)((idx + 1 + 255) / 256), 256, 0, st>>>(extrema, idx, n, e->d_flag);
-        int32_t bad = 0;
-        HIP_TRY(e, hipMemcpyAsync(&bad, e->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(e, hipStreamSynchronize(st));
-        if (bad) return ITD_ERR_INVALID_ARG;
-    }
-    if (idx_out) *idx_out = idx;
-    if (idx < 2) return ITD_OK;        // itd.cpp:170-172: break early, the baseline is left untouched
-    const int rc = cubic_core(e, x, n, ek, idx, baseline, st);
+    const CubicJob *jobs = nullptr;
+    int rc = cubic_batch(e, x, n, 1, n, extrema, 0, idx, baseline, n, st, &jobs, nullptr);
     if (rc) return rc;
+    CubicJob job;
+    HIP_TRY(e, hipMemcpyAsync(&job, jobs, sizeof(job), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
+    if (job.status == 1) return ITD_ERR_INVALID_ARG;
+    if (job.status == 2) return ITD_ERR_NONFINITE;
+    if (idx_out) *idx_out = job.idx;
+    if (knots_dev_out) {    // the detected knots (behind the workspace list's leading slot)
+        DetectWs w;
+        rc = detect_workspace(e, n, 1, w);   // no growth: same geometry as the call above
+        if (rc) return rc;
+        *knots_dev_out = w.kidx + 1;
+    }
     return ITD_OK;
 }
 }  // namespace
@@ -1519,13 +1587,14 @@ int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int
         ek = e->d_cub_e;
     }
     int64_t got = 0;
-    rc = cubic_dev(e, (const double *)e->d_io_x, n, ek, idx, e->d_io_rows, &got, st);
+    const int32_t *knots_dev = nullptr;
+    rc = cubic_dev(e, (const double *)e->d_io_x, n, ek, idx, e->d_io_rows, &got, st, extrema_host ? nullptr : &knots_dev);
     if (rc) return rc;
     if (idx_out) *idx_out = got;
     if (got >= 2) HIP_TRY(e, hipMemcpyAsync(baseline_host, e->d_io_rows, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     if (extrema_out_host && !extrema_host && got > 0) {
         int64_t *d_e64 = (int64_t *)(e->d_io_rows + n);
-        k_widen_idx<<<(unsigned)((got + 255) / 256), 256, 0, st>>>(e->d_kidx + 1, d_e64, got);
+        k_widen_idx<<<(unsigned)((got + 255) / 256), 256, 0, st>>>(knots_dev, d_e64, got);
         HIP_TRY(e, hipMemcpyAsync(extrema_out_host, d_e64, (size_t)got * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(e, hipStreamSynchronize(st));
@@ -1818,3 +1887,5 @@ int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_
 }
 
 }  // extern "C"
+
+#include "itd_engine_batch.inc"

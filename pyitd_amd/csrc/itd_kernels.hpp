@@ -544,7 +544,8 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
                                                    int32_t *__restrict__ kidx, int64_t kidx_stride,
                                                    int32_t *__restrict__ total_out, const SigState *__restrict__ state,
                                                    int64_t tail_value /* e[m+1]; < 0: n-1 (ITD.py:98) */,
-                                                   int32_t *__restrict__ tile_base_out = nullptr /* optional [n_tiles]: knots in front of each tile */)
+                                                   int32_t *__restrict__ tile_base_out = nullptr /* optional [n_tiles]: knots in front of each tile */,
+                                                   int lead = 1 /* 1: e = [0, knots, tail] (ITD.py:95-98); 0: the knots alone */)
 {
     const int sig = blockIdx.y;
     const int t = blockIdx.x;
@@ -563,14 +564,31 @@ __global__ __launch_bounds__(kWave) void k_compact(const int32_t *__restrict__ l
     if (tile_base_out && lane == 0) tile_base_out[(size_t)sig * n_tiles + t] = base;
     int32_t *e = kidx + (size_t)sig * kidx_stride;
     const int32_t *src = lists + ((size_t)sig * n_tiles + t) * TW;
-    for (int j = lane; j < c; j += kWave) e[1 + base + j] = src[j];
+    for (int j = lane; j < c; j += kWave) e[lead + base + j] = src[j];
     if (lane == 0 && t == n_tiles - 1) {
         const int m = base + c;
-        e[0] = 0;                    // ITD.py:96
-        e[m + 1] = (int32_t)(tail_value < 0 ? n - 1 : tail_value); // ITD.py:98
+        if (lead) {
+            e[0] = 0;                    // ITD.py:96
+            e[m + 1] = (int32_t)(tail_value < 0 ? n - 1 : tail_value); // ITD.py:98
+        }
         total_out[2 * sig] = m;
         total_out[2 * sig + 1] = state[sig].in_nan;   // set by k_detect, which has completed
     }
+}
+
+// knot totals of a batch without the ordered lists (count-only detection): one wavefront per signal sums its group sums;
+// totals[2b] = count, totals[2b+1] = the signal holds a NaN (like k_compact).  grid = ceil(batch / 4), 256 threads.
+__global__ __launch_bounds__(256) void k_batch_totals(const int32_t *__restrict__ gsum, int n_groups, int batch,
+                                                      const SigState *__restrict__ state, int32_t *__restrict__ totals)
+{
+    const int sig = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sig >= batch) return;
+    const int32_t *gs = gsum + (size_t)sig * n_groups * kGsumPitch;
+    int acc = 0;
+    for (int k = lane; k < n_groups; k += kWave) acc += gs[(size_t)k * kGsumPitch];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) { totals[2 * sig] = acc; totals[2 * sig + 1] = state[sig].in_nan; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -238,6 +238,22 @@ class Engine:
                                                                 ctypes.byref(got), None))
         return base, e, int(idx)
 
+    # ---- batched single-level operators on device buffers (asynchronous; include/pyitd_hip.h: *_batch_f64) ---------------
+    def extract_batch_dev(self, x_ptr, n, batch, x_stride, rot_ptr, rot_stride, base_ptr, base_stride, info_ptr=None, stream=None):
+        """itd_baseline_extract (ITD.py:79-121) of every row; info int32[batch]: knot count, -1 - count if the row holds a NaN."""
+        self._check(self._L.itd_baseline_extract_batch_f64(self._h, x_ptr, n, batch, x_stride, rot_ptr, rot_stride, base_ptr,
+                                                           base_stride, info_ptr, stream))
+
+    def detect_batch_dev(self, x_ptr, n, batch, x_stride, mode=DETECT_KNOTS, idx_ptr=None, idx_stride=0, info_ptr=None, stream=None):
+        """Knots of every row by predicate `mode`; idx_ptr None: counts only."""
+        self._check(self._L.itd_detect_batch_f64(self._h, x_ptr, n, batch, x_stride, mode, idx_ptr, idx_stride, info_ptr, stream))
+
+    def cubic_batch_dev(self, x_ptr, n, batch, x_stride, extrema_ptr, extrema_stride, idx, base_ptr, base_stride, info_ptr=None,
+                        stream=None):
+        """itd_baseline_extract_fast of every row; extrema_stride 0: one retained knot list for every row (itd.cpp:40-44)."""
+        self._check(self._L.itd_baseline_extract_cubic_batch_f64(self._h, x_ptr, n, batch, x_stride, extrema_ptr, extrema_stride,
+                                                                 idx, base_ptr, base_stride, info_ptr, stream))
+
     # ---- the FITPACK flavour of the baseline and its 2-D consumers (itd_baseline_extract_spline_*, itd_crossways_*) --------
     def spline_extract_host(self, x, min_extrema=10, want_rotation=False):
         """x[B, n] float64 -> (baseline[B, n], rotation[B, n] or None, knots[B]) (numba_accelerated_itd.py:182-211)."""
@@ -280,15 +296,17 @@ class DeviceBuffer:
             raise ITDError(rc, "itd_dev_alloc(%d bytes, device %d)" % (nbytes, device))
         self.ptr = p.value
 
-    def upload(self, a):
+    def upload(self, a, offset=0):
         a = np.ascontiguousarray(a)
-        assert a.nbytes <= self.nbytes
-        rc = self._L.itd_dev_copy(self.device, self.ptr, _np_ptr(a), a.nbytes, 1)
+        if offset < 0 or offset + a.nbytes > self.nbytes:
+            raise ValueError("upload of %d bytes at offset %d into a buffer of %d" % (a.nbytes, offset, self.nbytes))
+        rc = self._L.itd_dev_copy(self.device, self.ptr + offset, _np_ptr(a), a.nbytes, 1)
         if rc:
             raise ITDError(rc, "itd_dev_copy(host -> device)")
 
     def download(self, out, offset=0):
-        assert out.flags["C_CONTIGUOUS"] and offset + out.nbytes <= self.nbytes
+        if not out.flags["C_CONTIGUOUS"] or offset < 0 or offset + out.nbytes > self.nbytes:
+            raise ValueError("download of %d bytes at offset %d from a buffer of %d (or a non-contiguous target)" % (out.nbytes, offset, self.nbytes))
         rc = self._L.itd_dev_copy(self.device, _np_ptr(out), self.ptr + offset, out.nbytes, 0)
         if rc:
             raise ITDError(rc, "itd_dev_copy(device -> host)")

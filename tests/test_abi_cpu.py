@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.itd_abi_version() == 5
+    assert lib.itd_abi_version() == 6
     assert lib.itd_status_string(0) == b"ok"
     assert b"argument" in lib.itd_status_string(1)
 
@@ -69,6 +69,6 @@ def test_product_path_never_touches_the_oracle():
     """The oracle is test infrastructure: nothing under pyitd_amd/ may import, link or call it."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pyitd_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".inc")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower(), "%s mentions the oracle" % os.path.join(dirpath, f)
