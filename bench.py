@@ -21,10 +21,11 @@ Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kern
 algorithmic B/sample, timed with the launches' own hipEvents on the launch stream inside the timed region) + the per-kernel
 fractions + "cpu_baseline" (the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1)
 and the other CPU legs SURVEY 8d lists (all host cores over independent signals, numpy restatement, numba restatement).
-At N = 1 the line also carries "config3_batch" (BASELINE configs[2], 1024 x 2^20 signals): that leg is timed BEFORE the headline's
-warmup, so the headline's short timed region starts on a GPU at its sustained clocks (--no-extra skips the leg),
-and "short_signal_batches" (4096 x 4096 and 60 000 x 256 samples through the resident form and level by level, DESIGN.md section 11;
-timed after the headline, skipped by --no-extra as well).
+The headline has an untimed warm-up of its own (--warm-ms of its own steps, then the W warm-up steps), so it does not depend on any
+other leg.  At N = 1 the line also carries, all timed AFTER the headline and skipped by --no-extra: "config3_batch" (BASELINE
+configs[2], 1024 x 2^20 signals), "short_signal_batches" (4096 x 4096 and 60 000 x 256 samples through the resident form and level by
+level), "f_rows" (the SURVEY 8f operators: cubic baseline at 2^24, instantaneous step, totalextract2d on 512 x 512 beside the reference's
+recorded 10.1457 s, block-wise microseconds per block) and, with --wav PATH, "config5_audio" (BASELINE configs[4] on that file).
 """
 import argparse
 import json
@@ -88,28 +89,52 @@ def _free_port():
 
 def spawn_ranks(args):
     """The parent of a plain `bench.py --gpus N`: start N rank processes and relay rank 0's JSON line.  This process never
-    initialises HIP (fresh children, no exec of a GPU-holding process)."""
+    initialises HIP (fresh children, no exec of a GPU-holding process).  Every rank's stderr is captured and relayed with a
+    `[rank r]` prefix; the run has a deadline (--spawn-timeout): on expiry, or when any rank fails, the children this process
+    started are killed and the exit code is non-zero."""
+    import tempfile
     n = args.gpus
     port = _free_port()
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        ef = tempfile.TemporaryFile()
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef))
+    deadline = time.time() + args.spawn_timeout
+    out, rc, timed_out = b"", 0, False
+    try:
+        out, _ = procs[0].communicate(timeout=args.spawn_timeout)
+        rc = procs[0].returncode
+    except subprocess.TimeoutExpired:
+        timed_out = True
+    failed = []
+    for r, p in enumerate(procs):
+        if not timed_out and r > 0:
+            try:
+                p.wait(timeout=max(1.0, min(120.0, deadline - time.time())))
+            except subprocess.TimeoutExpired:
+                timed_out = True
+        if timed_out and p.poll() is None:
             p.kill()          # the exact child this process started
             p.wait()
-        rc = rc or p.returncode
+        if p.returncode:
+            failed.append((r, p.returncode))
+    for r, ef in enumerate(errs):
+        ef.seek(0)
+        for line in ef.read().decode(errors="replace").splitlines():
+            sys.stderr.write("[rank %d] %s\n" % (r, line))
+        ef.close()
+    if timed_out:
+        sys.stderr.write("bench.py: ranks did not finish within %d s (--spawn-timeout): killed\n" % args.spawn_timeout)
+        return 124
+    if failed:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % ", ".join("rank %d rc %d" % f for f in failed))
     sys.stdout.write(out.decode())
     sys.stdout.flush()
-    return rc
+    return rc or (failed[0][1] if failed else 0)
 
 
 class _StubEngine:
@@ -155,29 +180,30 @@ def run_rank(args):
             local_rank = 0   # rehearsal on a one-GPU box: every rank computes on cuda:0, the summaries travel over gloo
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    group = None           # the group that carries the path's collectives (None = the default gloo group)
     if world > 1:
+        import datetime
+        # The control plane always comes up over gloo first (bounded: a rank that never arrives fails the others after the
+        # timeout instead of hanging them).  RCCL is brought up as a SECOND group and probed; whether it works is agreed by an
+        # all-reduce over gloo, so either every rank uses RCCL or every rank uses gloo — never a mix.
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.pg_timeout))
         if coll_backend == "nccl":
-            # RCCL carries the path's only collectives (barrier, all-gather of times and summaries).  If it cannot come up on this
-            # node (every rank sees the same environment), the control plane falls back to gloo on host tensors and the line says
-            # so: the data path has no collective either way, so the measurement is the same
+            ok, why = 1, ""
             try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=args.pg_timeout), device_id=dev)
                 probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=group)
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError("RCCL all_reduce probe returned %r" % probe.item())
             except Exception as ex:  # noqa: BLE001
-                sys.stderr.write("bench.py rank %d: RCCL unavailable (%r): summaries over gloo\n" % (rank, ex))
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                coll_backend = "gloo (fallback: RCCL did not come up: %s)" % repr(ex)[:120]
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+                ok, why = 0, repr(ex)[:160]
+                sys.stderr.write("bench.py rank %d: RCCL did not come up (%s)\n" % (rank, why))
+            agree = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)          # over gloo
+            if int(agree.item()) != 1:
+                group = None
+                coll_backend = "gloo (fallback: RCCL did not come up on every rank%s)" % ((": " + why) if why else "")
     coll_dev = dev if coll_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
 
     from pyitd_amd.distributed import ShardedBatch
@@ -222,22 +248,21 @@ def run_rank(args):
 
     def barrier():
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(group=group)
 
     def step():
         sb.decompose(x_ptr, np.float32, n, rows_ptr, None, sp)
 
-    # BASELINE configs[2] beside the headline (informational: what one rank of the N > 1 runs does): 1024 x 2^20 signals.  It runs
-    # FIRST, its buffers stay allocated until the headline has been timed: ~0.25 s of sustained work, so the GPU enters the
-    # headline's warmup at its sustained clocks (the 12 ms of a 20-step timed region are too short to get there: 0.582 ms per
-    # step after an idle GPU + 5 warmup steps, 0.564 ms after 30 or more — `--no-extra` shows the former)
-    extra, extra_keep = None, None
-    if world == 1 and not stub and not args.no_extra and args.log2n == LOG2N and not args.chain:
-        try:
-            extra, extra_keep = batch_leg(torch, dev)
-        except Exception as ex:  # noqa: BLE001 — never at the cost of the headline line
-            extra = {"error": repr(ex)[:200]}
+    # Untimed warm-up inside bench.py, independent of every other leg: the headline's own step for at least --warm-ms (default
+    # 150 ms) — an idle GPU needs tens of milliseconds of sustained work to reach the clocks it then holds, and the 11 ms of
+    # a 20-step timed region are too short to get there (rounds 1-2 relied on the informational batch leg running first: 0.582
+    # vs 0.557 ms per step with --no-extra).  Then the driver's W warm-up steps.
     sync()
+    t_w = time.perf_counter()
+    while not stub and (time.perf_counter() - t_w) * 1e3 < args.warm_ms:
+        for _ in range(8):
+            step()
+        sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -261,15 +286,12 @@ def run_rank(args):
     if dist.is_initialized():
         tt = torch.tensor([elapsed_local], dtype=torch.float64, device=coll_dev)
         parts = [torch.empty_like(tt) for _ in range(world)]
-        dist.all_gather(parts, tt)
+        dist.all_gather(parts, tt, group=group)
         per_rank_ms = [float(p.item()) / args.steps * 1e3 for p in parts]
         elapsed = max(float(p.item()) for p in parts)
 
-    if extra_keep is not None:
-        extra_keep[2].close()
-        extra_keep = None
     # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal), all-gathered
-    table = sb.gather(device=coll_dev) if dist.is_initialized() else None
+    table = sb.gather(group=group, device=coll_dev) if dist.is_initialized() else None
 
     if not sharded and not stub:
         from pyitd_amd.engine import TIME_CHAIN, TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
@@ -316,6 +338,7 @@ def run_rank(args):
             "sharding": "contiguous ranges of independent signals per GPU (ShardedBatch), no data-path collective; "
                         "all-gather of the per-signal summaries only",
             "collective_backend": None if world == 1 else ("nccl (RCCL)" if coll_backend == "nccl" else coll_backend),
+            "device": None if stub else device_info(torch, dev),
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "rows_all_ranks": None if table is None else sorted(set(int(v) for v in table["n_rows"])),
             "signals_in_gathered_table": None if table is None else int(len(table["n_rows"])),
@@ -408,17 +431,164 @@ def run_rank(args):
         out["config"]["launch_form"] = "chain"
     if world == 1 and not stub and not args.no_cpu_baseline:
         out.update(cpu_legs(x_host, n, M, summ, rows, args))
-    if extra is not None:
-        out["config3_batch"] = extra
+    if world == 1 and not stub and not args.no_extra and args.log2n == LOG2N and not args.chain:
+        # informational legs, all timed AFTER the headline (never at its cost: each in its own try)
+        del rows, x
+        torch.cuda.empty_cache()
+        for key, leg in (("config3_batch", lambda: batch_leg(torch, dev)), ("short_signal_batches", lambda: short_signal_leg(torch, dev)),
+                         ("f_rows", lambda: f_rows_leg(torch, dev))):
+            try:
+                out[key] = leg()
+            except Exception as ex:  # noqa: BLE001
+                out[key] = {"error": repr(ex)[:200]}
+    wav = args.wav or os.environ.get("PYITD_WAV")
+    if world == 1 and not stub and wav:
         try:
-            out["short_signal_batches"] = short_signal_leg(torch, dev)
-        except Exception as ex:  # noqa: BLE001 — informational, never at the cost of the line
-            out["short_signal_batches"] = {"error": repr(ex)[:200]}
+            out["config5_audio"] = audio_leg(torch, dev, wav)
+        except Exception as ex:  # noqa: BLE001
+            out["config5_audio"] = {"error": repr(ex)[:200], "input": wav}
     print(json.dumps(out))
     sys.stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0
+
+
+def device_info(torch, dev):
+    """What the line was measured on: device name, visibility mask, RCCL version (for the first real N > 1 runs)."""
+    info = {"name": torch.cuda.get_device_name(dev), "index": dev.index,
+            "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"),
+            "hip": getattr(torch.version, "hip", None)}
+    try:
+        info["uuid"] = str(torch.cuda.get_device_properties(dev).uuid)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        info["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        info["rccl"] = None
+    return info
+
+
+def load_wav_mono(path):
+    """BASELINE.md section 3 / SURVEY 8d config 5: mono or first channel, float32 in [-1, 1]."""
+    from scipy.io import wavfile          # bench / tests only
+    sr, a = wavfile.read(path)
+    if a.ndim > 1:
+        a = a[:, 0]
+    if a.dtype.kind == "i":
+        a = a.astype(np.float64) / float(np.iinfo(a.dtype).max + 1)
+    elif a.dtype.kind == "u":             # 8-bit wavs are unsigned
+        a = (a.astype(np.float64) - 128.0) / 128.0
+    return sr, np.asarray(a, dtype=np.float32)
+
+
+def audio_leg(torch, dev, path, log2n=22, max_iteration=9):
+    """BASELINE configs[4] on real audio: the wav tiled to 2^22 samples (numpy.resize), 10 levels, device resident; knot indices
+    of every level bit-exact against the CPU oracle (the checker, outside the timed calls)."""
+    import pyitd_amd
+    from oracle import cpu_oracle
+    sr, a = load_wav_mono(path)
+    n = 1 << log2n
+    x_host = np.resize(a, n).astype(np.float32)
+    R = max_iteration + 2
+    x = torch.from_numpy(x_host).to(dev)
+    rows = torch.empty((R, n), dtype=torch.float64, device=dev)
+    bases = torch.empty((R, n), dtype=torch.float64, device=dev)
+    eng = pyitd_amd.Engine(n, 1, dev.index or 0)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, max_iteration, rows.data_ptr(), bases.data_ptr(), None)
+    s = eng.summary(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, max_iteration, rows.data_ptr(), None, None)
+    s = eng.summary(1)
+    dt = (time.perf_counter() - t0) / 10
+    nr = int(s["n_rows"][0])
+    ref = cpu_oracle.itd_lean(x_host, max_iteration, want_knots=True)
+    knots_ok = ref["rows"].shape[0] == nr
+    from pyitd_amd.itd import _engine_for
+    helper = _engine_for(n, dev.index or 0)
+    level_in = x_host.astype(np.float64)
+    for j in range(min(nr, len(ref["knots"]))):       # level j's input: the signal, then the stored baselines
+        got = helper.detect_host(level_in, 0)
+        knots_ok = knots_ok and np.array_equal(got, ref["knots"][j])
+        level_in = bases[j].cpu().numpy()
+    rows_ok = bool(np.array_equal(rows[:nr].cpu().numpy().view(np.uint64), ref["rows"].view(np.uint64)))
+    eng.close()
+    return {"input": os.path.basename(path), "sample_rate": int(sr), "samples_in_file": int(a.shape[0]),
+            "workload": "wav tiled to 2^%d float32 samples (numpy.resize), %d levels (max_iteration=%d)" % (log2n, max_iteration + 1, max_iteration),
+            "rows": nr, "knots_per_level": [int(v) for v in s["knot_counts"][0] if v >= 0],
+            "ms_per_decomposition": round(dt * 1e3, 4), "value": round(n / dt / 1e6, 1), "unit": "Msamples/s",
+            "knot_indices_bit_exact_every_level": bool(knots_ok), "rows_bit_exact": rows_ok}
+
+
+def f_rows_leg(torch, dev):
+    """SURVEY 8(f) operators, informational: ms, Msamples/s and the fraction of the HBM peak on each one's own byte model."""
+    import ctypes
+    import pyitd_amd
+    from pyitd_amd import _lib, spline, streaming
+    L = _lib.load()
+    n = 1 << 24
+    x = torch.from_numpy(sines_noise(n).astype(np.float64)).to(dev)
+    out = {}
+    eng = pyitd_amd.Engine(n, 1, dev.index or 0)
+    base = torch.empty(n, dtype=torch.float64, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def timed(f, reps=10):
+        f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # natural cubic (itd_fourier_decomposition.py:49-122), knots detected (itd.cpp:159-169): asynchronous batch entry
+    dt = timed(lambda: L.itd_baseline_extract_cubic_batch_f64(eng._h, x.data_ptr(), n, 1, n, None, 0, 0, base.data_ptr(), n, info.data_ptr(), None))
+    m = int(info[0].item())
+    # byte model: signal read by the detection (8) + baseline written (8) per sample; per knot: ordered list written and read by
+    # both sweeps and the evaluation (4 x 4), K / forward / final arrays written once and read once (3 x 16)
+    by = 16.0 * n + 64.0 * m
+    out["cubic_2p24"] = {"operator": "itd_baseline_extract_fast, knots by itd.cpp:161-168 (%d knots)" % m, "ms": round(dt * 1e3, 4),
+                         "Msamples_per_s": round(n / dt / 1e6, 1), "bytes_model": "16 B/sample + 64 B/knot", "frac_of_peak": round(by / dt / 1e9 / HBM_PEAK_GBPS, 4)}
+    # instantaneous amplitude / phase / frequency (README.md:13-21, 41-55): reads the rotation twice (8 + 8), writes three rows (24)
+    rot = x - base
+    amp, ph, fr = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    dt = timed(lambda: L.itd_instantaneous_f64(eng._h, rot.data_ptr(), n, amp.data_ptr(), ph.data_ptr(), fr.data_ptr(), None))
+    out["instantaneous_2p24"] = {"ms": round(dt * 1e3, 4), "Msamples_per_s": round(n / dt / 1e6, 1), "bytes_model": "8 + 24 B/sample (+ 8 for the crossing scan)",
+                                 "frac_of_peak": round(40.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 4)}
+    eng.close()
+    del x, base, rot, amp, ph, fr
+    # totalextract2d on a 512 x 512 image: the only timing the reference records (siftED2D.ipynb cell 3: 10.1457 s)
+    img = np.random.default_rng(5).integers(0, 256, (512, 512)).astype(np.float64)
+    np.random.seed(1)
+    spline.totalextract2d(img)
+    t0 = time.perf_counter()
+    spline.totalextract2d(img)
+    dt = time.perf_counter() - t0
+    out["totalextract2d_512x512"] = {"ms": round(dt * 1e3, 3), "reference_recorded_s": 10.1457, "reference_source": "siftED2D.ipynb cell 3 (author's machine, numba)",
+                                     "note": "host arrays in and out, host noise generation included"}
+    # block-wise operation (itd.cpp:31-44): microseconds per pushed 4096-sample block, device form
+    Lb, nb = 4096, 64
+    xs = torch.from_numpy(np.cumsum(np.random.default_rng(1).standard_normal(Lb * nb)) * 0.05).to(dev)[None].contiguous()
+    ob, orot = torch.empty_like(xs), torch.empty_like(xs)
+    for kind in ("cubic", "linear"):
+        st = streaming.Stream(Lb, 1, kind, margin=8)
+        sp = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            for k in range(nb):
+                o = max(k - 1, 0) * Lb
+                st.push_dev(xs[:, k * Lb:].data_ptr(), Lb * nb, ob[:, o:].data_ptr(), Lb * nb, orot[:, o:].data_ptr(), Lb * nb, sp)
+            st.flush_dev(ob[:, (nb - 1) * Lb:].data_ptr(), Lb * nb, orot[:, (nb - 1) * Lb:].data_ptr(), Lb * nb, sp)
+        dt = timed(run, 5)
+        out["stream_%s_block4096" % kind] = {"us_per_block": round(dt / nb * 1e6, 2), "form": "device buffers, asynchronous pushes"}
+        st.close()
+    return out
 
 
 def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
@@ -442,11 +612,13 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
     dt = (time.perf_counter() - t0) / steps
     s = eng.summary(batch)     # of the last timed call
     alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
-    return {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
+    out = {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
             "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "hbm_algorithmic_GBps": round(alg, 1), "frac_of_peak_whole_decomposition": round(alg / HBM_PEAK_GBPS, 4),
             "rows_per_signal": sorted(set(int(v) for v in s["n_rows"])),
-            "order": "timed before the headline's warmup; its buffers are released after the headline's timed region"}, (x, rows, eng)
+            "order": "timed after the headline"}
+    eng.close()
+    return out
 
 
 def short_signal_leg(torch, dev, steps=10):
@@ -580,6 +752,11 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 on a one-GPU box: all ranks compute on cuda:0 and gather over gloo (checks the sharded path end to end; "
                          "the line says so and is not a scaling measurement)")
+    ap.add_argument("--warm-ms", type=float, default=150.0, help="untimed warm-up of the headline's own step before the W warm-up steps (ms)")
+    ap.add_argument("--spawn-timeout", type=int, default=900, help="plain --gpus N: seconds until the parent kills its ranks")
+    ap.add_argument("--pg-timeout", type=int, default=120, help="seconds a rank waits for the process group / a collective")
+    ap.add_argument("--wav", default=None, help="BASELINE configs[4] on a user-supplied wav (mono / first channel, float32 in [-1, 1], "
+                                                "numpy.resize to 2^22, 10 levels): adds config5_audio to the line (also: PYITD_WAV)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher only
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -53,6 +53,13 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
     if (keep_in_nan) st[b].in_nan = in_nan;   // the NaN-input repeat needs to know which signals hold one (k_nan_level0)
 }
 
+// totals[2b + 1] = signal b holds a NaN (k_compact): OR them into one flag
+__global__ void k_or_nan_flags(const int32_t *__restrict__ totals, int batch, int32_t *__restrict__ flag)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch && totals[2 * b + 1]) atomicOr(flag, 1);
+}
+
 __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1755,23 +1762,34 @@ int itd_crossways_f64(itd_engine *e, const double *img_dev, int32_t planes, int3
     auto tr = [&](const double *in, int r, int c, double *out) {
         k_transpose<<<dim3((c + 31) / 32, (r + 31) / 32, planes), 256, 0, st>>>(in, r, c, out);
     };
-    auto ext = [&](const double *in, int sigs, int len, double *out) {   // every row of `sigs` x `len`
-        return spline_enqueue(e, in, len, sigs, len, min_extrema, out, len, nullptr, 0, st, w);
+    HIP_TRY(e, hipMemsetAsync(e->d_flag, 0, sizeof(int32_t), st));
+    // every row of `sigs` x `len`, in chunks of at most 65535 signals (they are the launches' grid.y: 20 ensemble planes of a
+    // 3840 x 2160 image are 76 800 rows per stage); the NaN-input flags of every chunk of every stage are OR-ed into d_flag
+    auto ext = [&](const double *in, int64_t sigs, int len, double *out) {
+        for (int64_t s0 = 0; s0 < sigs; s0 += kMaxGridY) {
+            const int nb = (int)std::min<int64_t>(kMaxGridY, sigs - s0);
+            const int rc2 = spline_enqueue(e, in + s0 * len, len, nb, len, min_extrema, out + s0 * len, len, nullptr, 0, st, w);
+            if (rc2) return rc2;
+            k_or_nan_flags<<<(nb + 255) / 256, 256, 0, st>>>(w.totals, nb, e->d_flag);
+        }
+        return (int)ITD_OK;
     };
     // lengthwise = rows(data); then its columns
-    if ((rc = ext(img_dev, planes * rows, cols, A))) return rc;             // A = lengthwise (rows done)
+    if ((rc = ext(img_dev, (int64_t)planes * rows, cols, A))) return rc;    // A = lengthwise (rows done)
     tr(A, rows, cols, Bq);                                                  // Bq = lengthwise^T  [cols][rows]
-    if ((rc = ext(Bq, planes * cols, rows, A))) return rc;                  // A = columns of lengthwise, transposed layout
+    if ((rc = ext(Bq, (int64_t)planes * cols, rows, A))) return rc;         // A = columns of lengthwise, transposed layout
     tr(A, cols, rows, C);                                                   // C = lengthwise, final [rows][cols]
     // crosswise = columns(data); then its rows
     tr(img_dev, rows, cols, A);                                             // A = data^T
-    if ((rc = ext(A, planes * cols, rows, Bq))) return rc;                  // Bq = columns of data (transposed layout)
+    if ((rc = ext(A, (int64_t)planes * cols, rows, Bq))) return rc;         // Bq = columns of data (transposed layout)
     tr(Bq, cols, rows, A);                                                  // A = crosswise [rows][cols]
-    if ((rc = ext(A, planes * rows, cols, Bq))) return rc;                  // Bq = rows of crosswise
+    if ((rc = ext(A, (int64_t)planes * rows, cols, Bq))) return rc;         // Bq = rows of crosswise
     k_mean2<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(C, Bq, (int64_t)cnt, out_dev);
     HIP_TRY(e, hipGetLastError());
-    // NaN input: the four detections' flags are gone but the last one's is representative enough for an error return
-    return spline_finish(e, planes * rows, w, nullptr, st);
+    int32_t nan_in = 0;     // a NaN in any row of any of the four stages
+    HIP_TRY(e, hipMemcpyAsync(&nan_in, e->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return nan_in ? ITD_ERR_NONFINITE : ITD_OK;
 }
 
 int itd_crossways_host_f64(itd_engine *e, const double *img_host, int32_t planes, int32_t rows, int32_t cols, int32_t min_extrema,

@@ -73,11 +73,16 @@ class ShardedBatch:
     `engine` may be injected (tests run the sharding logic against a stand-in on CPU ranks).
     """
 
-    def __init__(self, batch, n, max_iteration, world, rank, device=0, engine=None):
+    def __init__(self, batch, n, max_iteration, world, rank, device=0, engine=None, local_limit=None):
         self.batch, self.n, self.max_iteration = int(batch), int(n), int(max_iteration)
         self.world, self.rank = int(world), int(rank)
         self.lo, self.hi = shard_range(self.batch, self.world, self.rank)
         self.n_local = self.hi - self.lo
+        # local_limit (tests, rehearsals): only the first `local_limit` signals of the rank's real range [lo, hi) are
+        # decomposed — the range itself stays the real one; such an object cannot take part in the all-gather
+        self.local_limit = None if local_limit is None else int(local_limit)
+        if self.local_limit is not None:
+            self.n_local = min(self.n_local, self.local_limit)
         if engine is None:
             from .engine import Engine
             engine = Engine(self.n, max(self.n_local, 1), device)
@@ -97,4 +102,40 @@ class ShardedBatch:
 
     def gather(self, group=None, device=None):
         """Synchronise with the local decomposition and all-gather the summaries: the whole batch's table, in batch order."""
+        if self.local_limit is not None and self.n_local != self.hi - self.lo:
+            raise ValueError("a ShardedBatch with local_limit decomposes only part of its range: no all-gather")
         return gather_summaries(self.local_summary(), self.batch, group=group, device=device)
+
+    def scatter_from(self, root, x_root=None, group=None, out=None):
+        """The batch lives on ONE rank (`root`: x_root = its [batch, n] tensor, None elsewhere): hand every rank its contiguous
+        shard — the north star's "trivial batch scatter" — as ONE group of point-to-point transfers (grouped send / recv:
+        ncclSend / ncclRecv over xGMI under RCCL, all of the root's links busy at once; gloo on CPU tensors in the tests).
+        Returns this rank's [n_local, n] tensor (`out` if given).  Ranks that synthesise or load their own shard (the bench
+        default) never call this."""
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if world != self.world or rank != self.rank:
+            raise ValueError("process group and ShardedBatch disagree on world / rank")
+        if rank == root:
+            if x_root is None or tuple(x_root.shape) != (self.batch, self.n):
+                raise ValueError("the root passes the whole batch [%d, %d]" % (self.batch, self.n))
+            mine = x_root[self.lo:self.hi]
+            ops = []
+            for r in range(world):
+                lo, hi = shard_range(self.batch, world, r)
+                if r != root and hi > lo:
+                    ops.append(dist.P2POp(dist.isend, x_root[lo:hi].contiguous(), r, group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if out is None:
+                return mine
+            out.copy_(mine)
+            return out
+        if out is None:
+            raise ValueError("a receiving rank passes `out`: its [n_local, n] tensor of the batch's dtype, on its device")
+        if self.hi > self.lo:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, out, root, group)]):
+                w.wait()
+        return out

@@ -94,6 +94,62 @@ def test_two_ranks_decompose_their_shards_and_gather_in_batch_order():
         assert got["knot_counts"][b][: len(r["knot_counts"])] == r["knot_counts"].tolist()
 
 
+def _scatter_worker(rank, world, port, batch, n, m, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyitd_amd.distributed import ShardedBatch
+        sb = ShardedBatch(batch, n, m, world, rank, engine=_OracleEngine())
+        root = 1                                        # not rank 0: the root's own shard is the last one
+        x_root = torch.from_numpy(np.stack([sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0) for b in range(batch)])) if rank == root else None
+        out = torch.full((sb.n_local, n), -7.0, dtype=torch.float32)
+        mine = sb.scatter_from(root, x_root, out=out)   # one group of point-to-point transfers
+        x = mine.numpy()
+        rows = np.zeros((sb.n_local, m + 2, n))
+        sb.decompose(x, np.float32, n, rows)
+        full = sb.gather()
+        if rank == 0:
+            q.put({"table": {k: v.tolist() for k, v in full.items()}, "first": x[0, :8].tolist(), "lo": sb.lo})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scatter_from_one_rank_then_shard_and_gather():
+    """north star: "RCCL over xGMI only for the trivial batch scatter/gather" — the batch lives on rank 1, every rank receives
+    its contiguous shard, decomposes it and the summaries are all-gathered in batch order."""
+    import torch.multiprocessing as mp
+    batch, n, m = 5, 2048, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, 2, port, batch, n, m, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import cpu_oracle
+    assert got["lo"] == 0 and got["first"] == sines_noise(n, seed=0)[:8].tolist()      # rank 0 received signal 0
+    t = got["table"]
+    assert len(t["n_rows"]) == batch
+    for b in range(batch):
+        r = cpu_oracle.itd_lean(sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0), m)
+        assert t["n_rows"][b] == r["rows"].shape[0]
+        assert t["knot_counts"][b][: len(r["knot_counts"])] == r["knot_counts"].tolist()
+
+
+def test_local_limit_keeps_the_real_range():
+    from pyitd_amd.distributed import ShardedBatch
+    sb = ShardedBatch(8192, 1 << 20, 7, 8, 5, engine=_OracleEngine(), local_limit=4)
+    assert (sb.lo, sb.hi, sb.n_local) == (5 * 1024, 6 * 1024, 4)
+    with pytest.raises(ValueError):
+        sb.gather()
+
+
 def test_summary_packing_keeps_nan_levels():
     from pyitd_amd.distributed import MAX_ROWS, pack_summary, unpack_summary
     s = {"n_rows": np.array([3, 1], np.int32), "n_baselines": np.array([2, 0], np.int32), "stop": np.array([1, 0], np.int32),

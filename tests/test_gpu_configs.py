@@ -88,8 +88,9 @@ def test_config4_sharding_emulated_on_one_gpu(P, torch, oracle):
     for rank in range(world):
         lo, hi = shard_range(G, world, rank)
         assert hi - lo == 1024 and lo == rank * 1024
-        sb = ShardedBatch(per_rank, n, m, 1, 0, engine=eng)      # the rank's reduced shard: signals lo .. lo+per_rank-1
-        mine = list(range(lo, lo + per_rank))
+        sb = ShardedBatch(G, n, m, world, rank, engine=eng, local_limit=per_rank)   # the rank's REAL range of the 8192-signal batch,
+        assert (sb.lo, sb.hi, sb.n_local) == (lo, hi, per_rank)                      # of which the first per_rank signals run here
+        mine = list(range(sb.lo, sb.lo + sb.n_local))
         x_host = np.stack([_batch_signal(b, n) for b in mine])
         x = torch.from_numpy(x_host).cuda()
         torch.cuda.synchronize()

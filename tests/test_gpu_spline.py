@@ -95,3 +95,22 @@ def test_meitd_and_xitd_match_reference(P, name):
         _close(lo, g["low"], name + " low", 1e-10)
     _close(res, g["residual"], name + " residual", 1e-10)
     _close(meitd.XITD(g["x"].copy()), g["xitd"], name + " XITD", 1e-10)
+
+
+def test_crossways_with_more_rows_than_one_grid(P):
+    """20 planes x 3300 rows = 66 000 signals per sweep stage: more than one launch's grid.y (65 535) — the stages run in
+    chunks; every plane must equal the same plane run on its own, and a NaN anywhere is still reported."""
+    from pyitd_amd.itd import _engine_for
+    from pyitd_amd import ITDError
+    rng = np.random.default_rng(11)
+    planes, rows, cols = 20, 3300, 24
+    img = rng.integers(0, 256, (planes, rows, cols)).astype(np.float64)
+    eng = _engine_for(max(rows, cols))
+    full = eng.crossways_host(img, 10)
+    for p in (0, 7, 19):
+        one = eng.crossways_host(img[p:p + 1], 10)
+        assert np.array_equal(full[p].view(np.uint64), one[0].view(np.uint64)), "plane %d" % p
+    bad = img.copy()
+    bad[0, 5, 3] = np.nan            # in the FIRST chunk of the first stage only
+    with pytest.raises(ITDError):
+        eng.crossways_host(bad, 10)
