@@ -291,6 +291,15 @@ int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t 
                                     int64_t rot_stride, int32_t *knots_host, void *stream);
 int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
                                          double *baseline_host, double *rot_host, int32_t *knots_host);
+/* the host form with one more optional output (ABI revision 6): baseline_knots_host [batch] = the knot count (ITD_DETECT_KNOTS) of
+ * every PRODUCED baseline — MEITD's loops ask for it right after an extraction (MEITD.py:362-363, :497-505); it is counted on the
+ * device from the result that is already there (no second upload, no index list) */
+int itd_baseline_extract_spline_host2_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
+                                          double *baseline_host, double *rot_host, int32_t *knots_host, int32_t *baseline_knots_host);
+/* Knot counts of `batch` contiguous host signals under predicate `mode` (ITD_DETECT_*) without building or copying any index
+ * list — `matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size` (MEITD.py:350, :376, :409) is mode ITD_DETECT_KNOTS.
+ * Plain rules; returns ITD_ERR_NONFINITE (counts filled in) if a signal holds a NaN.  batch <= 65535. */
+int itd_count_knots_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t mode, int32_t *counts_host);
 /* crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols float64 (the ensemble
  * members of retrieve_statistical_image_component go through in one call): the operator over every row, then over every
  * column of that; over every column, then every row of that; the mean of the two.  Transposes and the mean run on the GPU. */

@@ -47,6 +47,8 @@ ABI = {
     "itd_find_extrema_host_f64": (_INT, [_P, _P, _I64, _P, _P]),
     "itd_baseline_extract_spline_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "itd_baseline_extract_spline_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "itd_baseline_extract_spline_host2_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "itd_count_knots_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P]),
     "itd_crossways_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "itd_crossways_host_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "itd_instantaneous_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P]),

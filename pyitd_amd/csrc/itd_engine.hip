@@ -1729,6 +1729,15 @@ int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t 
 int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
                                          double *baseline_host, double *rot_host, int32_t *knots_host)
 {
+    return itd_baseline_extract_spline_host2_f64(e, x_host, n, batch, min_extrema, baseline_host, rot_host, knots_host, nullptr);
+}
+
+// the same, plus (optionally) the knot count of every PRODUCED baseline — what MEITD's loops ask for right after an
+// extraction (MEITD.py:362-363, :497-505: `count = matlab_detect_peaks(baseline).size + ...`): one more launch on the data
+// already on the device instead of another upload / list download
+int itd_baseline_extract_spline_host2_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
+                                          double *baseline_host, double *rot_host, int32_t *knots_host, int32_t *baseline_knots_host)
+{
     if (!e || !x_host || !baseline_host) return ITD_ERR_INVALID_ARG;
     if (n < 3 || batch < 1) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
@@ -1740,10 +1749,42 @@ int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, in
     HIP_TRY(e, hipMemcpyAsync(d_x, x_host, cnt * sizeof(double), hipMemcpyHostToDevice, st));
     rc = itd_baseline_extract_spline_f64(e, d_x, n, batch, n, min_extrema, d_b, n, rot_host ? d_r : nullptr, n, knots_host, st);
     if (rc) return rc;
+    std::vector<int32_t> tot;
+    if (baseline_knots_host) {
+        if (batch > kMaxGridY) return ITD_ERR_INVALID_ARG;
+        DetectWs w;
+        rc = detect_enqueue(e, d_b, n, n, batch, (int)kKnots, -1, st, w, nullptr, 0, false);   // counts only
+        if (rc) return rc;
+        tot.resize(2 * (size_t)batch);
+        HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(e, hipMemcpyAsync(baseline_host, d_b, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
     if (rot_host) HIP_TRY(e, hipMemcpyAsync(rot_host, d_r, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
+    if (baseline_knots_host) for (int b = 0; b < batch; ++b) baseline_knots_host[b] = tot[2 * (size_t)b];
     return ITD_OK;
+}
+
+// knot counts of host signals without any index list (matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size for mode
+// ITD_DETECT_KNOTS, MEITD.py:350, :376, :409): upload, one counting launch pair, 4 bytes per signal back
+int itd_count_knots_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t mode, int32_t *counts_host)
+{
+    if (!e || !x_host || !counts_host || n < 3 || batch < 1 || batch > kMaxGridY || mode < 0 || mode > 4) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    const size_t cnt = (size_t)n * (size_t)batch;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, cnt * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, x_host, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    DetectWs w;
+    rc = detect_enqueue(e, (const double *)e->d_io_x, n, n, batch, mode, -1, st, w, nullptr, 0, false);
+    if (rc) return rc;
+    std::vector<int32_t> tot(2 * (size_t)batch);
+    HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    bool nan_in = false;
+    for (int b = 0; b < batch; ++b) { counts_host[b] = tot[2 * (size_t)b]; nan_in = nan_in || tot[2 * (size_t)b + 1]; }
+    return nan_in ? ITD_ERR_NONFINITE : ITD_OK;     // counted under the plain rules: see itd_detect_* for detect_peaks' NaN branch
 }
 
 // crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols (device, contiguous):

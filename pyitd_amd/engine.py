@@ -255,16 +255,27 @@ class Engine:
                                                                  idx, base_ptr, base_stride, info_ptr, stream))
 
     # ---- the FITPACK flavour of the baseline and its 2-D consumers (itd_baseline_extract_spline_*, itd_crossways_*) --------
-    def spline_extract_host(self, x, min_extrema=10, want_rotation=False):
-        """x[B, n] float64 -> (baseline[B, n], rotation[B, n] or None, knots[B]) (numba_accelerated_itd.py:182-211)."""
+    def spline_extract_host(self, x, min_extrema=10, want_rotation=False, want_baseline_knots=False):
+        """x[B, n] float64 -> (baseline[B, n], rotation[B, n] or None, knots[B]) (numba_accelerated_itd.py:182-211);
+        want_baseline_knots: a fourth item, the knot count of every produced baseline (counted on the device)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         B, n = x.shape
         base = np.empty((B, n))
         rot = np.empty((B, n)) if want_rotation else None
         knots = np.zeros(B, np.int32)
-        self._check(self._L.itd_baseline_extract_spline_host_f64(self._h, _np_ptr(x), n, B, int(min_extrema), _np_ptr(base),
-                                                                 _np_ptr(rot), _np_ptr(knots)))
-        return base, rot, knots
+        bk = np.zeros(B, np.int32) if want_baseline_knots else None
+        self._check(self._L.itd_baseline_extract_spline_host2_f64(self._h, _np_ptr(x), n, B, int(min_extrema), _np_ptr(base),
+                                                                  _np_ptr(rot), _np_ptr(knots), _np_ptr(bk)))
+        return (base, rot, knots, bk) if want_baseline_knots else (base, rot, knots)
+
+    def count_knots_host(self, x, mode=DETECT_KNOTS):
+        """Knot counts of x[B, n] (or one signal [n]) under predicate `mode`: no index list is built or copied."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        x2 = x.reshape(1, -1) if x.ndim == 1 else x
+        out = np.zeros(x2.shape[0], np.int32)
+        self._check(self._L.itd_count_knots_host_f64(self._h, _np_ptr(x2), x2.shape[1], x2.shape[0], int(mode), _np_ptr(out)),
+                    allow=(ITD_ERR_NONFINITE,))
+        return out
 
     def crossways_host(self, images, min_extrema=10):
         """images[P, rows, cols] float64 -> crossways_itd_baseline_extract of every plane (siftED2D.ipynb cell 1)."""

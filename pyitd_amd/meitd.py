@@ -51,8 +51,20 @@ def weighted_permutation_entropy(time_series, order=3, normalize=False):
 
 
 def _num_extrema(x, device):
-    """matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size: the knot count of x (GPU)."""
-    return int(len(_engine_for(len(x), device).detect_host(numpy.ascontiguousarray(x, dtype=numpy.float64))))
+    """matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size: the knot count of x — counted on the GPU, four bytes come
+    back (no index list is built or copied)."""
+    return int(_engine_for(len(x), device).count_knots_host(x)[0])
+
+
+def _extract_and_count(x, device):
+    """itd_baseline_extract(x) (MEITD.py:303-338) and the extrema count of its baseline in ONE engine call: the loops of
+    MEITD.py:362-363 and :497-505 ask for that count right after every extraction."""
+    from .spline import _eng
+    x = numpy.asarray(x, dtype=numpy.float64)
+    base, rot, knots, bk = _eng(len(x), device).spline_extract_host(x[None, :], 0, want_rotation=True, want_baseline_knots=True)
+    if knots[0] < 2:
+        raise TypeError("m > k must hold")        # what scipy.interpolate.splrep raises for fewer than 4 data sites
+    return rot[0], base[0], int(bk[0])
 
 
 def retrieve_proper_rotation(x, WPEMAX, device=0):
@@ -66,8 +78,7 @@ def retrieve_proper_rotation(x, WPEMAX, device=0):
     rotation = numpy.zeros(len(x))
     baseline = x.copy()
     while count > 5:
-        rotation, baseline = itd_baseline_extract_spline(baseline, device)
-        count = _num_extrema(baseline, device)
+        rotation, baseline, count = _extract_and_count(baseline, device)
         if accept:
             return rotation, 1
     return x, 0
@@ -139,8 +150,7 @@ def MEITD(data, max_iteration=40, WPEMAX=0.6, device=0):
             if count < 5:
                 continue
             for _ in range(digs):
-                rotation[:], baseline[:] = itd_baseline_extract_spline(baseline[:], device)
-                count = _num_extrema(baseline, device)
+                rotation[:], baseline[:], count = _extract_and_count(baseline[:], device)
                 if count < 5:
                     break
             digs += 1

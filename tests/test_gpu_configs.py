@@ -309,7 +309,12 @@ def _rank_main(rank, world, port, q):
         from pyitd_amd.distributed import ShardedBatch
         batch, n, m = 7, 1 << 16, 5
         sb = ShardedBatch(batch, n, m, world, rank, device=rank)
-        x = torch.from_numpy(np.stack([_batch_signal(b, n) for b in range(sb.lo, sb.hi)])).cuda()
+        # the batch lives on the LAST rank's GPU and is scattered from there (grouped ncclSend / ncclRecv under RCCL: the north
+        # star's "trivial batch scatter"); with one rank the root keeps its own range
+        root = world - 1
+        x_root = torch.from_numpy(np.stack([_batch_signal(b, n) for b in range(batch)])).cuda() if rank == root else None
+        x = sb.scatter_from(root, x_root, out=torch.full((sb.n_local, n), -1.0, dtype=torch.float32, device="cuda"))
+        assert bool((x[0] == torch.from_numpy(_batch_signal(sb.lo, n)).cuda()).all())
         rows = torch.empty((sb.n_local, m + 2, n), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
         sb.decompose(x.data_ptr(), np.float32, n, rows.data_ptr())

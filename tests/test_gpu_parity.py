@@ -1,5 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
 Bit-exact on knot indices (integers) AND on the float64 rows (stricter than the 1e-6 the north star allows)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -250,6 +252,33 @@ def test_config5_real_audio_tiled_2p22(P, oracle):
         assert got.dtype == np.int64
         np.testing.assert_array_equal(got, ref["knots"][j], err_msg="level %d" % j)
     assert [int(v) for v in dec.knot_counts[: len(ref["knot_counts"])]] == ref["knot_counts"].tolist()
+
+
+def _wav_inputs(tmp_path):
+    """A stereo 16-bit 48 kHz wav written here from the reference's own clip (the ingestion path always runs) and, when the
+    user supplies one, the file named by PYITD_WAV (daveandsimon.wav / girl.wav are missing blobs upstream)."""
+    from scipy.io import wavfile
+    radio = load_golden("radio8000_input")["x"]
+    pcm = np.clip(np.round(radio / np.max(np.abs(radio)) * 30000), -32768, 32767).astype(np.int16)
+    path = str(tmp_path / "clip_stereo16.wav")
+    wavfile.write(path, 48000, np.stack([pcm, pcm[::-1]], axis=1))
+    out = [(path, "generated stereo int16 clip")]
+    if os.environ.get("PYITD_WAV"):
+        out.append((os.environ["PYITD_WAV"], "user-supplied (PYITD_WAV)"))
+    return out
+
+
+def test_config5_from_wav_files(P, oracle, tmp_path):
+    """BASELINE configs[4] through the wav ingestion path of bench.py (--wav / PYITD_WAV): mono / first channel, float32 in
+    [-1, 1], numpy.resize to 2^22, 10 levels; knot indices of every level and the rows bit-exact against the oracle."""
+    import torch
+    import bench
+    for path, label in _wav_inputs(tmp_path):
+        sr, a = bench.load_wav_mono(path)
+        assert a.dtype == np.float32 and a.ndim == 1 and np.max(np.abs(a)) <= 1.0, label
+        res = bench.audio_leg(torch, torch.device("cuda", 0), path)
+        assert res["knot_indices_bit_exact_every_level"] and res["rows_bit_exact"], (label, res)
+        assert res["rows"] >= 2 and res["input"] == os.path.basename(path)
 
 
 @pytest.mark.parametrize("log2n,cycles", [(18, 3.0), (18, 0.8), (21, 2.5), (21, 40.0)])
