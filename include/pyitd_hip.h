@@ -291,6 +291,18 @@ int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t 
                                     int64_t rot_stride, int32_t *knots_host, void *stream);
 int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,
                                          double *baseline_host, double *rot_host, int32_t *knots_host);
+/* How the spline's coefficients are obtained (ABI revision 6):
+ *   ITD_SPLINE_SERIAL    FITPACK's own row-by-row sweep, one GPU thread per signal, bit-level against scipy's splrep: right for
+ *                        thousands of short rows (the image sweeps always use it)
+ *   ITD_SPLINE_PARALLEL  the same interpolating not-a-knot spline from its second derivatives, parallel in the knots
+ *                        (pyitd_amd/csrc/itd_nak.hpp): equal to FITPACK's result to rounding (~1e-14 of the signal's scale; the
+ *                        north star allows 1e-6), not bit for bit; right for ONE long signal (MEITD.py:344-549 calls the operator on
+ *                        single 1-D signals in a loop)
+ *   ITD_SPLINE_AUTO      (default) parallel for calls of fewer than 256 signals of at least 1024 samples, serial otherwise */
+#define ITD_SPLINE_AUTO 0
+#define ITD_SPLINE_SERIAL 1
+#define ITD_SPLINE_PARALLEL 2
+int itd_set_spline_solver(itd_engine *e, int32_t solver);
 /* the host form with one more optional output (ABI revision 6): baseline_knots_host [batch] = the knot count (ITD_DETECT_KNOTS) of
  * every PRODUCED baseline — MEITD's loops ask for it right after an extraction (MEITD.py:362-363, :497-505); it is counted on the
  * device from the result that is already there (no second upload, no index list) */

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_chain.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_stream.hpp"), os.path.join(_HERE, "csrc", "itd_engine_batch.inc"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"),
+HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_chain.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_stream.hpp"), os.path.join(_HERE, "csrc", "itd_engine_batch.inc"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"), os.path.join(_HERE, "csrc", "itd_nak.hpp"),
            os.path.join(_HERE, "csrc", "itd_fitpack.hpp"), os.path.join(_HERE, "csrc", "itd_resident.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
 
@@ -48,6 +48,7 @@ ABI = {
     "itd_baseline_extract_spline_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "itd_baseline_extract_spline_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "itd_baseline_extract_spline_host2_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "itd_set_spline_solver": (_INT, [_P, _I32]),
     "itd_count_knots_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P]),
     "itd_crossways_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "itd_crossways_host_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(kScanThreads) void k_cubic_sweep(CubicArgs A)
 // j(i) = number of k in [1, idx-1] with e[k] <= i (the j_lookup loop :107-111 for increasing knots), t = (i - e[j]) / h[j].
 // out holds the samples lo .. hi-1 of every signal (out[sig * out_stride + i - lo]); a signal without a valid job is left
 // untouched (itd.cpp:170-172) or, with copy_invalid, copied (the block-wise recipe: "the block is its own baseline").
-template <int TW>
+// NAK = the interpolating not-a-knot spline of itd_nak.hpp on the same representation (values K, second derivatives b at the
+// sites e[0..idx]): every segment is cubic — the reference operator's linear last segment (:117) is the natural variant's alone.
+template <int TW, bool NAK = false>
 __global__ __launch_bounds__(64) void k_cubic_eval(CubicArgs A, int64_t lo, int64_t hi, double *__restrict__ out, int64_t out_stride,
                                                    int copy_invalid, double *__restrict__ rot = nullptr, int64_t rot_stride = 0)
 {
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(64) void k_cubic_eval(CubicArgs A, int64_t lo, int6
         const double t = (double)(i - (int64_t)ej) / hj;                            // :115
         const double Kj = K[j], Kn = K[j + 1];
         double v;
-        if (j == idx - 2) {
+        if (!NAK && j == idx - 2) {
             v = (1 - t) * Kj + t * Kn;                                              // :117
         } else {
             const double omt = 1 - t;

@@ -26,6 +26,7 @@
 #include "itd_stream.hpp"
 #include "itd_tfe.hpp"
 #include "itd_spline.hpp"
+#include "itd_nak.hpp"
 
 #ifndef ITD_TILE
 #define ITD_TILE 512
@@ -122,6 +123,7 @@ struct itd_engine {
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
     bool resident_attr[12] = {};
     int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
+    int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
     int64_t ws_bytes = 0;
@@ -1695,11 +1697,42 @@ int spline_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t
     return ITD_OK;
 }
 
-// after spline_enqueue: synchronise, fetch the per-signal knot counts, report NaN input
-int spline_finish(itd_engine *e, int batch, const SplineWs &w, int32_t *knots_host, hipStream_t st)
+// The same operator, parallel in the knots (itd_nak.hpp): the interpolating not-a-knot spline from its second derivatives.
+// Asynchronous on st; *totals_out = the device array of {knot count, NaN flag} per signal.
+int nak_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_stride, int min_extrema, double *base,
+                int64_t base_stride, double *rot, int64_t rot_stride, hipStream_t st, const int32_t **totals_out)
+{
+    DetectWs w;
+    int rc = detect_enqueue(e, x, x_stride, n, batch, (int)kKnots, -1, st, w);     // kidx[b] = [0, knots, n-1]
+    if (rc) return rc;
+    const int64_t L = n + 2;
+    const size_t jobs_b = (((size_t)batch * sizeof(CubicJob)) + 255) & ~(size_t)255;
+    rc = grow(e, &e->d_cub, &e->cub_bytes, jobs_b + 4 * (size_t)batch * (size_t)L * sizeof(double));
+    if (rc) return rc;
+    CubicJob *jobs = (CubicJob *)e->d_cub;
+    double *arr = (double *)((char *)e->d_cub + jobs_b);
+    CubicArgs A;
+    A.x = x; A.x_stride = x_stride; A.n = n;
+    A.e = w.kidx; A.e_stride = w.kidx_stride;
+    A.jobs = jobs; A.job_stride = 1;
+    A.K = arr; A.bf = arr + (size_t)batch * L; A.b = arr + 2 * (size_t)batch * L; A.a_stride = L;
+    double *cp = arr + 3 * (size_t)batch * L;
+    k_nak_jobs<<<(batch + 255) / 256, 256, 0, st>>>(jobs, batch, w.totals, min_extrema);
+    k_nak_values<<<dim3((unsigned)((n + 255) / 256), batch), 256, 0, st>>>(A);
+    const unsigned runs = (unsigned)((n + kNakRun - 1) / kNakRun);
+    k_nak_forward<<<dim3((runs + 63) / 64, batch), 64, 0, st>>>(A, cp);
+    k_nak_backward<<<dim3((runs + 63) / 64, batch), 64, 0, st>>>(A, cp);
+    k_cubic_eval<T, true><<<dim3((unsigned)tiles_of(n), batch), kWave, 0, st>>>(A, 0, n, base, base_stride, 1, rot, rot_stride);
+    HIP_TRY(e, hipGetLastError());
+    *totals_out = w.totals;
+    return ITD_OK;
+}
+
+// after spline_enqueue / nak_enqueue: synchronise, fetch the per-signal knot counts, report NaN input
+int spline_finish(itd_engine *e, int batch, const int32_t *totals, int32_t *knots_host, hipStream_t st)
 {
     std::vector<int32_t> tot((size_t)batch * 2);
-    HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipMemcpyAsync(tot.data(), totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
     bool nan_in = false;
     for (int b = 0; b < batch; ++b) {
@@ -1720,10 +1753,25 @@ int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t 
     if (batch > 1 && (x_stride < n || baseline_stride < n || (rot_dev && rot_stride < n))) return ITD_ERR_INVALID_ARG;
     DevGuard g(e->device);
     hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    // few long signals: parallel in the knots; many short rows: one thread per signal, FITPACK's own sweep (bit-level)
+    const bool par = e->spline_solver == ITD_SPLINE_PARALLEL || (e->spline_solver == ITD_SPLINE_AUTO && batch < 256 && n >= 1024);
+    const int32_t *totals = nullptr;
     SplineWs w;
-    const int rc = spline_enqueue(e, x_dev, n, batch, x_stride, min_extrema, baseline_dev, baseline_stride, rot_dev, rot_stride, st, w);
+    int rc;
+    if (par) rc = nak_enqueue(e, x_dev, n, batch, x_stride, min_extrema, baseline_dev, baseline_stride, rot_dev, rot_stride, st, &totals);
+    else {
+        rc = spline_enqueue(e, x_dev, n, batch, x_stride, min_extrema, baseline_dev, baseline_stride, rot_dev, rot_stride, st, w);
+        totals = w.totals;
+    }
     if (rc) return rc;
-    return spline_finish(e, batch, w, knots_host, st);
+    return spline_finish(e, batch, totals, knots_host, st);
+}
+
+int itd_set_spline_solver(itd_engine *e, int32_t solver)
+{
+    if (!e || solver < ITD_SPLINE_AUTO || solver > ITD_SPLINE_PARALLEL) return ITD_ERR_INVALID_ARG;
+    e->spline_solver = solver;
+    return ITD_OK;
 }
 
 int itd_baseline_extract_spline_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t min_extrema,

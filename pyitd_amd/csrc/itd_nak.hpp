@@ -1,0 +1,132 @@
+// itd_nak.hpp — the FITPACK flavour of the baseline (numba_accelerated_itd.py:182-211, MEITD.py:303-338), solved PARALLEL IN
+// THE KNOTS for long single signals.
+//
+// What the reference computes there is scipy.interpolate.splrep(x, y, k=3) with its default s = 0 (numba_accelerated_itd.py:84):
+// the cubic spline that INTERPOLATES the baseline knot values at the data sites e = [0, knots, n-1] with FITPACK's knot choice
+// t = [x0 x4, x2 .. x_{m-3}, x_{m-1} x4] — i.e. the not-a-knot interpolant (third derivative continuous at x1 and x_{m-2}) —
+// evaluated at every sample (numba_splev, :89-164; for equally spaced sites its interval formula picks the true interval,
+// thanks to its clamps).  itd_fitpack.hpp restates FITPACK's own row-by-row Givens sweep (serial in the knots, one GPU thread
+// per signal, bit-level against scipy): right for thousands of image rows, a single serial lane for ONE long signal
+// (MEITD.py:344-549 calls the operator on single 1-D signals in a loop).
+//
+// Here the same spline comes from its second derivatives M_i at the sites (the classical moment form):
+//     mu_i M_{i-1} + 2 M_i + lambda_i M_{i+1} = 6 f[x_{i-1}, x_i, x_{i+1}],   mu_i = h_{i-1} / (h_{i-1} + h_i),  i = 1 .. m-2
+// with the not-a-knot ends folded into the first and last row ((2 + r) M_1 + (1 - r) M_2 = d_1, r = h_0 / h_1; mirrored at the
+// other end) — a strictly diagonally dominant tridiagonal system.  Thomas' two recurrences (pivots + forward, then back
+// substitution) contract: every pair of consecutive steps damps a perturbation by at least 1/2, so a thread solves a run of
+// kNakRun consecutive unknowns exactly (to far below rounding) by starting kNakWarm steps early from zero — no inter-thread
+// exchange, every thread independent, two launches.  The result equals FITPACK's to rounding (tests: 1e-10 of the signal's
+// scale against the reference-generated vectors; the north star allows 1e-6), not bit for bit: the serial form stays the one
+// the bit-level tests and the image sweeps use (itd_set_spline_solver).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "itd_cubic.hpp"
+#include "itd_spline.hpp"
+
+#pragma clang fp contract(off)
+
+namespace itd {
+
+constexpr int kNakRun = 32, kNakWarm = 128;
+
+// jobs of the batch from the detected knots: sites e = kidx[b][0 .. knots+1] (first = 0, idx = knots + 1); fewer than
+// max(min_extrema, 2) knots: invalid = the signal is its own baseline (numba_accelerated_itd.py:188-190)
+__global__ void k_nak_jobs(CubicJob *__restrict__ jobs, int batch, const int32_t *__restrict__ totals, int min_extrema)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    CubicJob j;
+    const int knots = totals[2 * b];
+    j.first = 0;
+    j.idx = knots + 1;
+    j.status = totals[2 * b + 1] ? 2 : 0;
+    j.valid = knots >= min_extrema && knots >= 2;
+    jobs[b] = j;
+}
+
+// baseline knot values at the sites (numba_accelerated_itd.py:196-206), into A.K
+__global__ void k_nak_values(CubicArgs A)
+{
+    const int sig = blockIdx.y;
+    const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
+    if (!job.valid) return;
+    const int m = job.idx + 1;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    A.K[(int64_t)sig * A.a_stride + k] = spline_knot_value(A.x + (int64_t)sig * A.x_stride, A.n, A.e + (int64_t)sig * A.e_stride, m, k);
+}
+
+// row j (1 <= j <= m-2) of the system: sub M_{j-1} + diag M_j + sup M_{j+1} = rhs
+struct NakRow { double sub, diag, sup, rhs; };
+__device__ __forceinline__ NakRow nak_row(const int32_t *__restrict__ e, const double *__restrict__ S, int m, int j)
+{
+    const double hm = (double)(e[j] - e[j - 1]), hi = (double)(e[j + 1] - e[j]);
+    NakRow r;
+    r.rhs = 6 * ((S[j + 1] - S[j]) / hi - (S[j] - S[j - 1]) / hm) / (hm + hi);
+    r.sub = hm / (hm + hi);
+    r.sup = 1 - r.sub;
+    r.diag = 2;
+    // m >= 4 (at least 2 knots), so the first row (j = 1) and the last (j = m-2) are different rows
+    if (j == 1) { const double q = hm / hi; r.diag = 2 + q; r.sup = 1 - q; r.sub = 0; }              // M_0 = (1 + q) M_1 - q M_2
+    if (j == m - 2) { const double q = hi / hm; r.sub = 1 - q; r.diag = 2 + q; r.sup = 0; }          // M_{m-1} = (1 + q) M_{m-2} - q M_{m-3}
+    return r;
+}
+
+// forward elimination of a run of kNakRun rows per thread: cp_j = sup / den, dp_j = (rhs - sub dp_{j-1}) / den,
+// den = diag - sub cp_{j-1}; into A.bf (dp) and A.b (cp, overwritten by the back substitution's M afterwards: separate array)
+__global__ __launch_bounds__(64) void k_nak_forward(CubicArgs A, double *__restrict__ cp_ws)
+{
+    const int sig = blockIdx.y;
+    const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
+    if (!job.valid) return;
+    const int m = job.idx + 1;
+    const int s = 1 + (blockIdx.x * blockDim.x + threadIdx.x) * kNakRun;
+    if (s > m - 2) return;
+    const int32_t *e = A.e + (int64_t)sig * A.e_stride;
+    const double *S = A.K + (int64_t)sig * A.a_stride;
+    double *dpv = A.bf + (int64_t)sig * A.a_stride, *cpv = cp_ws + (int64_t)sig * A.a_stride;
+    const int last = min(s + kNakRun - 1, m - 2);
+    double cp = 0.0, dp = 0.0;
+    for (int j = max(1, s - kNakWarm); j <= last; ++j) {
+        const NakRow r = nak_row(e, S, m, j);
+        const double den = r.diag - r.sub * cp;
+        cp = r.sup / den;
+        dp = (r.rhs - r.sub * dp) / den;
+        if (j >= s) { cpv[j] = cp; dpv[j] = dp; }
+    }
+}
+
+// back substitution M_j = dp_j - cp_j M_{j+1} of a run per thread, the two end moments from the not-a-knot conditions
+__global__ __launch_bounds__(64) void k_nak_backward(CubicArgs A, const double *__restrict__ cp_ws)
+{
+    const int sig = blockIdx.y;
+    const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
+    if (!job.valid) return;
+    const int m = job.idx + 1;
+    const int s = 1 + (blockIdx.x * blockDim.x + threadIdx.x) * kNakRun;
+    if (s > m - 2) return;
+    const int32_t *e = A.e + (int64_t)sig * A.e_stride;
+    const double *dpv = A.bf + (int64_t)sig * A.a_stride, *cpv = cp_ws + (int64_t)sig * A.a_stride;
+    double *M = A.b + (int64_t)sig * A.a_stride;
+    const int top = min(s + kNakRun - 1, m - 2);
+    double y = 0.0, y_next = 0.0;                      // M_{j+1}, M_{j+2} while walking down
+    for (int j = min(m - 2, top + kNakWarm); j >= s; --j) {
+        y_next = y;
+        y = dpv[j] - cpv[j] * y;
+        if (j <= top) M[j] = y;
+    }
+    if (s == 1) {                                      // M_0 from M_1 (= y) and M_2 (= y_next: the loop ran at least twice, m >= 4)
+        const double q = (double)(e[1] - e[0]) / (double)(e[2] - e[1]);
+        M[0] = (1 + q) * y - q * y_next;
+    }
+    if (top == m - 2) {                                // M_{m-1} from M_{m-2} and M_{m-3}
+        const double q = (double)(e[m - 1] - e[m - 2]) / (double)(e[m - 2] - e[m - 3]);
+        const double mt = dpv[m - 2];                  // cp_{m-2} = 0: M_{m-2} = dp_{m-2}
+        const double mb = dpv[m - 3] - cpv[m - 3] * mt;
+        M[m - 1] = (1 + q) * mt - q * mb;
+    }
+}
+
+}  // namespace itd

@@ -20,6 +20,7 @@ TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0, T
 CHAIN_AUTO, CHAIN_OFF, CHAIN_ONLY = 0, 1, 2
 NAN_INPUT_FOLLOW, NAN_INPUT_REJECT = 0, 1
 RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY = 0, 1, 2
+SPLINE_AUTO, SPLINE_SERIAL, SPLINE_PARALLEL = 0, 1, 2
 
 
 def _np_ptr(a):
@@ -267,6 +268,11 @@ class Engine:
         self._check(self._L.itd_baseline_extract_spline_host2_f64(self._h, _np_ptr(x), n, B, int(min_extrema), _np_ptr(base),
                                                                   _np_ptr(rot), _np_ptr(knots), _np_ptr(bk)))
         return (base, rot, knots, bk) if want_baseline_knots else (base, rot, knots)
+
+    def set_spline_solver(self, solver):
+        """SPLINE_AUTO (parallel in the knots for few long signals, FITPACK's serial sweep for many rows), SPLINE_SERIAL (bit-level
+        against scipy), SPLINE_PARALLEL (not-a-knot moment form: equal to rounding)."""
+        self._check(self._L.itd_set_spline_solver(self._h, int(solver)))
 
     def count_knots_host(self, x, mode=DETECT_KNOTS):
         """Knot counts of x[B, n] (or one signal [n]) under predicate `mode`: no index list is built or copied."""

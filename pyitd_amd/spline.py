@@ -17,30 +17,38 @@ import numpy
 from .itd import _engine_for
 
 
-def _eng(n, device):
-    return _engine_for(max(int(n), 4096), device)
+SOLVERS = {"auto": 0, "serial": 1, "parallel": 2}
 
 
-def itd_baseline_extract_modified(x, device=0):
+def _eng(n, device, solver="auto"):
+    """solver: "serial" = FITPACK's own sweep, one GPU thread per signal (bit-level against scipy's splrep); "parallel" = the same
+    interpolating not-a-knot spline from its second derivatives, parallel in the knots (equal to rounding); "auto" = parallel for
+    calls of few long signals (include/pyitd_hip.h: itd_set_spline_solver)."""
+    eng = _engine_for(max(int(n), 4096), device)
+    eng.set_spline_solver(SOLVERS[solver])
+    return eng
+
+
+def itd_baseline_extract_modified(x, device=0, solver="auto"):
     """numba_accelerated_itd.py:182-211 — the cubic-spline baseline (float64[N]); x itself when fewer than 10 extrema."""
     x = numpy.asarray(x, dtype=numpy.float64)
-    base, _, knots = _eng(len(x), device).spline_extract_host(x[None, :], 10)
+    base, _, knots = _eng(len(x), device, solver).spline_extract_host(x[None, :], 10)
     return x if knots[0] < 10 else base[0]
 
 
-def itd_baseline_extract_spline(data, device=0):
+def itd_baseline_extract_spline(data, device=0, solver="auto"):
     """MEITD.py:303-338 — (rotation, baseline), no early-out (scipy's splrep needs at least 2 extrema: TypeError like upstream)."""
     x = numpy.asarray(data, dtype=numpy.float64)
-    base, rot, knots = _eng(len(x), device).spline_extract_host(x[None, :], 0, want_rotation=True)
+    base, rot, knots = _eng(len(x), device, solver).spline_extract_host(x[None, :], 0, want_rotation=True)
     if knots[0] < 2:
         raise TypeError("m > k must hold")        # what scipy.interpolate.splrep raises for fewer than 4 data sites
     return rot[0], base[0]
 
 
-def itd_baseline_extract_rows(x, min_extrema=10, device=0):
+def itd_baseline_extract_rows(x, min_extrema=10, device=0, solver="auto"):
     """The batched form the reference only has as numba.prange over rows: x[B, N] -> baselines[B, N]."""
     x = numpy.asarray(x, dtype=numpy.float64)
-    return _eng(x.shape[1], device).spline_extract_host(x, min_extrema)[0]
+    return _eng(x.shape[1], device, solver).spline_extract_host(x, min_extrema)[0]
 
 
 def mad(arr):

@@ -39,8 +39,11 @@ def _close(got, ref, what, tol=1e-12):
 @pytest.mark.parametrize("name", row_cases())
 def test_rows_match_reference_goldens(P, name):
     g = np.load(os.path.join(SPLINE, name + ".npz"))
-    exact = _close(P.itd_baseline_extract_modified(g["x"]), g["baseline"], name)
+    from pyitd_amd import spline
+    exact = _close(spline.itd_baseline_extract_modified(g["x"], solver="serial"), g["baseline"], name)
     assert exact > 0.99, "%s: only %.4f of the values are bit-identical" % (name, exact)
+    # the same spline from its second derivatives, parallel in the knots (itd_nak.hpp): equal to rounding, not bit for bit
+    _close(spline.itd_baseline_extract_modified(g["x"], solver="parallel"), g["baseline"], name + " (parallel solver)", 1e-10)
     if "meitd_baseline" in g:
         rot, base = P.itd_baseline_extract_spline(g["x"])
         _close(base, g["meitd_baseline"], name + " (MEITD form)")
@@ -76,10 +79,32 @@ def test_batch_of_image_rows_vs_oracle(P, so):
 
 
 def test_long_signal(P, so):
-    """One long signal through the same operator (the coefficient sweep is serial per signal: slow but exact)."""
+    """One long signal through the same operator: FITPACK's sweep is serial in the knots (one GPU lane: slow but bit-level), the
+    moment form runs parallel in the knots (the automatic choice for one long signal) — both against scipy on the host."""
+    import time
+    from pyitd_amd import spline
     n = 1 << 17
     x = np.cumsum(np.random.default_rng(6).standard_normal(n))
-    _close(P.itd_baseline_extract_modified(x), so.baseline(x, 10), "2^17 samples")
+    ref = so.baseline(x, 10)
+    _close(spline.itd_baseline_extract_modified(x, solver="serial"), ref, "2^17 samples, serial")
+    _close(spline.itd_baseline_extract_modified(x, solver="parallel"), ref, "2^17 samples, parallel", 1e-10)
+    _close(P.itd_baseline_extract_modified(x), ref, "2^17 samples, automatic", 1e-10)
+    n = 1 << 20
+    x = np.cumsum(np.random.default_rng(7).standard_normal(n))
+    t0 = time.perf_counter(); ref = so.baseline(x, 10); t_cpu = time.perf_counter() - t0
+    P.itd_baseline_extract_modified(x[: 1 << 16])
+    t0 = time.perf_counter(); got = P.itd_baseline_extract_modified(x); t_gpu = time.perf_counter() - t0
+    _close(got, ref, "2^20 samples, automatic", 1e-10)
+    print("2^20-sample signal, FITPACK flavour: %.1f ms on the GPU (host arrays in and out) vs %.1f ms scipy on the host" % (t_gpu * 1e3, t_cpu * 1e3))
+    # mixed batch through the parallel solver: rows with fewer than 10 knots come back unchanged, every other row equals the oracle
+    rng = np.random.default_rng(8)
+    xb = rng.standard_normal((5, 3000))
+    xb[2] = np.linspace(0, 1, 3000)
+    xb[3] = ((-1.0) ** np.arange(3000)) * (1 + rng.random(3000))       # equally spaced sites: the reference's equi_spaced branch
+    xb[4, :2990] = np.sin(np.arange(2990) / 300.0)                     # 3 + a few knots
+    got = spline.itd_baseline_extract_rows(xb, solver="parallel")
+    for b in range(5):
+        _close(got[b], so.baseline(xb[b], 10), "parallel row %d" % b, 1e-10)
 
 
 @pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(SPLINE) if f.startswith("meitd_")))
