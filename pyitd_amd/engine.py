@@ -145,15 +145,23 @@ class Engine:
         return ms.value, cnt.value
 
     # ---- numpy in -> numpy out ----------------------------------------------------------------
-    def decompose_host(self, x, max_iteration, want_baselines=True):
+    def decompose_host(self, x, max_iteration, want_baselines=True, out=None):
         """want_baselines: True = copy them back now; False = none; "lazy" = leave them on the device: the result carries
-        `n_baselines` and `fetch_baselines()`, valid until this engine's next host-form decomposition."""
+        `n_baselines` and `fetch_baselines()`, valid until this engine's next host-form decomposition.
+        out: a caller-owned float64 C-contiguous array of at least (max_iteration + 2, n) the rows are written into (a loop over
+        calls then neither allocates nor releases 8 (max_iteration + 2) n bytes per call)."""
         x = np.ascontiguousarray(x)
         if x.dtype != np.float32:
             x = np.ascontiguousarray(x, dtype=np.float64)
         n = x.shape[0]
         R = max_iteration + 2
-        rows = np.empty((R, n), np.float64)
+        if out is None:
+            rows = np.empty((R, n), np.float64)
+        else:
+            if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.ndim == 2 and out.shape[0] >= R
+                    and out.shape[1] == n and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]):
+                raise ValueError("out must be a writable C-contiguous float64 array of shape (>= %d, %d)" % (R, n))
+            rows = out
         lazy = want_baselines == "lazy"
         self._check(self._L.itd_set_host_keep_baselines(self._h, 1 if lazy else 0))
         bases = np.zeros((R, n), np.float64) if (want_baselines and not lazy) else None

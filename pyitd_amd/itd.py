@@ -152,8 +152,11 @@ class ITD:
         # upstream passes a misspelt keyword here (ITD.py:189-190) and cannot run; the intent is clear
         return self.itd(S, max_iteration=max_iterations)
 
-    def itd(self, data, max_iteration: int = 11):
-        """ITD.py:351-432 — rows 0..c-1 are proper rotations, the last row is the residual."""
+    def itd(self, data, max_iteration: int = 11, out=None):
+        """ITD.py:351-432 — rows 0..c-1 are proper rotations, the last row is the residual.
+        out (an addition to the reference's signature): a caller-owned float64 array of at least (max_iteration + 2, len(data))
+        the result is written into; the returned array is a view of its first rows.  The reference allocates its [22, N] buffers
+        per call (ITD.py:384-388); a loop over calls that passes `out` pays for that once."""
         x = _as_signal(data)
         self.DTYPE = numpy.asarray(data).dtype
         n = len(x)
@@ -165,7 +168,7 @@ class ITD:
         m = min(int(max_iteration), _lib.MAX_ITERATION)
         self._fetch = None          # this instance's previous baselines are being replaced: nothing to bring home
         _flush_pending()            # another instance's may still sit in the engine's staging buffer: fetch those first
-        res = _engine_for(n, self.device).decompose_host(x, m, want_baselines="lazy")
+        res = _engine_for(n, self.device).decompose_host(x, m, want_baselines="lazy", out=out)
         if res["nonfinite"]:    # only an engine switched to NAN_INPUT_REJECT gets here
             raise ValueError("the input signal contains NaN")
         if max_iteration > _lib.MAX_ITERATION and res["stop"] == STOP_TIMEOUT:

@@ -138,6 +138,16 @@ def test_api_surface_and_errors(P):
     assert rot.shape == (3, 1000) and base.shape == (1000,)
     assert_bits_equal(np.vstack([rot, base[None]]), rows, "itd_levels")
     assert_bits_equal(P.itd(x, 2), rows, "free function")
+    # out=: the caller's result array, reused across calls (shape >= (max_iteration + 2, n)); the result is a view of it
+    buf = np.full((6, 1000), -5.0)
+    r2 = d.itd(x, max_iteration=2, out=buf)
+    assert r2.base is buf and r2.shape == (4, 1000) and np.all(buf[4:] == -5.0)
+    assert_bits_equal(r2, rows, "out= rows")
+    r3 = d.itd(x[::-1].copy(), max_iteration=2, out=buf)
+    assert r3.base is buf and not np.array_equal(r3, rows)
+    for bad_out in (np.empty((3, 1000)), np.empty((6, 999)), np.empty((6, 1000), np.float32), np.empty((6, 2000))[:, ::2]):
+        with pytest.raises(ValueError):
+            d.itd(x, max_iteration=2, out=bad_out)
     # more rows than the reference's 22-row buffers can hold
     rng = np.random.default_rng(5)
     z = np.where(np.arange(1024) % 2 == 0, -1.0, 1.0) * (1 + 0.001 * np.arange(1024))

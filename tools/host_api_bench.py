@@ -47,6 +47,11 @@ d = pyitd_amd.ITD()
 d.itd(x, 7)
 dt = best(lambda: d.itd(x, 7))
 print("ITD().itd(x, 7) (the previous call's rows are released inside; the baselines stay on the GPU): %.1f ms = %.0f Msamples/s" % (dt, n / dt / 1e3))
+buf = np.empty((9, n))
+buf.fill(0.0)
+d.itd(x, 7, out=buf)
+dt = best(lambda: d.itd(x, 7, out=buf), rep=5)
+print("ITD().itd(x, 7, out=buf) in a loop (the result array is the caller's, reused): %.1f ms = %.0f Msamples/s" % (dt, n / dt / 1e3))
 d.itd(x, 7)
 t0 = time.perf_counter()
 b = d.get_baselines()
