@@ -238,10 +238,6 @@ def run_rank(args):
         sp = stream.cuda_stream
         x_ptr, rows_ptr = x.data_ptr(), rows.data_ptr()
     eng = sb.engine
-    if args.chain and not stub:
-        from pyitd_amd.engine import CHAIN_ONLY
-        eng.set_chain_mode(CHAIN_ONLY)     # the whole decomposition as one persistent launch; a chain that cannot complete raises
-
     def sync():
         if not stub:
             torch.cuda.synchronize()
@@ -294,9 +290,9 @@ def run_rank(args):
     table = sb.gather(group=group, device=coll_dev) if dist.is_initialized() else None
 
     if not sharded and not stub:
-        from pyitd_amd.engine import TIME_CHAIN, TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
+        from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
         timing = {k: eng.kernel_timing(t) for k, t in (("ext", TIME_EXTRACT), ("l0", TIME_EXTRACT_L0), ("fin", TIME_EXTRACT_FINAL),
-                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0), ("chain", TIME_CHAIN))}
+                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0))}
         eng.set_timing(0)
     else:
         timing = None
@@ -415,23 +411,9 @@ def run_rank(args):
             "per_gpu": True,
         }
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only (the N = 1 line of the same build carries all four CPU legs)
-    if timing is not None and args.chain:
-        # --chain: the dominant (only) kernel is k_chain.  Two figures: against the SURVEY's algorithmic bytes (188 B/sample: what
-        # the reference's level-by-level data flow moves) and against what this launch itself has to move (4 B read + 8 B per row)
-        ch_us = timing["chain"][0] / max(timing["chain"][1], 1) * 1e3
-        own_bytes = 4.0 + 8.0 * R
-        out["roofline"].update({
-            "kernel": "k_chain (one persistent launch: all %d levels, the tile stays in registers; opt-in, itd_set_chain_mode)" % (M + 2),
-            "achieved": round(float(algorithmic_bytes_per_sample(LEVELS)) * n / (ch_us * 1e-6) / 1e9, 1) if ch_us > 0 else 0.0,
-            "frac": round(float(algorithmic_bytes_per_sample(LEVELS)) * n / (ch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if ch_us > 0 else 0.0,
-            "avg_launch_us": round(ch_us, 2), "launches_timed": timing["chain"][1], "traffic": None, "traffic_source": None,
-            "own_bytes_per_sample": own_bytes,
-            "own_frac": round(own_bytes * n / (ch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if ch_us > 0 else 0.0,
-        })
-        out["config"]["launch_form"] = "chain"
     if world == 1 and not stub and not args.no_cpu_baseline:
         out.update(cpu_legs(x_host, n, M, summ, rows, args))
-    if world == 1 and not stub and not args.no_extra and args.log2n == LOG2N and not args.chain:
+    if world == 1 and not stub and not args.no_extra and args.log2n == LOG2N:
         # informational legs, all timed AFTER the headline (never at its cost: each in its own try)
         del rows, x
         torch.cuda.empty_cache()
@@ -745,7 +727,6 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="N > 1: signals per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational BASELINE configs[2] leg (1024 x 2^20 signals)")
-    ap.add_argument("--chain", action="store_true", help="run the opt-in one-launch chain (itd_set_chain_mode) instead of one launch per level")
     ap.add_argument("--try-rccl", action="store_true",
                     help="with --rehearse-one-gpu: ask for RCCL first all the same (two ranks on one GPU: it refuses, which exercises "
                          "the fallback of the control plane to gloo)")

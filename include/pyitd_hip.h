@@ -146,23 +146,6 @@ int itd_set_nan_fallback(itd_engine *e, int enable);
 #define ITD_LEVEL0_RECORDS 1
 #define ITD_LEVEL0_FUSED 2   /* never repeat: itd_get_summary fails with ITD_ERR_HIP if the reach was exceeded (benchmarks) */
 int itd_set_level0_mode(itd_engine *e, int32_t mode);
-/* How a decomposition is launched:
- *   chain    ONE persistent launch: a wavefront keeps its 512-sample tile in registers through all levels and exchanges only
- *            the neighbours' 64-byte knot records (tagged 8-byte granules) — no baseline round trip between levels: 4 + 8 rows
- *            bytes per sample instead of 20 + 24 per level.  Optimistic: it runs every requested level; if the stop rule
- *            `num_extrema < 2` (ITD.py:404) fires inside them, or a tile's neighbouring knots lie more than ~500 k samples away,
- *            itd_get_summary repeats the call level by level before it returns (x_dev / rows_dev / baselines_dev must stay
- *            valid until then, as before) and the engine's next 16 decompositions start level by level.
- *   off      one launch per level (ABI revision 2's engine).
- * Results are identical in every mode. */
-#define ITD_CHAIN_AUTO 0
-#define ITD_CHAIN_OFF 1
-#define ITD_CHAIN_ONLY 2   /* never repeat: itd_get_summary fails with ITD_ERR_HIP if the chain did not complete (benchmarks, tests) */
-int itd_set_chain_mode(itd_engine *e, int32_t mode);
-/* workgroups (one wavefront each) of the chain launch; any number is correct (tickets), default about the chip's residency */
-int itd_set_chain_grid(itd_engine *e, int32_t workgroups);
-/* how many chained calls of this engine itd_get_summary has had to repeat level by level so far */
-int itd_get_chain_repeats(const itd_engine *e);
 /* Short signals (n <= 8192 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays
  * in LDS through all levels of the driver loop (ITD.py:384-432): the signal is read once and every result row written once
  * (4 + 8 rows bytes per sample; the level-by-level form is launch bound there: 10 dependent launches).  Baselines that go NaN
@@ -170,7 +153,7 @@ int itd_get_chain_repeats(const itd_engine *e);
  * only under ITD_NAN_INPUT_REJECT does a NaN input make itd_get_summary repeat the call level by level before it returns (x_dev /
  * rows_dev / baselines_dev must stay valid until then, as before; the engine's next 16 decompositions then start level by level).
  * Rows past n_rows are not written in this form.
- * ITD_RESIDENT_AUTO (default): resident for n <= 8192 unless the engine was given a level-0 mode, a chain mode or kernel timing;
+ * ITD_RESIDENT_AUTO (default): resident for n <= 8192 unless the engine was given a level-0 mode or kernel timing;
  * ITD_RESIDENT_OFF: never; ITD_RESIDENT_ONLY: always for n <= 8192, never repeat (itd_get_summary fails with ITD_ERR_HIP
  * instead; tests, benchmarks).  Results are identical in every mode. */
 #define ITD_RESIDENT_AUTO 0
@@ -183,9 +166,6 @@ int itd_get_resident_repeats(const itd_engine *e);
  * knots takes several passes.  0 = automatic (0.4 knots per sample: one pass for ordinary signals), otherwise >= 8 (cut to what
  * fits the LDS).  Results do not depend on it (tests run tiny windows to exercise the passes). */
 int itd_set_resident_window(itd_engine *e, int32_t segments);
-/* diagnostic builds only (-DITD_CHAIN_PROF=1): 16 counters summed over the chain's wavefronts (100 MHz ticks per phase, event
- * counts; itd_chain.hpp); all zero in the shipped build */
-int itd_debug_chain_prof(itd_engine *e, uint64_t *out16, int32_t reset);
 /* Batched decompositions run as launch sequences over chunks of `signals_per_chunk` signals, all levels of a chunk before
  * the next chunk (0 = automatic: about 2^24 samples in flight — per chunk over one stream, 3/4 of that per chunk over two —, so a
  * level's baseline is still in the 256 MiB Infinity Cache when the next level reads it).  Results do not depend on the chunk size. */
@@ -410,7 +390,6 @@ int itd_stream_status(itd_stream *s, int32_t *status);
 #define ITD_TIME_EXTRACT_FINAL 2  /* k_extract of the "Out of time!" level (writes rotation+baseline only) */
 #define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
 #define ITD_TIME_SCAN0 4          /* k_scan0: the level-0 knot scan of the caller's signal (4 B/sample for float32) */
-#define ITD_TIME_CHAIN 5          /* k_chain: the whole decomposition in one launch (4 + 8 rows B/sample for float32) */
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
 /* instrument only every stride-th decomposition (launches with events cost ~2 us more each, the span's marker records ~5 us each) */
 int itd_set_kernel_timing_stride(itd_engine *e, int stride);

@@ -20,7 +20,6 @@
 
 #include "../../include/pyitd_hip.h"
 #include "itd_kernels.hpp"
-#include "itd_chain.hpp"
 #include "itd_resident.hpp"
 #include "itd_cubic.hpp"
 #include "itd_stream.hpp"
@@ -101,19 +100,6 @@ struct itd_engine {
     int32_t *d_hgsum = nullptr;    // [3][groups*pitch]
     int64_t hgsum_third = 0;
     SigState *d_hstate = nullptr;  // [1]
-    // workspace of the one-launch chain (itd_chain.hpp): per level and tile one count granule and sixteen record granules,
-    // per level and signal eight end-sample granules, per level the group sums; tickets / give-up word / generation tag
-    unsigned long long *d_cntg = nullptr;   // [2][kChainLevels][batch * tiles]
-    unsigned long long *d_recg = nullptr;   // [2][kChainLevels][batch * tiles][16]
-    unsigned long long *d_endg = nullptr;   // [kChainLevels][batch][8]
-    int32_t *d_cgsum = nullptr;             // [kChainLevels + 1][batch][groups * pitch]
-    ChainCtl *d_ctl = nullptr;
-    ChainCtl *h_ctl = nullptr;              // pinned
-    int32_t chain_mode = ITD_CHAIN_OFF;     // itd_set_chain_mode
-    int32_t chain_off_left = 0;             // automatic mode: decompositions still to run level by level after a chain gave up
-    int32_t chain_repeats = 0;
-    int32_t last_give_up = 0;               // ChainCtl::give_up of the last chained call that had to be repeated
-    int32_t chain_grid = 6144;              // workgroups (= wavefronts) of the chain launch: about the chip's residency              // how often itd_get_summary had to repeat a chained call level by level
     int32_t chunk = 0;             // signals per launch sequence of a batched decomposition (0 = automatic, see enqueue_decompose)
     int32_t batch_streams = 2;     // chunks of a batch rotate over this many streams (itd_set_batch_streams): 1 .. kMaxBatchStreams
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // the others besides the caller's, created on demand
@@ -153,7 +139,6 @@ struct itd_engine {
     int64_t last_x_stride = 0;
     double *last_rows = nullptr, *last_bases = nullptr;
     bool last_fused = false;
-    bool last_chain = false;
     bool last_resident = false;        // the last run was the one-workgroup form (k_resident)
     bool last_nan_input = false;       // the last run was the NaN-input repeat (k_nan_level0): its results follow the reference
     int32_t nan_input_mode = ITD_NAN_INPUT_FOLLOW;   // itd_set_nan_input_mode
@@ -399,118 +384,13 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_rows = rows;
     e->last_bases = bases_user;
     e->last_fused = fuse0;
-    e->last_chain = false;
     e->last_resident = false;
     e->last_nan_input = nan_input;
     return ITD_OK;
 }
 
-constexpr int kChainLevels = ITD_MAX_ITERATION + 2;   // levels 0 .. max_iteration + 1
-
-// The chain's workspace is allocated at the first chained call (most engines never run one): two copies of the per-level
-// granule arrays, the end-sample granules, the per-level group sums, the control block.
-int ensure_chain_ws(itd_engine *e)
-{
-    if (e->d_ctl) return ITD_OK;
-    const size_t B = (size_t)e->max_batch;
-    const size_t cg_b = 2 * (size_t)kChainLevels * (size_t)e->tiles_half * sizeof(unsigned long long);   // two copies (gran_store2)
-    const size_t eg_b = (size_t)kChainLevels * B * 8 * sizeof(unsigned long long);
-    const size_t gs_b = (size_t)(kChainLevels + 1) * (size_t)e->gsum_third * sizeof(int32_t);
-    hipError_t rc = hipMalloc((void **)&e->d_cntg, cg_b);
-    if (rc == hipSuccess) rc = hipMalloc((void **)&e->d_recg, 16 * cg_b);
-    if (rc == hipSuccess) rc = hipMalloc((void **)&e->d_endg, eg_b);
-    if (rc == hipSuccess) rc = hipMalloc((void **)&e->d_cgsum, gs_b);
-    // granule tags start at 0 = "never published" (the first call's generation is 1)
-    if (rc == hipSuccess) rc = hipMemset(e->d_cntg, 0, cg_b);
-    if (rc == hipSuccess) rc = hipMemset(e->d_recg, 0, 16 * cg_b);
-    if (rc == hipSuccess) rc = hipMemset(e->d_endg, 0, eg_b);
-    if (rc == hipSuccess && !e->h_ctl) rc = hipHostMalloc((void **)&e->h_ctl, sizeof(ChainCtl));
-    ChainCtl *ctl = nullptr;
-    if (rc == hipSuccess) rc = hipMalloc((void **)&ctl, sizeof(ChainCtl));
-    if (rc == hipSuccess) rc = hipMemset(ctl, 0, sizeof(ChainCtl));
-    if (rc != hipSuccess) {
-        (void)hipFree(e->d_cntg); (void)hipFree(e->d_recg); (void)hipFree(e->d_endg); (void)hipFree(e->d_cgsum); (void)hipFree(ctl);
-        e->d_cntg = e->d_recg = e->d_endg = nullptr;
-        e->d_cgsum = nullptr;
-        fail_hip(e, rc, "chain workspace");
-        return rc == hipErrorOutOfMemory ? ITD_ERR_NOMEM : ITD_ERR_HIP;
-    }
-    e->d_ctl = ctl;
-    e->ws_bytes += (int64_t)(17 * cg_b + eg_b + gs_b + sizeof(ChainCtl));
-    return ITD_OK;
-}
-
-// The whole decomposition as ONE persistent launch (k_chain) between an init and a check kernel.  Optimistic: the stop rule
-// and the walk / spin limits are checked afterwards; itd_get_summary repeats the call level by level when they fired.
-template <typename Tin>
-int enqueue_chain(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, double *rows,
-                  double *bases_user, hipStream_t st)
-{
-    {
-        const int rc = ensure_chain_ws(e);
-        if (rc) return rc;
-    }
-    const int n_tiles = (int)((n + kChainTile - 1) / kChainTile);   // the chain's own tile width
-    const int n_groups = groups_of(n_tiles);
-    const int n_levels = M + 2;
-    const int64_t R = (int64_t)M + 2;
-    const int64_t rows_stride = R * n;
-    const int64_t lv_tiles = (int64_t)batch * n_tiles;
-    const int64_t gpitch = (int64_t)batch * n_groups * kGsumPitch;   // one level's group sums
-    e->timing_now = e->timing && (e->timing_seq++ % e->timing_stride == 0);
-    const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
-    {
-        const int64_t ge = (int64_t)(n_levels + 1) * gpitch;
-        const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
-        k_chain_init<<<gb, 256, 0, st>>>(e->d_ctl, e->d_state, batch, e->d_cgsum, ge);
-        e->cur_set = 0;   // the chain keeps to set 0 of the states and initialises them itself
-        e->dirty_sig[0] = std::max(e->dirty_sig[0], batch);
-    }
-    if (bases_user)  // the reference's timeout result keeps an all-zero last baselines row (ITD.py:385,424)
-        HIP_TRY(e, hipMemset2DAsync(bases_user + (R - 1) * n, (size_t)rows_stride * sizeof(double), 0,
-                                    (size_t)n * sizeof(double), (size_t)batch, st));
-    {
-        const int pair = time_slot(e, ITD_TIME_CHAIN);
-        const Tin *a_x = x; int64_t a_xs = x_stride, a_n = n, a_gp = gpitch, a_rs = rows_stride, a_bs = rows_stride;
-        int a_nt = n_tiles, a_b = batch, a_nl = n_levels;
-        // the level pitch of the granule arrays is the call's own batch * tiles: a call uses the front of each array
-        unsigned long long *a_cg = e->d_cntg, *a_rg = e->d_recg, *a_eg = e->d_endg;
-        int64_t a_copy = (int64_t)kChainLevels * e->tiles_half;   // elements between the two copies of the count granules
-        int32_t *a_gs = e->d_cgsum; double *a_rows = rows, *a_bas = bases_user;
-        SigState *a_st = e->d_state; ChainCtl *a_ctl = e->d_ctl;
-        void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_cg, &a_rg, &a_copy, &a_gs, &a_gp, &a_eg, &a_rows, &a_rs, &a_bas, &a_bs,
-                        &a_st, &a_ctl, &a_nl};
-        // every XCD serves only its own ticket list, so each needs its share of wavefronts whatever the problem size (a grid cut
-        // down to the tile count would leave a list with fewer wavefronts than its tiles' mutual reach): surplus ones leave at once
-        const unsigned grid = (unsigned)e->chain_grid;
-        (void)lv_tiles;
-        const void *fn = bases_user ? reinterpret_cast<const void *>(&k_chain<Tin, kChainTile, kChainCap, true>)
-                                    : reinterpret_cast<const void *>(&k_chain<Tin, kChainTile, kChainCap, false>);
-        HIP_TRY(e, hipExtLaunchKernel(fn, dim3(grid), dim3(kWave), args, 0, st, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,
-                                      pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
-    }
-    k_chain_finalize<<<batch, 256, 0, st>>>(e->d_cgsum, gpitch, n_tiles, n_levels, e->d_state);
-    time_end(e, span_pair, st);
-    HIP_TRY(e, hipGetLastError());
-    e->ran = true;
-    e->last_batch = batch;
-    e->last_m = M;
-    e->last_n = n;
-    e->last_stream = st;
-    e->last_x = x;
-    e->last_x_f32 = sizeof(Tin) == 4;
-    e->last_x_stride = x_stride;
-    e->last_rows = rows;
-    e->last_bases = bases_user;
-    e->last_fused = false;
-    e->last_chain = true;
-    e->last_resident = false;
-    e->last_nan_input = false;
-    return ITD_OK;
-}
-
 // Short signals (n <= kResidentMax): the whole decomposition as ONE launch, one workgroup per signal, the signal resident
-// in LDS (itd_resident.hpp).  Optimistic like the chain: the kernel handles finite data only and raises SigState::res_fail
+// in LDS (itd_resident.hpp).  Optimistic: the kernel handles finite data only and raises SigState::res_fail
 // otherwise; itd_get_summary then repeats the call level by level.  The kernel initialises the states it works on itself
 // and leaves the other set's states as k_finalize would (the group sums are not touched).
 bool want_fused(itd_engine *e);
@@ -520,7 +400,7 @@ bool want_resident(itd_engine *e, int64_t n)
     if (e->resident_mode == ITD_RESIDENT_ONLY) return true;
     // an engine that was told how to run its level 0 / its launches, or that is being timed launch by launch, means the
     // level-by-level form
-    if (e->l0_mode != ITD_LEVEL0_AUTO || e->chain_mode != ITD_CHAIN_OFF || e->timing) return false;
+    if (e->l0_mode != ITD_LEVEL0_AUTO || e->timing) return false;
     if (e->resident_off_left > 0) { --e->resident_off_left; return false; }
     return true;
 }
@@ -586,30 +466,16 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
     e->last_rows = rows;
     e->last_bases = bases_user;
     e->last_fused = false;
-    e->last_chain = false;
     e->last_resident = true;
     e->last_nan_input = false;
     return ITD_OK;
-}
-
-bool want_fused(itd_engine *e);
-bool want_chain(itd_engine *e)
-{
-    if (e->chain_mode == ITD_CHAIN_OFF) return false;
-    if (e->chain_mode == ITD_CHAIN_ONLY) return true;
-    if (e->chain_off_left > 0) { --e->chain_off_left; return false; }
-    return true;
 }
 
 template <typename Tin>
 int enqueue_any(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, double *rows,
                 double *bases_user, hipStream_t st)
 {
-    // the chain kernel works in 32-bit sample / tile arithmetic (itd_chain.hpp)
-    static_assert(kChainTile >= T, "the granule arrays are sized for tiles of T samples");
     if (want_resident(e, n)) return enqueue_resident<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
-    const bool fits = n <= ((int64_t)1 << 31) - 65536 && (int64_t)batch * tiles_of(n) < ((int64_t)1 << 31) - 65536;
-    if (fits && want_chain(e)) return enqueue_chain<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
     return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, want_fused(e));
 }
 
@@ -799,8 +665,6 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
     (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_flag);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
-    (void)hipFree(e->d_cntg); (void)hipFree(e->d_recg); (void)hipFree(e->d_endg); (void)hipFree(e->d_cgsum); (void)hipFree(e->d_ctl);
-    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -876,8 +740,6 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     DevGuard g(e->device);
     const int B = e->last_batch;
     HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
-    if (e->last_chain)
-        HIP_TRY(e, hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(ChainCtl), hipMemcpyDeviceToHost, e->last_stream));
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
     auto any_nan_input = [&]() {
         for (int b = 0; b < B; ++b) if (e->h_state[b].in_nan) return true;
@@ -915,38 +777,6 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         // that follows the reference (k_nan_level0); SigState::in_nan stays set and tells it which signals are concerned.
         const int rc = repeat(false, true);
         if (rc) return rc;
-    } else
-    if (e->last_chain) {
-        // the one-launch chain is optimistic: it ran every requested level.  If the stop rule fired inside them (chain_stop),
-        // a tile's halo knots lay beyond its walk / a spin outlasted its limit (give_up), or level 0 fell short of its reach
-        // (l0_fail), the rows are not the reference's: repeat the call level by level, and let the engine's next
-        // decompositions start that way — workloads tend to be homogeneous
-        bool redo = e->h_ctl->give_up != 0, l0 = false, nan_in = false;
-        for (int b = 0; b < B; ++b) {
-            nan_in = nan_in || e->h_state[b].in_nan;
-            l0 = l0 || e->h_state[b].l0_fail;
-            redo = redo || e->h_state[b].chain_stop || e->h_state[b].l0_fail;
-        }
-        if (redo && !(nan_in && B == 1)) {
-            if (e->chain_mode == ITD_CHAIN_ONLY) {
-                snprintf(e->err, sizeof(e->err), "one-launch chain: not completed (give_up=%d, stop rule or level-0 reach otherwise); ITD_CHAIN_ONLY forbids the level-by-level repeat",
-                         e->h_ctl->give_up);
-                return ITD_ERR_HIP;
-            }
-            ++e->chain_repeats;
-            e->last_give_up = e->h_ctl->give_up;
-            e->chain_off_left = 16;
-            if (l0) e->l0_records_left = 16;
-            // the repeat's level 0: as the engine was told (forced fused / records), else record-driven if the chain's own
-            // level 0 (the fused front end) fell short of its reach
-            const bool f0 = e->l0_mode == ITD_LEVEL0_FUSED ? true : (e->l0_mode == ITD_LEVEL0_RECORDS ? false : !l0);
-            const int rc = e->last_x_f32
-                ? enqueue_decompose<float>(e, (const float *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0)
-                : enqueue_decompose<double>(e, (const double *)e->last_x, e->last_n, B, e->last_x_stride, e->last_m, e->last_rows, e->last_bases, e->last_stream, f0);
-            if (rc) return rc;
-            HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
-            HIP_TRY(e, hipStreamSynchronize(e->last_stream));
-        }
     }
     if (e->last_fused) {
         // the fused level-0 launch reaches kReach windows beyond a tile for its halo knots; a signal smoother than that
@@ -1032,14 +862,6 @@ int itd_get_last_baselines_host(itd_engine *e, double *baselines_host, int64_t n
     return copy_to_host(e, baselines_host, e->d_io_bases, (size_t)n_baselines * (size_t)n * sizeof(double), e->own_stream);
 }
 
-int itd_set_chain_mode(itd_engine *e, int32_t mode)
-{
-    if (!e || mode < ITD_CHAIN_AUTO || mode > ITD_CHAIN_ONLY) return ITD_ERR_INVALID_ARG;
-    e->chain_mode = mode;
-    e->chain_off_left = 0;
-    return ITD_OK;
-}
-
 int itd_set_resident_mode(itd_engine *e, int32_t mode)
 {
     if (!e || mode < ITD_RESIDENT_AUTO || mode > ITD_RESIDENT_ONLY) return ITD_ERR_INVALID_ARG;
@@ -1054,28 +876,6 @@ int itd_set_resident_window(itd_engine *e, int32_t segments)
 {
     if (!e || segments < 0 || (segments > 0 && segments < 8)) return ITD_ERR_INVALID_ARG;
     e->resident_window = segments;
-    return ITD_OK;
-}
-
-int itd_set_chain_grid(itd_engine *e, int32_t workgroups)
-{
-    if (!e || workgroups < 1 || workgroups > (1 << 20)) return ITD_ERR_INVALID_ARG;
-    e->chain_grid = workgroups;
-    return ITD_OK;
-}
-
-int itd_get_chain_repeats(const itd_engine *e) { return e ? e->chain_repeats : -1; }
-
-int itd_debug_chain_prof(itd_engine *e, uint64_t *out16, int32_t reset)
-{
-    if (!e || !out16) return ITD_ERR_INVALID_ARG;
-    DevGuard g(e->device);
-    if (!e->d_ctl) { for (int k = 0; k < 16; ++k) out16[k] = 0; return ITD_OK; }
-    HIP_TRY(e, hipDeviceSynchronize());
-    HIP_TRY(e, hipMemcpy(e->h_ctl, e->d_ctl, sizeof(ChainCtl), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 16; ++k) out16[k] = e->h_ctl->prof[k];
-    if (!ITD_CHAIN_PROF) { out16[14] = e->h_ctl->gen; out16[15] = (uint64_t)(uint32_t)e->last_give_up; }
-    if (reset) HIP_TRY(e, hipMemset(e->d_ctl->prof, 0, sizeof(e->h_ctl->prof)));
     return ITD_OK;
 }
 
@@ -1975,7 +1775,7 @@ int itd_set_kernel_timing_stride(itd_engine *e, int stride)
 
 int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches)
 {
-    if (!e || which < 0 || which > ITD_TIME_CHAIN) return ITD_ERR_INVALID_ARG;
+    if (!e || which < 0 || which > ITD_TIME_SCAN0) return ITD_ERR_INVALID_ARG;
     if (!e->ran || !e->timing) return ITD_ERR_NOT_RUN;
     DevGuard g(e->device);
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));

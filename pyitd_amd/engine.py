@@ -16,8 +16,7 @@ STOP_NATURAL, STOP_TIMEOUT = 0, 1
 DETECT_KNOTS, DETECT_VALLEYS, DETECT_PEAKS = 0, 1, 2
 ITD_OK, ITD_ERR_INVALID_ARG, ITD_ERR_NONFINITE = 0, 1, 6
 LEVEL0_AUTO, LEVEL0_RECORDS, LEVEL0_FUSED = 0, 1, 2
-TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0, TIME_CHAIN = 0, 1, 2, 3, 4, 5
-CHAIN_AUTO, CHAIN_OFF, CHAIN_ONLY = 0, 1, 2
+TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0 = 0, 1, 2, 3, 4
 NAN_INPUT_FOLLOW, NAN_INPUT_REJECT = 0, 1
 RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY = 0, 1, 2
 SPLINE_AUTO, SPLINE_SERIAL, SPLINE_PARALLEL = 0, 1, 2
@@ -41,9 +40,6 @@ class Engine:
         mode = os.environ.get("PYITD_LEVEL0_MODE")      # diagnostic override: run a whole test suite in one level-0 mode
         if mode:
             self.set_level0_mode(int(mode))
-        mode = os.environ.get("PYITD_CHAIN_MODE")       # the same for the launch form (CHAIN_AUTO / CHAIN_OFF / CHAIN_ONLY)
-        if mode:
-            self.set_chain_mode(int(mode))
         mode = os.environ.get("PYITD_RESIDENT_MODE")    # and for the one-workgroup form of short signals (RESIDENT_*)
         if mode:
             self.set_resident_mode(int(mode))
@@ -103,11 +99,6 @@ class Engine:
         """LEVEL0_AUTO (fused level 0, record-driven repeat if the input is too smooth), LEVEL0_RECORDS, LEVEL0_FUSED."""
         self._check(self._L.itd_set_level0_mode(self._h, int(mode)))
 
-    def set_chain_mode(self, mode):
-        """CHAIN_AUTO (one persistent launch for the whole decomposition, level-by-level repeat when the stop rule fires inside
-        the requested levels or the knots are too sparse), CHAIN_OFF (one launch per level), CHAIN_ONLY (never repeat)."""
-        self._check(self._L.itd_set_chain_mode(self._h, int(mode)))
-
     def set_resident_mode(self, mode):
         """RESIDENT_AUTO (signals of <= 8192 samples run as one workgroup each in one launch, the signal resident in LDS; a call
         that meets a non-finite value is repeated level by level), RESIDENT_OFF, RESIDENT_ONLY (never repeat)."""
@@ -121,14 +112,6 @@ class Engine:
     def resident_repeats(self):
         """Resident calls of this engine that itd_get_summary had to repeat level by level so far."""
         return self._L.itd_get_resident_repeats(self._h)
-
-    def set_chain_grid(self, workgroups):
-        self._check(self._L.itd_set_chain_grid(self._h, int(workgroups)))
-
-    @property
-    def chain_repeats(self):
-        """Chained calls of this engine that itd_get_summary had to repeat level by level so far."""
-        return self._L.itd_get_chain_repeats(self._h)
 
     def set_batch_chunk(self, signals_per_chunk):
         """Signals per launch sequence of a batched decomposition (0 = automatic, about 2^24 samples per chunk)."""

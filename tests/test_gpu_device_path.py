@@ -193,8 +193,6 @@ def test_kernel_timing_api(P, torch, oracle):
     # itd_set_kernel_timing / _stride / itd_get_kernel_timing: instrumented decompositions launch the extraction kernels with
     # their own events; results must not change and the tallies must count exactly the instrumented launches
     from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0
-    if os.environ.get("PYITD_CHAIN_MODE", "1") != "1":
-        pytest.skip("the launch classes counted here are the level-by-level engine's (the suite is being run through the chain)")
     n, m = 1 << 16, 5
     x = sines_noise(n, seed=2, dtype=np.float32)
     ref = oracle.itd(x, m)
@@ -221,22 +219,17 @@ def test_kernel_timing_api(P, torch, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("chain", [False, True])
-def test_decomposition_is_graph_capturable(P, torch, oracle, chain):
+def test_decomposition_is_graph_capturable(P, torch, oracle):
     """include/pyitd_hip.h: the decompose calls allocate nothing and synchronise nothing, so a caller can capture them in a HIP
-    graph; replays on new data in the same buffers give that data's decomposition (the chain's generation tag lives in device
-    memory and advances with every replay)."""
-    from pyitd_amd.engine import CHAIN_ONLY
+    graph; replays on new data in the same buffers give that data's decomposition."""
     n, M = 1 << 18, 5
     eng = P.Engine(n, 1, 0)
-    if chain:
-        eng.set_chain_mode(CHAIN_ONLY)
     x = torch.zeros(n, dtype=torch.float32, device="cuda")
     rows = torch.zeros((M + 2, n), dtype=torch.float64, device="cuda")
     s = torch.cuda.Stream()
     x.copy_(torch.from_numpy(sines_noise(n, seed=1)))
     torch.cuda.synchronize()
-    with torch.cuda.stream(s):       # once outside the capture (the chain's workspace is allocated at its first call)
+    with torch.cuda.stream(s):       # once outside the capture (workspaces that are allocated at first use)
         eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, s.cuda_stream)
     eng.summary(1)
     g = torch.cuda.CUDAGraph()

@@ -31,15 +31,13 @@ def oracle():
 
 
 def _run(P, torch, x_np, m, mode, keep=True, window=0):
-    from pyitd_amd.engine import CHAIN_OFF, LEVEL0_AUTO, RESIDENT_OFF
+    from pyitd_amd.engine import LEVEL0_AUTO, RESIDENT_OFF
     B, n = x_np.shape
     xd = torch.from_numpy(x_np).cuda()
     rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
     bases = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda") if keep else None
     eng = P.Engine(n, B, 0)
-    eng.set_level0_mode(LEVEL0_AUTO)     # whatever PYITD_LEVEL0_MODE / PYITD_CHAIN_MODE say: the automatic resident form needs
-    if mode != RESIDENT_OFF:             # the automatic level 0 and no chain
-        eng.set_chain_mode(CHAIN_OFF)
+    eng.set_level0_mode(LEVEL0_AUTO)     # whatever PYITD_LEVEL0_MODE says: the automatic resident form needs
     eng.set_resident_mode(mode)
     eng.set_resident_window(window)
     torch.cuda.synchronize()
@@ -134,7 +132,7 @@ def test_nan_in_the_input_follows_the_reference_inside_the_resident_kernel(P, to
     away from the NaNs; the NaNs become +inf in place) and detect_peaks(-x) of the mutated array (ITD.py:46-51, 87-95), and
     decomposes the mutated values.  The resident kernel does that in LDS (RESIDENT_ONLY: no repeat); an engine told to reject NaN
     input leaves the kernel instead and the level-by-level engine reports the signal (nan_levels = -2)."""
-    from pyitd_amd.engine import CHAIN_OFF, LEVEL0_AUTO, NAN_INPUT_REJECT, RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY
+    from pyitd_amd.engine import LEVEL0_AUTO, NAN_INPUT_REJECT, RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY
     n, m = 3000, 9
     x = np.stack([sines_noise(n, seed=b, fscale=20.0 + b, dtype=np.float64) for b in range(10)])
     x[1, 1500] = np.nan
@@ -167,7 +165,6 @@ def test_nan_in_the_input_follows_the_reference_inside_the_resident_kernel(P, to
     r = torch.zeros((B, m + 2, n), dtype=torch.float64, device="cuda")
     eng = P.Engine(n, B, 0)
     eng.set_level0_mode(LEVEL0_AUTO)
-    eng.set_chain_mode(CHAIN_OFF)
     eng.set_resident_mode(RESIDENT_AUTO)
     eng.set_nan_input_mode(NAN_INPUT_REJECT)
     torch.cuda.synchronize()

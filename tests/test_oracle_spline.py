@@ -54,6 +54,12 @@ def test_meitd_driver_logic_matches_reference(name, monkeypatch):
 
     monkeypatch.setattr(mm, "itd_baseline_extract_spline", extract)
     monkeypatch.setattr(mm, "_num_extrema", lambda x, device=0: int(cpu_oracle.knots(np.asarray(x, dtype=np.float64)).size))
+
+    def extract_and_count(x, device=0):       # the fused "extraction + count of its baseline" call of the GPU path
+        r, b = extract(x)
+        return r, b, int(cpu_oracle.knots(b).size)
+
+    monkeypatch.setattr(mm, "_extract_and_count", extract_and_count)
     g = np.load(os.path.join(SPLINE, name + ".npz"))
     assert mm.weighted_permutation_entropy(g["x"], order=3, normalize=True) == float(g["wpe"])
     hi, lo, res = mm.MEITD(g["x"].copy())

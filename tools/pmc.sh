@@ -6,7 +6,7 @@ ctrs=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --warm-ms 0 "$@" > $out/bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

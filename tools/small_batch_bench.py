@@ -32,8 +32,6 @@ def main():
              + 0.05 * torch.randn((B, n), generator=g, dtype=torch.float64)).to(torch.float32).to(dev)
         rows = torch.empty((B, M + 2, n), dtype=torch.float64, device=dev)
         eng = pyitd_amd.Engine(n, B, 0)
-        if os.environ.get("SMALL_CHAIN"):
-            eng.set_chain_mode(int(os.environ["SMALL_CHAIN"]))   # 1: CHAIN_AUTO, 2: CHAIN_ONLY (pyitd_amd/engine.py)
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize()
         for _ in range(3):
@@ -46,8 +44,6 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         s = eng.summary(B)
-        if os.environ.get("SMALL_CHAIN"):
-            print("        chain repeats so far: %d" % eng.chain_repeats)
         alg = (20 + 24 * M) * B * n / dt / 1e9
         print("%6d x %7d: %8.3f ms  %7.2f Gsamples/s  %6.0f GB/s algorithmic = %.3f of peak   rows %s" % (
             B, n, dt * 1e3, B * n / dt / 1e9, alg, alg / 8000.0, sorted(set(int(v) for v in s["n_rows"]))), flush=True)

@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/traffic_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 > $out/$c.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --warm-ms 0 --steps 3 --warmup 1 > $out/$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 - "$out" "$tag" <<'PY'
@@ -25,8 +25,8 @@ dom = [k for k in allk["FETCH_SIZE"] if "k_extract<double" in k and ", false," i
 dom = dom[0] if dom else None
 res = {"round": tag, "kernel": dom, "all_kernels": allk,
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section) -> reads = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact for streaming stores",
-       "commands": ["rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1",
-                    "rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1"]}
+       "commands": ["rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-extra --warm-ms 0 --steps 3 --warmup 1",
+                    "rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -- python3 bench.py --no-cpu-baseline --no-extra --warm-ms 0 --steps 3 --warmup 1"]}
 if dom:
     f, w = allk["FETCH_SIZE"][dom]["mean_KB"], allk["WRITE_SIZE"][dom]["mean_KB"]
     res["counters_KB_per_launch"] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
