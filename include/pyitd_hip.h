@@ -146,6 +146,25 @@ int itd_set_nan_fallback(itd_engine *e, int enable);
 #define ITD_LEVEL0_RECORDS 1
 #define ITD_LEVEL0_FUSED 2   /* never repeat: itd_get_summary fails with ITD_ERR_HIP if the reach was exceeded (benchmarks) */
 int itd_set_level0_mode(itd_engine *e, int32_t mode);
+/* The sparse levels fused ("knot first", pyitd_amd/csrc/itd_knotfirst.hpp; ABI revision 6).  An extraction maps every sample
+ * through an affine function of itself inside its segment (ITD.py:114-117), so the next level's knots sit at this level's knots
+ * (apart from places where exact ties let rounding make or break a plateau): from level `first_fused_level` on the level recursion
+ * runs on the knot list alone and the samples take ONE pass for all remaining levels — 8 B read + 8 B per row written per sample
+ * instead of 24 B per sample and level.  The sample pass re-derives every level's knots from the values it computes; where they
+ * differ from the knot side's (or a list outgrows its workspace, or knot data go non-finite, or the input holds too many exact
+ * ties: smooth and quantised signals) itd_get_summary repeats the call level by level before it returns (x_dev / rows_dev /
+ * baselines_dev must stay valid until then, as before) and the engine's next 16 decompositions start level by level.
+ * Results are bit-identical in every mode: what the fused form cannot deliver it reports.
+ * ITD_FUSE_AUTO (default): signals of >= 65536 samples with the fused level 0; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
+ * repeat (itd_get_summary fails with ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 1 ..
+ * max_iteration (default 3: levels 0, 1, 2 as one launch each). */
+#define ITD_FUSE_AUTO 0
+#define ITD_FUSE_OFF 1
+#define ITD_FUSE_ONLY 2
+int itd_set_fuse_mode(itd_engine *e, int32_t mode);
+int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
+/* how many calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
+int itd_get_fuse_repeats(const itd_engine *e);
 /* Short signals (n <= 8192 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays
  * in LDS through all levels of the driver loop (ITD.py:384-432): the signal is read once and every result row written once
  * (4 + 8 rows bytes per sample; the level-by-level form is launch bound there: 10 dependent launches).  Baselines that go NaN

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_stream.hpp"), os.path.join(_HERE, "csrc", "itd_engine_batch.inc"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"), os.path.join(_HERE, "csrc", "itd_nak.hpp"),
-           os.path.join(_HERE, "csrc", "itd_fitpack.hpp"), os.path.join(_HERE, "csrc", "itd_resident.hpp"),
+           os.path.join(_HERE, "csrc", "itd_fitpack.hpp"), os.path.join(_HERE, "csrc", "itd_resident.hpp"), os.path.join(_HERE, "csrc", "itd_knotfirst.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
 
 MAX_ROWS = 22
@@ -74,6 +74,9 @@ ABI = {
     "itd_set_level0_mode": (_INT, [_P, _I32]),
     "itd_set_host_keep_baselines": (_INT, [_P, _I32]),
     "itd_get_last_baselines_host": (_INT, [_P, _P, _I64, _I32]),
+    "itd_set_fuse_mode": (_INT, [_P, _I32]),
+    "itd_set_fuse_level": (_INT, [_P, _I32]),
+    "itd_get_fuse_repeats": (_INT, [_P]),
     "itd_set_resident_mode": (_INT, [_P, _I32]),
     "itd_get_resident_repeats": (_INT, [_P]),
     "itd_set_resident_window": (_INT, [_P, _I32]),

@@ -21,6 +21,7 @@
 #include "../../include/pyitd_hip.h"
 #include "itd_kernels.hpp"
 #include "itd_resident.hpp"
+#include "itd_knotfirst.hpp"
 #include "itd_cubic.hpp"
 #include "itd_stream.hpp"
 #include "itd_tfe.hpp"
@@ -109,6 +110,11 @@ struct itd_engine {
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
     bool resident_attr[12] = {};
     int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
+    // the fused sparse levels (itd_knotfirst.hpp): workspace (allocated at first use), mode, first fused level
+    void *d_kf = nullptr; size_t kf_bytes = 0;
+    KfWs kf{};                       // pointers into d_kf, for signal 0
+    int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
+    bool last_kf = false;
     int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
@@ -214,14 +220,62 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
     return (int)std::min<int64_t>(std::min<int64_t>(c, kMaxGridY), batch);   // a chunk's signals are the launches' grid.y
 }
 
+// The workspace of the fused sparse levels (itd_knotfirst.hpp), allocated at the first call that takes that path.  Per signal:
+// two candidate lists of `cap` entries (position + three values), the next level's triples, survival flags / prefixes, the
+// tables' pool (32 B per knot and level), and per level and tile the knots' flag words and first-index.  cap = max_n / 8: a list
+// holds the knots of level L0 >= 1 (typically 0.12 / 0.04 / 0.012 n at levels 1 / 2 / 3); a longer one fails over to the
+// level-by-level engine (kKfFailCapacity).
+constexpr int kKfLevels = ITD_MAX_ITERATION + 3;
+int ensure_kf_ws(itd_engine *e)
+{
+    if (e->d_kf) return ITD_OK;
+    const size_t B = (size_t)e->max_batch;
+    const size_t cap = (size_t)std::max<int64_t>(2048, e->max_n / 8 + 256), pool_cap = 2 * cap + 64;
+    const size_t nchunk = (cap + kKfChunk - 1) / kKfChunk;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_sig = al(B * sizeof(KfSig)), b_P = al(B * 2 * cap * 4), b_T = al(B * 2 * cap * 24), b_nT = al(B * cap * 24);
+    const size_t b_fl = al(B * cap * 4), b_cnt = al(B * nchunk * 4), b_pool = al(B * pool_cap * sizeof(KfEntry));
+    const size_t b_first = al(B * kKfLevels * ((size_t)e->max_tiles + 1) * 4), b_tf = al(B * kKfLevels * (size_t)e->max_tiles * 64);
+    const size_t b_tie = al(B * (size_t)e->max_tiles * 4), b_gpre = al(B * (size_t)groups_of((int)e->max_tiles) * 4);
+    const size_t total = b_sig + b_P + b_T + b_nT + 2 * b_fl + b_cnt + b_pool + b_first + b_tf + b_tie + b_gpre;
+    const hipError_t rc = hipMalloc(&e->d_kf, total);
+    if (rc != hipSuccess) { e->d_kf = nullptr; fail_hip(e, rc, "hipMalloc(fused levels' workspace)"); return rc == hipErrorOutOfMemory ? ITD_ERR_NOMEM : ITD_ERR_HIP; }
+    e->kf_bytes = total;
+    e->ws_bytes += (int64_t)total;
+    char *p = (char *)e->d_kf;
+    KfWs &w = e->kf;
+    w.sig = (KfSig *)p; p += b_sig;
+    w.candP = (int32_t *)p; p += b_P;
+    w.candT = (double *)p; p += b_T;
+    w.newT = (double *)p; p += b_nT;
+    w.flag = (int32_t *)p; p += b_fl;
+    w.pref = (int32_t *)p; p += b_fl;
+    w.cnt = (int32_t *)p; p += b_cnt;
+    w.pool = (KfEntry *)p; p += b_pool;
+    w.first = (int32_t *)p; p += b_first;
+    w.tflags = (unsigned long long *)p; p += b_tf;
+    w.tie = (int32_t *)p; p += b_tie;
+    w.gpre = (int32_t *)p;
+    if (hipMemset(w.tie, 0, b_tie) != hipSuccess) return ITD_ERR_HIP;     // the tie flags clean themselves from here on
+    w.cap = (int32_t)cap; w.pool_cap = (int32_t)pool_cap; w.nchunk = (int32_t)nchunk;
+    return ITD_OK;
+}
+
 template <typename Tin>
 int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M,
-                      double *rows, double *bases_user, hipStream_t st, bool fuse0, bool nan_input = false)
+                      double *rows, double *bases_user, hipStream_t st, bool fuse0, bool nan_input = false, bool kf = false)
 {
     // nan_input: the caller's signal holds a NaN (found by the previous, rejected run of this call): level 0 the way the
     // reference runs it — k_nan_level0 writes the mutated signal (NaN -> +inf, ITD.py:50) into the third baseline slot, which
     // nothing touches before level 2, and the level-0 records; the record-driven level-0 extraction then reads that copy
     if (nan_input) fuse0 = false;
+    // kf: levels L0 .. max_iteration + 1 run fused (itd_knotfirst.hpp): one launch per level only for levels 0 .. L0 - 1
+    const int L0 = e->fuse_level;
+    kf = kf && fuse0 && L0 >= 1 && L0 <= M && n < ((int64_t)1 << 31) - 65536;
+    if (kf) {
+        const int rc = ensure_kf_ws(e);
+        if (rc) return rc;
+    }
     const int n_tiles = (int)tiles_of(n);
     const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
@@ -303,7 +357,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                                           pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
         }
 
-        for (int j = 0; j <= M + 1; ++j) {
+        const int j_last = kf ? L0 - 1 : M + 1;
+        int32_t *tie_c = kf ? e->kf.tie + (size_t)b0 * n_tiles : nullptr;
+        for (int j = 0; j <= j_last; ++j) {
             // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
             double *base_out;
             int64_t base_stride;
@@ -319,28 +375,29 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 if (j >= 1) { base_in = pp_c + (int64_t)((j - 1) % 3) * e->pp_pitch; base_in_stride = 3 * e->pp_pitch; }
             }
             double *rot_out = rows_c + (int64_t)j * n;
-            const bool final_level = (j == M + 1);
+            const bool final_level = !kf && (j == M + 1);
             const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
             // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
             // begin / end timestamps (no marker packets in the stream: nothing is added to the timed region)
-#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE) ITD_LAUNCH_EXTRACT_KT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE, kTilesPerWave)
-#define ITD_LAUNCH_EXTRACT_KT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE, KTW)                                                      \
+#define ITD_LAUNCH_EXTRACT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE) ITD_LAUNCH_EXTRACT_KT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE, kTilesPerWave, false)
+#define ITD_LAUNCH_EXTRACT_KT(TIN, FIN, XIN, XSTRIDE, CAPK, FUSE, KTW, TIES)                                                \
     do {                                                                                                                   \
         const TIN *a_x = XIN; int64_t a_xs = XSTRIDE, a_n = n, a_rs = rows_stride, a_bs = base_stride;                     \
         int a_nt = n_tiles, a_b = nb, a_lvl = j, a_keep = 0;                                                               \
         const int32_t *a_ci = cnt(j), *a_gi = gs(j); int32_t *a_co = cnt(j + 1), *a_go = gs(j + 1), *a_gc = gs(j + 2);      \
         const TileRec *a_ri = rec(j); TileRec *a_ro = rec(j + 1); double *a_rot = rot_out, *a_bas = base_out;              \
-        SigState *a_st = state;                                                                                            \
+        SigState *a_st = state; int32_t *a_tie = (FUSE) ? tie_c : nullptr;                                                 \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
-                        &a_bas, &a_bs, &a_st, &a_lvl, &a_keep};                                                            \
-        HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, KTW, FUSE>),                    \
+                        &a_bas, &a_bs, &a_st, &a_lvl, &a_keep, &a_tie};                                                    \
+        HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, KTW, FUSE, TIES>),              \
                                       dim3((n_tiles + (KTW) - 1) / (KTW), nb),                                               \
                                       blk, args, 0, cst, pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,                    \
                                       pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));                              \
     } while (0)
             if (j == 0) {   // never the last level: M >= 0
                 if (nan_input) ITD_LAUNCH_EXTRACT(double, false, xm_c, 3 * e->pp_pitch, kRankCap0, false);
-                else if (fuse0) ITD_LAUNCH_EXTRACT_KT(Tin, false, xc, x_stride, kRankCap0, true, kFuse0TilesPerWave);
+                else if (fuse0 && kf) ITD_LAUNCH_EXTRACT_KT(Tin, false, xc, x_stride, kRankCap0, true, kFuse0TilesPerWave, true);
+                else if (fuse0) ITD_LAUNCH_EXTRACT_KT(Tin, false, xc, x_stride, kRankCap0, true, kFuse0TilesPerWave, false);
                 else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, false);
             } else {
                 if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap, false);
@@ -354,12 +411,37 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             // blocks per signal: a thread of the row fix-up moves 8 samples (four 16-byte accesses) before the grid is widened
             const int fb = (int)std::min<int64_t>(std::max<int64_t>((n + 8 * kFinalizeThreads - 1) / (8 * kFinalizeThreads), 1), 1024);
             int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
+            const int jf = j_last + 1;      // the level whose input is pending: max_iteration + 2, or the first fused level
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
-                                                                       gs(M + 2), n_tiles, M + 2, state, other_state + b0, og, e->gsum_third);
+                                                                       gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
             else
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
-                                                                       e->pp_pitch, 3, gs(M + 2), n_tiles, M + 2, state, other_state + b0, og, e->gsum_third);
+                                                                       e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
+        }
+        if (kf) {
+            // ---- levels L0 .. M + 1 fused: hand-over, the knot-side steps, ONE pass over the samples, the verdict ----
+            KfWs w = e->kf;
+            w.n_tiles = n_tiles; w.L0 = L0; w.nlev = M + 3 - L0;
+            const size_t B0 = (size_t)b0;
+            w.sig += B0; w.candP += B0 * 2 * w.cap; w.candT += B0 * 2 * w.cap * 3; w.newT += B0 * w.cap * 3; w.flag += B0 * w.cap;
+            w.pref += B0 * w.cap; w.cnt += B0 * w.nchunk; w.pool += B0 * w.pool_cap;
+            w.first += B0 * (size_t)w.nlev * (n_tiles + 1); w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.tie += B0 * n_tiles;
+            // (the per-signal strides of `first` / `tflags` follow this call's geometry: nlev levels x n_tiles tiles per signal)
+            const double *xl = bases_c ? bases_c + (int64_t)(L0 - 1) * n : pp_c + (int64_t)((L0 - 1) % 3) * e->pp_pitch;
+            const int64_t xl_stride = bases_c ? rows_stride : 3 * e->pp_pitch;
+            w.gpre += B0 * n_groups;
+            k_kf_prepare<<<dim3((unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (int64_t)(w.nlev - 1) * n_tiles / 512)), nb), 256, 0, cst>>>(w, gs(L0));
+            k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
+            k_kf_sticky_init<T><<<nb, kWave, 0, cst>>>(w, xl, xl_stride, n, state);
+            for (int lev = L0; lev <= M + 1; ++lev) {
+                // the lists shrink ~3x per level; any grid is correct (the blocks take the chunks in turn)
+                const unsigned blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(w.nchunk, (int64_t)768 >> std::min(lev - L0, 6)));
+                k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, n);
+                k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, M);
+            }
+            k_kf_apply<T, kKfCap><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xl, xl_stride, n, rec(L0), rows_c, rows_stride, bases_c, rows_stride);
+            k_kf_finish<<<(nb + 63) / 64, 64, 0, cst>>>(w, nb, state);
         }
     }
     for (int k = 0; k < S - 1; ++k) {
@@ -386,6 +468,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_fused = fuse0;
     e->last_resident = false;
     e->last_nan_input = nan_input;
+    e->last_kf = kf;
     return ITD_OK;
 }
 
@@ -471,12 +554,25 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
     return ITD_OK;
 }
 
+// The sparse levels fused (itd_knotfirst.hpp)?  Automatic: long signals (the per-level launches are memory bound there), at least
+// two fused extractions, the fused level 0 (it flags the input's exact ties), no per-launch timing; not while a recent call had to
+// be repeated level by level (smooth or quantised input keeps failing the verification: workloads tend to be homogeneous).
+bool want_kf(itd_engine *e, int64_t n, int32_t M, bool fuse0)
+{
+    if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || e->fuse_level < 1 || e->fuse_level > M) return false;
+    if (e->fuse_mode == ITD_FUSE_ONLY) return true;
+    if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO) return false;
+    if (e->fuse_off_left > 0) { --e->fuse_off_left; return false; }
+    return true;
+}
+
 template <typename Tin>
 int enqueue_any(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, double *rows,
                 double *bases_user, hipStream_t st)
 {
     if (want_resident(e, n)) return enqueue_resident<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
-    return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, want_fused(e));
+    const bool f0 = want_fused(e);
+    return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, f0, false, want_kf(e, n, M, f0));
 }
 
 // how the next decomposition's level 0 finds its knots: fused (one pass over the signal) unless the engine was told
@@ -663,7 +759,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
-    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_flag);
+    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); (void)hipFree(e->d_flag);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
@@ -778,6 +874,25 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         const int rc = repeat(false, true);
         if (rc) return rc;
     }
+    if (e->last_kf) {
+        // the fused sparse levels deliver the reference's result or report that they cannot (SigState::kf_fail: the sample pass
+        // found a knot the knot side had missed, a list / table outgrew its workspace, non-finite knot data, too many exact ties):
+        // repeat the call level by level, and let the engine's next decompositions start that way
+        bool redo = false;
+        for (int b = 0; b < B; ++b) redo = redo || e->h_state[b].kf_fail != 0;
+        if (redo) {
+            if (e->fuse_mode == ITD_FUSE_ONLY) {
+                int code = 0;
+                for (int b = 0; b < B; ++b) code |= e->h_state[b].kf_fail;
+                snprintf(e->err, sizeof(e->err), "fused sparse levels: not the reference's result (fail bits 0x%x: 1 verification, 2 capacity, 4 non-finite, 8 ties); ITD_FUSE_ONLY forbids the level-by-level repeat", code);
+                return ITD_ERR_HIP;
+            }
+            ++e->fuse_repeats;
+            e->fuse_off_left = 16;
+            const int rc = repeat(want_fused(e), false);
+            if (rc) return rc;
+        }
+    }
     if (e->last_fused) {
         // the fused level-0 launch reaches kReach windows beyond a tile for its halo knots; a signal smoother than that
         // (knots more than ~4000 samples apart at level 0) raised l0_fail: repeat the call record-driven (k_scan0 + records),
@@ -871,6 +986,23 @@ int itd_set_resident_mode(itd_engine *e, int32_t mode)
 }
 
 int itd_get_resident_repeats(const itd_engine *e) { return e ? e->resident_repeats : -1; }
+
+int itd_set_fuse_mode(itd_engine *e, int32_t mode)
+{
+    if (!e || mode < ITD_FUSE_AUTO || mode > ITD_FUSE_ONLY) return ITD_ERR_INVALID_ARG;
+    e->fuse_mode = mode;
+    e->fuse_off_left = 0;
+    return ITD_OK;
+}
+
+int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level)
+{
+    if (!e || first_fused_level < 1 || first_fused_level > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
+    e->fuse_level = first_fused_level;
+    return ITD_OK;
+}
+
+int itd_get_fuse_repeats(const itd_engine *e) { return e ? e->fuse_repeats : -1; }
 
 int itd_set_resident_window(itd_engine *e, int32_t segments)
 {

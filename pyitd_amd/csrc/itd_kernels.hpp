@@ -100,8 +100,9 @@ struct SigState {
                              // level 0 has to be repeated through k_scan0 + the record-driven launch
     int32_t fin_stopped;     // written by k_finalize only: the verdict after the last pending baseline's stop test
     int32_t fin_stop_level;  // (kept apart from stop_level, which k_finalize's own workgroups still read)
-    int32_t chain_stop;      // written by k_chain_finalize only (itd_chain.hpp): some pending baseline inside the run had < 2
-                             // knots, the one-launch chain's rows past that level are not the reference's: repeat level by level
+    int32_t kf_fail;         // written by the fused sparse levels only (itd_knotfirst.hpp): != 0 = their result for this signal is not
+                             // the reference's (a knot the knot-side recursion missed, capacity, non-finite knot data): the call is
+                             // repeated level by level
     int32_t res_fail;        // written by k_resident only (itd_resident.hpp): the one-workgroup form met a non-finite sample (it
                              // handles finite data only): the call is repeated through the level-by-level engine
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
@@ -697,11 +698,16 @@ __device__ __forceinline__ int lane_bit(unsigned long long mask)
 // d > 0 <=> !(d <= 0) and d < 0 <=> !(d >= 0), so four ordered compares and one unordered compare per group do instead of
 // eight ordered ones plus a DPP shift of the differences.  No exec-masked short circuits, no bool -> mask round trips.
 // ---------------------------------------------------------------------------------------------
+// zero_inner (optional): receives a non-zero word if any difference of the INNER groups 1 .. NG-2 is exactly zero (an exact tie of
+// two neighbouring samples; NaN differences count too): the fused level-0 launch flags such tiles for the fused sparse levels
+// (itd_knotfirst.hpp).  The masks exist anyway: two scalar operations per group.
 template <typename T, int NG>
 __device__ __forceinline__ void knot_predicate(const T (&d0)[NG], const T (&d1)[NG], T dlast,
-                                               unsigned long long (&E)[NG], unsigned long long (&O)[NG])
+                                               unsigned long long (&E)[NG], unsigned long long (&O)[NG],
+                                               unsigned long long *zero_inner = nullptr)
 {
     using ull = unsigned long long;
+    ull zacc = 0;
     constexpr ull kTop = 1ull << 63;
     ull unord = __ballot(dlast != dlast) & kTop;
 #pragma unroll
@@ -719,10 +725,12 @@ __device__ __forceinline__ void knot_predicate(const T (&d0)[NG], const T (&d1)[
             const ull n2 = (~ge >> 1) | (g + 1 < NG ? ~ge_n << 63 : nlast);
             E[g] = (p1 & le) | (n1 & ge);
             O[g] = (p2 & ~p1) | (n2 & ~n1);
+            if (g >= 1 && g + 2 <= NG) zacc |= (le & ge) | ~(p1 | n1);   // d0 == 0 / d1 == 0
             le = le_n;
             ge = ge_n;
         }
     } else {   // some difference is NaN: all eight ordered compares
+        zacc = ~0ull;
         ull p0 = __ballot(d0[0] > (T)0), n0 = __ballot(d0[0] < (T)0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -739,6 +747,7 @@ __device__ __forceinline__ void knot_predicate(const T (&d0)[NG], const T (&d1)[
             n0 = n0_n;
         }
     }
+    if (zero_inner) *zero_inner = zacc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -753,7 +762,9 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
                                             TileRec *__restrict__ recs_out, int32_t *__restrict__ gsum_out,
                                             int32_t *s_rec /* sizeof(TileRec) bytes, 16-byte aligned */, int32_t *s_pos /* 8 ints */,
                                             int count_hi = 0 /* added to the int behind the group sum by the same (64-bit) atomic:
-                                                                the fused level-0 launch's own knot count, for m[0] */)
+                                                                the fused level-0 launch's own knot count, for m[0] */,
+                                            int32_t *tie_slot = nullptr /* non-null (rare): the tile's input held an exact tie of two
+                                                                neighbouring samples: set its flag for the fused sparse levels */)
 {
     constexpr int G2 = TW / 128;
     const int lane = lane_id();
@@ -791,6 +802,7 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
     // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
     if (lane == 0) {
         if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
+        if (tie_slot) *tie_slot = 1;
         if (count_hi)   // the group sums are 128 bytes apart: element +1 is free, and 8-byte aligned with element 0
             atomicAdd(reinterpret_cast<unsigned long long *>(&gsum_out[gsum_index]), ((unsigned long long)(unsigned)count_hi << 32) | (unsigned)total);
         else if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[gsum_index], total);
@@ -858,7 +870,8 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
 // `lo`, `hi`: window-relative positions allowed to flag (the signal's first/last-sample rule ITD.py:70-73, clipping).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NG>
-__device__ __forceinline__ void knot_masks(const T (&v)[NG][2], int lo, int hi, unsigned long long (&E)[NG], unsigned long long (&O)[NG])
+__device__ __forceinline__ void knot_masks(const T (&v)[NG][2], int lo, int hi, unsigned long long (&E)[NG], unsigned long long (&O)[NG],
+                                           unsigned long long *zero_inner = nullptr)
 {
     T d0[NG], d1[NG];
 #pragma unroll
@@ -868,7 +881,7 @@ __device__ __forceinline__ void knot_masks(const T (&v)[NG][2], int lo, int hi, 
         d0[g] = v[g][0] - left;
         d1[g] = v[g][1] - v[g][0];
     }
-    knot_predicate<T, NG>(d0, d1, (T)0, E, O);   // last window position: right neighbour unknown (a zero difference never flags)
+    knot_predicate<T, NG>(d0, d1, (T)0, E, O, zero_inner);   // last window position: right neighbour unknown (a zero difference never flags)
     E[0] &= ~1ull;                                // window position 0: left neighbour unknown
     if (lo > 1 || hi < 128 * NG - 2) {
 #pragma unroll
@@ -1132,7 +1145,7 @@ __device__ unsigned long long *g_prof_buf;   // [wavefronts][16]
 #else
 #define PROF_MARK(i)
 #endif
-template <typename Tin, int TW, bool FINAL, int CAP, int KT, bool FUSE0 = false>
+template <typename Tin, int TW, bool FINAL, int CAP, int KT, bool FUSE0 = false, bool TIES = false>
 __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, int64_t x_stride, int64_t n,
                                                      int n_tiles, int batch,
                                                      const int32_t *__restrict__ counts_in,
@@ -1145,7 +1158,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                                                      double *__restrict__ base_out, int64_t base_stride,
                                                      SigState *__restrict__ state, int level,
                                                      int keep_nan = 0 /* single-level helper: store the baseline as computed (the NaN -> +inf
-                                                                         write, ITD.py:50, belongs to the driver's stop test) */)
+                                                                         write, ITD.py:50, belongs to the driver's stop test) */,
+                                                     int32_t *__restrict__ tie_out = nullptr /* FUSE0, optional [batch][n_tiles]: 1 = the tile
+                                                                         holds an exact tie of neighbouring samples (itd_knotfirst.hpp) */)
 {
     constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
@@ -1282,6 +1297,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int rem = ni - si;            // samples of the signal from the tile's first on (>= 1)
     const bool full = rem >= TW;
     int nb = 0, nf = 0, own_c = 0;   // real knots found in front (0..2) / behind (0..3); the tile's own knots
+    bool tie_here = false;           // FUSE0: the tile's samples hold an exact tie (wave-uniform; flagged with the tile's count store)
     // the tile's own knots, decoded once: kinfo[g] = ke | bitE << 16 | bitO << 17 with ke = knots of the tile at or before the
     // lane's even sample of group g; gcnt = the groups' knot counts, 8 bits each
     int kinfo[G2];
@@ -1435,7 +1451,12 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
         // window = [s-128, s+TW+128): positions allowed to flag are the signal's 1 .. n-2 (ITD.py:70-73)
         unsigned long long E[G2 + 2], O[G2 + 2];
-        knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O);
+        if constexpr (TIES) {   // the launch in front of the fused sparse levels: flag tiles that hold an exact tie
+            unsigned long long zero_any = 0;
+            knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O, &zero_any);
+            tie_here = zero_any != 0;   // (padding zeros beyond the row flag the last tile: harmless)
+        } else
+            knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O);
         PROF_MARK(1)   // the tile has arrived; knot predicate on tile + halo groups
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
@@ -1767,7 +1788,8 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
             }
         }
         scan_publish<TW, FINAL>(xr, x_lo, x_hi, s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
-                                counts_out, recs_out, gsum_out, s_rec, s_pos, FUSE0 ? own_c : 0);
+                                counts_out, recs_out, gsum_out, s_rec, s_pos, FUSE0 ? own_c : 0,
+                                (TIES && tie_here) ? tie_out + slot0 + t : nullptr);
     }
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
     PROF_MARK(7)   // next level's scan + record
@@ -1834,7 +1856,7 @@ __device__ __forceinline__ void sig_state_reset(SigState *st)
     st->l0_fail = 0;
     st->fin_stopped = 0;
     st->fin_stop_level = -1;
-    st->chain_stop = 0;
+    st->kf_fail = 0;
     st->res_fail = 0;
 }
 

@@ -20,6 +20,7 @@ TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0 = 
 NAN_INPUT_FOLLOW, NAN_INPUT_REJECT = 0, 1
 RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY = 0, 1, 2
 SPLINE_AUTO, SPLINE_SERIAL, SPLINE_PARALLEL = 0, 1, 2
+FUSE_AUTO, FUSE_OFF, FUSE_ONLY = 0, 1, 2
 
 
 def _np_ptr(a):
@@ -40,6 +41,9 @@ class Engine:
         mode = os.environ.get("PYITD_LEVEL0_MODE")      # diagnostic override: run a whole test suite in one level-0 mode
         if mode:
             self.set_level0_mode(int(mode))
+        mode = os.environ.get("PYITD_FUSE_MODE")        # the fused sparse levels (FUSE_*)
+        if mode:
+            self.set_fuse_mode(int(mode))
         mode = os.environ.get("PYITD_RESIDENT_MODE")    # and for the one-workgroup form of short signals (RESIDENT_*)
         if mode:
             self.set_resident_mode(int(mode))
@@ -98,6 +102,20 @@ class Engine:
     def set_level0_mode(self, mode):
         """LEVEL0_AUTO (fused level 0, record-driven repeat if the input is too smooth), LEVEL0_RECORDS, LEVEL0_FUSED."""
         self._check(self._L.itd_set_level0_mode(self._h, int(mode)))
+
+    def set_fuse_mode(self, mode):
+        """FUSE_AUTO (long signals: the sparse levels run on the knot list, the samples take one pass for all of them; a call whose
+        verification fails is repeated level by level), FUSE_OFF, FUSE_ONLY (never repeat)."""
+        self._check(self._L.itd_set_fuse_mode(self._h, int(mode)))
+
+    def set_fuse_level(self, first_fused_level):
+        """The first fused level (default 3: levels 0, 1, 2 are one launch each)."""
+        self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))
+
+    @property
+    def fuse_repeats(self):
+        """Calls of this engine that itd_get_summary had to repeat level by level because the fused levels reported a failure."""
+        return self._L.itd_get_fuse_repeats(self._h)
 
     def set_resident_mode(self, mode):
         """RESIDENT_AUTO (signals of <= 8192 samples run as one workgroup each in one launch, the signal resident in LDS; a call
