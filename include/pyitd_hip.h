@@ -409,6 +409,8 @@ int itd_stream_status(itd_stream *s, int32_t *status);
 #define ITD_TIME_EXTRACT_FINAL 2  /* k_extract of the "Out of time!" level (writes rotation+baseline only) */
 #define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
 #define ITD_TIME_SCAN0 4          /* k_scan0: the level-0 knot scan of the caller's signal (4 B/sample for float32) */
+#define ITD_TIME_KF_APPLY 5       /* k_kf_apply: the one pass over the samples for all fused levels (8 B read + 8 B per row written) */
+#define ITD_TIME_KF_KNOTS 6       /* the knot side of the fused levels: hand-over + two short launches per level (a span, not a launch) */
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
 /* instrument only every stride-th decomposition (launches with events cost ~2 us more each, the span's marker records ~5 us each) */
 int itd_set_kernel_timing_stride(itd_engine *e, int stride);

@@ -431,16 +431,25 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const double *xl = bases_c ? bases_c + (int64_t)(L0 - 1) * n : pp_c + (int64_t)((L0 - 1) % 3) * e->pp_pitch;
             const int64_t xl_stride = bases_c ? rows_stride : 3 * e->pp_pitch;
             w.gpre += B0 * n_groups;
+            const int p_kn = time_begin(e, ITD_TIME_KF_KNOTS, cst);
             k_kf_prepare<<<dim3((unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (int64_t)(w.nlev - 1) * n_tiles / 512)), nb), 256, 0, cst>>>(w, gs(L0));
             k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
-            k_kf_sticky_init<T><<<nb, kWave, 0, cst>>>(w, xl, xl_stride, n, state);
+            k_kf_sticky_init<T><<<nb, kWave, 0, cst>>>(w, xl, xl_stride, state);
             for (int lev = L0; lev <= M + 1; ++lev) {
                 // the lists shrink ~3x per level; any grid is correct (the blocks take the chunks in turn)
                 const unsigned blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(w.nchunk, (int64_t)768 >> std::min(lev - L0, 6)));
                 k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, n);
                 k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, M);
             }
-            k_kf_apply<T, kKfCap><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xl, xl_stride, n, rec(L0), rows_c, rows_stride, bases_c, rows_stride);
+            time_end(e, p_kn, cst);
+            {
+                const int pair = time_slot(e, ITD_TIME_KF_APPLY);
+                KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
+                const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
+                void *args[] = {&a_w, &a_xl, &a_xs, &a_n, &a_rec, &a_rows, &a_rs, &a_bases, &a_bs};
+                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap>), dim3(n_tiles, nb), dim3(kWave), args, 0, cst,
+                                              pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr, pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
+            }
             k_kf_finish<<<(nb + 63) / 64, 64, 0, cst>>>(w, nb, state);
         }
     }
@@ -1907,7 +1916,7 @@ int itd_set_kernel_timing_stride(itd_engine *e, int stride)
 
 int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches)
 {
-    if (!e || which < 0 || which > ITD_TIME_SCAN0) return ITD_ERR_INVALID_ARG;
+    if (!e || which < 0 || which > ITD_TIME_KF_KNOTS) return ITD_ERR_INVALID_ARG;
     if (!e->ran || !e->timing) return ITD_ERR_NOT_RUN;
     DevGuard g(e->device);
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));

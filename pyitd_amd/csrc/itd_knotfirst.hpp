@@ -52,7 +52,7 @@ struct KfSig {
     int32_t lend;         // -1 while the steps run; then the last fused level: rows 0 .. lend are the result
     int32_t natural;      // at lend: 1 = natural stop (row lend = the level's input), 0 = "Out of time!" (rotation + baseline)
     int32_t m_exact;      // knots of the last pending baseline, counted by the sample pass
-    int32_t pad0;
+    int32_t done_tiles;   // tiles of the sample pass that have finished (the last one writes the verdict)
     int32_t mlev[kMaxLevels + 2];   // knots of level j's input
     int32_t toff[kMaxLevels + 2];   // level j's table starts at this entry of the signal's pool
     double ends[2][4];              // [level & 1]: x[0], x[1], x[n-2], x[n-1] of the level's input
@@ -250,16 +250,14 @@ __device__ __forceinline__ int kf_sticky_sort(KfSig *ks, int cnt, int par, int l
     return kept;
 }
 
-// grid = (batch), 64 threads: the sticky candidates sorted, with their list ranks and triples at level L0; the level's end samples
+// one wavefront: the sticky candidates sorted, with their list ranks and triples at level L0; the level's end samples
 template <int TW>
-__global__ __launch_bounds__(kWave) void k_kf_sticky_init(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64_t n,
-                                                          const SigState *__restrict__ state)
+__device__ __forceinline__ void kf_sticky_init(const KfWs &ws, int sig, const double *__restrict__ xl, int64_t xl_stride,
+                                               const SigState *__restrict__ state, int lane)
 {
     __shared__ int32_t s_p[kKfSticky + 64], s_k[kKfSticky + 64];
     __shared__ double s_t[kKfSticky + 64][3];
-    const int sig = blockIdx.x, lane = lane_id();
     KfSig *ks = ws.sig + sig;
-    if (!ks->active || ks->fail) return;
     const int L0 = ws.L0, par = L0 & 1;
     const double *xs = xl + (int64_t)sig * xl_stride;
     const int cnt = min(ks->n_sticky, kKfSticky);
@@ -279,7 +277,7 @@ __global__ __launch_bounds__(kWave) void k_kf_sticky_init(KfWs ws, const double 
 
 // ---- one knot-side step, part a: the level's table (B, S), the next level's triples and survival flags of the list entries, the
 //      per-tile structures of THIS level for the sample pass, the next level's end samples; the sticky candidates' evaluation.
-//      grid = (blocks + 1, batch), 256 threads: the blocks take the list's 256-entry chunks in turn, the last block the sticky ones.
+//      The signal's blocks take the list's 256-entry chunks in turn; the last block also evaluates the sticky ones.
 struct KfList {       // a level's list with its two virtual end knots
     const int32_t *P; const double *Tr; int m; int32_t n1; double e0, e3;
     __device__ __forceinline__ int32_t pos(int k) const { return k <= 0 ? 0 : (k > m ? n1 : P[k]); }
@@ -298,14 +296,13 @@ __device__ __forceinline__ double kf_B(const KfList &L, int k, double m0, double
 }
 
 template <int TW>
-__global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_t n)
+__device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int64_t n, int blk, int nblk)
 {
     __shared__ int32_t sP[kKfChunk + 4];
     __shared__ double sX[kKfChunk + 4], sB[kKfChunk + 4], sS[kKfChunk + 4];
     __shared__ int s_red[kKfChunk / 64];
-    const int sig = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     KfSig *ks = ws.sig + sig;
-    if (!ks->active || ks->lend >= 0 || ks->fail) return;
     const int m = ks->mlev[lev], par = (lev - ws.L0) & 1, lp = lev & 1;
     const int toff = ks->toff[lev];
     if (toff + m + 2 > ws.pool_cap || m + kKfSticky + 4 > ws.cap) {
@@ -317,9 +314,8 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_
     const double m0 = (e0 + e1) / 2.0, mn = (e2 + e3) / 2.0;                // ITD.py:101-102
     KfList L{ws.candP + ((size_t)sig * 2 + par) * ws.cap, ws.candT + ((size_t)sig * 2 + par) * ws.cap * 3, m, n1, e0, e3};
     KfEntry *pool = ws.pool + (size_t)sig * ws.pool_cap + toff;
-    if (blockIdx.x == gridDim.x - 1) {
+    if (blk == nblk - 1 && wave == 0) {
         // ---- sticky candidates: the segments their three samples lie in from the list itself (a handful of entries each) ----
-        if (wave != 0) return;
         const int cnt = ks->n_sticky_lev;
         for (int i = lane; i < cnt; i += kWave) {
             const int32_t s = ks->spos[i];
@@ -341,10 +337,11 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_
             ks->sins[i] = (!is_knot && kf_pred(yl, yc, yr)) ? 1 : 0;
             if (!(yl - yl == 0.0) || !(yc - yc == 0.0) || !(yr - yr == 0.0)) atomicOr(&ks->fail, kKfFailNonFinite);
         }
-        return;
     }
     const int nck = max(1, (m + kKfChunk - 1) / kKfChunk);      // chunk 0 runs even for an empty list (entry 0, the end samples)
-  for (int c = blockIdx.x; c < nck; c += gridDim.x - 1) {
+  // (with more than one block the last one works on the sticky candidates only)
+  const int nwork = nblk > 1 ? nblk - 1 : 1;
+  for (int c = (nblk > 1 && blk == nblk - 1) ? nck : blk; c < nck; c += nwork) {
     const int k0 = 1 + c * kKfChunk;
     __syncthreads();                                            // the previous chunk's LDS reads are done
     // entries k0 - 2 .. k0 + 257 (LDS index j <-> entry k0 - 2 + j)
@@ -448,15 +445,14 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_
 
 // ---- part b: the survivors, and the sticky candidates that became knots, in order into the other list buffer; the stop rules
 //      (ITD.py:400-426); the sticky candidates' ranks in the new list.  grid = (blocks + 1, batch), 256 threads.
-__global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int max_iteration)
+__device__ __forceinline__ void kf_step_b(const KfWs &ws, int sig, int lev, int max_iteration, int blk, int nblk)
 {
     __shared__ int32_t s_ins[kKfSticky + 64];
     __shared__ int s_nins, s_red[kKfChunk / 64];
     __shared__ int32_t s_p[kKfSticky + 64], s_k[kKfSticky + 64];
     __shared__ double s_t[kKfSticky + 64][3];
-    const int sig = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     KfSig *ks = ws.sig + sig;
-    if (!ks->active || ks->lend >= 0 || ks->fail) return;
     const int m = ks->mlev[lev], par = (lev - ws.L0) & 1, lp = lev & 1;
     const int nck = (m + kKfChunk - 1) / kKfChunk;
     const int32_t *P = ws.candP + ((size_t)sig * 2 + par) * ws.cap;
@@ -482,8 +478,9 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int ma
     }
     __syncthreads();
     const int nins = s_nins;
-    if (blockIdx.x != gridDim.x - 1) {
-      for (int c = blockIdx.x; c < nck; c += gridDim.x - 1) {
+    {
+      const int nwork = nblk > 1 ? nblk - 1 : 1;
+      for (int c = (nblk > 1 && blk == nblk - 1) ? nck : blk; c < nck; c += nwork) {
         __syncthreads();
         int acc = 0;
         for (int q = tid; q < c; q += kKfChunk) acc += cnt[q];
@@ -504,7 +501,8 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int ma
             nT[3 * (size_t)out] = newT[3 * (size_t)k]; nT[3 * (size_t)out + 1] = newT[3 * (size_t)k + 1]; nT[3 * (size_t)out + 2] = newT[3 * (size_t)k + 2];
         }
       }
-      return;
+      if (blk != nblk - 1) return;
+      __syncthreads();
     }
     // ---- the sticky block: inserts, bookkeeping, stop rules ----
     // exclusive prefix of the chunk counts, in place in global memory's place: LDS holds up to kKfPre of them, the rest is summed
@@ -568,6 +566,33 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int ma
         if (m_next < 2) { ks->lend = lev; ks->natural = 1; }                 // "No more decompositions possible", ITD.py:404-416
         else if (lev > max_iteration) { ks->lend = lev; ks->natural = 0; }  // "Out of time!", ITD.py:418-426
     }
+}
+
+// ---- the knot side as launches: hand-over (sticky candidates), then two launches per level.  grid = (blocks, batch), 256
+//      threads; the blocks take the list's chunks in turn, the last block also works on the sticky candidates.  (One persistent
+//      launch with grid barriers between the phases was measured slower: 188 us with 128 blocks, 864 us with 768, against 12
+//      launches of ~7.5 us — the phases are short chains of dependent loads, and a barrier costs more than a launch boundary.)
+template <int TW>
+__global__ __launch_bounds__(kWave) void k_kf_sticky_init(KfWs ws, const double *__restrict__ xl, int64_t xl_stride,
+                                                          const SigState *__restrict__ state)
+{
+    const int sig = blockIdx.x;
+    KfSig *ks = ws.sig + sig;
+    if (!ks->active || ks->fail) return;
+    kf_sticky_init<TW>(ws, sig, xl, xl_stride, state, threadIdx.x);
+}
+template <int TW>
+__global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_t n)
+{
+    const KfSig *ks = ws.sig + blockIdx.y;
+    if (!ks->active || ks->lend >= 0 || ks->fail) return;      // (a failure raised by a running block of this launch: the others
+    kf_step_a<TW>(ws, blockIdx.y, lev, n, blockIdx.x, gridDim.x);   //  may or may not see it — either way the result is discarded)
+}
+__global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int max_iteration)
+{
+    const KfSig *ks = ws.sig + blockIdx.y;
+    if (!ks->active || ks->lend >= 0 || ks->fail) return;
+    kf_step_b(ws, blockIdx.y, lev, max_iteration, blockIdx.x, gridDim.x);
 }
 
 // ---- the sample pass: every fused level of a tile in registers.  grid = (tiles, batch), 64 threads. -----------------------

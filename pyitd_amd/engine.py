@@ -16,7 +16,7 @@ STOP_NATURAL, STOP_TIMEOUT = 0, 1
 DETECT_KNOTS, DETECT_VALLEYS, DETECT_PEAKS = 0, 1, 2
 ITD_OK, ITD_ERR_INVALID_ARG, ITD_ERR_NONFINITE = 0, 1, 6
 LEVEL0_AUTO, LEVEL0_RECORDS, LEVEL0_FUSED = 0, 1, 2
-TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0 = 0, 1, 2, 3, 4
+TIME_EXTRACT, TIME_EXTRACT_L0, TIME_EXTRACT_FINAL, TIME_DECOMPOSE, TIME_SCAN0, TIME_KF_APPLY, TIME_KF_KNOTS = 0, 1, 2, 3, 4, 5, 6
 NAN_INPUT_FOLLOW, NAN_INPUT_REJECT = 0, 1
 RESIDENT_AUTO, RESIDENT_OFF, RESIDENT_ONLY = 0, 1, 2
 SPLINE_AUTO, SPLINE_SERIAL, SPLINE_PARALLEL = 0, 1, 2

@@ -199,6 +199,8 @@ def test_kernel_timing_api(P, torch, oracle):
     xd = torch.from_numpy(x).cuda()
     rows = torch.empty((m + 2, n), dtype=torch.float64, device="cuda")
     eng = P.Engine(n, 1, 0)
+    from pyitd_amd.engine import FUSE_OFF
+    eng.set_fuse_mode(FUSE_OFF)       # the launch classes counted here are the level-by-level engine's (the fused levels: below)
     torch.cuda.synchronize()
     steps, stride = 6, 2
     eng.set_timing(steps, stride=stride)
@@ -216,6 +218,21 @@ def test_kernel_timing_api(P, torch, oracle):
     nr = int(s["n_rows"][0])
     assert nr == ref["rows"].shape[0]
     assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "rows with instrumented launches")
+    eng.close()
+    # with the sparse levels fused: levels 0 .. 2 as launches, one instrumented sample pass, a span over the knot side
+    from pyitd_amd.engine import FUSE_ONLY, TIME_KF_APPLY, TIME_KF_KNOTS
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_ONLY)
+    eng.set_timing(steps, stride=stride)
+    for _ in range(steps):
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+    s = eng.summary(1)
+    assert eng.kernel_timing(TIME_EXTRACT)[1] == timed * 2 and eng.kernel_timing(TIME_EXTRACT_FINAL)[1] == 0
+    ms_a, cnt_a = eng.kernel_timing(TIME_KF_APPLY)
+    ms_k, cnt_k = eng.kernel_timing(TIME_KF_KNOTS)
+    assert cnt_a == timed and cnt_k == timed and ms_a > 0.0 and ms_k > 0.0
+    eng.set_timing(0)
+    assert_bits_equal(rows[: int(s["n_rows"][0])].cpu().numpy(), ref["rows"], "rows of the fused form with instrumented launches")
     eng.close()
 
 

@@ -1,0 +1,160 @@
+"""The fused sparse levels (itd_set_fuse_mode; pyitd_amd/csrc/itd_knotfirst.hpp) on the GPU: whatever they deliver is the
+reference's result bit for bit (rows, baselines, knot counts, stop reasons, against the pinned oracle), and what they cannot
+deliver — smooth, quantised, NaN-producing input — they report, after which the engine repeats the call level by level."""
+import numpy as np
+import pytest
+
+from helpers import assert_bits_equal, chirp, fuzz_signal, load_golden, sines_noise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyitd_amd
+    return pyitd_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cpu_oracle
+    return cpu_oracle
+
+
+def _run(P, torch, x, m, mode, L0=3, bases=True):
+    n = len(x)
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(mode)
+    eng.set_fuse_level(L0)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    bs = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda") if bases else None
+    torch.cuda.synchronize()
+    eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), bs.data_ptr() if bases else None, None)
+    s = eng.summary(1)
+    out = {"rows": rows[: int(s["n_rows"][0])].cpu().numpy(), "bases": bs[: int(s["n_baselines"][0])].cpu().numpy() if bases else None,
+           "stop": ("natural", "timeout")[int(s["stop"][0])], "knots": [int(v) for v in s["knot_counts"][0] if v >= 0],
+           "repeats": eng.fuse_repeats}
+    eng.close()
+    return out
+
+
+def _check(got, ref, what):
+    assert got["stop"] == ref["stop"], what
+    assert_bits_equal(got["rows"], ref["rows"], what + " rows")
+    if got["bases"] is not None:
+        assert_bits_equal(got["bases"], ref["baselines"], what + " baselines")
+    assert got["knots"][1: 1 + len(ref["knot_counts"])] == ref["knot_counts"].tolist(), what + " knots per level"
+
+
+# (name, signal, max_iteration, first fused level, must the fused form deliver it?)  Deep decompositions (>= ~10 levels) meet
+# plateaus born from rounding at their deepest levels now and then (differences shrink geometrically from level to level): there the
+# fused form may refuse — tests/test_oracle_knotfirst.py's CPU model refuses the very same cases — and the automatic mode repeats.
+CASES = [
+    ("sines 2^20 f32", lambda: sines_noise(1 << 20), 7, 3, True),
+    ("sines 2^20 f32, fused from level 2", lambda: sines_noise(1 << 20, seed=1), 7, 2, True),
+    ("sines 2^18 f32, fused from level 5", lambda: sines_noise(1 << 18, seed=2), 7, 5, True),
+    ("sines 2^19 f64", lambda: sines_noise(1 << 19, seed=3, dtype=np.float64), 7, 3, True),
+    ("ragged length", lambda: sines_noise((1 << 19) + 777, seed=4), 7, 3, True),
+    ("12 rows", lambda: sines_noise(1 << 18, seed=5), 10, 3, False),
+    ("natural stop inside the fused levels", lambda: sines_noise(1 << 17, seed=6), 20, 3, False),
+    ("white noise f64", lambda: fuzz_signal(np.random.default_rng(7), 0, 300000), 9, 3, False),
+    ("random walk f32", lambda: fuzz_signal(np.random.default_rng(8), 1, 300000).astype(np.float32), 9, 2, False),
+    ("alternating (every sample a knot at level 0)", lambda: fuzz_signal(np.random.default_rng(9), 6, 200000), 9, 3, False),
+    ("max_iteration = first fused level", lambda: sines_noise(1 << 17, seed=10), 3, 3, True),
+]
+
+
+@pytest.mark.parametrize("name,make,m,L0,must_fuse", CASES)
+def test_fused_levels_deliver_the_oracle_bit_for_bit(P, torch, oracle, name, make, m, L0, must_fuse):
+    from pyitd_amd import ITDError
+    from pyitd_amd.engine import FUSE_AUTO, FUSE_ONLY
+    x = make()
+    ref = oracle.itd(x, m)
+    _check(_run(P, torch, x, m, FUSE_AUTO, L0), ref, name + " (automatic)")
+    try:
+        got = _run(P, torch, x, m, FUSE_ONLY, L0)        # ONLY: a refusal is an error, not a silent repeat
+    except ITDError:
+        assert not must_fuse, name + ": the fused form refused"
+        return
+    _check(got, ref, name + " (fused only)")             # what it delivers is the reference's result
+
+
+def test_full_size_headline_signal(P, torch, oracle):
+    """BASELINE configs[1] (2^24 samples, 8 levels) through the fused levels, never repeated: rows bit-exact."""
+    from pyitd_amd.engine import FUSE_ONLY
+    x = sines_noise(1 << 24)
+    ref = oracle.itd_lean(x, 7)
+    got = _run(P, torch, x, 7, FUSE_ONLY, 3, bases=False)
+    assert got["stop"] == ref["stop"] == "timeout"
+    assert_bits_equal(got["rows"], ref["rows"], "2^24 rows")
+    assert got["knots"][: len(ref["knot_counts"])] == ref["knot_counts"].tolist()      # itd_lean: knots of every level's input
+
+
+def test_what_the_fused_levels_cannot_deliver_is_reported_and_repeated(P, torch, oracle):
+    """Smooth (float32 chirp: plateaus at its extrema), tiled, quantised and plateau-led (NaN-producing) input: ONLY refuses,
+    AUTO repeats level by level — the result is the oracle's either way — and then starts the next calls level by level."""
+    from pyitd_amd import ITDError
+    from pyitd_amd.engine import FUSE_AUTO, FUSE_ONLY
+    radio = load_golden("radio8000_input")["x"]
+    lead = np.concatenate([np.zeros(3000), sines_noise(1 << 17, seed=11)[3000:].astype(np.float64)])
+    refused = 0
+    for name, x, m in (("chirp", chirp(1 << 17), 5), ("tiled clip", np.resize(radio, 1 << 18).astype(np.float32), 9),
+                       ("quantised", np.round(fuzz_signal(np.random.default_rng(12), 0, 200000) * 3) / 4.0, 9),
+                       ("leading plateau", lead, 6)):
+        ref = oracle.itd(x, m)
+        got = _run(P, torch, x, m, FUSE_AUTO, 3)
+        _check(got, ref, name + " (automatic)")
+        try:
+            got2 = _run(P, torch, x, m, FUSE_ONLY, 3)
+            _check(got2, ref, name + " (fused only)")     # if it did not refuse it must be right
+        except ITDError:
+            refused += 1
+            assert got["repeats"] == 1, name
+    assert refused >= 3
+
+
+def test_few_knots_stop_before_the_fused_levels(P, torch, oracle):
+    from pyitd_amd.engine import FUSE_AUTO
+    n = 1 << 17
+    t = np.arange(n) / n
+    for x in (np.sin(2 * np.pi * 3 * t) + 0.3 * t * t, np.linspace(0, 1, n) ** 2, np.sin(2 * np.pi * 40 * t)):
+        ref = oracle.itd(x, 7)
+        got = _run(P, torch, x, 7, FUSE_AUTO, 3)
+        _check(got, ref, "smooth signal")
+
+
+def test_batches_and_the_drop_in_class(P, torch, oracle):
+    """A batch of 2^17-sample signals (the fused levels run per chunk of signals); one signal of the batch is a chirp: the whole
+    call is repeated level by level and every signal still equals the oracle.  The drop-in class takes the same path."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m, B = 1 << 17, 6, 9
+    xs = np.stack([sines_noise(n, seed=20 + b, fscale=1 + b / 50.0) for b in range(B)])
+    for with_chirp in (False, True):
+        x = xs.copy()
+        if with_chirp:
+            x[4] = chirp(n)
+        eng = P.Engine(n, B, 0)
+        eng.set_fuse_mode(FUSE_AUTO)
+        xd = torch.from_numpy(x).cuda()
+        rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
+        s = eng.summary(B)
+        assert eng.fuse_repeats == (1 if with_chirp else 0)
+        for b in range(B):
+            ref = oracle.itd_lean(x[b], m)
+            assert int(s["n_rows"][b]) == ref["rows"].shape[0]
+            assert_bits_equal(rows[b, : ref["rows"].shape[0]].cpu().numpy(), ref["rows"], "signal %d" % b)
+        eng.close()
+    d = P.ITD()
+    x = sines_noise(1 << 18, seed=31)
+    ref = oracle.itd(x, 7)
+    assert_bits_equal(d.itd(x, 7), ref["rows"], "ITD().itd")
+    assert_bits_equal(d.get_baselines(), ref["baselines"], "get_baselines")

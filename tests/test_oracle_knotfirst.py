@@ -1,0 +1,66 @@
+"""The idea behind the fused sparse levels (pyitd_amd/csrc/itd_knotfirst.hpp), held to the pinned oracle on the CPU through its
+numpy model (oracle/knotfirst_model.py): the level recursion run on the knot list alone reproduces the oracle's per-level knot
+lists and baselines bit for bit, the sample pass's re-derived knots confirm it — or the model says honestly that it cannot
+(smooth / quantised input), which is what sends the GPU path back to the level-by-level engine."""
+import numpy as np
+import pytest
+
+from helpers import canon_u64, chirp, fuzz_signal, load_golden, sines_noise
+from oracle import cpu_oracle, knotfirst_model as kf
+
+
+def _levels_of(x, m):
+    ref = cpu_oracle.itd_lean(x, m, want_knots=True)
+    lv, cur = [np.asarray(x, dtype=np.float64)], np.asarray(x, dtype=np.float64)
+    for _ in range(len(ref["knots"])):
+        _, b = cpu_oracle.itd_baseline_extract(cur)
+        lv.append(b)
+        cur = b
+    return ref, lv
+
+
+@pytest.mark.parametrize("name,x,m,L0", [
+    ("sines 2^17 f32", sines_noise(1 << 17), 7, 3),
+    ("sines 2^17 f32, from level 2", sines_noise(1 << 17, seed=3), 7, 2),
+    ("sines 2^16 f64, 12 levels", sines_noise(1 << 16, seed=5, dtype=np.float64), 11, 3),
+    ("white noise", fuzz_signal(np.random.default_rng(1), 0, 50000), 9, 2),
+    ("random walk f32", fuzz_signal(np.random.default_rng(2), 1, 50000).astype(np.float32), 9, 3),
+    ("alternating", fuzz_signal(np.random.default_rng(3), 6, 30000), 9, 2),
+    ("radio clip", load_golden("radio8000_input")["x"], 11, 2),
+])
+def test_knot_side_recursion_reproduces_the_oracle(name, x, m, L0):
+    ref, lv = _levels_of(x, m)
+    ks = ref["knots"]
+    nlev = len(ks)
+    assert nlev > L0 + 1, name
+    levels, last = kf.knot_side(lv[L0], np.asarray(x, dtype=np.float64), nlev - L0, cpu_oracle.knots)
+    for q in range(nlev - L0):
+        np.testing.assert_array_equal(levels[q]["pos"], ks[L0 + q], err_msg="%s: knots of level %d" % (name, L0 + q))
+    bases, found = kf.sample_pass(lv[L0], levels, last)
+    for q in range(nlev - L0):
+        assert np.array_equal(canon_u64(bases[q]), canon_u64(lv[L0 + q + 1])), "%s: baseline of level %d" % (name, L0 + q)
+    for q in range(nlev - L0 - 1):          # the verification every fused level but the last is held to
+        np.testing.assert_array_equal(found[q], levels[q + 1]["pos"])
+    assert (len(found[-1]) < 2) == (len(last) < 2)      # the last pending baseline feeds only the stop test (ITD.py:400-404)
+
+
+def test_smooth_and_quantised_input_is_refused_not_wrong():
+    """A float32 chirp (plateaus at its extrema), tiled audio, quantised data: either the model refuses up front (too many exact
+    ties) or the sample pass's re-derived knots differ from the knot side's — never a silent wrong answer."""
+    radio = load_golden("radio8000_input")["x"]
+    refused = 0
+    for x, m, L0 in ((chirp(1 << 16), 5, 2), (np.resize(radio, 1 << 17).astype(np.float32), 9, 3),
+                     (np.round(fuzz_signal(np.random.default_rng(4), 0, 40000) * 3) / 4.0, 9, 2)):
+        ref, lv = _levels_of(x, m)
+        nlev = len(ref["knots"])
+        try:
+            levels, last = kf.knot_side(lv[L0], np.asarray(x, dtype=np.float64), nlev - L0, cpu_oracle.knots)
+        except kf.NeedFallback:
+            refused += 1
+            continue
+        bases, found = kf.sample_pass(lv[L0], levels, last)
+        ok = all(np.array_equal(found[q], levels[q + 1]["pos"]) for q in range(nlev - L0 - 1))
+        exact = all(np.array_equal(canon_u64(bases[q]), canon_u64(lv[L0 + q + 1])) for q in range(nlev - L0))
+        assert ok == exact or not ok, "a passed verification must mean exact baselines"
+        refused += 0 if ok else 1
+    assert refused >= 2
