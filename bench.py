@@ -159,6 +159,8 @@ class _StubEngine:
 
 
 def run_rank(args):
+    if args.no_fuse:
+        os.environ["PYITD_FUSE_MODE"] = "1"     # every engine of this process: one launch per level throughout (pyitd_amd/engine.py)
     import torch
     import torch.distributed as dist
 
@@ -238,6 +240,7 @@ def run_rank(args):
         sp = stream.cuda_stream
         x_ptr, rows_ptr = x.data_ptr(), rows.data_ptr()
     eng = sb.engine
+
     def sync():
         if not stub:
             torch.cuda.synchronize()
@@ -268,15 +271,35 @@ def run_rank(args):
     # begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
     if not sharded:
         eng.set_timing(args.steps, stride=4)
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed_local = t1 - t0
+    def timed_region():
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        barrier()
+        return time.perf_counter() - t0
+
+    fused_refused = False
+    rep0 = 0 if stub else eng.fuse_repeats
+    elapsed_local = timed_region()
+    if not stub:
+        # A decomposition whose fused sparse levels failed their verification is REPEATED level by level when its summary is read
+        # (itd_get_summary) — i.e. behind the timed region.  Such a timing would leave work out: read the summary now, and if a
+        # repeat happened (on any rank's shard) time the steps again — the engine then runs them level by level by itself.
+        sb.local_summary()
+        fused_refused = eng.fuse_repeats > rep0
+        if dist.is_initialized():
+            fr = torch.tensor([1 if fused_refused else 0], dtype=torch.int32)
+            dist.all_reduce(fr, op=dist.ReduceOp.MAX)
+            fused_refused = bool(fr.item())
+        if fused_refused:
+            from pyitd_amd.engine import FUSE_OFF
+            eng.set_fuse_mode(FUSE_OFF)
+            if not sharded:
+                eng.set_timing(args.steps, stride=4)
+            elapsed_local = timed_region()
     elapsed = elapsed_local
     per_rank_ms = [elapsed_local / args.steps * 1e3]
     if dist.is_initialized():
@@ -290,9 +313,11 @@ def run_rank(args):
     table = sb.gather(group=group, device=coll_dev) if dist.is_initialized() else None
 
     if not sharded and not stub:
-        from pyitd_amd.engine import TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_SCAN0
+        from pyitd_amd.engine import (TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_KF_APPLY, TIME_KF_KNOTS,
+                                      TIME_SCAN0)
         timing = {k: eng.kernel_timing(t) for k, t in (("ext", TIME_EXTRACT), ("l0", TIME_EXTRACT_L0), ("fin", TIME_EXTRACT_FINAL),
-                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0))}
+                                                        ("dec", TIME_DECOMPOSE), ("scan0", TIME_SCAN0), ("kfa", TIME_KF_APPLY), ("kfk", TIME_KF_KNOTS))}
+        fuse_repeats = eng.fuse_repeats
         eng.set_timing(0)
     else:
         timing = None
@@ -336,6 +361,7 @@ def run_rank(args):
             "collective_backend": None if world == 1 else ("nccl (RCCL)" if coll_backend == "nccl" else coll_backend),
             "device": None if stub else device_info(torch, dev),
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+            "fused_levels_refused_and_retimed_level_by_level": fused_refused,
             "rows_all_ranks": None if table is None else sorted(set(int(v) for v in table["n_rows"])),
             "signals_in_gathered_table": None if table is None else int(len(table["n_rows"])),
         },
@@ -366,34 +392,81 @@ def run_rank(args):
 
         def frac(bytes_per_sample, us):
             return round(bytes_per_sample * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us > 0 else 0.0
-        out["roofline"] = {
-            "bound": "hbm",
-            "kernel": "k_extract<double> (levels>=1: read 8 B + write 16 B per sample)",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "avg_launch_us": round(ext_us, 2),
-            "launches_timed": ext_cnt,
-            "read_frac": frac(8.0, ext_us) if ext_cnt else 0.0,
-            "read_frac_note": "the north star's '>= 40 % of HBM-read roofline' read as 8 B/sample / t / peak (SURVEY 8d) needs t <= 42 us "
-                              "per 2^24-sample level, i.e. 24 B/sample of total traffic at 9.6 TB/s: above the 8 TB/s peak, unreachable "
-                              "for any kernel that also writes the two float64 rows; frac (all 24 algorithmic bytes) is the figure to read",
-            "level0_launch_us": round(avg_us("l0"), 2),
-            "scan0_launch_us": round(avg_us("scan0"), 2),
-            "final_launch_us": round(avg_us("fin"), 2),
-            "decompose_gpu_us": round(avg_us("dec"), 2),
-            "per_kernel_frac": {
-                "extract_levels_ge1 (24 B/sample)": frac(24.0, ext_us),
-                "level0 pair: k_scan0 + k_extract<float> (20 B/sample)": frac(20.0, avg_us("scan0") + avg_us("l0")),
-                "k_extract<float> level 0 alone (20 B/sample)": frac(20.0, avg_us("l0")),
-                "k_scan0 (4 B/sample)": frac(4.0, avg_us("scan0")),
-                "final extract (16 B/sample)": frac(16.0, avg_us("fin")),
-                "whole decomposition (188 B/sample)": frac(float(algorithmic_bytes_per_sample(LEVELS)), avg_us("dec")),
-            },
-        }
+        fused = timing["kfa"][1] > 0
+        rows_out = int(summ["n_rows"][0])
+        if fused:
+            # The sparse levels ran fused (pyitd_amd/csrc/itd_knotfirst.hpp): levels 0 .. L0-1 one launch each, then ONE pass over the
+            # samples for levels L0 .. (k_kf_apply) — the launch that dominates.  Its algorithmic bytes: 8 B read + 8 B per row written.
+            L0 = 1 + timing["ext"][1] // max(timing["l0"][1], 1)          # extraction launches of levels >= 1 per decomposition, + level 0
+            apply_bytes = 8.0 + 8.0 * (rows_out - L0)
+            apply_us = avg_us("kfa")
+            own_bytes = 20.0 + 24.0 * (L0 - 1) + apply_bytes
+            traffic_a = None
+            try:
+                traffic_a = json.load(open(tpath)).get("k_kf_apply_bytes_per_launch")
+            except Exception:
+                pass
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_kf_apply (levels %d..%d of every tile in one pass, in registers: read 8 B + write 8 B x %d rows per sample)"
+                          % (L0, rows_out - 1, rows_out - L0),
+                "achieved": round(apply_bytes * n / (apply_us * 1e-6) / 1e9, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": frac(apply_bytes, apply_us),
+                "traffic": traffic_a,
+                "traffic_source": traffic_src if traffic_a else None,
+                "algorithmic_bytes_per_sample": apply_bytes,
+                "avg_launch_us": round(apply_us, 2),
+                "launches_timed": timing["kfa"][1],
+                "reference_flow_bytes_per_sample": 24.0 * (rows_out - L0),
+                "note": "the reference's level-by-level data flow moves 24 B per sample and level for these levels (SURVEY 8d: %d B/sample); "
+                        "the fused pass needs %d — frac is its own bytes over the peak" % (24 * (rows_out - L0), int(apply_bytes)),
+                "level0_launch_us": round(avg_us("l0"), 2),
+                "extract_launch_us": round(ext_us, 2),
+                "knot_side_us": round(avg_us("kfk"), 2),
+                "decompose_gpu_us": round(avg_us("dec"), 2),
+                "fuse_repeats": fuse_repeats,
+                "per_kernel_frac": {
+                    "k_kf_apply (%d B/sample)" % int(apply_bytes): frac(apply_bytes, apply_us),
+                    "k_extract<double> levels 1..%d (24 B/sample)" % (L0 - 1): frac(24.0, ext_us),
+                    "k_extract<float> level 0 (20 B/sample)": frac(20.0, avg_us("l0")),
+                    "whole decomposition, own bytes (%d B/sample)" % int(own_bytes): frac(own_bytes, avg_us("dec")),
+                    "whole decomposition, the reference flow's bytes (188 B/sample: SURVEY 8d)": frac(float(algorithmic_bytes_per_sample(LEVELS)), avg_us("dec")),
+                },
+            }
+            out["config"]["launch_form"] = "levels 0..%d one launch each; levels %d..%d fused (knot-side recursion + one verified sample pass)" % (L0 - 1, L0, rows_out - 1)
+        else:
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "k_extract<double> (levels>=1: read 8 B + write 16 B per sample)",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "avg_launch_us": round(ext_us, 2),
+                "launches_timed": ext_cnt,
+                "read_frac": frac(8.0, ext_us) if ext_cnt else 0.0,
+                "read_frac_note": "the north star's '>= 40 % of HBM-read roofline' read as 8 B/sample / t / peak (SURVEY 8d) needs t <= 42 us "
+                                  "per 2^24-sample level, i.e. 24 B/sample of total traffic at 9.6 TB/s: above the 8 TB/s peak, unreachable "
+                                  "for any kernel that also writes the two float64 rows; frac (all 24 algorithmic bytes) is the figure to read",
+                "level0_launch_us": round(avg_us("l0"), 2),
+                "scan0_launch_us": round(avg_us("scan0"), 2),
+                "final_launch_us": round(avg_us("fin"), 2),
+                "decompose_gpu_us": round(avg_us("dec"), 2),
+                "fuse_repeats": fuse_repeats,
+                "per_kernel_frac": {
+                    "extract_levels_ge1 (24 B/sample)": frac(24.0, ext_us),
+                    "level0 pair: k_scan0 + k_extract<float> (20 B/sample)": frac(20.0, avg_us("scan0") + avg_us("l0")),
+                    "k_extract<float> level 0 alone (20 B/sample)": frac(20.0, avg_us("l0")),
+                    "k_scan0 (4 B/sample)": frac(4.0, avg_us("scan0")),
+                    "final extract (16 B/sample)": frac(16.0, avg_us("fin")),
+                    "whole decomposition (188 B/sample)": frac(float(algorithmic_bytes_per_sample(LEVELS)), avg_us("dec")),
+                },
+            }
+            out["config"]["launch_form"] = "one launch per level"
     if sharded and not stub:
         # N > 1: every GPU runs its shard as chunks whose launches overlap on two streams, so a single launch's duration is not
         # a rate; the figure is the whole decomposition's algorithmic bytes (188 B/sample) per GPU over the max-over-ranks time.
@@ -548,9 +621,9 @@ def f_rows_leg(torch, dev):
     # totalextract2d on a 512 x 512 image: the only timing the reference records (siftED2D.ipynb cell 3: 10.1457 s)
     img = np.random.default_rng(5).integers(0, 256, (512, 512)).astype(np.float64)
     np.random.seed(1)
-    spline.totalextract2d(img)
+    spline.totalextract2d(img, verbose=False)
     t0 = time.perf_counter()
-    spline.totalextract2d(img)
+    spline.totalextract2d(img, verbose=False)
     dt = time.perf_counter() - t0
     out["totalextract2d_512x512"] = {"ms": round(dt * 1e3, 3), "reference_recorded_s": 10.1457, "reference_source": "siftED2D.ipynb cell 3 (author's machine, numba)",
                                      "note": "host arrays in and out, host noise generation included"}
@@ -586,19 +659,29 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
     #                            showed rows_per_signal [1, 9] for that reason; the timed calls were never affected)
     for _ in range(2):
         eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    def timed():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    eng.summary(batch)
+    rep0 = eng.fuse_repeats
+    dt = timed()
     s = eng.summary(batch)     # of the last timed call
+    refused = eng.fuse_repeats > rep0
+    if refused:                # a signal's fused levels failed their verification: that call was repeated behind the timed region
+        from pyitd_amd.engine import FUSE_OFF
+        eng.set_fuse_mode(FUSE_OFF)
+        dt = timed()
+        s = eng.summary(batch)
     alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
     out = {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
             "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "hbm_algorithmic_GBps": round(alg, 1), "frac_of_peak_whole_decomposition": round(alg / HBM_PEAK_GBPS, 4),
             "rows_per_signal": sorted(set(int(v) for v in s["n_rows"])),
-            "order": "timed after the headline"}
+            "fused_levels_refused_and_retimed_level_by_level": refused, "order": "timed after the headline"}
     eng.close()
     return out
 
@@ -733,6 +816,7 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 on a one-GPU box: all ranks compute on cuda:0 and gather over gloo (checks the sharded path end to end; "
                          "the line says so and is not a scaling measurement)")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per level throughout (itd_set_fuse_mode OFF): the round-2 engine")
     ap.add_argument("--warm-ms", type=float, default=150.0, help="untimed warm-up of the headline's own step before the W warm-up steps (ms)")
     ap.add_argument("--spawn-timeout", type=int, default=900, help="plain --gpus N: seconds until the parent kills its ranks")
     ap.add_argument("--pg-timeout", type=int, default=120, help="seconds a rank waits for the process group / a collective")

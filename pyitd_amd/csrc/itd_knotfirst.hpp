@@ -295,53 +295,71 @@ __device__ __forceinline__ double kf_B(const KfList &L, int k, double m0, double
     return 0.5 * u + 0.5 * x1;                               // ITD.py:107-110
 }
 
+// what a level's step works on (the same in every block of the signal)
+struct KfLevel {
+    KfSig *ks; int m, par, lp, toff; int32_t n1; double e0, e1, e2, e3, m0, mn; KfList L; KfEntry *pool;
+};
+__device__ __forceinline__ bool kf_level(const KfWs &ws, int sig, int lev, int64_t n, KfLevel &V)
+{
+    KfSig *ks = ws.sig + sig;
+    V.ks = ks;
+    V.m = ks->mlev[lev]; V.par = (lev - ws.L0) & 1; V.lp = lev & 1; V.toff = ks->toff[lev];
+    if (V.toff + V.m + 2 > ws.pool_cap || V.m + kKfSticky + 4 > ws.cap) return false;
+    V.n1 = (int32_t)(n - 1);
+    V.e0 = ks->ends[V.lp][0]; V.e1 = ks->ends[V.lp][1]; V.e2 = ks->ends[V.lp][2]; V.e3 = ks->ends[V.lp][3];
+    V.m0 = (V.e0 + V.e1) / 2.0; V.mn = (V.e2 + V.e3) / 2.0;                  // ITD.py:101-102
+    V.L = KfList{ws.candP + ((size_t)sig * 2 + V.par) * ws.cap, ws.candT + ((size_t)sig * 2 + V.par) * ws.cap * 3, V.m, V.n1, V.e0, V.e3};
+    V.pool = ws.pool + (size_t)sig * ws.pool_cap + V.toff;
+    return true;
+}
+
+// the sticky candidates of a level (one wavefront): their next-level triples and whether they become knots that the list lacks;
+// the segments their three samples lie in come from the list itself (a handful of entries each)
+__device__ __forceinline__ void kf_sticky_eval(const KfLevel &V, int lane)
+{
+    KfSig *ks = V.ks;
+    const KfList &L = V.L;
+    const int m = V.m, lp = V.lp;
+    const int cnt = ks->n_sticky_lev;
+    for (int i = lane; i < cnt; i += kWave) {
+        const int32_t s = ks->spos[i];
+        const int sk = ks->ssk[i];
+        const bool is_knot = sk >= 1 && L.pos(sk) == s;
+        const int seg_l = is_knot ? sk - 1 : sk;
+        const bool adj = sk + 1 <= m && L.pos(sk + 1) == s + 1;
+        const int seg_r = adj ? sk + 1 : sk;
+        const double xl_ = ks->stri[lp][i][0], xc = ks->stri[lp][i][1], xr = ks->stri[lp][i][2];
+        auto mapv = [&](int k, double v) {
+            const double Bk = kf_B(L, k, V.m0, V.mn), Bn = kf_B(L, k + 1, V.m0, V.mn);
+            const double Xk = L.X(k);
+            const double Sk = (Bn - Bk) / (L.X(k + 1) - Xk);           // ITD.py:115-116
+            return Bk + Sk * (v - Xk);
+        };
+        const double yl = mapv(seg_l, xl_), yc = mapv(sk, xc);
+        const double yr = (s + 1 == V.n1) ? 0.0 : mapv(seg_r, xr);     // baseline[n-1] stays 0, ITD.py:112-117
+        ks->stri[lp ^ 1][i][0] = yl; ks->stri[lp ^ 1][i][1] = yc; ks->stri[lp ^ 1][i][2] = yr;
+        ks->sins[i] = (!is_knot && kf_pred(yl, yc, yr)) ? 1 : 0;
+        if (!(yl - yl == 0.0) || !(yc - yc == 0.0) || !(yr - yr == 0.0)) atomicOr(&ks->fail, kKfFailNonFinite);
+    }
+}
+
+// One 256-entry chunk of a level's list (all threads of the block): the table entries, the next level's triple of the thread's
+// entry (tri), its survival flag, the survivors of the chunk in front of it (before) and in all (returned); the per-tile
+// structures of THIS level; chunk 0 / the last knot's chunk: the virtual end entries and the next level's end samples.
 template <int TW>
-__device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int64_t n, int blk, int nblk)
+__device__ __forceinline__ int kf_chunk_a(const KfWs &ws, int sig, int lev, const KfLevel &V, int c, int &fl_out, int &before_out,
+                                          double (&tri)[3], int32_t &pos_out)
 {
     __shared__ int32_t sP[kKfChunk + 4];
     __shared__ double sX[kKfChunk + 4], sB[kKfChunk + 4], sS[kKfChunk + 4];
     __shared__ int s_red[kKfChunk / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    KfSig *ks = ws.sig + sig;
-    const int m = ks->mlev[lev], par = (lev - ws.L0) & 1, lp = lev & 1;
-    const int toff = ks->toff[lev];
-    if (toff + m + 2 > ws.pool_cap || m + kKfSticky + 4 > ws.cap) {
-        if (tid == 0) atomicOr(&ks->fail, kKfFailCapacity);
-        return;
-    }
-    const int32_t n1 = (int32_t)(n - 1);
-    const double e0 = ks->ends[lp][0], e1 = ks->ends[lp][1], e2 = ks->ends[lp][2], e3 = ks->ends[lp][3];
-    const double m0 = (e0 + e1) / 2.0, mn = (e2 + e3) / 2.0;                // ITD.py:101-102
-    KfList L{ws.candP + ((size_t)sig * 2 + par) * ws.cap, ws.candT + ((size_t)sig * 2 + par) * ws.cap * 3, m, n1, e0, e3};
-    KfEntry *pool = ws.pool + (size_t)sig * ws.pool_cap + toff;
-    if (blk == nblk - 1 && wave == 0) {
-        // ---- sticky candidates: the segments their three samples lie in from the list itself (a handful of entries each) ----
-        const int cnt = ks->n_sticky_lev;
-        for (int i = lane; i < cnt; i += kWave) {
-            const int32_t s = ks->spos[i];
-            const int sk = ks->ssk[i];
-            const bool is_knot = sk >= 1 && L.pos(sk) == s;
-            const int seg_l = is_knot ? sk - 1 : sk;
-            const bool adj = sk + 1 <= m && L.pos(sk + 1) == s + 1;
-            const int seg_r = adj ? sk + 1 : sk;
-            const double xl_ = ks->stri[lp][i][0], xc = ks->stri[lp][i][1], xr = ks->stri[lp][i][2];
-            auto mapv = [&](int k, double v) {
-                const double Bk = kf_B(L, k, m0, mn), Bn = kf_B(L, k + 1, m0, mn);
-                const double Xk = L.X(k);
-                const double Sk = (Bn - Bk) / (L.X(k + 1) - Xk);           // ITD.py:115-116
-                return Bk + Sk * (v - Xk);
-            };
-            const double yl = mapv(seg_l, xl_), yc = mapv(sk, xc);
-            const double yr = (s + 1 == n1) ? 0.0 : mapv(seg_r, xr);       // baseline[n-1] stays 0, ITD.py:112-117
-            ks->stri[lp ^ 1][i][0] = yl; ks->stri[lp ^ 1][i][1] = yc; ks->stri[lp ^ 1][i][2] = yr;
-            ks->sins[i] = (!is_knot && kf_pred(yl, yc, yr)) ? 1 : 0;
-            if (!(yl - yl == 0.0) || !(yc - yc == 0.0) || !(yr - yr == 0.0)) atomicOr(&ks->fail, kKfFailNonFinite);
-        }
-    }
-    const int nck = max(1, (m + kKfChunk - 1) / kKfChunk);      // chunk 0 runs even for an empty list (entry 0, the end samples)
-  // (with more than one block the last one works on the sticky candidates only)
-  const int nwork = nblk > 1 ? nblk - 1 : 1;
-  for (int c = (nblk > 1 && blk == nblk - 1) ? nck : blk; c < nck; c += nwork) {
+    KfSig *ks = V.ks;
+    const KfList &L = V.L;
+    const int m = V.m, lp = V.lp;
+    const int32_t n1 = V.n1;
+    const double e0 = V.e0, e1 = V.e1, e2 = V.e2, e3 = V.e3, m0 = V.m0, mn = V.mn;
+    KfEntry *pool = V.pool;
     const int k0 = 1 + c * kKfChunk;
     __syncthreads();                                            // the previous chunk's LDS reads are done
     // entries k0 - 2 .. k0 + 257 (LDS index j <-> entry k0 - 2 + j)
@@ -350,47 +368,49 @@ __device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int6
         sP[j] = L.pos(k);
         sX[j] = L.X(k);
     }
+    const int k = k0 + tid, j = tid + 2;
+    double xl_ = 0.0, xr = 0.0;
+    if (k >= 1 && k <= m) { xl_ = L.Tr[3 * (size_t)k]; xr = L.Tr[3 * (size_t)k + 2]; }   // (requested with the list: one round trip)
     __syncthreads();
-    for (int j = tid; j < kKfChunk + 4; j += kKfChunk) {
-        const int k = k0 - 2 + j;
+    for (int jj = tid; jj < kKfChunk + 4; jj += kKfChunk) {
+        const int kk = k0 - 2 + jj;
         double Bv = 0.0;
-        if (j >= 1 && j <= kKfChunk + 2 && k >= 0 && k <= m + 1) {
-            if (k == 0) Bv = m0;
-            else if (k == m + 1) Bv = mn;
+        if (jj >= 1 && jj <= kKfChunk + 2 && kk >= 0 && kk <= m + 1) {
+            if (kk == 0) Bv = m0;
+            else if (kk == m + 1) Bv = mn;
             else {
-                const double frac = (double)(sP[j] - sP[j - 1]) / (double)(sP[j + 1] - sP[j - 1]);
-                const double tt = frac * (sX[j + 1] - sX[j - 1]);
-                const double u = sX[j - 1] + tt;
-                Bv = 0.5 * u + 0.5 * sX[j];
+                const double frac = (double)(sP[jj] - sP[jj - 1]) / (double)(sP[jj + 1] - sP[jj - 1]);
+                const double tt = frac * (sX[jj + 1] - sX[jj - 1]);
+                const double u = sX[jj - 1] + tt;
+                Bv = 0.5 * u + 0.5 * sX[jj];
             }
         }
-        sB[j] = Bv;
+        sB[jj] = Bv;
     }
     __syncthreads();
-    for (int j = tid; j < kKfChunk + 4; j += kKfChunk) {
-        const int k = k0 - 2 + j;
+    for (int jj = tid; jj < kKfChunk + 4; jj += kKfChunk) {
+        const int kk = k0 - 2 + jj;
         double Sv = 0.0;
-        if (j >= 1 && j <= kKfChunk + 1 && k >= 0 && k <= m) Sv = (sB[j + 1] - sB[j]) / (sX[j + 1] - sX[j]);
-        sS[j] = Sv;
+        if (jj >= 1 && jj <= kKfChunk + 1 && kk >= 0 && kk <= m) Sv = (sB[jj + 1] - sB[jj]) / (sX[jj + 1] - sX[jj]);
+        sS[jj] = Sv;
     }
     __syncthreads();
-    const int k = k0 + tid, j = tid + 2;
     int fl = 0;
+    pos_out = 0;
+    tri[0] = tri[1] = tri[2] = 0.0;
     if (k >= 1 && k <= m) {
         const int32_t pos = sP[j];
         const double Bk = sB[j], Sk = sS[j], Xk = sX[j];
         KfEntry en; en.X = Xk; en.B = Bk; en.S = Sk; en.pos = pos; en.pad = 0;
         pool[k] = en;
-        const size_t t3 = 3 * (size_t)k;
-        const double xl_ = L.Tr[t3], xr = L.Tr[t3 + 2];
         const double yl = sB[j - 1] + sS[j - 1] * (xl_ - sX[j - 1]);
         const double yc = Bk + Sk * (Xk - Xk);
         double yr;
         if (pos + 1 == n1) yr = 0.0;                                        // baseline[n-1] stays 0, ITD.py:112-117
         else if (pos + 1 == sP[j + 1]) yr = sB[j + 1] + sS[j + 1] * (xr - sX[j + 1]);
         else yr = Bk + Sk * (xr - Xk);
-        double *nt = ws.newT + ((size_t)sig * ws.cap) * 3 + t3;
-        nt[0] = yl; nt[1] = yc; nt[2] = yr;
+        tri[0] = yl; tri[1] = yc; tri[2] = yr;
+        pos_out = pos;
         fl = kf_pred(yl, yc, yr) ? 1 : 0;
         if (!(Bk - Bk == 0.0) || !(Sk - Sk == 0.0) || !(yl - yl == 0.0) || !(yr - yr == 0.0)) atomicOr(&ks->fail, kKfFailNonFinite);
         if (yl == yc || yc == yr) {                                         // an exact tie: rounding may move the knot next time
@@ -420,7 +440,6 @@ __device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int6
 #pragma unroll
     for (int w = 0; w < kKfChunk / 64; ++w) { if (w < wave) before += s_red[w]; total += s_red[w]; }
     if (k >= 1 && k <= m) ws.pref[(size_t)sig * ws.cap + k] = before;
-    if (tid == 0) ws.cnt[(size_t)sig * ws.nchunk + c] = total;
     if (c == 0 && tid == 0) {
         KfEntry en; en.X = e0; en.B = sB[1]; en.S = sS[1]; en.pos = 0; en.pad = 0;     // entry 0: the virtual knot at sample 0
         pool[0] = en;
@@ -440,7 +459,36 @@ __device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int6
         ne[2] = sB[jm] + sS[jm] * (e2 - sX[jm]);             // sample n-2 lies in the last knot's segment (knots are <= n-2)
         ne[3] = 0.0;
     }
-  }
+    fl_out = fl;
+    before_out = before;
+    return total;
+}
+
+// part a as a launch of its own (the two-launch form of a step): every chunk's results go through memory
+template <int TW>
+__device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int64_t n, int blk, int nblk)
+{
+    KfLevel V;
+    if (!kf_level(ws, sig, lev, n, V)) {
+        if (threadIdx.x == 0) atomicOr(&ws.sig[sig].fail, kKfFailCapacity);
+        return;
+    }
+    if (blk == nblk - 1 && threadIdx.x < kWave) kf_sticky_eval(V, threadIdx.x);
+    const int nck = max(1, (V.m + kKfChunk - 1) / kKfChunk);      // chunk 0 runs even for an empty list (entry 0, the end samples)
+    // (with more than one block the last one works on the sticky candidates only)
+    const int nwork = nblk > 1 ? nblk - 1 : 1;
+    for (int c = (nblk > 1 && blk == nblk - 1) ? nck : blk; c < nck; c += nwork) {
+        int fl, before;
+        double tri[3];
+        int32_t pos;
+        const int total = kf_chunk_a<TW>(ws, sig, lev, V, c, fl, before, tri, pos);
+        const int k = 1 + c * kKfChunk + (int)threadIdx.x;
+        if (k >= 1 && k <= V.m) {
+            double *nt = ws.newT + ((size_t)sig * ws.cap) * 3 + 3 * (size_t)k;
+            nt[0] = tri[0]; nt[1] = tri[1]; nt[2] = tri[2];
+        }
+        if (threadIdx.x == 0) ws.cnt[(size_t)sig * ws.nchunk + c] = total;
+    }
 }
 
 // ---- part b: the survivors, and the sticky candidates that became knots, in order into the other list buffer; the stop rules
@@ -569,9 +617,12 @@ __device__ __forceinline__ void kf_step_b(const KfWs &ws, int sig, int lev, int 
 }
 
 // ---- the knot side as launches: hand-over (sticky candidates), then two launches per level.  grid = (blocks, batch), 256
-//      threads; the blocks take the list's chunks in turn, the last block also works on the sticky candidates.  (One persistent
-//      launch with grid barriers between the phases was measured slower: 188 us with 128 blocks, 864 us with 768, against 12
-//      launches of ~7.5 us — the phases are short chains of dependent loads, and a barrier costs more than a launch boundary.)
+//      threads; the blocks take the list's chunks in turn, the last block works on the sticky candidates.  Measured alternatives,
+//      both correct and both slower than these 12 launches of ~7.5 us (2^24 samples, 200 k knots at level 3): ONE persistent launch
+//      with grid barriers between the phases (188 us with 128 blocks, 864 us with 768), and a step as one launch with single-pass
+//      compaction (ticketed work items, decoupled look-back over level-tagged status words, agent-scope release / acquire:
+//      32 us per level, 93 us at level 3) — the phases are short chains of dependent loads, and in-launch synchronisation across
+//      8 XCDs costs more than the launch boundary it replaces (profiles/r03/kf_knot_side_alternatives.txt).
 template <int TW>
 __global__ __launch_bounds__(kWave) void k_kf_sticky_init(KfWs ws, const double *__restrict__ xl, int64_t xl_stride,
                                                           const SigState *__restrict__ state)

@@ -44,6 +44,9 @@ class Engine:
         mode = os.environ.get("PYITD_FUSE_MODE")        # the fused sparse levels (FUSE_*)
         if mode:
             self.set_fuse_mode(int(mode))
+        mode = os.environ.get("PYITD_FUSE_LEVEL")       # the first fused level (diagnostic sweeps)
+        if mode:
+            self.set_fuse_level(int(mode))
         mode = os.environ.get("PYITD_RESIDENT_MODE")    # and for the one-workgroup form of short signals (RESIDENT_*)
         if mode:
             self.set_resident_mode(int(mode))
