@@ -87,6 +87,7 @@ struct itd_engine {
     int64_t pp_pitch = 0;          // elements between consecutive slots: max_n + kSlotPad (breaks the power-of-two distance)
     SigState *d_state = nullptr;   // [2][batch]
     SigState *h_state = nullptr;   // pinned
+    char *h_kf = nullptr;          // pinned: the heads of the fused levels' KfSig (kKfSigHead bytes per signal), on demand
     // Per-signal states and group sums exist twice.  A decomposition works on the set the previous one did not use, and its last
     // launch (k_finalize) re-initialises the other set for the call after it: no initialising launch in front of a decomposition,
     // and the summary of the last call stays readable.  dirty_*: the leading part of a set that may not be in its initial state
@@ -115,6 +116,7 @@ struct itd_engine {
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
     bool last_kf = false;
+    int last_kf_level = 0;         // the first fused level of that call
     int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
@@ -412,12 +414,26 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const int fb = (int)std::min<int64_t>(std::max<int64_t>((n + 8 * kFinalizeThreads - 1) / (8 * kFinalizeThreads), 1), 1024);
             int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
             const int jf = j_last + 1;      // the level whose input is pending: max_iteration + 2, or the first fused level
+            // fused sparse levels: this launch also prepares their workspace (the signals' bookkeeping, the flag words, the group prefixes)
+            int32_t *kf_gpre = nullptr, *kf_sig = nullptr;
+            unsigned long long *kf_tf = nullptr;
+            size_t kf_tf_words = 0, kf_tf_skip = 0;
+            if (kf) {
+                const size_t nlev = (size_t)(M + 3 - L0);
+                kf_gpre = e->kf.gpre + (size_t)b0 * n_groups;
+                kf_sig = reinterpret_cast<int32_t *>(e->kf.sig + b0);
+                kf_tf_words = nlev * n_tiles * 8;
+                kf_tf_skip = (size_t)n_tiles * 8;          // (the hand-over writes the first fused level's words in full)
+                kf_tf = e->kf.tflags + (size_t)b0 * kf_tf_words;
+            }
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
-                                                                       gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
+                                                                       gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
+                                                                       kf_gpre, kf_sig, (int)(sizeof(KfSig) / 4), kf_tf, kf_tf_words, kf_tf_skip);
             else
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
-                                                                       e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
+                                                                       e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
+                                                                       kf_gpre, kf_sig, (int)(sizeof(KfSig) / 4), kf_tf, kf_tf_words, kf_tf_skip);
         }
         if (kf) {
             // ---- levels L0 .. M + 1 fused: hand-over, the knot-side steps, ONE pass over the samples, the verdict ----
@@ -431,17 +447,30 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const double *xl = bases_c ? bases_c + (int64_t)(L0 - 1) * n : pp_c + (int64_t)((L0 - 1) % 3) * e->pp_pitch;
             const int64_t xl_stride = bases_c ? rows_stride : 3 * e->pp_pitch;
             w.gpre += B0 * n_groups;
-            const int p_kn = time_begin(e, ITD_TIME_KF_KNOTS, cst);
-            k_kf_prepare<<<dim3((unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (int64_t)(w.nlev - 1) * n_tiles / 512)), nb), 256, 0, cst>>>(w, gs(L0));
-            k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
-            k_kf_sticky_init<T><<<nb, kWave, 0, cst>>>(w, xl, xl_stride, state);
+            // (timed: the span from the hand-over's begin to the last step's end, taken from the two dispatches' own timestamps)
+            const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
+            if (p_kn >= 0) {
+                KfWs a_w = w; const Tin *a_x = xc; int64_t a_xs = x_stride, a_ls = xl_stride, a_n = n; const double *a_xl = xl;
+                const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); const SigState *a_st = state;
+                void *args[] = {&a_w, &a_x, &a_xs, &a_xl, &a_ls, &a_n, &a_c, &a_r, &a_st};
+                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_gather<Tin, T>), dim3(n_tiles, nb), dim3(kWave), args, 0, cst,
+                                              e->ev[2 * (size_t)p_kn], nullptr, 0));
+            } else {
+                k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
+            }
             for (int lev = L0; lev <= M + 1; ++lev) {
                 // the lists shrink ~3x per level; any grid is correct (the blocks take the chunks in turn)
                 const unsigned blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(w.nchunk, (int64_t)768 >> std::min(lev - L0, 6)));
-                k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, n);
-                k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, M);
+                k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, n, xl, xl_stride);
+                if (p_kn >= 0 && lev == M + 1) {
+                    KfWs a_w = w; int a_lev = lev, a_m = M;
+                    void *args[] = {&a_w, &a_lev, &a_m};
+                    HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_step_b), dim3(blocks + 1, nb), dim3(kKfChunk), args, 0, cst,
+                                                  nullptr, e->ev[2 * (size_t)p_kn + 1], 0));
+                } else {
+                    k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, M);
+                }
             }
-            time_end(e, p_kn, cst);
             {
                 const int pair = time_slot(e, ITD_TIME_KF_APPLY);
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
@@ -450,7 +479,6 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap>), dim3(n_tiles, nb), dim3(kWave), args, 0, cst,
                                               pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr, pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
             }
-            k_kf_finish<<<(nb + 63) / 64, 64, 0, cst>>>(w, nb, state);
         }
     }
     for (int k = 0; k < S - 1; ++k) {
@@ -478,6 +506,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_resident = false;
     e->last_nan_input = nan_input;
     e->last_kf = kf;
+    e->last_kf_level = L0;
     return ITD_OK;
 }
 
@@ -559,6 +588,7 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
     e->last_bases = bases_user;
     e->last_fused = false;
     e->last_resident = true;
+    e->last_kf = false;
     e->last_nan_input = false;
     return ITD_OK;
 }
@@ -771,6 +801,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); (void)hipFree(e->d_flag);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
     if (e->h_state) (void)hipHostFree(e->h_state);
+    if (e->h_kf) (void)hipHostFree(e->h_kf);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -837,6 +868,33 @@ int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t bat
                                stream ? (hipStream_t)stream : e->own_stream);
 }
 
+// The verdict of the fused sparse levels, drawn from the heads of their KfSig into the signals' states as the host sees them
+// (no launch of its own behind the sample pass): the knot counts of the fused levels, the stop; or kf_fail — the sample pass found a
+// knot the knot side had missed, a list outgrew its workspace, non-finite knot data, too many exact ties.
+void kf_verdict(itd_engine *e, int B)
+{
+    const int L0 = e->last_kf_level;
+    for (int b = 0; b < B; ++b) {
+        KfSig ks;
+        memcpy(&ks, e->h_kf + (size_t)b * kKfSigHead, kKfSigHead);
+        SigState &st = e->h_state[b];
+        if (!ks.active) {
+            if (ks.fail) st.kf_fail = ks.fail;
+            continue;
+        }
+        int fail = ks.fail;
+        const int lend = ks.lend;
+        if (lend < 0) fail |= kKfFailCapacity;      // the steps never reached a stop rule (cannot happen: they run to max_iteration + 1)
+        // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
+        if (!fail && (ks.natural ? ks.m_exact >= 2 : ks.m_exact < 2)) fail |= kKfFailVerify;
+        if (fail) { st.kf_fail = fail; continue; }
+        for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
+        st.m[lend + 1] = ks.m_exact;
+        st.fin_stopped = ks.natural;
+        st.fin_stop_level = ks.natural ? lend + 1 : -1;
+    }
+}
+
 int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_t *stop_reason,
                     int64_t *knot_counts, int32_t *nan_levels)
 {
@@ -845,7 +903,12 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     DevGuard g(e->device);
     const int B = e->last_batch;
     HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState) * (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+    if (e->last_kf) {
+        if (!e->h_kf) HIP_TRY(e, hipHostMalloc((void **)&e->h_kf, kKfSigHead * (size_t)e->max_batch));
+        HIP_TRY(e, hipMemcpy2DAsync(e->h_kf, kKfSigHead, e->kf.sig, sizeof(KfSig), kKfSigHead, (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
+    }
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    if (e->last_kf) kf_verdict(e, B);
     auto any_nan_input = [&]() {
         for (int b = 0; b < B; ++b) if (e->h_state[b].in_nan) return true;
         return false;

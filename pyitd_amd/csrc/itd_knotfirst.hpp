@@ -25,7 +25,7 @@
 //
 // Traffic of the fused levels L0 .. L: 8 B read + 8 B per row written per sample, against 24 B per sample and level.
 // Smooth or quantised input (plateaus everywhere) does not take this path for long: too many ties (> kKfSticky) or a failed
-// verification send it back to the level-by-level engine.  oracle/ holds a numpy model of exactly this algorithm.
+// verification send it back to the level-by-level engine.  A numpy statement of exactly this algorithm lives with the tests.
 #pragma once
 #include "itd_kernels.hpp"
 
@@ -45,22 +45,25 @@ static_assert(sizeof(KfEntry) == 32, "table entries are two 16-byte words");
 constexpr int kKfFailVerify = 1, kKfFailCapacity = 2, kKfFailNonFinite = 4, kKfFailTies = 8;
 
 struct KfSig {
+    // ---- the head: what itd_get_summary copies to the host (kKfSigHead bytes) ----
     int32_t fail;
     int32_t active;       // the fused levels run for this signal (it had not stopped before the hand-over, no NaN anywhere)
-    int32_t n_sticky;     // entries of spos (grows by atomic appends inside a step)
-    int32_t n_sticky_lev; // of which the first n_sticky_lev are sorted, unique and carry triples of the level in flight
     int32_t lend;         // -1 while the steps run; then the last fused level: rows 0 .. lend are the result
     int32_t natural;      // at lend: 1 = natural stop (row lend = the level's input), 0 = "Out of time!" (rotation + baseline)
     int32_t m_exact;      // knots of the last pending baseline, counted by the sample pass
-    int32_t done_tiles;   // tiles of the sample pass that have finished (the last one writes the verdict)
+    int32_t n_sticky;     // entries of spos (the hand-over's appends; then = n_sticky_lev)
+    int32_t n_sticky_lev; // of which the first n_sticky_lev are sorted, unique and carry triples of the level in flight
+    int32_t n_app;        // appends of the step in flight: slots kKfSticky + i
     int32_t mlev[kMaxLevels + 2];   // knots of level j's input
+    // ---- device only ----
     int32_t toff[kMaxLevels + 2];   // level j's table starts at this entry of the signal's pool
     double ends[2][4];              // [level & 1]: x[0], x[1], x[n-2], x[n-1] of the level's input
-    int32_t spos[kKfSticky + 64];   // sticky positions (appends of a step in flight go behind n_sticky_lev)
+    int32_t spos[kKfSticky + 64];   // sticky positions
     int32_t ssk[kKfSticky + 64];    // knots of the level's list at or before the position; for a fresh append: its list index
     int32_t sins[kKfSticky + 64];   // scratch of a step: 1 = a knot of the next level that is not in the list
     double stri[2][kKfSticky + 64][3];
 };
+constexpr size_t kKfSigHead = (8 + kMaxLevels + 2) * sizeof(int32_t);
 
 struct KfWs {
     KfSig *sig;                   // [batch]
@@ -84,43 +87,8 @@ __device__ __forceinline__ bool kf_pred(double yl, double yc, double yr)
     return ((dn > 0.0) && (dp <= 0.0)) || ((dn < 0.0) && (dp >= 0.0));      // ITD.py:59 on x and on -x
 }
 
-// ---- before the hand-over: the signals' KfSig and the flag words of levels > L0 cleared, the group prefixes of level L0's knot
-//      counts.  grid = (blocks, batch), 256 threads.
-__global__ __launch_bounds__(256) void k_kf_prepare(KfWs ws, const int32_t *__restrict__ gsum)
-{
-    __shared__ int s_part[256];
-    const int sig = blockIdx.y, tid = threadIdx.x;
-    const int n_tiles = ws.n_tiles, n_groups = groups_of(n_tiles);
-    // flag words of the levels behind L0 (the gather writes level L0's in full)
-    unsigned long long *tf = ws.tflags + ((size_t)sig * ws.nlev + 1) * n_tiles * 8;
-    const size_t words = (size_t)(ws.nlev - 1) * n_tiles * 8;
-    using U2 = unsigned long long __attribute__((ext_vector_type(2)));
-    U2 *tf2 = reinterpret_cast<U2 *>(tf);                      // (16-byte aligned: the level stride is a multiple of 64 bytes)
-    const U2 z = {0ull, 0ull};
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < words / 2; i += (size_t)gridDim.x * 256) tf2[i] = z;
-    if (blockIdx.x != 0) return;
-    // block 0: the signal's KfSig and the exclusive prefix of the level-L0 group sums
-    int32_t *kz = reinterpret_cast<int32_t *>(ws.sig + sig);
-    for (int i = tid; i < (int)(sizeof(KfSig) / 4); i += 256) kz[i] = 0;
-    const int32_t *gs = gsum + (size_t)sig * n_groups * kGsumPitch;
-    int32_t *gp = ws.gpre + (size_t)sig * n_groups;
-    int carry = 0;
-    for (int g0 = 0; g0 < n_groups; g0 += 256) {
-        const int g = g0 + tid;
-        const int v = g < n_groups ? gs[(size_t)g * kGsumPitch] : 0;
-        s_part[tid] = v;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {          // Hillis-Steele inclusive scan
-            const int a = tid >= d ? s_part[tid - d] : 0;
-            __syncthreads();
-            s_part[tid] += a;
-            __syncthreads();
-        }
-        if (g < n_groups) gp[g] = carry + s_part[tid] - v;
-        carry += s_part[255];
-        __syncthreads();
-    }
-}
+// Before the hand-over k_finalize (itd_kernels.hpp) clears the signals' KfSig and the flag words of the levels behind L0 and
+// leaves the exclusive prefix of level L0's group sums in gpre.
 
 // ---- hand-over: the level-L0 knots of every tile (flag words of the records the launch for level L0 - 1 left) with the values
 //      of that level's input around them; exact ties of the caller's signal; the tile bases.  grid = (tiles, batch), 64 threads.
@@ -133,6 +101,17 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
     const int sig = blockIdx.y, t = blockIdx.x, lane = lane_id();
     const SigState *st = state + sig;
     KfSig *ks = ws.sig + sig;
+    // everything the tile needs is requested before the first use (one round trip in front of the knots' values)
+    const int n_tiles = ws.n_tiles, n_groups = groups_of(n_tiles);
+    const int32_t *cnts = counts + (size_t)sig * n_tiles;
+    const int g = t / kTilesPerGroup;
+    int acc = (lane < t - g * kTilesPerGroup) ? cnts[g * kTilesPerGroup + lane] : 0;
+    const int c = cnts[t], gp = ws.gpre[(size_t)sig * n_groups + g];
+    const unsigned long long *rf = recs[(size_t)sig * n_tiles + t].flags;
+    unsigned long long w[2 * G2];
+#pragma unroll
+    for (int q = 0; q < 2 * G2; ++q) w[q] = rf[q];
+    const int tie_here = ws.tie[(size_t)sig * n_tiles + t];
     const bool active = !st->fin_stopped && st->nan_mask == 0 && !st->in_nan && !st->l0_fail;
     if (t == 0 && lane == 0) {
         ks->active = active ? 1 : 0;
@@ -140,18 +119,21 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
         if (!active && !st->fin_stopped) ks->fail = kKfFailNonFinite;     // NaN rules / an unfinished level 0: not this path's
     }
     if (!active) return;
-    const int n_tiles = ws.n_tiles, n_groups = groups_of(n_tiles);
-    const int32_t *cnts = counts + (size_t)sig * n_tiles;
-    const int g = t / kTilesPerGroup;
-    int acc = (lane < t - g * kTilesPerGroup) ? cnts[g * kTilesPerGroup + lane] : 0;
+    if (t == 0 && lane < 4) ks->ends[ws.L0 & 1][lane] = st->ends[ws.L0 & 1][lane];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    const int base = acc + ws.gpre[(size_t)sig * n_groups + g], c = cnts[t];
+    const int base = acc + gp;
+    if (c == 0) {                                                    // an empty tile's record holds no flag words
+#pragma unroll
+        for (int q = 0; q < 2 * G2; ++q) w[q] = 0ull;
+    }
     int32_t *first = ws.first + ((size_t)sig * ws.nlev) * (n_tiles + 1);
     unsigned long long *tf = ws.tflags + (((size_t)sig * ws.nlev) * n_tiles + t) * 8;
-    const unsigned long long *rf = recs[(size_t)sig * n_tiles + t].flags;
-    if (lane == 0) first[t] = base;
-    if (lane < 2 * G2) tf[lane] = c > 0 ? rf[lane] : 0ull;          // an empty tile's record holds no flag words
+    if (lane == 0) {
+        first[t] = base;
+#pragma unroll
+        for (int q = 0; q < 2 * G2; ++q) tf[q] = w[q];
+    }
     if (t == n_tiles - 1 && lane == 0) {
         first[n_tiles] = base + c;
         ks->mlev[ws.L0] = base + c;
@@ -161,26 +143,43 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
     const int64_t s = (int64_t)t * TW;
     const double *xs = xl + (int64_t)sig * xl_stride;
     if (c > 0 && base + c + 2 <= ws.cap) {
+        // a lane per knot: the j-th knot of the tile from the flag words (within a 128-sample group the knots run E_0, O_0, E_1, O_1, ...),
+        // so that the three values around every knot are requested in ONE round trip
         int32_t *P = ws.candP + ((size_t)sig * 2) * ws.cap;
         double *Tr = ws.candT + ((size_t)sig * 2) * ws.cap * 3;
-        int gbase = base;
-#pragma unroll 1
-        for (int gg = 0; gg < G2; ++gg) {
-            const unsigned long long E = rf[2 * gg], O = rf[2 * gg + 1];
-            const int bE = (int)((E >> lane) & 1ull), bO = (int)((O >> lane) & 1ull);
-            const int re = mbcnt64(O, mbcnt64(E, gbase));       // knots in front of the even sample
-            const int64_t pe = s + 128 * gg + 2 * lane;
-            if (bE) {
-                const int k = re + 1;
-                P[k] = (int32_t)pe;
-                Tr[3 * (size_t)k] = xs[pe - 1]; Tr[3 * (size_t)k + 1] = xs[pe]; Tr[3 * (size_t)k + 2] = xs[pe + 1];
+        int cum[G2 + 1];
+        cum[0] = 0;
+#pragma unroll
+        for (int gg = 0; gg < G2; ++gg) cum[gg + 1] = cum[gg] + __popcll(w[2 * gg]) + __popcll(w[2 * gg + 1]);
+        for (int j0 = 0; j0 < c; j0 += kWave) {
+            const int j = j0 + lane;
+            if (j < c) {
+                int gg = 0;
+                unsigned long long E = w[0], O = w[1];
+#pragma unroll
+                for (int q = 1; q < G2; ++q) if (j >= cum[q]) { gg = q; E = w[2 * q]; O = w[2 * q + 1]; }
+                int jr = j;
+#pragma unroll
+                for (int q = 1; q < G2; ++q) if (gg == q) jr = j - cum[q];
+                // smallest l with (knots of the group at pairs 0 .. l) > jr
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const unsigned long long mk = mid >= 63 ? ~0ull : ((1ull << (mid + 1)) - 1ull);
+                    const int f = __popcll(E & mk) + __popcll(O & mk);
+                    if (f > jr) hi = mid; else lo = mid + 1;
+                }
+                const int l = lo;
+                const unsigned long long mb = (1ull << l) - 1ull;
+                const int before = __popcll(E & mb) + __popcll(O & mb);
+                const int odd = (((E >> l) & 1ull) && jr == before) ? 0 : 1;
+                const int64_t pos = s + 128 * gg + 2 * l + odd;
+                const size_t k = (size_t)base + 1 + j;
+                const double a = xs[pos - 1], bb = xs[pos], cc = xs[pos + 1];
+                P[k] = (int32_t)pos;
+                Tr[3 * k] = a; Tr[3 * k + 1] = bb; Tr[3 * k + 2] = cc;
             }
-            if (bO) {
-                const int k = re + bE + 1;
-                P[k] = (int32_t)(pe + 1);
-                Tr[3 * (size_t)k] = xs[pe]; Tr[3 * (size_t)k + 1] = xs[pe + 1]; Tr[3 * (size_t)k + 2] = xs[pe + 2];
-            }
-            gbase += __popcll(E) + __popcll(O);
         }
     }
     // sticky candidates: sample n-2, and both samples of every exact tie of the caller's signal (rare: the tile was flagged)
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
         else atomicOr(&ks->fail, kKfFailTies);
     };
     if (lane == 0 && s <= n - 2 && n - 2 < s + TW) append(n - 2);
-    if (ws.tie[(size_t)sig * n_tiles + t]) {
+    if (tie_here) {
         if (lane == 0) ws.tie[(size_t)sig * n_tiles + t] = 0;        // the flags clean themselves: the fused level-0 launch only ever sets them
         const Tin *x = x0 + (int64_t)sig * x0_stride;
         for (int i = lane; i < TW; i += kWave) {
@@ -216,15 +215,18 @@ __device__ __forceinline__ int kf_rank_in_tile(const unsigned long long *__restr
     return acc;
 }
 
-// sorts the first `cnt` sticky entries by position and drops duplicates (one wavefront; cnt <= 128); payload: ssk and the
-// triples of parity `par`.  Returns the number kept.
-__device__ __forceinline__ int kf_sticky_sort(KfSig *ks, int cnt, int par, int lane, int32_t *s_p, int32_t *s_k, double (*s_t)[3])
+// sorts the sticky entries — the first `nsl` and the `napp` appends of the step in flight (slots kKfSticky + i) — by position
+// and drops duplicates (one wavefront; nsl + napp <= 128); payload: ssk and the triples of parity `par`.  They end up in slots
+// 0 .. kept-1.  Returns the number kept.
+__device__ __forceinline__ int kf_sticky_sort(KfSig *ks, int nsl, int napp, int par, int lane, int32_t *s_p, int32_t *s_k, double (*s_t)[3])
 {
     __shared__ int32_t s_first[kKfSticky + 64];
+    const int cnt = nsl + napp;
     for (int i = lane; i < cnt; i += kWave) {        // everything is staged before anything is written back
-        s_p[i] = ks->spos[i];
-        s_k[i] = ks->ssk[i];
-        s_t[i][0] = ks->stri[par][i][0]; s_t[i][1] = ks->stri[par][i][1]; s_t[i][2] = ks->stri[par][i][2];
+        const int src = i < nsl ? i : kKfSticky + (i - nsl);
+        s_p[i] = ks->spos[src];
+        s_k[i] = ks->ssk[src];
+        s_t[i][0] = ks->stri[par][src][0]; s_t[i][1] = ks->stri[par][src][1]; s_t[i][2] = ks->stri[par][src][2];
     }
     wave_sync();
     for (int i = lane; i < cnt; i += kWave) {        // 1 = the first occurrence of its position
@@ -250,10 +252,9 @@ __device__ __forceinline__ int kf_sticky_sort(KfSig *ks, int cnt, int par, int l
     return kept;
 }
 
-// one wavefront: the sticky candidates sorted, with their list ranks and triples at level L0; the level's end samples
+// one wavefront: the sticky candidates sorted, with their list ranks and triples at level L0
 template <int TW>
-__device__ __forceinline__ void kf_sticky_init(const KfWs &ws, int sig, const double *__restrict__ xl, int64_t xl_stride,
-                                               const SigState *__restrict__ state, int lane)
+__device__ __forceinline__ void kf_sticky_init(const KfWs &ws, int sig, const double *__restrict__ xl, int64_t xl_stride, int lane)
 {
     __shared__ int32_t s_p[kKfSticky + 64], s_k[kKfSticky + 64];
     __shared__ double s_t[kKfSticky + 64][3];
@@ -270,9 +271,8 @@ __device__ __forceinline__ void kf_sticky_init(const KfWs &ws, int sig, const do
         ks->stri[par][i][0] = xs[p - 1]; ks->stri[par][i][1] = xs[p]; ks->stri[par][i][2] = xs[p + 1];
     }
     wave_sync();
-    const int kept = kf_sticky_sort(ks, cnt, par, lane, s_p, s_k, s_t);
+    const int kept = kf_sticky_sort(ks, cnt, 0, par, lane, s_p, s_k, s_t);
     if (lane == 0) { ks->n_sticky = kept; ks->n_sticky_lev = kept; }
-    if (lane < 4) ks->ends[par][lane] = state[sig].ends[par][lane];
 }
 
 // ---- one knot-side step, part a: the level's table (B, S), the next level's triples and survival flags of the list entries, the
@@ -414,8 +414,9 @@ __device__ __forceinline__ int kf_chunk_a(const KfWs &ws, int sig, int lev, cons
         fl = kf_pred(yl, yc, yr) ? 1 : 0;
         if (!(Bk - Bk == 0.0) || !(Sk - Sk == 0.0) || !(yl - yl == 0.0) || !(yr - yr == 0.0)) atomicOr(&ks->fail, kKfFailNonFinite);
         if (yl == yc || yc == yr) {                                         // an exact tie: rounding may move the knot next time
-            const int idx = atomicAdd(&ks->n_sticky, 1);
-            if (idx < kKfSticky + 64) {
+            const int ia = atomicAdd(&ks->n_app, 1);            // (a region of its own: the sticky block may be sorting the others)
+            if (ia < 64) {
+                const int idx = kKfSticky + ia;
                 ks->spos[idx] = pos; ks->ssk[idx] = k; ks->sins[idx] = 0;
                 ks->stri[lp ^ 1][idx][0] = yl; ks->stri[lp ^ 1][idx][1] = yc; ks->stri[lp ^ 1][idx][2] = yr;
             } else atomicOr(&ks->fail, kKfFailTies);
@@ -466,14 +467,21 @@ __device__ __forceinline__ int kf_chunk_a(const KfWs &ws, int sig, int lev, cons
 
 // part a as a launch of its own (the two-launch form of a step): every chunk's results go through memory
 template <int TW>
-__device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, int64_t n, int blk, int nblk)
+__device__ __forceinline__ void kf_step_a(const KfWs &ws, int sig, int lev, const KfLevel &V, bool fits, int blk, int nblk,
+                                          const double *__restrict__ xl, int64_t xl_stride)
 {
-    KfLevel V;
-    if (!kf_level(ws, sig, lev, n, V)) {
+    if (!fits) {
         if (threadIdx.x == 0) atomicOr(&ws.sig[sig].fail, kKfFailCapacity);
         return;
     }
-    if (blk == nblk - 1 && threadIdx.x < kWave) kf_sticky_eval(V, threadIdx.x);
+    if (blk == nblk - 1 && threadIdx.x < kWave) {
+        if (lev == ws.L0) {                   // the hand-over's sticky candidates: sorted, ranked, with their triples
+            kf_sticky_init<TW>(ws, sig, xl, xl_stride, threadIdx.x);
+            __threadfence_block();
+            wave_sync();
+        }
+        kf_sticky_eval(V, threadIdx.x);
+    }
     const int nck = max(1, (V.m + kKfChunk - 1) / kKfChunk);      // chunk 0 runs even for an empty list (entry 0, the end samples)
     // (with more than one block the last one works on the sticky candidates only)
     const int nwork = nblk > 1 ? nblk - 1 : 1;
@@ -578,13 +586,14 @@ __device__ __forceinline__ void kf_step_b(const KfWs &ws, int sig, int lev, int 
     }
     const int total = carry;
     if (wave != 0) return;
-    const int ns_all = min(ks->n_sticky, kKfSticky + 64);
+    const int napp = min(ks->n_app, 64), ns_all = nsl + napp;
     for (int i0 = 0; i0 < ns_all; i0 += kWave) {       // a lane per candidate
         const int i = i0 + lane;
         if (i < ns_all) {
-            const int32_t s = ks->spos[i];
+            const int src = i < nsl ? i : kKfSticky + (i - nsl);
+            const int32_t s = ks->spos[src];
             // old entries: ssk = list knots at or before s; fresh appends (i >= nsl): ssk = their own list index (they ARE list knots)
-            const int K = ks->ssk[i];
+            const int K = ks->ssk[src];
             int sv = 0;
             if (K > 0) {
                 const int ck = (K - 1) / kKfChunk;
@@ -599,15 +608,17 @@ __device__ __forceinline__ void kf_step_b(const KfWs &ws, int sig, int lev, int 
                 nP[out] = s;
                 nT[3 * (size_t)out] = ks->stri[lp ^ 1][i][0]; nT[3 * (size_t)out + 1] = ks->stri[lp ^ 1][i][1]; nT[3 * (size_t)out + 2] = ks->stri[lp ^ 1][i][2];
             }
-            ks->ssk[i] = sv + ile;      // knots of the NEW list at or before s
+            ks->ssk[src] = sv + ile;      // knots of the NEW list at or before s
         }
     }
+    __threadfence_block();
     wave_sync();
-    const int kept = kf_sticky_sort(ks, ns_all, lp ^ 1, lane, s_p, s_k, s_t);
+    const int kept = kf_sticky_sort(ks, nsl, napp, lp ^ 1, lane, s_p, s_k, s_t);
     if (lane == 0) {
         if (kept > kKfSticky) atomicOr(&ks->fail, kKfFailTies);
         ks->n_sticky = kept;
         ks->n_sticky_lev = kept;
+        ks->n_app = 0;
         const int m_next = total + nins;
         ks->mlev[lev + 1] = m_next;
         ks->toff[lev + 1] = ks->toff[lev] + m + 2;
@@ -624,20 +635,14 @@ __device__ __forceinline__ void kf_step_b(const KfWs &ws, int sig, int lev, int 
 //      32 us per level, 93 us at level 3) — the phases are short chains of dependent loads, and in-launch synchronisation across
 //      8 XCDs costs more than the launch boundary it replaces (profiles/r03/kf_knot_side_alternatives.txt).
 template <int TW>
-__global__ __launch_bounds__(kWave) void k_kf_sticky_init(KfWs ws, const double *__restrict__ xl, int64_t xl_stride,
-                                                          const SigState *__restrict__ state)
-{
-    const int sig = blockIdx.x;
-    KfSig *ks = ws.sig + sig;
-    if (!ks->active || ks->fail) return;
-    kf_sticky_init<TW>(ws, sig, xl, xl_stride, state, threadIdx.x);
-}
-template <int TW>
-__global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_t n)
+__global__ __launch_bounds__(kKfChunk) void k_kf_step_a(KfWs ws, int lev, int64_t n, const double *__restrict__ xl, int64_t xl_stride)
 {
     const KfSig *ks = ws.sig + blockIdx.y;
+    // (the level's bookkeeping is requested together with the three words of the test: one round trip instead of two)
+    KfLevel V;
+    const bool fits = kf_level(ws, blockIdx.y, lev, n, V);
     if (!ks->active || ks->lend >= 0 || ks->fail) return;      // (a failure raised by a running block of this launch: the others
-    kf_step_a<TW>(ws, blockIdx.y, lev, n, blockIdx.x, gridDim.x);   //  may or may not see it — either way the result is discarded)
+    kf_step_a<TW>(ws, blockIdx.y, lev, V, fits, blockIdx.x, gridDim.x, xl, xl_stride);   //  may or may not see it — either way the result is discarded)
 }
 __global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int max_iteration)
 {
@@ -773,29 +778,7 @@ __global__ __launch_bounds__(kWave) void k_kf_apply(KfWs ws, const double *__res
     if (bad && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
 }
 
-// grid = ceil(batch / 64), 64 threads: the verdict of the fused levels into the signal's state (what itd_get_summary reads)
-__global__ void k_kf_finish(KfWs ws, int batch, SigState *__restrict__ state)
-{
-    const int sig = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sig >= batch) return;
-    KfSig *ks = ws.sig + sig;
-    SigState *st = state + sig;
-    if (!ks->active) {
-        if (ks->fail) st->kf_fail = ks->fail;
-        return;
-    }
-    int fail = ks->fail;
-    const int lend = ks->lend;
-    if (lend < 0) fail |= kKfFailCapacity;                     // the steps never reached a stop rule (cannot happen: they run to max_iteration + 1)
-    if (!fail) {
-        // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
-        if (ks->natural ? ks->m_exact >= 2 : ks->m_exact < 2) fail |= kKfFailVerify;
-    }
-    if (fail) { st->kf_fail = fail; return; }
-    for (int j = ws.L0 + 1; j <= lend; ++j) st->m[j] = ks->mlev[j];
-    st->m[lend + 1] = ks->m_exact;
-    st->fin_stopped = ks->natural;
-    st->fin_stop_level = ks->natural ? lend + 1 : -1;
-}
+// The verdict of the fused levels — what k_kf_finish did as a launch of its own — is drawn on the host by itd_get_summary from
+// the head of KfSig (itd_engine.hip: kf_verdict).
 
 }  // namespace itd

@@ -9,7 +9,7 @@ import pyitd_amd
 from pyitd_amd.engine import FUSE_AUTO, FUSE_OFF, FUSE_ONLY
 from pyitd_amd import ITDError
 from oracle import cpu_oracle
-from helpers import sines_noise, fuzz_signal, chirp, load_golden
+from helpers import sines_noise, fuzz_signal, chirp, load_golden, canon_u64
 
 def run(name, x, m, L0=3, bases=False):
     n = len(x)
@@ -27,7 +27,7 @@ def run(name, x, m, L0=3, bases=False):
             eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), bs.data_ptr() if bases else None, None)
             s = eng.summary(1)
             nr = int(s["n_rows"][0])
-            ok = nr == ref["rows"].shape[0] and np.array_equal(rows[:nr].cpu().numpy().view(np.uint64), ref["rows"].view(np.uint64))
+            ok = nr == ref["rows"].shape[0] and np.array_equal(canon_u64(rows[:nr].cpu().numpy()), canon_u64(ref["rows"]))   # (NaN payloads canonical, as in the tests)
             kc = [int(v) for v in s["knot_counts"][0] if v >= 0]
             out[mode] = "ok" if ok else "MISMATCH rows %d vs %d" % (nr, ref["rows"].shape[0])
             if mode == FUSE_AUTO: out[mode] += " (repeats %d)" % eng.fuse_repeats
