@@ -156,8 +156,8 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * baselines_dev must stay valid until then, as before) and the engine's next 16 decompositions start level by level.
  * Results are bit-identical in every mode: what the fused form cannot deliver it reports.
  * ITD_FUSE_AUTO (default): signals of >= 65536 samples with the fused level 0; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
- * repeat (itd_get_summary fails with ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 1 ..
- * max_iteration (default 3: levels 0, 1, 2 as one launch each). */
+ * repeat (itd_get_summary fails with ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 ..
+ * max_iteration (default 3: levels 0, 1, 2 as one launch each; measured on 2^24 samples: 0.499 / 0.482 / 0.501 ms for 2 / 3 / 4). */
 #define ITD_FUSE_AUTO 0
 #define ITD_FUSE_OFF 1
 #define ITD_FUSE_ONLY 2

@@ -273,7 +273,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     if (nan_input) fuse0 = false;
     // kf: levels L0 .. max_iteration + 1 run fused (itd_knotfirst.hpp): one launch per level only for levels 0 .. L0 - 1
     const int L0 = e->fuse_level;
-    kf = kf && fuse0 && L0 >= 1 && L0 <= M && n < ((int64_t)1 << 31) - 65536;
+    kf = kf && fuse0 && L0 >= 2 && L0 <= M && n < ((int64_t)1 << 31) - 65536;
     if (kf) {
         const int rc = ensure_kf_ws(e);
         if (rc) return rc;
@@ -598,7 +598,7 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
 // be repeated level by level (smooth or quantised input keeps failing the verification: workloads tend to be homogeneous).
 bool want_kf(itd_engine *e, int64_t n, int32_t M, bool fuse0)
 {
-    if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || e->fuse_level < 1 || e->fuse_level > M) return false;
+    if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || e->fuse_level < 2 || e->fuse_level > M) return false;
     if (e->fuse_mode == ITD_FUSE_ONLY) return true;
     if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO) return false;
     if (e->fuse_off_left > 0) { --e->fuse_off_left; return false; }
@@ -1069,7 +1069,8 @@ int itd_set_fuse_mode(itd_engine *e, int32_t mode)
 
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level)
 {
-    if (!e || first_fused_level < 1 || first_fused_level > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
+    // (level 1's launch completes the signal's own knot count, and a level-1 list would not fit the workspace: 2 at least)
+    if (!e || first_fused_level < 2 || first_fused_level > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
     e->fuse_level = first_fused_level;
     return ITD_OK;
 }

@@ -112,7 +112,7 @@ class Engine:
         self._check(self._L.itd_set_fuse_mode(self._h, int(mode)))
 
     def set_fuse_level(self, first_fused_level):
-        """The first fused level (default 3: levels 0, 1, 2 are one launch each)."""
+        """The first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2 are one launch each)."""
         self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))
 
     @property

@@ -158,3 +158,15 @@ def test_batches_and_the_drop_in_class(P, torch, oracle):
     ref = oracle.itd(x, 7)
     assert_bits_equal(d.itd(x, 7), ref["rows"], "ITD().itd")
     assert_bits_equal(d.get_baselines(), ref["baselines"], "get_baselines")
+
+
+def test_first_fused_level_is_two_at_least(P):
+    """Level 1's launch completes the signal's own knot count and a level-1 list does not fit the workspace: 2 .. max."""
+    from pyitd_amd import ITDError
+    eng = P.Engine(1 << 16, 1, 0)
+    for bad in (0, 1, 21):
+        with pytest.raises(ITDError):
+            eng.set_fuse_level(bad)
+    eng.set_fuse_level(2)
+    eng.set_fuse_level(20)
+    eng.close()

@@ -1,8 +1,9 @@
 """Randomised parity sweep of the GPU path against the CPU oracle (bit-exact rows, baselines, stop reason).
 usage (GPU box): python tools/fuzz_parity.py [cases] [seed]          single signals through ITD.itd
                  python tools/fuzz_parity.py batch [cases] [seed]    random batches through itd_batch (grid.y = signal)
-A third of the inputs get NaNs sprinkled in (the reference's NaN branch at level 0), some an infinity.  PYITD_CHAIN_MODE=0 in
-the environment runs everything through the one-launch chain, PYITD_LEVEL0_MODE=1 through the record-driven level 0.
+A third of the inputs get NaNs sprinkled in (the reference's NaN branch at level 0), some an infinity.  PYITD_FUSE_MODE=1 in
+the environment switches the fused sparse levels off (long signals), PYITD_LEVEL0_MODE=1 selects the record-driven level 0.
+FUZZ_MIN_N=65536 lifts every length into the fused levels' range.
 FUZZ_MAX_N=4096 folds every length into 3 .. 4096 (the resident form's range), FUZZ_NO_NAN=1 leaves the inputs as drawn (a NaN input
 sends the engine's next 16 decompositions level by level: without them nearly every case runs resident; PYITD_RESIDENT_MODE=1 = none)."""
 import os, sys, time
@@ -17,9 +18,12 @@ cases = int(argv[0]) if len(argv) > 0 else 200
 rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
 cpu_oracle.lib()
 MAX_N = int(os.environ.get("FUZZ_MAX_N", "0"))
+MIN_N = int(os.environ.get("FUZZ_MIN_N", "0"))
 
 
 def fold(n):
+    if MIN_N and n < MIN_N:
+        n += MIN_N
     return 3 + (n - 3) % (MAX_N - 2) if MAX_N and n > MAX_N else n
 
 

@@ -40,7 +40,7 @@ def run(name, x, m, L0=3, bases=False):
 radio = load_golden("radio8000_input")["x"]
 run("sines 2^20 f32", sines_noise(1 << 20), 7)
 run("sines 2^20 f32 L0=2", sines_noise(1 << 20), 7, 2)
-run("sines 2^20 f32 L0=1", sines_noise(1 << 20), 7, 1)
+run("sines 2^20 f32 L0=5", sines_noise(1 << 20), 7, 5)
 run("sines 2^20 f32 bases", sines_noise(1 << 20), 7, 3, True)
 run("sines 2^20 f64", sines_noise(1 << 20).astype(np.float64), 7)
 run("sines 2^22 s3", sines_noise(1 << 22, seed=3, fscale=1 + 5 / 8192.), 7)

@@ -1,0 +1,62 @@
+"""How often do the fused sparse levels (itd_set_fuse_mode) deliver, per signal family?  ITD_FUSE_ONLY on random draws: a case
+either equals the C oracle bit for bit ("delivered") or the engine reports that the fused form cannot deliver it ("refused",
+with the failure bits: 1 verification, 2 capacity, 4 non-finite, 8 ties) — a third outcome would be a bug and is counted as
+WRONG.  usage (GPU box): python tools/kf_rates.py [cases per family] [seed]"""
+import os, sys, re
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import pyitd_amd
+from pyitd_amd.engine import FUSE_ONLY
+from pyitd_amd import ITDError
+from oracle import cpu_oracle
+from helpers import sines_noise, fuzz_signal, canon_u64
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+NAMES = ["white noise", "random walk", "quantised (plateaus)", "smooth + few knots", "sine + noise at a random level",
+         "constant stretches with bursts", "alternating, random amplitudes", "extreme magnitudes", "sines + noise (the bench signal)"]
+
+
+def one(x, m):
+    n = len(x)
+    ref = cpu_oracle.itd_lean(x, m)
+    eng = pyitd_amd.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_ONLY)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    try:
+        eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), None, None)
+        s = eng.summary(1)
+        nr = int(s["n_rows"][0])
+        ok = nr == ref["rows"].shape[0] and np.array_equal(canon_u64(rows[:nr].cpu().numpy()), canon_u64(ref["rows"]))
+        return "delivered" if ok else "WRONG"
+    except ITDError as ex:
+        mm = re.search(r"fail bits (0x[0-9a-f]+)", str(ex))
+        return "refused " + (mm.group(1) if mm else "?")
+    finally:
+        eng.close()
+
+
+print("%-36s %-6s %s" % ("family", "levels", "outcomes over %d draws (n in 70 000 .. 400 000, float32 / float64)" % cases))
+wrong = 0
+for kind in range(9):
+    for m in (3, 7, 11):
+        tally = {}
+        for c in range(cases):
+            n = int(rng.integers(70000, 400000))
+            if kind == 8:
+                x = sines_noise(n, seed=int(rng.integers(0, 1 << 30)))
+            else:
+                x = fuzz_signal(rng, kind, n)
+            if not np.all(np.isfinite(x)):
+                continue
+            if kind not in (7,) and rng.random() < 0.5:
+                x = x.astype(np.float32)
+            r = one(x, m)
+            tally[r] = tally.get(r, 0) + 1
+            wrong += r == "WRONG"
+        print("%-36s %-6d %s" % (NAMES[kind], m + 1, ", ".join("%s: %d" % kv for kv in sorted(tally.items()))), flush=True)
+print("WRONG results: %d" % wrong)
+sys.exit(1 if wrong else 0)
