@@ -153,7 +153,9 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * instead of 24 B per sample and level.  The sample pass re-derives every level's knots from the values it computes; where they
  * differ from the knot side's (or a list outgrows its workspace, or knot data go non-finite, or the input holds too many exact
  * ties: smooth and quantised signals) itd_get_summary repeats the call level by level before it returns (x_dev / rows_dev /
- * baselines_dev must stay valid until then, as before) and the engine's next 16 decompositions start level by level.
+ * baselines_dev must stay valid until then, as before) and the engine's next 16 decompositions start level by level; when
+ * only a few signals of a batch are concerned (at most one in eight) just those are run again, each on its own, and the
+ * engine stays in the fused form.
  * Results are bit-identical in every mode: what the fused form cannot deliver it reports.
  * ITD_FUSE_AUTO (default): signals of >= 65536 samples with the fused level 0; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
  * repeat (itd_get_summary fails with ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 ..
@@ -163,8 +165,10 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
 #define ITD_FUSE_ONLY 2
 int itd_set_fuse_mode(itd_engine *e, int32_t mode);
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
-/* how many calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
+/* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);
+/* ... and how many single signals of batches it has re-run on their own (the rest of their batch kept the fused result) */
+int64_t itd_get_fuse_signal_repairs(const itd_engine *e);
 /* Short signals (n <= 8192 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays
  * in LDS through all levels of the driver loop (ITD.py:384-432): the signal is read once and every result row written once
  * (4 + 8 rows bytes per sample; the level-by-level form is launch bound there: 10 dependent launches).  Baselines that go NaN

@@ -115,6 +115,7 @@ struct itd_engine {
     void *d_kf = nullptr; size_t kf_bytes = 0;
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
+    int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
     bool last_kf = false;
     int last_kf_level = 0;         // the first fused level of that call
     int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
@@ -868,6 +869,52 @@ int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t bat
                                stream ? (hipStream_t)stream : e->own_stream);
 }
 
+// The signals of the last call whose fused levels reported a failure (h_state[b].kf_fail), each run again on its own: level by level,
+// record-driven level 0, into its own rows (and baselines) of the caller's buffers; its state replaces h_state[b].  The engine's
+// record of the last call (what a later itd_get_summary, itd_get_timing, ... refer to) is put back afterwards.
+int repair_signals(itd_engine *e, int B)
+{
+    const auto keep_batch = e->last_batch; const auto keep_m = e->last_m; const auto keep_n = e->last_n; const auto keep_stream = e->last_stream;
+    const void *keep_x = e->last_x; const bool keep_f32 = e->last_x_f32; const auto keep_xs = e->last_x_stride;
+    double *keep_rows = e->last_rows, *keep_bases = e->last_bases;
+    const bool keep_fused = e->last_fused; const int keep_kfl = e->last_kf_level;
+    const bool keep_timing = e->timing;
+    const int main_set = e->cur_set;
+    const int64_t main_gs = e->dirty_gs[main_set];
+    e->timing = false;                       // (the repairs are not part of any timed launch class)
+    const int64_t rs = (int64_t)(keep_m + 2) * keep_n;
+    int rc = ITD_OK;
+    for (int b = 0; b < B && rc == ITD_OK; ++b) {
+        if (!e->h_state[b].kf_fail) continue;
+        double *rows_b = keep_rows + (int64_t)b * rs, *bases_b = keep_bases ? keep_bases + (int64_t)b * rs : nullptr;
+        rc = keep_f32 ? enqueue_decompose<float>(e, (const float *)keep_x + (int64_t)b * keep_xs, keep_n, 1, keep_xs, keep_m, rows_b, bases_b, keep_stream, false)
+                      : enqueue_decompose<double>(e, (const double *)keep_x + (int64_t)b * keep_xs, keep_n, 1, keep_xs, keep_m, rows_b, bases_b, keep_stream, false);
+        if (rc) break;
+        // (stream ordered: the copy leaves before the next repair's last launch puts this state set back into its initial state)
+        if (hipMemcpyAsync(&e->h_state[b], e->d_state + (size_t)e->cur_set * e->max_batch, sizeof(SigState), hipMemcpyDeviceToHost, keep_stream) != hipSuccess) { rc = ITD_ERR_HIP; break; }
+        ++e->fuse_signal_repairs;
+    }
+    if (hipStreamSynchronize(keep_stream) != hipSuccess && rc == ITD_OK) rc = ITD_ERR_HIP;
+    e->timing = keep_timing;
+    // The call's state set on the device becomes what the host now knows (fused verdicts and repaired signals merged), and the
+    // engine's current set again: a later itd_get_summary of this call reads it as it stands (last_kf = false: nothing left to
+    // draw or repair); the other set was last used by a one-signal repair.
+    if (rc == ITD_OK) {
+        for (int b = 0; b < B; ++b) e->h_state[b].kf_fail = 0;
+        if (hipMemcpyAsync(e->d_state + (size_t)main_set * e->max_batch, e->h_state, sizeof(SigState) * (size_t)B, hipMemcpyHostToDevice, keep_stream) != hipSuccess ||
+            hipStreamSynchronize(keep_stream) != hipSuccess) rc = ITD_ERR_HIP;
+    }
+    e->cur_set = main_set;
+    e->dirty_sig[main_set] = std::max(e->dirty_sig[main_set], keep_batch);
+    e->dirty_sig[main_set ^ 1] = std::max(e->dirty_sig[main_set ^ 1], 1);
+    e->dirty_gs[main_set] = std::max(e->dirty_gs[main_set], main_gs);
+    e->dirty_gs[main_set ^ 1] = std::max<int64_t>(e->dirty_gs[main_set ^ 1], (int64_t)groups_of((int)tiles_of(keep_n)) * kGsumPitch);
+    e->last_batch = keep_batch; e->last_m = keep_m; e->last_n = keep_n; e->last_stream = keep_stream; e->last_x = keep_x; e->last_x_f32 = keep_f32;
+    e->last_x_stride = keep_xs; e->last_rows = keep_rows; e->last_bases = keep_bases; e->last_fused = keep_fused; e->last_kf = false;
+    e->last_kf_level = keep_kfl; e->last_resident = false; e->last_nan_input = false;
+    return rc;
+}
+
 // The verdict of the fused sparse levels, drawn from the heads of their KfSig into the signals' states as the host sees them
 // (no launch of its own behind the sample pass): the knot counts of the fused levels, the stop; or kf_fail — the sample pass found a
 // knot the knot side had missed, a list outgrew its workspace, non-finite knot data, too many exact ties.
@@ -948,21 +995,28 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     }
     if (e->last_kf) {
         // the fused sparse levels deliver the reference's result or report that they cannot (SigState::kf_fail: the sample pass
-        // found a knot the knot side had missed, a list / table outgrew its workspace, non-finite knot data, too many exact ties):
-        // repeat the call level by level, and let the engine's next decompositions start that way
-        bool redo = false;
-        for (int b = 0; b < B; ++b) redo = redo || e->h_state[b].kf_fail != 0;
-        if (redo) {
+        // found a knot the knot side had missed, a list / table outgrew its workspace, non-finite knot data, too many exact ties).
+        // A few signals of a batch: each of them is run again on its own, level by level (record-driven level 0: any knot
+        // spacing), into its rows — the rest of the batch keeps its fused result.  Many, or a single signal: the whole call is
+        // repeated level by level and the engine's next decompositions start that way.
+        int nfail = 0;
+        for (int b = 0; b < B; ++b) nfail += e->h_state[b].kf_fail != 0;
+        if (nfail) {
             if (e->fuse_mode == ITD_FUSE_ONLY) {
                 int code = 0;
                 for (int b = 0; b < B; ++b) code |= e->h_state[b].kf_fail;
                 snprintf(e->err, sizeof(e->err), "fused sparse levels: not the reference's result (fail bits 0x%x: 1 verification, 2 capacity, 4 non-finite, 8 ties); ITD_FUSE_ONLY forbids the level-by-level repeat", code);
                 return ITD_ERR_HIP;
             }
-            ++e->fuse_repeats;
-            e->fuse_off_left = 16;
-            const int rc = repeat(want_fused(e), false);
-            if (rc) return rc;
+            if (B >= 8 && nfail * 8 <= B) {
+                const int rc = repair_signals(e, B);
+                if (rc) return rc;
+            } else {
+                ++e->fuse_repeats;
+                e->fuse_off_left = 16;
+                const int rc = repeat(want_fused(e), false);
+                if (rc) return rc;
+            }
         }
     }
     if (e->last_fused) {
@@ -1076,6 +1130,7 @@ int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level)
 }
 
 int itd_get_fuse_repeats(const itd_engine *e) { return e ? e->fuse_repeats : -1; }
+int64_t itd_get_fuse_signal_repairs(const itd_engine *e) { return e ? e->fuse_signal_repairs : -1; }
 
 int itd_set_resident_window(itd_engine *e, int32_t segments)
 {

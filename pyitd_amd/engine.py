@@ -120,6 +120,12 @@ class Engine:
         """Calls of this engine that itd_get_summary had to repeat level by level because the fused levels reported a failure."""
         return self._L.itd_get_fuse_repeats(self._h)
 
+    @property
+    def fuse_signal_repairs(self):
+        """Single signals of batches that itd_get_summary re-ran on their own (at most one in eight of a batch refused the fused
+        form: the rest of the batch kept its fused result)."""
+        return int(self._L.itd_get_fuse_signal_repairs(self._h))
+
     def set_resident_mode(self, mode):
         """RESIDENT_AUTO (signals of <= 8192 samples run as one workgroup each in one launch, the signal resident in LDS; a call
         that meets a non-finite value is repeated level by level), RESIDENT_OFF, RESIDENT_ONLY (never repeat)."""

@@ -131,8 +131,8 @@ def test_few_knots_stop_before_the_fused_levels(P, torch, oracle):
 
 
 def test_batches_and_the_drop_in_class(P, torch, oracle):
-    """A batch of 2^17-sample signals (the fused levels run per chunk of signals); one signal of the batch is a chirp: the whole
-    call is repeated level by level and every signal still equals the oracle.  The drop-in class takes the same path."""
+    """A batch of 2^17-sample signals (the fused levels run per chunk of signals); one signal of the batch is a chirp: just that
+    signal is run again level by level (one in nine) and every signal still equals the oracle.  The drop-in class takes the same path."""
     from pyitd_amd.engine import FUSE_AUTO
     n, m, B = 1 << 17, 6, 9
     xs = np.stack([sines_noise(n, seed=20 + b, fscale=1 + b / 50.0) for b in range(B)])
@@ -147,7 +147,7 @@ def test_batches_and_the_drop_in_class(P, torch, oracle):
         torch.cuda.synchronize()
         eng.decompose_dev(xd.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
         s = eng.summary(B)
-        assert eng.fuse_repeats == (1 if with_chirp else 0)
+        assert (eng.fuse_repeats, eng.fuse_signal_repairs) == (0, 1 if with_chirp else 0)
         for b in range(B):
             ref = oracle.itd_lean(x[b], m)
             assert int(s["n_rows"][b]) == ref["rows"].shape[0]
@@ -169,4 +169,35 @@ def test_first_fused_level_is_two_at_least(P):
             eng.set_fuse_level(bad)
     eng.set_fuse_level(2)
     eng.set_fuse_level(20)
+    eng.close()
+
+
+def test_a_few_refusing_signals_of_a_batch_are_rerun_on_their_own(P, torch, oracle):
+    """Signal 51 of the bench's batch recipe (2^20 samples, 8 levels) grows a knot from rounding at level 8 that the knot side cannot
+    know (tests/test_oracle_knotfirst.py's model refuses it too): itd_get_summary re-runs just that signal level by level, the rest
+    of the batch keeps its fused result, the engine stays in the fused form, and a second summary of the same call does no work."""
+    n, M = 1 << 20, 7
+    ids = list(range(40, 56))
+    xs = np.stack([sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0) for b in ids])
+    eng = P.Engine(n, len(ids), 0)
+    x = torch.from_numpy(xs).cuda()
+    rows = torch.full((len(ids), M + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for call in range(2):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, len(ids), n, M, rows.data_ptr(), None, None)
+        s = eng.summary(len(ids))
+        assert eng.fuse_repeats == 0, "the whole call was repeated"
+        assert eng.fuse_signal_repairs >= call + 1, "no signal refused: the recipe changed?"
+        assert eng.fuse_signal_repairs <= 2 * (call + 1)
+        s2 = eng.summary(len(ids))
+        assert all(np.array_equal(s[k], s2[k]) for k in s)
+        for j, b in enumerate(ids):
+            if call == 1 and b not in (40, 51, 55):
+                continue
+            ref = oracle.itd_lean(xs[j], M)
+            nr = int(s["n_rows"][j])
+            assert nr == ref["rows"].shape[0]
+            assert_bits_equal(rows[j, :nr].cpu().numpy(), ref["rows"], "call %d signal %d" % (call, b))
+            kc = [int(v) for v in s["knot_counts"][j] if v >= 0]
+            assert kc[: len(ref["knot_counts"])] == ref["knot_counts"].tolist(), "signal %d knots per level" % b   # (itd_lean counts every level's input)
     eng.close()
