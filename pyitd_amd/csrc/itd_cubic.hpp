@@ -13,8 +13,8 @@
 //   k_cubic_sweep<true>   knot values K[k] (:61-83), the right-hand side and pivots (:88-96) computed on the fly, and the
 //                         forward sweep  b[i] = (b0[i] - u[i] b[i-1]) / d[i]  (:93-98);
 //   k_cubic_sweep<false>  the back substitution  b[i] = b[i] - v[i] b[i+1]  (:100-101), natural ends (:104-105).
-//       Both are first-order linear recurrences y -> a_i + c_i y.  A workgroup owns 4096 consecutive elements and walks them in
-//       coalesced rounds of 256: the maps of a round are composed in order by wave scans (shuffles), across the four waves through
+//       Both are first-order linear recurrences y -> a_i + c_i y.  A workgroup owns 1792 consecutive elements and walks them in
+//       rounds of 1024 (four per thread): the maps of a round are composed in order by wave scans (shuffles), across the four waves through
 //       LDS, across rounds by a running carry.  ACROSS workgroups nothing is exchanged: a workgroup starts kWarm = 256 elements
 //       early from y = 0.  That is exact to far below rounding because the maps contract — forward |c_i c_{i+1}| <= 1/2 for
 //       every pair (c_i = u_i / (2 - u_i v_{i-1}) <= u_i / (2 - u_i), c_{i+1} <= 1 / (1 + u_i)), so 256 elements damp the
@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -49,9 +50,15 @@ struct CubicArgs {
     const int32_t *e; int64_t e_stride;       // knot lists (e_stride = 0: one list for every signal)
     const CubicJob *jobs; int job_stride;     // 0: one job for every signal (shared knots), 1: one each
     double *K, *bf, *b; int64_t a_stride;     // per-signal knot arrays: values, forward sweep, final second derivatives
+    const int32_t *tbase = nullptr; int64_t tb_stride = 0;   // optional: detected knots in front of every 512-sample tile (k_compact), per list
 };
 
-constexpr int kScanThreads = 256, kScanRounds = 16, kScanBlockElems = kScanRounds * kScanThreads, kWarm = kScanThreads;
+#ifndef ITD_SCAN_ROUNDS
+#define ITD_SCAN_ROUNDS 2      // rounds of 1024 elements a sweep workgroup walks, its 256 warm-up elements included (A/B builds)
+#endif
+constexpr int kScanThreads = 256, kScanPer = 4, kScanRoundElems = kScanThreads * kScanPer, kScanRounds = ITD_SCAN_ROUNDS, kWarm = 256;
+constexpr int kScanBlockElems = kScanRounds * kScanRoundElems - kWarm;   // elements a workgroup owns
+constexpr int kScanStage = kScanRounds * kScanRoundElems + 4;            // knots a forward workgroup stages: its span and two either side
 
 // ---- jobs -------------------------------------------------------------------------------------------------------------
 // mode 0: the caller's list (idx given; validated by k_cubic_validate afterwards); mode 1: the detected knots of signal b,
@@ -110,14 +117,33 @@ __device__ __forceinline__ double cubic_knot_value(const double *__restrict__ I,
     return 0.5 * (ap + weight * (an - ap)) + (1 - 0.5) * ac;                      // :80
 }
 
+// 1 / x for the sweeps' divisors (knot spacings: integers below 2^31; pivots 2 - u v in [1.5, 2]): hardware estimate + two Newton
+// steps, ~1 ulp.  The sweeps were bound by IEEE divisions (8 per knot, ~40 instructions each); their results are held to a
+// tolerance anyway (the recurrences run as scans), so the reciprocal form costs no parity.
+__device__ __forceinline__ double sweep_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // FWD: element q (q = 0 .. idx-2) is knot i = 1 + q:  y = (b0[i] - u[i] * y_prev) / d[i], y in front of knot 1 = b[0] = 0
 // BWD: element q is knot i = idx-2-q (running downwards):  y = bf[i] - v[i] * y_prev, v[i] = 1 - u[i]; y in front = bf[idx-1]
+// A thread owns kScanPer = 4 consecutive elements of a round (composed serially: the wave scan runs once per 256 elements), and
+// everything a workgroup's rounds read is requested BEFORE the first scan: FWD stages the knots' positions and the signal's values
+// there for its whole span in LDS (one coalesced load + one gather per knot, all in flight together) and turns them into knot
+// values in place; BWD computes its rounds' maps into registers first.  (One element per thread with the loads inside the rounds:
+// 100 + 52 us at 6.7 M knots — 17 dependent round trips per workgroup, then bound by the scans' and divisions' instruction count.)
 template <bool FWD>
 __global__ __launch_bounds__(kScanThreads) void k_cubic_sweep(CubicArgs A)
 {
+    constexpr int NR = kScanRounds;
+    constexpr int NI = (kScanStage + kScanThreads - 1) / kScanThreads;
     __shared__ Affine s_wave[kScanThreads / 64];
     __shared__ double s_y;
-    __shared__ double s_K[kScanThreads + 2];
+    __shared__ int32_t s_E[FWD ? kScanStage : 1];
+    __shared__ double s_V[FWD ? kScanStage : 1];                     // the signal at the staged knots; then the knot values K
     const int sig = blockIdx.y;
     const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
     if (!job.valid) return;
@@ -128,56 +154,124 @@ __global__ __launch_bounds__(kScanThreads) void k_cubic_sweep(CubicArgs A)
     const double *I = A.x + (int64_t)sig * A.x_stride;
     double *K = A.K + (int64_t)sig * A.a_stride, *bf = A.bf + (int64_t)sig * A.a_stride, *bo = A.b + (int64_t)sig * A.a_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r_first = base >= kWarm ? -1 : 0;        // one warm-up round in front of the workgroup's own elements
-    double y_in = 0.0;                                  // FWD at the very front: b[0] = 0
-    if (!FWD && r_first == 0) y_in = bf[idx - 1];       // BWD at the very front: the forward sweep's last value
-    for (int round = r_first; round < kScanRounds; ++round) {
-        const int q0 = base + round * kScanThreads;     // uniform
-        if (q0 >= count) break;
-        const int q = q0 + tid;
-        Affine m{0.0, 1.0};
-        if (FWD) {
-            // knot values of the round's knots 1+q0 .. 1+q0+255 and the two next to them, through LDS
-            const int i = 1 + q;
-            if (i <= idx) s_K[tid + 1] = cubic_knot_value(I, e, i, idx);
-            if (tid == 0) s_K[0] = cubic_knot_value(I, e, q0, idx);
-            if (tid == 1 && q0 + kScanThreads + 1 <= idx) s_K[kScanThreads + 1] = cubic_knot_value(I, e, q0 + kScanThreads + 1, idx);
-            __syncthreads();
-            if (q < count) {
-                const double Km = s_K[tid], Kc = s_K[tid + 1], Kp = s_K[tid + 2];
-                const double hm = (double)(e[i] - e[i - 1]), hi = (double)(e[i + 1] - e[i]);           // :86
-                const double ui = hm / (hm + hi);                                                       // :89
-                double vm = 0.0;                                                                        // v[0] = 0
-                if (i >= 2) { const double hmm = (double)(e[i - 1] - e[i - 2]); vm = 1 - hmm / (hmm + hm); }   // :90
-                const double b0 = 6 * ((Kp - Kc) / hi - (Kc - Km) / hm) / (hm + hi);                    // :91
-                const double di = 2 - ui * vm;                                                          // :94,96 (original u and v)
-                m = Affine{b0 / di, -(ui / di)};
-                if (round >= 0) {
-                    K[i] = Kc;
-                    if (q == 0) K[0] = Km;
-                    if (q == count - 1) K[idx] = Kp;
+    const int q_first = base >= kWarm ? base - kWarm : base;       // the warm-up elements in front of the workgroup's own
+    const int q_end = min(base + kScanBlockElems, count);          // one past the last element walked
+    double y_in = 0.0;                                              // FWD at the very front: b[0] = 0
+    if (!FWD && q_first == 0) y_in = bf[idx - 1];                   // BWD at the very front: the forward sweep's last value
+    Affine mb[FWD ? 1 : NR * kScanPer];
+    const int k_start = q_first - 1;                                // FWD: staged knot j is knot k_start + j (two either side of the span)
+    if (FWD) {
+        int32_t ev[NI];
+        double vv[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int j = tid + it * kScanThreads, kk = k_start + j;
+            ev[it] = (j < kScanStage && kk >= 0 && kk <= idx) ? e[kk] : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) vv[it] = ev[it] >= 0 ? I[ev[it]] : 0.0;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int j = tid + it * kScanThreads;
+            if (j < kScanStage) { s_E[j] = ev[it]; s_V[j] = vv[it]; }
+        }
+        __syncthreads();
+        // knot values K[k] (:61-83) of the staged knots 1 .. kScanStage-2 (what the span's maps read)
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int j = tid + it * kScanThreads, kk = k_start + j;
+            double kv = 0.0;
+            if (j >= 1 && j <= kScanStage - 2 && kk >= 0 && kk <= idx) {
+                if (kk == 0 || kk == idx) kv = s_V[j];                           // :83 the end values are the data
+                else if (kk == idx - 1) kv = 0.0;                                // the loop at :61 stops at idx-2
+                else {
+                    const int32_t ep = s_E[j - 1], ec = s_E[j], en = s_E[j + 1];
+                    const double ap = s_V[j - 1], ac = s_V[j], an = s_V[j + 1];
+                    const double weight = (double)(ec - ep) * sweep_rcp((double)(en - ep));   // :77
+                    kv = 0.5 * (ap + weight * (an - ap)) + (1 - 0.5) * ac;        // :80
                 }
             }
-        } else if (q < count) {
-            const int i = idx - 2 - q;
-            m = Affine{0.0, 0.0};                                                   // i = 0: v[0] = 0 and b[0] is forced to 0 (:104)
-            if (i >= 1) {
-                const double hm = (double)(e[i] - e[i - 1]), hi = (double)(e[i + 1] - e[i]);
-                m = Affine{bf[i], -(1 - hm / (hm + hi))};                           // v[i] = 1 - u[i], :90, :101
+            vv[it] = kv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int j = tid + it * kScanThreads;
+            if (j < kScanStage) s_V[j] = vv[it];
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+            for (int c = 0; c < kScanPer; ++c) {
+                const int q = q_first + r * kScanRoundElems + tid * kScanPer + c;
+                Affine m{0.0, 1.0};
+                if (q < q_end) {
+                    const int i = idx - 2 - q;
+                    m = Affine{0.0, 0.0};                                         // i = 0: v[0] = 0 and b[0] is forced to 0 (:104)
+                    if (i >= 1) {
+                        const double hm = (double)(e[i] - e[i - 1]), hi = (double)(e[i + 1] - e[i]);
+                        m = Affine{bf[i], -(1 - hm * sweep_rcp(hm + hi))};        // v[i] = 1 - u[i], :90, :101
+                    }
+                }
+                mb[r * kScanPer + c] = m;
             }
         }
-        const Affine inc = wave_inclusive(m, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int q0 = q_first + r * kScanRoundElems;    // uniform
+        if (q0 >= q_end) break;
+        const int qt = q0 + tid * kScanPer;               // the thread's first element of this round
+        Affine loc[kScanPer];                             // loc[c] = m_c o ... o m_0 (the thread's elements composed in order)
+#pragma unroll
+        for (int c = 0; c < kScanPer; ++c) {
+            const int q = qt + c;
+            Affine m{0.0, 1.0};
+            if (FWD) {
+                if (q < q_end) {
+                    const int i = 1 + q, j = q - q_first + 2;
+                    const double Km = s_V[j - 1], Kc = s_V[j], Kp = s_V[j + 1];
+                    const double hm = (double)(s_E[j] - s_E[j - 1]), hi = (double)(s_E[j + 1] - s_E[j]);   // :86
+                    const double rhm = sweep_rcp(hm), rhi = sweep_rcp(hi), rs = sweep_rcp(hm + hi);
+                    const double ui = hm * rs;                                                              // :89
+                    double vm = 0.0;                                                                        // v[0] = 0
+                    if (i >= 2) { const double hmm = (double)(s_E[j - 1] - s_E[j - 2]); vm = 1 - hmm * sweep_rcp(hmm + hm); }   // :90
+                    const double b0 = 6 * ((Kp - Kc) * rhi - (Kc - Km) * rhm) * rs;                         // :91
+                    const double rdi = sweep_rcp(2 - ui * vm);                                              // :94,96 (original u and v)
+                    m = Affine{b0 * rdi, -(ui * rdi)};
+                    if (q >= base) {
+                        K[i] = Kc;
+                        if (q == 0) K[0] = Km;
+                        if (q == count - 1) K[idx] = Kp;
+                    }
+                }
+            } else {
+                m = mb[r * kScanPer + c];
+            }
+            loc[c] = c == 0 ? m : compose(m, loc[c > 0 ? c - 1 : 0]);
+        }
+        const Affine inc = wave_inclusive(loc[kScanPer - 1], lane);
         if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
         Affine pre{0.0, 1.0};             // the waves of this round in front of mine
         for (int w = 0; w < wave; ++w) pre = compose(s_wave[w], pre);
         const double y_wave = pre.a + pre.c * y_in;          // y in front of my wave
-        const double y = inc.a + inc.c * y_wave;
-        if (q < count && round >= 0) {
-            if (FWD) bf[1 + q] = y;
-            else { const int i = idx - 2 - q; bo[i] = i == 0 ? 0.0 : y; }           // :104 b[0] = 0
+        const double exa = __shfl_up(inc.a, 1), exc = __shfl_up(inc.c, 1);
+        const double y_thr = lane == 0 ? y_wave : exa + exc * y_wave;   // y in front of my elements
+        double yv[kScanPer];
+#pragma unroll
+        for (int c = 0; c < kScanPer; ++c) yv[c] = loc[c].a + loc[c].c * y_thr;
+#pragma unroll
+        for (int c = 0; c < kScanPer; ++c) {
+            const int q = qt + c;
+            if (q < q_end && q >= base) {
+                if (FWD) bf[1 + q] = yv[c];
+                else { const int i = idx - 2 - q; bo[i] = i == 0 ? 0.0 : yv[c]; }   // :104 b[0] = 0
+            }
         }
-        if (tid == kScanThreads - 1) s_y = y;                // the round's last element (identity maps carry it on)
+        if (tid == kScanThreads - 1) s_y = yv[kScanPer - 1];  // the round's last element (identity maps carry it on)
         __syncthreads();
         y_in = s_y;
     }
@@ -215,54 +309,117 @@ __global__ __launch_bounds__(64) void k_cubic_eval(CubicArgs A, int64_t lo, int6
     const int64_t idx = job.idx;
     const int32_t *e = A.e + (int64_t)sig * A.e_stride + job.first;
     const double *K = A.K + (int64_t)sig * A.a_stride, *b = A.b + (int64_t)sig * A.a_stride;
-    // j0 = number of knots e[1..idx-1] strictly in front of the tile (<= s-1): lower bound of s, wave-uniform
-    int64_t l = 1, h = idx;             // first k in [1, idx) with e[k] >= s
-    while (l < h) {
-        const int64_t mid = (l + h) >> 1;
-        if (e[mid] < s) l = mid + 1; else h = mid;
-    }
-    const int64_t kfirst = l;           // knots kfirst, kfirst+1, ... lie at or behind s
+    // Slots for 320 knots (tiles of ordinary signals hold ~200 at most: 0.4 knots per sample; 6.5 KB of LDS keeps 24 wavefronts
+    // per CU in flight); a denser tile reads its knots from global memory (the same values).
+    constexpr int SL = 320 + 2;
+    __shared__ int32_t s_e[SL];
+    __shared__ double s_K[SL], s_b[SL];
     if (lane < TW / 64) s_bits[lane] = 0ull;
     __syncthreads();
-    for (int64_t k = kfirst + lane; k < idx; k += 64) {     // at most TW of them fall into the tile
-        const int64_t p = (int64_t)e[k] - s;
-        const bool in = p < TW;
-        if (in) atomicOr(&s_bits[p >> 6], 1ull << (p & 63));
-        if (!__any(in)) break;
+    bool dense = false, staged = false;
+    int64_t kfirst = 1;                 // first k in [1, idx) with e[k] >= s: knots kfirst, kfirst+1, ... lie at or behind s
+    const int64_t n_wt = (A.n + TW - 1) / TW;
+    const bool have_tb = A.tbase && (s % TW) == 0;
+    if (have_tb) {
+        // detected knots: the compaction left the knots in front of every tile, so the tile's part of the list is known at once and
+        // everything is requested in ONE round trip (a wavefront used to walk the list 64 knots at a time, each step waiting for
+        // its loads: the launch was a chain of 5-6 dependent round trips per wavefront at 24 wavefronts per CU, 81-100 us)
+        const int32_t *tb = A.tbase + (int64_t)sig * A.tb_stride;
+        const int64_t t = s / TW;
+        const int64_t g = (int64_t)tb[t] - job.first + 1;          // (list entry first + k is detected knot first + k - 1)
+        kfirst = g < 1 ? 1 : (g > idx ? idx : g);
+        if (t + 1 < n_wt) {
+            const int64_t g1 = (int64_t)tb[t + 1] - job.first + 1;
+            const int64_t k_hi = g1 < kfirst ? kfirst : (g1 > idx ? idx : g1);   // the tile's knots are kfirst .. k_hi - 1; k_hi is staged too
+            if (k_hi - (kfirst - 1) + 1 <= 320) {
+                int32_t ek[5];
+                double Kk[5], bk[5];
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int64_t k = kfirst - 1 + it * 64 + lane;
+                    const bool ok = k <= k_hi;
+                    ek[it] = ok ? e[k] : 0; Kk[it] = ok ? K[k] : 0.0; bk[it] = ok ? b[k] : 0.0;
+                }
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int64_t k = kfirst - 1 + it * 64 + lane;
+                    if (k <= k_hi) {
+                        const int r = it * 64 + lane;
+                        s_e[r] = ek[it]; s_K[r] = Kk[it]; s_b[r] = bk[it];
+                        const int64_t p = (int64_t)ek[it] - s;
+                        if (k >= kfirst && k < k_hi && p >= 0 && p < TW) atomicOr(&s_bits[p >> 6], 1ull << (p & 63));
+                    }
+                }
+                staged = true;
+            }
+        }
+    } else {
+        int64_t l = 1, h = idx;         // a caller's list: searched
+        while (l < h) {
+            const int64_t mid = (l + h) >> 1;
+            if (e[mid] < s) l = mid + 1; else h = mid;
+        }
+        kfirst = l;
     }
+    if (!staged) {
+        for (int64_t k0 = kfirst - 1; k0 <= idx; k0 += 64) {
+            const int64_t k = k0 + lane;
+            int64_t p = (int64_t)TW;                      // (beyond the list: behaves like a knot behind the tile)
+            if (k <= idx) {
+                const int32_t ek = e[k];
+                const int r = (int)(k - (kfirst - 1));
+                if (r < SL) { s_e[r] = ek; s_K[r] = K[k]; s_b[r] = b[k]; }
+                p = (int64_t)ek - s;
+                if (k >= kfirst && k < idx && p < TW) {
+                    atomicOr(&s_bits[p >> 6], 1ull << (p & 63));
+                    dense = dense || r + 1 >= SL;         // this knot's segment needs slot r + 1
+                }
+            }
+            if (__any(k >= kfirst && (p >= TW || k >= idx))) break;   // the first knot behind the tile (or the list's end) is staged
+        }
+    }
+    dense = __any(dense);
     __syncthreads();
     unsigned long long w[TW / 64];
     int pre[TW / 64];
-    int acc = (int)(kfirst - 1);        // knots in front of the tile
+    int acc = 0;                        // slot of the knot at or before the sample = the tile's knots at or before it
 #pragma unroll
     for (int q = 0; q < TW / 64; ++q) {
         w[q] = s_bits[q];
         pre[q] = acc;
         acc += __popcll(w[q]);
     }
+    // (wave-uniform cases hoisted out of the sample loop, the natural variant's linear last segment as a select: the loop body is
+    //  straight-line code; the rows leave with nontemporal stores)
+    auto eval = [&](auto dense_c, auto full_c) {
+        constexpr bool DENSE = decltype(dense_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int q = 0; q < TW / 64; ++q) {
-        const int p = q * 64 + lane;
-        const int64_t i = s + p;
-        if (i >= hi) continue;
-        const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-        const int64_t j = pre[q] + __popcll(w[q] & upto);        // knots at or before the sample
-        const int32_t ej = e[j];
-        const double hj = (double)(e[j + 1] - ej);                                  // :86
-        const double t = (double)(i - (int64_t)ej) / hj;                            // :115
-        const double Kj = K[j], Kn = K[j + 1];
-        double v;
-        if (!NAK && j == idx - 2) {
-            v = (1 - t) * Kj + t * Kn;                                              // :117
-        } else {
+        for (int q = 0; q < TW / 64; ++q) {
+            const int p = q * 64 + lane;
+            const int64_t i = s + p;
+            if (!FULL && i >= hi) continue;
+            const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+            const int r = pre[q] + __popcll(w[q] & upto);           // slot; the knot itself is j = kfirst - 1 + r
+            const int64_t j = kfirst - 1 + r;
+            int32_t ej, en;
+            double Kj, Kn, bj, bn;
+            if (!DENSE) { ej = s_e[r]; en = s_e[r + 1]; Kj = s_K[r]; Kn = s_K[r + 1]; bj = s_b[r]; bn = s_b[r + 1]; }
+            else { ej = e[j]; en = e[j + 1]; Kj = K[j]; Kn = K[j + 1]; bj = b[j]; bn = b[j + 1]; }
+            const double hj = (double)(en - ej);                                        // :86
+            const double t = (double)(i - (int64_t)ej) * sweep_rcp(hj);                 // :115
             const double omt = 1 - t;
-            const double c1 = hj * hj / 6 * ((omt * omt * omt - 1) + t) * b[j];     // :119 ((1-t)**3 - 1 + t)
-            const double c2 = hj * hj / 6 * (t * t * t - t) * b[j + 1];
-            v = ((omt * Kj + t * Kn) + c1) + c2;
+            const double h26 = hj * hj * (1.0 / 6);
+            double c1 = h26 * ((omt * omt * omt - 1) + t) * bj;                         // :119 ((1-t)**3 - 1 + t)
+            double c2 = h26 * (t * t * t - t) * bn;
+            if (!NAK && j == idx - 2) { c1 = 0.0; c2 = 0.0; }                           // :117 the natural variant's linear last segment
+            const double v = ((omt * Kj + t * Kn) + c1) + c2;
+            __builtin_nontemporal_store(v, &o[i]);
+            if (ro) __builtin_nontemporal_store(xs[i] - v, &ro[i]);
         }
-        o[i] = v;
-        if (ro) ro[i] = xs[i] - v;
-    }
+    };
+    const bool full = s + TW <= hi;
+    if (dense) { if (full) eval(std::true_type{}, std::true_type{}); else eval(std::true_type{}, std::false_type{}); }
+    else { if (full) eval(std::false_type{}, std::true_type{}); else eval(std::false_type{}, std::false_type{}); }
 }
 
 // find_extrema's tail (itd_fourier_decomposition.py:29-30): e[m+1] = 2 e[m] - e[m-1]; python's e[-1] (= 0) when m = 0

@@ -1479,7 +1479,7 @@ namespace {
 // Batched knot detection into a workspace of its own (grow-only): per-tile lists, counts, records, group sums, per-signal
 // states, the ordered knot lists kidx[b] = [lead slot, knots, tail] and totals[b] = {knot count, the signal holds a NaN}.
 struct DetectWs {
-    int32_t *lists, *counts, *gsum, *kidx, *totals;
+    int32_t *lists, *counts, *gsum, *kidx, *totals, *tbase;
     TileRec *recs;
     SigState *state;
     int64_t kidx_stride;
@@ -1495,7 +1495,7 @@ int detect_workspace(itd_engine *e, int64_t n, int batch, DetectWs &w)
     const size_t b_lists = al(tiles * T * sizeof(int32_t)), b_counts = al(tiles * sizeof(int32_t)), b_recs = al(tiles * sizeof(TileRec));
     const size_t b_gsum = al(B * (size_t)w.n_groups * kGsumPitch * sizeof(int32_t)), b_state = al(B * sizeof(SigState));
     const size_t b_kidx = al(B * (size_t)w.kidx_stride * sizeof(int32_t)), b_tot = al(B * 2 * sizeof(int32_t));
-    const int rc = grow(e, &e->d_dw, &e->dw_bytes, b_lists + b_counts + b_recs + b_gsum + b_state + b_kidx + b_tot);
+    const int rc = grow(e, &e->d_dw, &e->dw_bytes, b_lists + 2 * b_counts + b_recs + b_gsum + b_state + b_kidx + b_tot);
     if (rc) return rc;
     char *p = (char *)e->d_dw;
     w.lists = (int32_t *)p; p += b_lists;
@@ -1504,7 +1504,8 @@ int detect_workspace(itd_engine *e, int64_t n, int batch, DetectWs &w)
     w.gsum = (int32_t *)p; p += b_gsum;
     w.state = (SigState *)p; p += b_state;
     w.kidx = (int32_t *)p; p += b_kidx;
-    w.totals = (int32_t *)p;
+    w.totals = (int32_t *)p; p += b_tot;
+    w.tbase = (int32_t *)p;          // the knots in front of every tile (k_compact)
     return ITD_OK;
 }
 // knots of `batch` signals (batch <= 65535: grid.y) by predicate `mode`, ordered, no host synchronisation.  kidx_out = NULL: into
@@ -1521,7 +1522,7 @@ int detect_enqueue(itd_engine *e, const double *x, int64_t x_stride, int64_t n, 
     k_detect<double, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, w.n_tiles, mode, want_lists ? w.lists : nullptr, w.counts, w.recs, w.gsum, w.state);
     if (want_lists)
         k_compact<T><<<grid_t, blk, 0, st>>>(w.lists, w.counts, w.gsum, w.n_tiles, n, kidx_out ? kidx_out : w.kidx,
-                                              kidx_out ? kidx_out_stride : w.kidx_stride, w.totals, w.state, tail_value, nullptr, kidx_out ? 0 : 1);
+                                              kidx_out ? kidx_out_stride : w.kidx_stride, w.totals, w.state, tail_value, w.tbase, kidx_out ? 0 : 1);
     else
         k_batch_totals<<<(batch + 3) / 4, 256, 0, st>>>(w.gsum, w.n_groups, batch, w.state, w.totals);
     HIP_TRY(e, hipGetLastError());
@@ -1553,6 +1554,7 @@ int cubic_batch(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_
         n_jobs = batch;
         k_cubic_jobs<<<(batch + 255) / 256, 256, 0, st>>>(jobs, batch, 1, 0, w.totals);
         A.e = w.kidx; A.e_stride = w.kidx_stride; A.job_stride = 1;
+        A.tbase = w.tbase; A.tb_stride = w.n_tiles;
         max_count = n;
     } else {
         n_jobs = e_stride ? batch : 1;
@@ -1703,7 +1705,7 @@ int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, in
 }  // extern "C"
 namespace {
 struct SplineWs {
-    int32_t *lists, *counts, *gsum, *kidx, *totals;
+    int32_t *lists, *counts, *gsum, *kidx, *totals, *tbase;
     TileRec *recs;
     SigState *state;
     double *a, *c;
