@@ -157,7 +157,9 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * only a few signals of a batch are concerned (at most one in eight) just those are run again, each on its own, and the
  * engine stays in the fused form.
  * Results are bit-identical in every mode: what the fused form cannot deliver it reports.
- * ITD_FUSE_AUTO (default): signals of >= 65536 samples with the fused level 0; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
+ * ITD_FUSE_AUTO (default): calls whose launch sequences cover at least itd_set_fuse_min_samples samples (signals per chunk x n; default
+ * 6 * 2^20: the fused form has more launches — 18 instead of 10 at 8 levels — and pays once they are memory bound: one signal of 2^22
+ * samples is 6 % slower fused, one of 2^23 9 % faster), signals of >= 65536 samples; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
  * repeat (itd_get_summary fails with ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 ..
  * max_iteration (default 3: levels 0, 1, 2 as one launch each; measured on 2^24 samples: 0.499 / 0.482 / 0.501 ms for 2 / 3 / 4). */
 #define ITD_FUSE_AUTO 0
@@ -165,6 +167,7 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
 #define ITD_FUSE_ONLY 2
 int itd_set_fuse_mode(itd_engine *e, int32_t mode);
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
+int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
 /* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);
 /* ... and how many single signals of batches it has re-run on their own (the rest of their batch kept the fused result) */

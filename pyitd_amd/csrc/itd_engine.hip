@@ -115,6 +115,7 @@ struct itd_engine {
     void *d_kf = nullptr; size_t kf_bytes = 0;
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
+    int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
     bool last_kf = false;
     int last_kf_level = 0;         // the first fused level of that call
@@ -594,14 +595,18 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
     return ITD_OK;
 }
 
-// The sparse levels fused (itd_knotfirst.hpp)?  Automatic: long signals (the per-level launches are memory bound there), at least
-// two fused extractions, the fused level 0 (it flags the input's exact ties), no per-launch timing; not while a recent call had to
-// be repeated level by level (smooth or quantised input keeps failing the verification: workloads tend to be homogeneous).
-bool want_kf(itd_engine *e, int64_t n, int32_t M, bool fuse0)
+// The sparse levels fused (itd_knotfirst.hpp)?  Automatic: when a launch sequence covers enough samples for its launches to be
+// memory bound — the fused form trades traffic for launches (18 instead of 10 at 8 levels), and below ~2^22.5 samples per
+// sequence every launch is bound by its ~6.5 us boundary: measured one signal of 2^16 / 2^20 / 2^22 / 2^23 samples 64 / 88 / 180 /
+// 305 us level by level against 102 / 116 / 191 / 277 us fused (tools/fuse_threshold.py) —, the fused level 0 (it flags the input's
+// exact ties), no per-launch timing; not while a recent call had to be repeated level by level (smooth or quantised input
+// keeps failing the verification: workloads tend to be homogeneous).
+bool want_kf(itd_engine *e, int64_t n, int32_t batch, int32_t M, bool fuse0)
 {
     if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || e->fuse_level < 2 || e->fuse_level > M) return false;
     if (e->fuse_mode == ITD_FUSE_ONLY) return true;
     if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO) return false;
+    if ((int64_t)std::min<int32_t>(chunk_of(e, n, batch), batch) * n < e->fuse_min_samples) return false;
     if (e->fuse_off_left > 0) { --e->fuse_off_left; return false; }
     return true;
 }
@@ -612,7 +617,7 @@ int enqueue_any(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x
 {
     if (want_resident(e, n)) return enqueue_resident<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
     const bool f0 = want_fused(e);
-    return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, f0, false, want_kf(e, n, M, f0));
+    return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, f0, false, want_kf(e, n, batch, M, f0));
 }
 
 // how the next decomposition's level 0 finds its knots: fused (one pass over the signal) unless the engine was told
@@ -1126,6 +1131,13 @@ int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level)
     // (level 1's launch completes the signal's own knot count, and a level-1 list would not fit the workspace: 2 at least)
     if (!e || first_fused_level < 2 || first_fused_level > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
     e->fuse_level = first_fused_level;
+    return ITD_OK;
+}
+
+int itd_set_fuse_min_samples(itd_engine *e, int64_t samples)
+{
+    if (!e || samples < 0) return ITD_ERR_INVALID_ARG;
+    e->fuse_min_samples = samples;
     return ITD_OK;
 }
 

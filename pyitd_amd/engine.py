@@ -47,6 +47,9 @@ class Engine:
         mode = os.environ.get("PYITD_FUSE_LEVEL")       # the first fused level (diagnostic sweeps)
         if mode:
             self.set_fuse_level(int(mode))
+        mode = os.environ.get("PYITD_FUSE_MIN")         # samples per launch sequence from which FUSE_AUTO fuses (tests: 65536)
+        if mode:
+            self.set_fuse_min_samples(int(mode))
         mode = os.environ.get("PYITD_RESIDENT_MODE")    # and for the one-workgroup form of short signals (RESIDENT_*)
         if mode:
             self.set_resident_mode(int(mode))
@@ -114,6 +117,11 @@ class Engine:
     def set_fuse_level(self, first_fused_level):
         """The first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2 are one launch each)."""
         self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))
+
+    def set_fuse_min_samples(self, samples):
+        """FUSE_AUTO fuses calls whose launch sequences cover at least this many samples (default 6 * 2^20: below that every
+        launch is bound by its boundary and the fused form has more of them)."""
+        self._check(self._L.itd_set_fuse_min_samples(self._h, int(samples)))
 
     @property
     def fuse_repeats(self):

@@ -32,6 +32,7 @@ def _run(P, torch, x, m, mode, L0=3, bases=True):
     eng = P.Engine(n, 1, 0)
     eng.set_fuse_mode(mode)
     eng.set_fuse_level(L0)
+    eng.set_fuse_min_samples(65536)          # (the automatic mode fuses from 6 * 2^20 samples per launch sequence by default)
     xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
     bs = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda") if bases else None
@@ -142,6 +143,7 @@ def test_batches_and_the_drop_in_class(P, torch, oracle):
             x[4] = chirp(n)
         eng = P.Engine(n, B, 0)
         eng.set_fuse_mode(FUSE_AUTO)
+        eng.set_fuse_min_samples(65536)
         xd = torch.from_numpy(x).cuda()
         rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
