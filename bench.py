@@ -692,6 +692,9 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
     out = {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
             "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "hbm_algorithmic_GBps": round(alg, 1), "frac_of_peak_whole_decomposition": round(alg / HBM_PEAK_GBPS, 4),
+            "bytes_note": "the reference flow's 20 + 24 x 7 = 188 B/sample (SURVEY 8d); with levels 3..8 fused the engine itself moves "
+                          "124 B/sample: frac_of_peak_own_bytes",
+            "frac_of_peak_own_bytes": None if refused else round(124.0 * batch * n / dt / 1e9 / HBM_PEAK_GBPS, 4),
             "rows_per_signal": sorted(set(int(v) for v in s["n_rows"])),
             "fused_levels_refused_and_retimed_level_by_level": refused,
             "signals_rerun_on_their_own_per_step": repaired, "summary_read_every_step": True, "order": "timed after the headline"}

@@ -168,6 +168,9 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
 int itd_set_fuse_mode(itd_engine *e, int32_t mode);
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
 int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
+/* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot side of the fused levels (default 4: its launches are
+ * bound by their boundaries, not by the lists' lengths, so they are amortised over more signals than a level launch takes) */
+int itd_set_fuse_group(itd_engine *e, int32_t chunks);
 /* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);
 /* ... and how many single signals of batches it has re-run on their own (the rest of their batch kept the fused result) */

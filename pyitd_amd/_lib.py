@@ -77,6 +77,7 @@ ABI = {
     "itd_set_fuse_mode": (_INT, [_P, _I32]),
     "itd_set_fuse_level": (_INT, [_P, _I32]),
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),
+    "itd_set_fuse_group": (_INT, [_P, _I32]),
     "itd_get_fuse_repeats": (_INT, [_P]),
     "itd_get_fuse_signal_repairs": (_I64, [_P]),
     "itd_set_resident_mode": (_INT, [_P, _I32]),

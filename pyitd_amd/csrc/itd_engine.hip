@@ -106,6 +106,7 @@ struct itd_engine {
     int32_t batch_streams = 2;     // chunks of a batch rotate over this many streams (itd_set_batch_streams): 1 .. kMaxBatchStreams
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // the others besides the caller's, created on demand
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+
     int32_t resident_mode = ITD_RESIDENT_AUTO;   // short signals as one workgroup each, one launch (itd_set_resident_mode)
     int32_t resident_off_left = 0;  // automatic mode: decompositions still to run level by level after a resident call met a non-finite value
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
@@ -115,6 +116,7 @@ struct itd_engine {
     void *d_kf = nullptr; size_t kf_bytes = 0;
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
+    int32_t fuse_group = 4;                          // chunks of a batch that share one knot side of the fused levels
     int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
     bool last_kf = false;
@@ -321,7 +323,10 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int n_chunks = (batch + chunk - 1) / chunk;
     // streams in use: the caller's and S - 1 of the engine's; signals too long for two of them to share the Infinity Cache
     // (more than 3 * 2^22 samples each) keep to one stream
-    const int S = (e->chunk == 0 && (int64_t)chunk * n > ((int64_t)3 << 22)) ? 1 : std::min<int>(e->batch_streams, n_chunks);
+    // chunks that share one knot side of the fused levels (grid.y of its launches: at most 65535 signals)
+    const int group = (kf && n_chunks > 1) ? std::max(1, std::min<int>(e->fuse_group, kMaxGridY / chunk)) : 1;
+    const int n_seqs = (n_chunks + group - 1) / group;
+    const int S = (e->chunk == 0 && (int64_t)chunk * n > ((int64_t)3 << 22)) ? 1 : std::min<int>(e->batch_streams, n_seqs);
     if (S > 1) {
         if (!e->ev_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(e, hipEventRecord(e->ev_fork, st));
@@ -333,11 +338,14 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             HIP_TRY(e, hipStreamWaitEvent(e->aux_stream[k], e->ev_fork, 0));
         }
     }
-    int chunk_no = 0;
-    for (int b0 = 0; b0 < batch; b0 += chunk, ++chunk_no) {
-        const int lane_s = chunk_no % S;
-        const hipStream_t cst = lane_s == 0 ? st : e->aux_stream[lane_s - 1];   // this chunk's stream
-        const int nb = std::min(chunk, batch - b0);   // signals b0 .. b0+nb-1: grid.y, every per-signal pointer offset by b0
+    // One chunk's launches, in three phases: 1 = the level launches + k_finalize, 2 = the fused levels' knot side, 4 = their sample
+    // pass.  Without fused levels a chunk is phase 1 alone.  With them, `group` consecutive chunks share ONE knot side: its dozen
+    // launches are bound by their boundaries (6-9 us each whatever the list lengths) and cannot hide behind another stream's
+    // memory-bound launches (measured: a short launch that meets a long one from the other stream ends when the long one ends, on a
+    // stream of the highest priority as well), so they are amortised over more signals instead — while the level launches keep the
+    // chunk size at which a level's baseline is still in the Infinity Cache for the next level.
+    auto run_chunk = [&](const int b0, const int nb, const hipStream_t cst, const int phase) -> int {
+        // signals b0 .. b0+nb-1: grid.y, every per-signal pointer offset by b0
         auto gs = [&](int level) { return set_gsum + (int64_t)(level % 3) * e->gsum_third + (int64_t)b0 * n_groups * kGsumPitch; };
         auto cnt = [&](int level) { return e->d_counts + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
         auto rec = [&](int level) { return e->d_recs + (int64_t)(level & 1) * e->tiles_half + (int64_t)b0 * n_tiles; };
@@ -347,6 +355,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *bases_c = bases_user ? bases_user + (int64_t)b0 * rows_stride : nullptr;
         double *pp_c = e->d_pp + (int64_t)b0 * 3 * e->pp_pitch;
         double *xm_c = pp_c + 2 * e->pp_pitch;   // NaN-input repeat: the mutated signal, one per signal at the slots' stride
+        if (phase & 1) {
         if (nan_input) {
             k_nan_level0<Tin, T><<<dim3(n_tiles, nb), blk, 0, cst>>>(xc, x_stride, n, n_tiles, xm_c, 3 * e->pp_pitch, cnt(0), rec(0),
                                                                     gs(0), state);
@@ -437,7 +446,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                                                                        e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
                                                                        kf_gpre, kf_sig, (int)(sizeof(KfSig) / 4), kf_tf, kf_tf_words, kf_tf_skip);
         }
-        if (kf) {
+        }
+        if (kf && (phase & 6)) {
             // ---- levels L0 .. M + 1 fused: hand-over, the knot-side steps, ONE pass over the samples, the verdict ----
             KfWs w = e->kf;
             w.n_tiles = n_tiles; w.L0 = L0; w.nlev = M + 3 - L0;
@@ -449,31 +459,34 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const double *xl = bases_c ? bases_c + (int64_t)(L0 - 1) * n : pp_c + (int64_t)((L0 - 1) % 3) * e->pp_pitch;
             const int64_t xl_stride = bases_c ? rows_stride : 3 * e->pp_pitch;
             w.gpre += B0 * n_groups;
+            const hipStream_t kst = cst;
+            if (phase & 2) {
             // (timed: the span from the hand-over's begin to the last step's end, taken from the two dispatches' own timestamps)
             const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
             if (p_kn >= 0) {
                 KfWs a_w = w; const Tin *a_x = xc; int64_t a_xs = x_stride, a_ls = xl_stride, a_n = n; const double *a_xl = xl;
                 const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); const SigState *a_st = state;
                 void *args[] = {&a_w, &a_x, &a_xs, &a_xl, &a_ls, &a_n, &a_c, &a_r, &a_st};
-                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_gather<Tin, T>), dim3(n_tiles, nb), dim3(kWave), args, 0, cst,
+                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_gather<Tin, T>), dim3(n_tiles, nb), dim3(kWave), args, 0, kst,
                                               e->ev[2 * (size_t)p_kn], nullptr, 0));
             } else {
-                k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, cst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
+                k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, kst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
             }
             for (int lev = L0; lev <= M + 1; ++lev) {
                 // the lists shrink ~3x per level; any grid is correct (the blocks take the chunks in turn)
                 const unsigned blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(w.nchunk, (int64_t)768 >> std::min(lev - L0, 6)));
-                k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, n, xl, xl_stride);
+                k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, kst>>>(w, lev, n, xl, xl_stride);
                 if (p_kn >= 0 && lev == M + 1) {
                     KfWs a_w = w; int a_lev = lev, a_m = M;
                     void *args[] = {&a_w, &a_lev, &a_m};
-                    HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_step_b), dim3(blocks + 1, nb), dim3(kKfChunk), args, 0, cst,
+                    HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_step_b), dim3(blocks + 1, nb), dim3(kKfChunk), args, 0, kst,
                                                   nullptr, e->ev[2 * (size_t)p_kn + 1], 0));
                 } else {
-                    k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, cst>>>(w, lev, M);
+                    k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, kst>>>(w, lev, M);
                 }
             }
-            {
+            }
+            if (phase & 4) {
                 const int pair = time_slot(e, ITD_TIME_KF_APPLY);
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
                 const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
@@ -482,6 +495,21 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                                               pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr, pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
             }
         }
+        return ITD_OK;
+    };
+    int seq_no = 0;
+    for (int s0 = 0; s0 < batch; s0 += chunk * group, ++seq_no) {
+        const int lane_s = seq_no % S;
+        const hipStream_t cst = lane_s == 0 ? st : e->aux_stream[lane_s - 1];   // this launch sequence's stream
+        const int s1 = std::min(batch, s0 + chunk * group);
+        int rc = ITD_OK;
+        if (group == 1) rc = run_chunk(s0, s1 - s0, cst, 7);
+        else {
+            for (int b0 = s0; b0 < s1 && !rc; b0 += chunk) rc = run_chunk(b0, std::min(chunk, s1 - b0), cst, 1);
+            if (!rc) rc = run_chunk(s0, s1 - s0, cst, 2);
+            for (int b0 = s0; b0 < s1 && !rc; b0 += chunk) rc = run_chunk(b0, std::min(chunk, s1 - b0), cst, 4);
+        }
+        if (rc) return rc;
     }
     for (int k = 0; k < S - 1; ++k) {
         HIP_TRY(e, hipEventRecord(e->ev_join[k], e->aux_stream[k]));
@@ -1131,6 +1159,13 @@ int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level)
     // (level 1's launch completes the signal's own knot count, and a level-1 list would not fit the workspace: 2 at least)
     if (!e || first_fused_level < 2 || first_fused_level > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
     e->fuse_level = first_fused_level;
+    return ITD_OK;
+}
+
+int itd_set_fuse_group(itd_engine *e, int32_t chunks)
+{
+    if (!e || chunks < 1 || chunks > 1024) return ITD_ERR_INVALID_ARG;
+    e->fuse_group = chunks;
     return ITD_OK;
 }
 

@@ -47,6 +47,9 @@ class Engine:
         mode = os.environ.get("PYITD_FUSE_LEVEL")       # the first fused level (diagnostic sweeps)
         if mode:
             self.set_fuse_level(int(mode))
+        mode = os.environ.get("PYITD_FUSE_GROUP")       # chunks of a batch per knot side of the fused levels (sweeps)
+        if mode:
+            self.set_fuse_group(int(mode))
         mode = os.environ.get("PYITD_FUSE_MIN")         # samples per launch sequence from which FUSE_AUTO fuses (tests: 65536)
         if mode:
             self.set_fuse_min_samples(int(mode))
@@ -122,6 +125,10 @@ class Engine:
         """FUSE_AUTO fuses calls whose launch sequences cover at least this many samples (default 6 * 2^20: below that every
         launch is bound by its boundary and the fused form has more of them)."""
         self._check(self._L.itd_set_fuse_min_samples(self._h, int(samples)))
+
+    def set_fuse_group(self, chunks):
+        """Batches: consecutive chunks that share one knot side of the fused levels (default 4)."""
+        self._check(self._L.itd_set_fuse_group(self._h, int(chunks)))
 
     @property
     def fuse_repeats(self):
