@@ -156,7 +156,9 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * baselines_dev must stay valid until then, as before) and the engine's next 16 decompositions start level by level; when
  * only a few signals of a batch are concerned (at most one in eight) just those are run again, each on its own, and the
  * engine stays in the fused form.
- * Results are bit-identical in every mode: what the fused form cannot deliver it reports.
+ * Results are bit-identical in every mode: what the fused form cannot deliver it reports.  The fused levels' workspace is allocated
+ * by the first call that takes this path; a call being captured into a graph cannot allocate: on an engine that has not fused yet it is
+ * captured level by level (run one decomposition before the capture to get the fused form into the graph).
  * ITD_FUSE_AUTO (default): calls whose launch sequences cover at least itd_set_fuse_min_samples samples (signals per chunk x n; default
  * 6 * 2^20: the fused form has more launches — 18 instead of 10 at 8 levels — and pays once they are memory bound: one signal of 2^22
  * samples is 6 % slower fused, one of 2^23 9 % faster), signals of >= 65536 samples; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
@@ -342,7 +344,8 @@ int itd_instantaneous_host_f64(itd_engine *e, const double *rot_host, int64_t n,
 /* ---- batched single-level operators (ABI revision 6): asynchronous on `stream`, no host synchronisation, graph-capturable ---
  * The reference applies its single-level functions row by row (siftED2D.ipynb cell 1: itd_baseline_extract over the rows of an
  * image under numba.prange) and along channels (itd.cpp:40-44).  Signal b starts at x_dev + b * x_stride.  These calls work in
- * workspaces of their own (grown on demand: the first call of a size allocates), apart from the decomposition's.
+ * workspaces of their own (grown on demand: the first call of a size allocates — so capture a call only after one of its size has
+ * run), apart from the decomposition's.
  *
  * itd_baseline_extract_batch_f64: itd_baseline_extract (ITD.py:79-121) of every signal: rot_dev / base_dev [batch] rows of n.
  *   info_dev (optional) [batch]: the signal's interior knot count; -1 - count if the signal holds a NaN — its rows then follow

@@ -278,6 +278,12 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // kf: levels L0 .. max_iteration + 1 run fused (itd_knotfirst.hpp): one launch per level only for levels 0 .. L0 - 1
     const int L0 = e->fuse_level;
     kf = kf && fuse0 && L0 >= 2 && L0 <= M && n < ((int64_t)1 << 31) - 65536;
+    // a call that is being captured into a graph must be complete in itself (the graph may be replayed any number of times) and
+    // cannot allocate: a captured call on an engine whose fused workspace does not exist yet runs level by level
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (kf && capturing && !e->d_kf) kf = false;
     if (kf) {
         const int rc = ensure_kf_ws(e);
         if (rc) return rc;
@@ -300,10 +306,6 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     SigState *const other_state = e->d_state + (size_t)(set ^ 1) * e->max_batch;
     int32_t *const other_gsum = e->d_gsum + (size_t)(set ^ 1) * 3 * e->gsum_third;
     const int64_t gs_extent = (int64_t)batch * n_groups * kGsumPitch;
-    // a call that is being captured into a graph must be complete in itself (the graph may be replayed any number of times)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    const bool capturing = cap != hipStreamCaptureStatusNone;
     if (nan_input || capturing || e->dirty_sig[set] > 0 || e->dirty_gs[set] > 0) {
         const int64_t ge = 3 * e->gsum_third;   // the buffers are small: clear all of them
         const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
