@@ -260,3 +260,38 @@ def test_fused_call_is_graph_capturable(P, torch, oracle):
             assert_bits_equal(rows[b, :nr].cpu().numpy(), ref["rows"], "replay seed %d signal %d" % (seed, b))
     assert eng.fuse_repeats >= 1          # the chirp replay: one of six signals refused (more than one in eight)
     eng.close()
+
+
+def test_fused_batch_with_odd_members(P, torch, oracle):
+    """A float64 batch of ragged length with the caller's baselines buffer under the fused levels: a signal that stops at once, one
+    the fused form refuses (re-run on its own, baselines included), then the same batch with a NaN in one input (the reference's NaN
+    branch: the whole call is repeated record-driven)."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m, B = (1 << 17) + 333, 6, 10
+    xs = np.stack([sines_noise(n, seed=80 + b, fscale=1 + b / 40.0, dtype=np.float64) for b in range(B)])
+    xs[6] = np.linspace(-1.0, 1.0, n)
+    xs[7] = chirp(n)
+    eng = P.Engine(n, B, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_min_samples(65536)
+    for with_nan in (False, True):
+        x = xs.copy()
+        if with_nan:
+            x[8, n // 3] = np.nan
+        xd = torch.from_numpy(x).cuda()
+        rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        bs = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        fix0 = eng.fuse_signal_repairs
+        eng.decompose_dev(xd.data_ptr(), np.float64, n, B, n, m, rows.data_ptr(), bs.data_ptr(), None)
+        s = eng.summary(B)
+        if not with_nan:
+            assert eng.fuse_signal_repairs - fix0 >= 1 and eng.fuse_repeats == 0
+        for b in range(B):
+            ref = oracle.itd(x[b], m)
+            nr, nb = int(s["n_rows"][b]), int(s["n_baselines"][b])
+            assert nr == ref["rows"].shape[0] and nb == ref["baselines"].shape[0], "signal %d" % b
+            assert ("natural", "timeout")[int(s["stop"][b])] == ref["stop"]
+            assert_bits_equal(rows[b, :nr].cpu().numpy(), ref["rows"], "nan %s signal %d rows" % (with_nan, b))
+            assert_bits_equal(bs[b, :nb].cpu().numpy(), ref["baselines"], "nan %s signal %d baselines" % (with_nan, b))
+    eng.close()
