@@ -652,8 +652,15 @@ __global__ __launch_bounds__(kKfChunk) void k_kf_step_b(KfWs ws, int lev, int ma
 }
 
 // ---- the sample pass: every fused level of a tile in registers.  grid = (tiles, batch), 64 threads. -----------------------
+#ifndef ITD_KF_APPLY_WAVES
+#define ITD_KF_APPLY_WAVES 0      // A/B builds: wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice: 6)
+#endif
 template <int TW, int CAP>
-__global__ __launch_bounds__(kWave) void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64_t n,
+__global__ __launch_bounds__(kWave)
+#if ITD_KF_APPLY_WAVES
+__attribute__((amdgpu_waves_per_eu(ITD_KF_APPLY_WAVES, ITD_KF_APPLY_WAVES)))
+#endif
+void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64_t n,
                                                     const TileRec *__restrict__ recs_l0, double *__restrict__ rows, int64_t rows_stride,
                                                     double *__restrict__ bases, int64_t bases_stride)
 {

@@ -73,6 +73,63 @@ __global__ __launch_bounds__(64) void k_tfe_phase(const double *__restrict__ x, 
     const int lane = threadIdx.x;
     const int64_t s = (int64_t)blockIdx.x * kTfeTile;
     int64_t hw0 = tile_base[blockIdx.x];
+    if (s >= 64 && s + kTfeTile + 2 <= n) {
+        // An inner tile (every sample has its two successors, none is the signal's first): everything is requested before anything
+        // is used — the tile, the half waves' amplitudes of all eight 64-sample steps — and a step's last lane takes the next sample's
+        // phase from the next step's first lane instead of a second arcsine.  (The generic loop below waits for its loads step by
+        // step, two dependent round trips each: 171 us at 2^24 samples against 537 MB of traffic.)
+        constexpr int G = kTfeTile / 64;
+        double xr[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) xr[g] = x[s + g * 64 + lane];
+        const double ext = lane < 2 ? x[s + kTfeTile + lane] : 0.0;
+        const double ext0 = __shfl(ext, 0), ext1 = __shfl(ext, 1);
+        double xn[G];
+        unsigned long long cm[G];
+        int before[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const double nxt = __shfl_down(xr[g], 1);
+            const double first_next = g + 1 < G ? __shfl(xr[g + 1 < G ? g + 1 : g], 0) : ext0;
+            xn[g] = lane == 63 ? first_next : nxt;
+            const bool cross = ((xr[g] > 0.0) && (0.0 > xn[g])) || ((xr[g] < 0.0) && (0.0 < xn[g]));   // (1 <= j <= n-2 holds here)
+            cm[g] = __ballot(cross);
+            before[g] = __popcll(cm[g] & ((1ull << lane) - 1ull));
+        }
+        double A[G];
+        int64_t hw = hw0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            A[g] = __builtin_bit_cast(double, amp_bits[hw + before[g]]);
+            hw += __popcll(cm[g]);
+        }
+        const double A_ext = __builtin_bit_cast(double, amp_bits[hw]);       // the half wave of sample s + 512
+        auto phase_in = [&](double xi, double slope, double Aa) {
+            if (!(Aa > 0.0)) return 0.0;                    // an all-zero half wave
+            const double r = xi / Aa;
+            const double as = asin(r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r));
+            if (xi >= 0.0) return slope >= 0.0 ? as : pi - as;
+            return slope < 0.0 ? pi - as : 2.0 * pi + as;
+        };
+        double ph[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) ph[g] = phase_in(xr[g], xn[g] - xr[g], A[g]);
+        const double ph_ext = phase_in(ext0, ext1 - ext0, A_ext);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t j = s + g * 64 + lane;
+            if (amp_out) __builtin_nontemporal_store(A[g], &amp_out[j]);
+            if (phase_out) __builtin_nontemporal_store(ph[g], &phase_out[j]);
+            if (freq_out) {
+                const double nxt = __shfl_down(ph[g], 1);
+                const double first_next = g + 1 < G ? __shfl(ph[g + 1 < G ? g + 1 : g], 0) : ph_ext;
+                double dp = (lane == 63 ? first_next : nxt) - ph[g];
+                if (dp < 0.0) dp += 2.0 * pi;            // the phase wraps once per wave
+                __builtin_nontemporal_store(dp / (2.0 * pi), &freq_out[j]);
+            }
+        }
+        return;
+    }
     // phase of sample i in half wave k (amplitude A): rising or falling from the forward difference (the backward one at the last sample)
     auto phase_of = [&](int64_t i, double xi, double slope, double A) {
         if (!(A > 0.0)) return 0.0;                     // an all-zero half wave
