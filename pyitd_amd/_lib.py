@@ -4,15 +4,16 @@ There is NO CPU fallback: if the HIP library is missing or no GPU is present the
 path raises.  `build()` compiles the library in-tree with hipcc for gfx950.
 """
 import ctypes
+import glob
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYITD_HIP_LIB") or os.path.join(_HERE, "libpyitd_hip.so")  # env override: diagnostic builds
 SOURCES = [os.path.join(_HERE, "csrc", "itd_engine.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "itd_kernels.hpp"), os.path.join(_HERE, "csrc", "itd_cubic.hpp"), os.path.join(_HERE, "csrc", "itd_stream.hpp"), os.path.join(_HERE, "csrc", "itd_engine_batch.inc"), os.path.join(_HERE, "csrc", "itd_tfe.hpp"), os.path.join(_HERE, "csrc", "itd_spline.hpp"), os.path.join(_HERE, "csrc", "itd_nak.hpp"),
-           os.path.join(_HERE, "csrc", "itd_fitpack.hpp"), os.path.join(_HERE, "csrc", "itd_resident.hpp"), os.path.join(_HERE, "csrc", "itd_knotfirst.hpp"),
-           os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
+# everything the library is compiled from (a header that is not listed here would not trigger a rebuild: list by pattern)
+HEADERS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) + glob.glob(os.path.join(_HERE, "csrc", "*.inc"))) + \
+    [os.path.join(os.path.dirname(_HERE), "include", "pyitd_hip.h")]
 
 MAX_ROWS = 22
 MAX_ITERATION = 20

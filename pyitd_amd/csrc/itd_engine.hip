@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <atomic>
 #include <memory>
 #include <new>
@@ -23,6 +24,7 @@
 #include "itd_resident.hpp"
 #include "itd_knotfirst.hpp"
 #include "itd_cubic.hpp"
+#include "itd_detect_fast.hpp"
 #include "itd_stream.hpp"
 #include "itd_tfe.hpp"
 #include "itd_spline.hpp"
@@ -1266,6 +1268,17 @@ int scan_level0(itd_engine *e, const Tin *x, int64_t n, int mode, bool compact, 
     // the helpers' own state, counts, records and group sums: a decomposition's workspace is never touched
     k_init_state<<<(unsigned)std::min<int64_t>((3 * e->hgsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_hstate, 1, e->d_hgsum,
                                                                                                    3 * e->hgsum_third, nan_follow ? 1 : 0);
+    if constexpr (std::is_same<Tin, double>::value) {
+        if (!nan_follow && compact && (mode == (int)kCpp || mode == (int)kZeroCross)) {       // the short pair (itd_detect_fast.hpp)
+            unsigned long long *fw = reinterpret_cast<unsigned long long *>(e->d_lists);
+            if (mode == (int)kCpp) k_detect_fast<(int)kCpp><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, e->d_hcounts, fw, e->d_hgsum, e->d_hstate);
+            else k_detect_fast<(int)kZeroCross><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, e->d_hcounts, fw, e->d_hgsum, e->d_hstate);
+            k_compact_fast<<<grid_t, blk, 0, st>>>(fw, e->d_hcounts, e->d_hgsum, n_tiles, n, e->d_kidx, e->max_n + 2, e->d_total, e->d_hstate,
+                                                   tail_value, e->d_hcounts + e->max_tiles, 1);
+            HIP_TRY(e, hipGetLastError());
+            return ITD_OK;
+        }
+    }
     if (nan_follow)
         k_nan_level0<Tin, T><<<grid_t, blk, 0, st>>>(x, n, n, n_tiles, nan_xm, n, e->d_hcounts, e->d_hrecs, e->d_hgsum, e->d_hstate,
                                                      mode, compact ? e->d_lists : nullptr);
@@ -1568,6 +1581,17 @@ int detect_enqueue(itd_engine *e, const double *x, int64_t x_stride, int64_t n, 
     const dim3 grid_t(w.n_tiles, batch), blk(kWave);
     const int64_t ge = (int64_t)batch * w.n_groups * kGsumPitch;
     k_init_state<<<(unsigned)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048), 256, 0, st>>>(w.state, batch, w.gsum, ge);
+    if (want_lists && (mode == (int)kCpp || mode == (int)kZeroCross)) {
+        // the two predicates without NaN rules and without an extraction behind them: the short pair (itd_detect_fast.hpp); the
+        // tiles' flag words live where the general pair keeps its per-tile position lists
+        unsigned long long *fw = reinterpret_cast<unsigned long long *>(w.lists);
+        if (mode == (int)kCpp) k_detect_fast<(int)kCpp><<<grid_t, blk, 0, st>>>(x, x_stride, n, w.n_tiles, w.counts, fw, w.gsum, w.state);
+        else k_detect_fast<(int)kZeroCross><<<grid_t, blk, 0, st>>>(x, x_stride, n, w.n_tiles, w.counts, fw, w.gsum, w.state);
+        k_compact_fast<<<grid_t, blk, 0, st>>>(fw, w.counts, w.gsum, w.n_tiles, n, kidx_out ? kidx_out : w.kidx,
+                                               kidx_out ? kidx_out_stride : w.kidx_stride, w.totals, w.state, tail_value, w.tbase, kidx_out ? 0 : 1);
+        HIP_TRY(e, hipGetLastError());
+        return ITD_OK;
+    }
     k_detect<double, T><<<grid_t, blk, 0, st>>>(x, x_stride, n, w.n_tiles, mode, want_lists ? w.lists : nullptr, w.counts, w.recs, w.gsum, w.state);
     if (want_lists)
         k_compact<T><<<grid_t, blk, 0, st>>>(w.lists, w.counts, w.gsum, w.n_tiles, n, kidx_out ? kidx_out : w.kidx,
