@@ -17,10 +17,14 @@ fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child) and rel
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE already in the environment) the
 process IS one rank.
 
-Printed JSON (one line, rank 0): the driver contract + "roofline" (dominant kernel k_extract<double>, levels >= 1: 24
-algorithmic B/sample, timed with the launches' own hipEvents on the launch stream inside the timed region) + the per-kernel
-fractions + "cpu_baseline" (the C oracle = single-thread port of the reference algorithm, timed on this box's host at N = 1)
-and the other CPU legs SURVEY 8d lists (all host cores over independent signals, numpy restatement, numba restatement).
+Printed JSON (one line, rank 0): the driver contract + "roofline" — the dominant kernel: with the sparse levels fused (the
+default for this workload) k_kf_apply, the one pass over the samples for levels 3 .. 8 (8 B read + 6 x 8 B written per sample);
+with --no-fuse k_extract<double> (24 B per sample and level) — timed with the launch's own hipEvents on the launch stream
+inside the timed region, + the per-kernel fractions + "cpu_baseline" (the C oracle = single-thread port of the reference
+algorithm, timed on this box's host at N = 1) and the other CPU legs SURVEY 8d lists (all host cores over independent signals,
+numpy restatement, numba restatement).  A step whose fused levels refuse is repeated level by level when
+its summary is read: the headline checks for that behind its timed region and times again level by level if it happened; the
+batch legs and the N > 1 path read the summary inside every step.
 The headline has an untimed warm-up of its own (--warm-ms of its own steps, then the W warm-up steps), so it does not depend on any
 other leg.  At N = 1 the line also carries, all timed AFTER the headline and skipped by --no-extra: "config3_batch" (BASELINE
 configs[2], 1024 x 2^20 signals), "short_signal_batches" (4096 x 4096 and 60 000 x 256 samples through the resident form and level by
