@@ -295,3 +295,16 @@ def test_fused_batch_with_odd_members(P, torch, oracle):
             assert_bits_equal(rows[b, :nr].cpu().numpy(), ref["rows"], "nan %s signal %d rows" % (with_nan, b))
             assert_bits_equal(bs[b, :nb].cpu().numpy(), ref["baselines"], "nan %s signal %d baselines" % (with_nan, b))
     eng.close()
+
+
+def test_host_api_through_the_fused_levels(P, oracle, monkeypatch):
+    """numpy in, numpy out (ITD().itd, get_baselines) with the fused levels taking every signal of >= 65536 samples: the rows are
+    copied to the host only after the summary has drawn the verdict — a refused result (chirp) is repeated level by level first."""
+    monkeypatch.setenv("PYITD_FUSE_MIN", "65536")
+    d = P.ITD()
+    for name, x, m in (("sines", sines_noise(1 << 18, seed=31), 7), ("chirp (refused)", chirp(1 << 17), 5),
+                       ("sines again", sines_noise((1 << 17) + 5, seed=32, dtype=np.float64), 9)):
+        ref = oracle.itd(x, m)
+        assert_bits_equal(d.itd(x, m), ref["rows"], name + ": ITD().itd")
+        assert d.stop_reason == ref["stop"]
+        assert_bits_equal(d.get_baselines(), ref["baselines"], name + ": get_baselines")
