@@ -48,6 +48,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achie
 LEVELS = 8                  # BASELINE configs[1]
 MAX_ITERATION = LEVELS - 1  # -> LEVELS rotations + residual = 9 rows
 LOG2N = 24
+TIMING_STRIDE = int(os.environ.get("BENCH_TIMING_STRIDE", "4"))   # every n-th timed step carries hipEvents on its launches
 SINES = ((1, 110, 0.1), (0.5, 440, 1.3), (0.25, 1760, 2.1), (0.125, 7040, 0.7))
 
 
@@ -279,7 +280,7 @@ def run_rank(args):
     # on every 4th step of the timed region the launches carry their own hipEvent pair (hipExtLaunchKernel: the dispatch's
     # begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
     if not sharded:
-        eng.set_timing(args.steps, stride=4)
+        eng.set_timing(args.steps, stride=TIMING_STRIDE)
     def timed_region():
         barrier()
         sync()
@@ -308,7 +309,7 @@ def run_rank(args):
             from pyitd_amd.engine import FUSE_OFF
             eng.set_fuse_mode(FUSE_OFF)
             if not sharded:
-                eng.set_timing(args.steps, stride=4)
+                eng.set_timing(args.steps, stride=TIMING_STRIDE)
             elapsed_local = timed_region()
     elapsed = elapsed_local
     per_rank_ms = [elapsed_local / args.steps * 1e3]

@@ -160,6 +160,8 @@ struct itd_engine {
     bool timing = false;
     std::vector<hipEvent_t> ev;   // event pairs: [2k] start, [2k+1] stop
     std::vector<int> ev_tag;      // what pair k brackets (ITD_TIME_*)
+    std::vector<int> ev_from, ev_to;   // the pair's two events (normally 2k, 2k+1; a span borrows the events of the launches at its ends)
+    int span_first = -1, span_last = -1;   // of the decomposition being enqueued: its first / last instrumented launch
     int n_timed = 0;              // pairs recorded since timing was (re)enabled
     bool timing_overflow = false;
     int timing_stride = 1;        // instrument every stride-th decomposition only (event records cost ~5 us each)
@@ -191,15 +193,6 @@ struct DevGuard {
 inline int64_t tiles_of(int64_t n) { return (n + T - 1) / T; }
 
 // hipEvent pairs on the launch stream around selected launches (bench instrumentation, off by default)
-int time_begin(itd_engine *e, int tag, hipStream_t st)
-{
-    if (!e->timing || !e->timing_now) return -1;
-    if (2 * (size_t)e->n_timed + 1 >= e->ev.size()) { e->timing_overflow = true; return -1; }
-    const int k = e->n_timed++;
-    e->ev_tag[(size_t)k] = tag;
-    (void)hipEventRecord(e->ev[2 * (size_t)k], st);
-    return k;
-}
 // a pair of events for a launch that records them itself (hipExtLaunchKernel)
 int time_slot(itd_engine *e, int tag)
 {
@@ -207,11 +200,12 @@ int time_slot(itd_engine *e, int tag)
     if (2 * (size_t)e->n_timed + 1 >= e->ev.size()) { e->timing_overflow = true; return -1; }
     const int k = e->n_timed++;
     e->ev_tag[(size_t)k] = tag;
+    e->ev_from[(size_t)k] = 2 * k; e->ev_to[(size_t)k] = 2 * k + 1;
+    if (tag != ITD_TIME_DECOMPOSE && tag != ITD_TIME_KF_KNOTS) {      // a launch of its own: the ends of the decomposition's span
+        if (e->span_first < 0) e->span_first = k;
+        e->span_last = k;
+    }
     return k;
-}
-void time_end(itd_engine *e, int k, hipStream_t st)
-{
-    if (k >= 0) (void)hipEventRecord(e->ev[2 * (size_t)k + 1], st);
 }
 
 // signals per launch sequence of a batched decomposition.  All levels of a chunk run before the next chunk starts, so
@@ -299,7 +293,11 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // instrument every timing_stride-th decomposition only: a launch that carries events needs a completion signal of its own
     // (~2 us per launch, measured), the whole-decomposition span two marker records (~5 us each)
     e->timing_now = e->timing && (e->timing_seq++ % e->timing_stride == 0);
-    const int span_pair = time_begin(e, ITD_TIME_DECOMPOSE, st);
+    // the whole-decomposition span: from the first instrumented launch's begin to the last one's end — their dispatches' own
+    // timestamps, no marker packets in the stream (two markers cost ~10 us of the instrumented step; k_finalize, not instrumented,
+    // lies outside the span of a level-by-level call)
+    const int span_pair = time_slot(e, ITD_TIME_DECOMPOSE);
+    e->span_first = e->span_last = -1;
     // the set of states / group sums this call works on: the one the previous call did not use (the NaN-input repeat: the same
     // again, its states carry the in_nan flags), initialised by that call's k_finalize unless the bookkeeping says otherwise
     const int set = nan_input ? e->cur_set : (e->cur_set ^ 1);
@@ -524,7 +522,10 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         e->dirty_sig[set ^ 1] = 0;
         e->dirty_gs[set ^ 1] = 0;
     }
-    time_end(e, span_pair, st);
+    if (span_pair >= 0) {
+        if (e->span_first >= 0) { e->ev_from[(size_t)span_pair] = 2 * e->span_first; e->ev_to[(size_t)span_pair] = 2 * e->span_last + 1; }
+        else e->ev_tag[(size_t)span_pair] = -1;           // nothing instrumented in this call
+    }
     HIP_TRY(e, hipGetLastError());
     e->ran = true;
     e->last_batch = batch;
@@ -2098,6 +2099,8 @@ int itd_set_kernel_timing(itd_engine *e, int max_decompositions)
         e->ev.push_back(ev);
     }
     e->ev_tag.resize(e->ev.size() / 2, 0);
+    e->ev_from.resize(e->ev.size() / 2, 0);
+    e->ev_to.resize(e->ev.size() / 2, 0);
     return ITD_OK;
 }
 
@@ -2119,7 +2122,7 @@ int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_
     for (int k = 0; k < e->n_timed; ++k) {
         if (e->ev_tag[(size_t)k] != which) continue;
         float ms = 0.f;
-        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev[2 * (size_t)k], e->ev[2 * (size_t)k + 1]));
+        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev[(size_t)e->ev_from[(size_t)k]], e->ev[(size_t)e->ev_to[(size_t)k]]));
         tot += ms;
         ++cnt;
     }

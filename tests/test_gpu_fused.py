@@ -181,7 +181,9 @@ def test_a_few_refusing_signals_of_a_batch_are_rerun_on_their_own(P, torch, orac
     n, M = 1 << 20, 7
     ids = list(range(40, 56))
     xs = np.stack([sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0) for b in ids])
+    from pyitd_amd.engine import FUSE_AUTO
     eng = P.Engine(n, len(ids), 0)
+    eng.set_fuse_mode(FUSE_AUTO)          # (whatever PYITD_FUSE_MODE says: this test is about the automatic mode's repairs)
     x = torch.from_numpy(xs).cuda()
     rows = torch.full((len(ids), M + 2, n), float("nan"), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
