@@ -435,9 +435,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 const size_t nlev = (size_t)(M + 3 - L0);
                 kf_gpre = e->kf.gpre + (size_t)b0 * n_groups;
                 kf_sig = reinterpret_cast<int32_t *>(e->kf.sig + b0);
-                kf_tf_words = nlev * n_tiles * 8;
-                kf_tf_skip = (size_t)n_tiles * 8;          // (the hand-over writes the first fused level's words in full)
-                kf_tf = e->kf.tflags + (size_t)b0 * kf_tf_words;
+                (void)nlev;          // (the flag words of the fused levels are written / cleared by the hand-over, tile by tile)
             }
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
@@ -469,10 +467,10 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 KfWs a_w = w; const Tin *a_x = xc; int64_t a_xs = x_stride, a_ls = xl_stride, a_n = n; const double *a_xl = xl;
                 const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); const SigState *a_st = state;
                 void *args[] = {&a_w, &a_x, &a_xs, &a_xl, &a_ls, &a_n, &a_c, &a_r, &a_st};
-                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_gather<Tin, T>), dim3(n_tiles, nb), dim3(kWave), args, 0, kst,
+                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_gather<Tin, T>), dim3((n_tiles + 1) / 2, nb), dim3(kWave), args, 0, kst,
                                               e->ev[2 * (size_t)p_kn], nullptr, 0));
             } else {
-                k_kf_gather<Tin, T><<<dim3(n_tiles, nb), kWave, 0, kst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
+                k_kf_gather<Tin, T><<<dim3((n_tiles + 1) / 2, nb), kWave, 0, kst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
             }
             for (int lev = L0; lev <= M + 1; ++lev) {
                 // the lists shrink ~3x per level; any grid is correct (the blocks take the chunks in turn)

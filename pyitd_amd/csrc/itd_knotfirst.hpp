@@ -97,48 +97,60 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
                                                      int64_t xl_stride, int64_t n, const int32_t *__restrict__ counts,
                                                      const TileRec *__restrict__ recs, const SigState *__restrict__ state)
 {
+    // grid = (ceil(tiles / 2), batch): a wavefront takes TWO consecutive tiles, 32 lanes each (sparse levels hold a handful of knots
+    // per tile: with a wavefront per tile the launch was four rounds of two dependent round trips; a lane takes knot hl, hl + 32, ...)
     constexpr int G2 = TW / 128;
-    const int sig = blockIdx.y, t = blockIdx.x, lane = lane_id();
+    const int sig = blockIdx.y, lane = lane_id(), half = lane >> 5, hl = lane & 31;
+    const int n_tiles = ws.n_tiles, n_groups = groups_of(n_tiles);
+    const int t0 = 2 * blockIdx.x, t = t0 + half;
+    const bool have = t < n_tiles;
     const SigState *st = state + sig;
     KfSig *ks = ws.sig + sig;
-    // everything the tile needs is requested before the first use (one round trip in front of the knots' values)
-    const int n_tiles = ws.n_tiles, n_groups = groups_of(n_tiles);
+    // everything the tiles need is requested before the first use (one round trip in front of the knots' values)
     const int32_t *cnts = counts + (size_t)sig * n_tiles;
-    const int g = t / kTilesPerGroup;
-    int acc = (lane < t - g * kTilesPerGroup) ? cnts[g * kTilesPerGroup + lane] : 0;
-    const int c = cnts[t], gp = ws.gpre[(size_t)sig * n_groups + g];
-    const unsigned long long *rf = recs[(size_t)sig * n_tiles + t].flags;
+    const int g = t0 / kTilesPerGroup;                                   // (t0 is even: both tiles lie in the same 64-tile group)
+    int acc = (lane < t0 - g * kTilesPerGroup) ? cnts[g * kTilesPerGroup + lane] : 0;
+    const int c = have ? cnts[t] : 0, gp = ws.gpre[(size_t)sig * n_groups + g];
+    const unsigned long long *rf = recs[(size_t)sig * n_tiles + (have ? t : t0)].flags;
     unsigned long long w[2 * G2];
 #pragma unroll
     for (int q = 0; q < 2 * G2; ++q) w[q] = rf[q];
-    const int tie_here = ws.tie[(size_t)sig * n_tiles + t];
+    const int tie_here = have ? ws.tie[(size_t)sig * n_tiles + t] : 0;
     const bool active = !st->fin_stopped && st->nan_mask == 0 && !st->in_nan && !st->l0_fail;
-    if (t == 0 && lane == 0) {
+    if (t0 == 0 && lane == 0) {
         ks->active = active ? 1 : 0;
         ks->lend = -1;
         if (!active && !st->fin_stopped) ks->fail = kKfFailNonFinite;     // NaN rules / an unfinished level 0: not this path's
     }
     if (!active) return;
-    if (t == 0 && lane < 4) ks->ends[ws.L0 & 1][lane] = st->ends[ws.L0 & 1][lane];
+    if (t0 == 0 && lane < 4) ks->ends[ws.L0 & 1][lane] = st->ends[ws.L0 & 1][lane];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    const int base = acc + gp;
-    if (c == 0) {                                                    // an empty tile's record holds no flag words
+    const int c_first = __shfl(c, 0);                                    // tile t0's count
+    const int base = acc + gp + (half ? c_first : 0);
+    if (c == 0) {                                                        // an empty tile's record holds no flag words
 #pragma unroll
         for (int q = 0; q < 2 * G2; ++q) w[q] = 0ull;
     }
     int32_t *first = ws.first + ((size_t)sig * ws.nlev) * (n_tiles + 1);
-    unsigned long long *tf = ws.tflags + (((size_t)sig * ws.nlev) * n_tiles + t) * 8;
-    if (lane == 0) {
-        first[t] = base;
+    if (have) {
+        // the first fused level's flag words as the records hold them; the words of the levels behind it cleared (the steps set them
+        // with atomic ORs; the sample pass reads them)
+        if (hl == 0) first[t] = base;
+        if (hl < 2 * G2) {
+            unsigned long long mine = 0ull;
 #pragma unroll
-        for (int q = 0; q < 2 * G2; ++q) tf[q] = w[q];
-    }
-    if (t == n_tiles - 1 && lane == 0) {
-        first[n_tiles] = base + c;
-        ks->mlev[ws.L0] = base + c;
-        ks->toff[ws.L0] = 0;
-        if (base + c + kKfSticky + 4 > ws.cap) atomicOr(&ks->fail, kKfFailCapacity);
+            for (int q = 0; q < 2 * G2; ++q) if (hl == q) mine = w[q];
+            unsigned long long *tf = ws.tflags + ((size_t)sig * ws.nlev) * n_tiles * 8 + (size_t)t * 8;
+            tf[hl] = mine;
+            for (int li = 1; li < ws.nlev; ++li) tf[(size_t)li * n_tiles * 8 + hl] = 0ull;
+        }
+        if (t == n_tiles - 1 && hl == 0) {
+            first[n_tiles] = base + c;
+            ks->mlev[ws.L0] = base + c;
+            ks->toff[ws.L0] = 0;
+            if (base + c + kKfSticky + 4 > ws.cap) atomicOr(&ks->fail, kKfFailCapacity);
+        }
     }
     const int64_t s = (int64_t)t * TW;
     const double *xs = xl + (int64_t)sig * xl_stride;
@@ -151,35 +163,32 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
         cum[0] = 0;
 #pragma unroll
         for (int gg = 0; gg < G2; ++gg) cum[gg + 1] = cum[gg] + __popcll(w[2 * gg]) + __popcll(w[2 * gg + 1]);
-        for (int j0 = 0; j0 < c; j0 += kWave) {
-            const int j = j0 + lane;
-            if (j < c) {
-                int gg = 0;
-                unsigned long long E = w[0], O = w[1];
+        for (int j = hl; j < c; j += 32) {
+            int gg = 0;
+            unsigned long long E = w[0], O = w[1];
 #pragma unroll
-                for (int q = 1; q < G2; ++q) if (j >= cum[q]) { gg = q; E = w[2 * q]; O = w[2 * q + 1]; }
-                int jr = j;
+            for (int q = 1; q < G2; ++q) if (j >= cum[q]) { gg = q; E = w[2 * q]; O = w[2 * q + 1]; }
+            int jr = j;
 #pragma unroll
-                for (int q = 1; q < G2; ++q) if (gg == q) jr = j - cum[q];
-                // smallest l with (knots of the group at pairs 0 .. l) > jr
-                int lo = 0, hi = 63;
+            for (int q = 1; q < G2; ++q) if (gg == q) jr = j - cum[q];
+            // smallest l with (knots of the group at pairs 0 .. l) > jr
+            int lo = 0, hi = 63;
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int mid = (lo + hi) >> 1;
-                    const unsigned long long mk = mid >= 63 ? ~0ull : ((1ull << (mid + 1)) - 1ull);
-                    const int f = __popcll(E & mk) + __popcll(O & mk);
-                    if (f > jr) hi = mid; else lo = mid + 1;
-                }
-                const int l = lo;
-                const unsigned long long mb = (1ull << l) - 1ull;
-                const int before = __popcll(E & mb) + __popcll(O & mb);
-                const int odd = (((E >> l) & 1ull) && jr == before) ? 0 : 1;
-                const int64_t pos = s + 128 * gg + 2 * l + odd;
-                const size_t k = (size_t)base + 1 + j;
-                const double a = xs[pos - 1], bb = xs[pos], cc = xs[pos + 1];
-                P[k] = (int32_t)pos;
-                Tr[3 * k] = a; Tr[3 * k + 1] = bb; Tr[3 * k + 2] = cc;
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const unsigned long long mk = mid >= 63 ? ~0ull : ((1ull << (mid + 1)) - 1ull);
+                const int f = __popcll(E & mk) + __popcll(O & mk);
+                if (f > jr) hi = mid; else lo = mid + 1;
             }
+            const int l = lo;
+            const unsigned long long mb = (1ull << l) - 1ull;
+            const int before = __popcll(E & mb) + __popcll(O & mb);
+            const int odd = (((E >> l) & 1ull) && jr == before) ? 0 : 1;
+            const int64_t pos = s + 128 * gg + 2 * l + odd;
+            const size_t k = (size_t)base + 1 + j;
+            const double a = xs[pos - 1], bb = xs[pos], cc = xs[pos + 1];
+            P[k] = (int32_t)pos;
+            Tr[3 * k] = a; Tr[3 * k + 1] = bb; Tr[3 * k + 2] = cc;
         }
     }
     // sticky candidates: sample n-2, and both samples of every exact tie of the caller's signal (rare: the tile was flagged)
@@ -189,12 +198,15 @@ __global__ __launch_bounds__(kWave) void k_kf_gather(KfWs ws, const Tin *__restr
         if (idx < kKfSticky) ks->spos[idx] = (int32_t)p;
         else atomicOr(&ks->fail, kKfFailTies);
     };
-    if (lane == 0 && s <= n - 2 && n - 2 < s + TW) append(n - 2);
-    if (tie_here) {
-        if (lane == 0) ws.tie[(size_t)sig * n_tiles + t] = 0;        // the flags clean themselves: the fused level-0 launch only ever sets them
+    if (have && hl == 0 && s <= n - 2 && n - 2 < s + TW) append(n - 2);
+    for (int h = 0; h < 2; ++h) {
+        if (!__shfl(tie_here, 32 * h)) continue;                         // (wave-uniform)
+        const int tt = t0 + h;
+        if (lane == 0) ws.tie[(size_t)sig * n_tiles + tt] = 0;           // the flags clean themselves: the fused level-0 launch only ever sets them
         const Tin *x = x0 + (int64_t)sig * x0_stride;
+        const int64_t st_ = (int64_t)tt * TW;
         for (int i = lane; i < TW; i += kWave) {
-            const int64_t p = s + i;
+            const int64_t p = st_ + i;
             if (p >= 1 && p <= n - 1 && x[p] == x[p - 1]) { append(p - 1); append(p); }
         }
     }
