@@ -118,6 +118,7 @@ struct itd_engine {
     void *d_kf = nullptr; size_t kf_bytes = 0;
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
+    bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
     int32_t fuse_group = 4;                          // chunks of a batch that share one knot side of the fused levels
     int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
@@ -282,7 +283,13 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     if (kf && capturing && !e->d_kf) kf = false;
     if (kf) {
         const int rc = ensure_kf_ws(e);
-        if (rc) return rc;
+        if (rc == ITD_ERR_NOMEM && e->fuse_mode != ITD_FUSE_ONLY) {
+            // no room for the fused levels' workspace (136 B x max_n / 8 + 136 B per tile and level, per signal): this engine stays
+            // level by level — the result is the same
+            (void)hipGetLastError();
+            e->fuse_no_memory = true;
+            kf = false;
+        } else if (rc) return rc;
     }
     const int n_tiles = (int)tiles_of(n);
     const int n_groups = groups_of(n_tiles);
@@ -636,7 +643,7 @@ bool want_kf(itd_engine *e, int64_t n, int32_t batch, int32_t M, bool fuse0)
 {
     if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || e->fuse_level < 2 || e->fuse_level > M) return false;
     if (e->fuse_mode == ITD_FUSE_ONLY) return true;
-    if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO) return false;
+    if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO || e->fuse_no_memory) return false;
     if ((int64_t)std::min<int32_t>(chunk_of(e, n, batch), batch) * n < e->fuse_min_samples) return false;
     if (e->fuse_off_left > 0) { --e->fuse_off_left; return false; }
     return true;
