@@ -266,20 +266,27 @@ def run_rank(args):
     # 150 ms) — an idle GPU needs tens of milliseconds of sustained work to reach the clocks it then holds, and the 11 ms of
     # a 20-step timed region are too short to get there (rounds 1-2 relied on the informational batch leg running first: 0.582
     # vs 0.557 ms per step with --no-extra).  Then the driver's W warm-up steps.
+    # Everything that takes host time with the GPU idle happens BEFORE the last warm-up steps (creating the instrumentation's events:
+    # ~1000 hipEventCreate calls on the first use; reading the summary), so that the timed region follows them directly: a 20-step
+    # region is 9 ms, and a GPU left idle for a millisecond or two in front of it ran its first steps below its sustained clocks
+    # (measured: 0.470-0.484 ms per step at 20 steps against 0.458-0.461 at 200 with the idle gap).
+    if not sharded and not stub:
+        eng.set_timing(args.steps, stride=TIMING_STRIDE)      # (allocates the events; re-armed below)
+        eng.set_timing(0)
     sync()
     t_w = time.perf_counter()
     while not stub and (time.perf_counter() - t_w) * 1e3 < args.warm_ms:
         for _ in range(8):
             step()
         sync()
-    for _ in range(args.warmup):
-        step()
+    step()
     sync()
     summ = sb.local_summary()
-
     # on every 4th step of the timed region the launches carry their own hipEvent pair (hipExtLaunchKernel: the dispatch's
     # begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
-    if not sharded:
+    for _ in range(args.warmup):
+        step()
+    if not sharded and not stub:
         eng.set_timing(args.steps, stride=TIMING_STRIDE)
     def timed_region():
         barrier()
