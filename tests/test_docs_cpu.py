@@ -1,0 +1,56 @@
+"""The documents point at evidence: every profiles/... and tools/... path that DESIGN.md, README.md, INTEGRATION.md and
+profiles/README.md name must exist in the tree (a renamed or deleted file must not leave a dangling reference), and no file
+under profiles/ may claim more than the HBM peak."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md")]
+
+
+def _paths(text, base):
+    out = set()
+    for m in re.finditer(r"`((?:profiles|tools|tests|oracle|include|pyitd_amd)/[A-Za-z0-9_./\-]+)`", text):
+        out.add(m.group(1))
+    # profiles/README.md and tools/README.md name their own files without the directory
+    ext = {"profiles": "txt|csv|json|log", "tools": "py|sh|hip|c"}.get(base)
+    if ext:
+        for m in re.finditer(r"`((?:r0[0-9]/)?[A-Za-z0-9_\-]+\.(?:%s))`" % ext, text):
+            name = m.group(1)
+            out.add(name if name in ("bench.py",) else os.path.join(base, name))     # (the root's bench.py is named everywhere)
+    return out
+
+
+# named on purpose although absent from the tree: the reference build that cannot exist, binaries built on the GPU box
+ABSENT_ON_PURPOSE = {"oracle/_ref", "tools/membench", "tools/membench2", "tools/membench3", "tools/dispatch_bench", "tools/c_timing"}
+
+
+def test_every_named_evidence_file_exists():
+    missing = []
+    for doc in DOCS:
+        text = open(os.path.join(ROOT, doc)).read()
+        base = os.path.dirname(doc)
+        for p in sorted(_paths(text, base)):
+            if "*" in p or p.endswith("/") or "..." in p or p in ABSENT_ON_PURPOSE:
+                continue
+            full = os.path.join(ROOT, p)
+            if not os.path.exists(full):
+                # profiles/README.md keeps rows for older rounds' raw session files by prefix (r02/session1_*): checked by pattern above
+                missing.append("%s: %s" % (doc, p))
+    assert not missing, "dangling references:\n" + "\n".join(missing)
+
+
+def test_no_profile_claims_more_than_the_peak():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "profiles")):
+        for f in files:
+            if not f.endswith((".txt", ".json")):
+                continue
+            text = open(os.path.join(dirpath, f), errors="replace").read()
+            for m in re.finditer(r"= (\d+\.\d+) of peak", text):
+                if float(m.group(1)) > 1.0:
+                    bad.append("%s: %s" % (f, m.group(0)))
+            for m in re.finditer(r'"frac[a-z_]*": (\d+\.\d+)', text):
+                if float(m.group(1)) > 1.0:
+                    bad.append("%s: %s" % (f, m.group(0)))
+    assert not bad, "\n".join(bad[:20])
