@@ -70,6 +70,11 @@ __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict
 }
 }  // namespace
 
+#ifdef ITD_DEBUG_GAP
+// experiment build only: an idle gap of ITD_DEBUG_GAP microseconds in front of the sample pass (does the memory system use it?)
+namespace { __global__ void k_debug_gap(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); } }
+#endif
+
 struct itd_engine {
     int device = 0;
     int64_t max_n = 0;
@@ -119,6 +124,7 @@ struct itd_engine {
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
     bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
+    int64_t kf_resident_wgs = 0;                     // knot-side workgroups the device holds at once (occupancy query at creation of the workspace)
     int32_t fuse_group = 4;                          // chunks of a batch that share one knot side of the fused levels
     int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
@@ -223,24 +229,29 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
     return (int)std::min<int64_t>(std::min<int64_t>(c, kMaxGridY), batch);   // a chunk's signals are the launches' grid.y
 }
 
-// The workspace of the fused sparse levels (itd_knotfirst.hpp), allocated at the first call that takes that path.  Per signal:
-// two candidate lists of `cap` entries (position + three values), the next level's triples, survival flags / prefixes, the
-// tables' pool (32 B per knot and level), and per level and tile the knots' flag words and first-index.  cap = max_n / 8: a list
-// holds the knots of level L0 >= 1 (typically 0.12 / 0.04 / 0.012 n at levels 1 / 2 / 3); a longer one fails over to the
-// level-by-level engine (kKfFailCapacity).
+// The workspace of the fused sparse levels (itd_knotfirst.hpp), allocated at the first call that takes that path.  Per signal and
+// knot-side workgroup (kKcTiles tiles): a slab of table entries (32 B per knot and level: kKcSlab of them) and one 256-byte
+// boundary record per level; per level and tile the knots' flag words and the tile's first table index; per tile a tie flag.
 constexpr int kKfLevels = ITD_MAX_ITERATION + 3;
-int ensure_kf_ws(itd_engine *e)
+// tiles per knot-side workgroup: its LDS holds kKcCap candidates — the first fused level's knots of its tiles (typically 0.04 /
+// 0.012 n at levels 2 / 3: 20 / 6 per tile) plus the sticky ones
+inline int kf_tiles_per_wg(int first_fused_level) { return first_fused_level >= 3 ? kKcTiles : kKcTiles / 4; }
+int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
 {
-    if (e->d_kf) return ITD_OK;
+    const size_t wgs = (size_t)(e->max_tiles + tpw - 1) / tpw;
+    if (e->d_kf && (size_t)e->kf.wgs_max >= wgs) return ITD_OK;
+    if (!may_allocate) return ITD_ERR_NOMEM;
+    if (e->d_kf) {                        // the first fused level was lowered: more, smaller workgroups per signal
+        if (hipDeviceSynchronize() != hipSuccess || hipFree(e->d_kf) != hipSuccess) return ITD_ERR_HIP;
+        e->d_kf = nullptr;
+        e->ws_bytes -= (int64_t)e->kf_bytes;
+    }
     const size_t B = (size_t)e->max_batch;
-    const size_t cap = (size_t)std::max<int64_t>(2048, e->max_n / 8 + 256), pool_cap = 2 * cap + 64;
-    const size_t nchunk = (cap + kKfChunk - 1) / kKfChunk;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_sig = al(B * sizeof(KfSig)), b_P = al(B * 2 * cap * 4), b_T = al(B * 2 * cap * 24), b_nT = al(B * cap * 24);
-    const size_t b_fl = al(B * cap * 4), b_cnt = al(B * nchunk * 4), b_pool = al(B * pool_cap * sizeof(KfEntry));
-    const size_t b_first = al(B * kKfLevels * ((size_t)e->max_tiles + 1) * 4), b_tf = al(B * kKfLevels * (size_t)e->max_tiles * 64);
-    const size_t b_tie = al(B * (size_t)e->max_tiles * 4), b_gpre = al(B * (size_t)groups_of((int)e->max_tiles) * 4);
-    const size_t total = b_sig + b_P + b_T + b_nT + 2 * b_fl + b_cnt + b_pool + b_first + b_tf + b_tie + b_gpre;
+    const size_t b_sig = al(B * sizeof(KfSig)), b_pool = al(B * wgs * kKcSlab * sizeof(KfEntry));
+    const size_t b_first = al(B * kKfLevels * (size_t)e->max_tiles * 4), b_tf = al(B * kKfLevels * (size_t)e->max_tiles * 64);
+    const size_t b_tie = al(B * (size_t)e->max_tiles * 4), b_rec = al(B * kKfLevels * wgs * kKcRecGran * 8);
+    const size_t total = b_sig + b_pool + b_first + b_tf + b_tie + b_rec;
     const hipError_t rc = hipMalloc(&e->d_kf, total);
     if (rc != hipSuccess) { e->d_kf = nullptr; fail_hip(e, rc, "hipMalloc(fused levels' workspace)"); return rc == hipErrorOutOfMemory ? ITD_ERR_NOMEM : ITD_ERR_HIP; }
     e->kf_bytes = total;
@@ -248,19 +259,25 @@ int ensure_kf_ws(itd_engine *e)
     char *p = (char *)e->d_kf;
     KfWs &w = e->kf;
     w.sig = (KfSig *)p; p += b_sig;
-    w.candP = (int32_t *)p; p += b_P;
-    w.candT = (double *)p; p += b_T;
-    w.newT = (double *)p; p += b_nT;
-    w.flag = (int32_t *)p; p += b_fl;
-    w.pref = (int32_t *)p; p += b_fl;
-    w.cnt = (int32_t *)p; p += b_cnt;
     w.pool = (KfEntry *)p; p += b_pool;
     w.first = (int32_t *)p; p += b_first;
     w.tflags = (unsigned long long *)p; p += b_tf;
     w.tie = (int32_t *)p; p += b_tie;
-    w.gpre = (int32_t *)p;
-    if (hipMemset(w.tie, 0, b_tie) != hipSuccess) return ITD_ERR_HIP;     // the tie flags clean themselves from here on
-    w.cap = (int32_t)cap; w.pool_cap = (int32_t)pool_cap; w.nchunk = (int32_t)nchunk;
+    w.rec = (unsigned long long *)p;
+    // the tie flags clean themselves from here on; the signals' generation counters start at 0 and no record carries a tag yet
+    if (hipMemset(w.sig, 0, b_sig) != hipSuccess || hipMemset(w.tie, 0, b_tie) != hipSuccess || hipMemset(w.rec, 0, b_rec) != hipSuccess) return ITD_ERR_HIP;
+    w.wgs_max = (int32_t)wgs; w.rec_levels = kKfLevels;
+    {   // how many knot-side workgroups are resident at once: a grid within that takes its ids from blockIdx (itd_knotfirst.hpp)
+        int per_cu = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_kf_knots<float, T>), kKcThreads, 0) != hipSuccess ||
+            hipGetDeviceProperties(&prop, e->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        else cus = prop.multiProcessorCount;
+        // (the float64 instance has the same footprint.  Should the hardware admit fewer than the API says, the surplus workgroups
+        //  start in blockIdx order as others finish — observed, not promised; a wait that can never end is given up after
+        //  ITD_KC_TIMEOUT and the call repeated level by level)
+        e->kf_resident_wgs = (int64_t)per_cu * cus;
+    }
     return ITD_OK;
 }
 
@@ -280,9 +297,10 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
-    if (kf && capturing && !e->d_kf) kf = false;
+    const int kf_tpw = kf_tiles_per_wg(L0);
+    if (kf && capturing && ensure_kf_ws(e, kf_tpw, false) != ITD_OK) kf = false;
     if (kf) {
-        const int rc = ensure_kf_ws(e);
+        const int rc = ensure_kf_ws(e, kf_tpw, true);
         if (rc == ITD_ERR_NOMEM && e->fuse_mode != ITD_FUSE_ONLY) {
             // no room for the fused levels' workspace (136 B x max_n / 8 + 136 B per tile and level, per signal): this engine stays
             // level by level — the result is the same
@@ -434,66 +452,44 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             const int fb = (int)std::min<int64_t>(std::max<int64_t>((n + 8 * kFinalizeThreads - 1) / (8 * kFinalizeThreads), 1), 1024);
             int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
             const int jf = j_last + 1;      // the level whose input is pending: max_iteration + 2, or the first fused level
-            // fused sparse levels: this launch also prepares their workspace (the signals' bookkeeping, the flag words, the group prefixes)
-            int32_t *kf_gpre = nullptr, *kf_sig = nullptr;
-            unsigned long long *kf_tf = nullptr;
-            size_t kf_tf_words = 0, kf_tf_skip = 0;
-            if (kf) {
-                const size_t nlev = (size_t)(M + 3 - L0);
-                kf_gpre = e->kf.gpre + (size_t)b0 * n_groups;
-                kf_sig = reinterpret_cast<int32_t *>(e->kf.sig + b0);
-                (void)nlev;          // (the flag words of the fused levels are written / cleared by the hand-over, tile by tile)
-            }
+            // fused sparse levels: this launch also clears their per-signal bookkeeping and bumps the signals' record generation
+            int32_t *kf_sig = kf ? reinterpret_cast<int32_t *>(e->kf.sig + b0) : nullptr;
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
                                                                        gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
-                                                                       kf_gpre, kf_sig, (int)(sizeof(KfSig) / 4), kf_tf, kf_tf_words, kf_tf_skip);
+                                                                       kf_sig, kKfSigZeroWords, (int)(sizeof(KfSig) / 4));
             else
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
                                                                        e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
-                                                                       kf_gpre, kf_sig, (int)(sizeof(KfSig) / 4), kf_tf, kf_tf_words, kf_tf_skip);
+                                                                       kf_sig, kKfSigZeroWords, (int)(sizeof(KfSig) / 4));
         }
         }
         if (kf && (phase & 6)) {
             // ---- levels L0 .. M + 1 fused: hand-over, the knot-side steps, ONE pass over the samples, the verdict ----
             KfWs w = e->kf;
             w.n_tiles = n_tiles; w.L0 = L0; w.nlev = M + 3 - L0;
+            w.tpw = kf_tpw; w.wgs = (n_tiles + kf_tpw - 1) / kf_tpw; w.nb = nb;
+            w.ticketed = (int64_t)w.wgs * nb > e->kf_resident_wgs ? 1 : 0;
             const size_t B0 = (size_t)b0;
-            w.sig += B0; w.candP += B0 * 2 * w.cap; w.candT += B0 * 2 * w.cap * 3; w.newT += B0 * w.cap * 3; w.flag += B0 * w.cap;
-            w.pref += B0 * w.cap; w.cnt += B0 * w.nchunk; w.pool += B0 * w.pool_cap;
-            w.first += B0 * (size_t)w.nlev * (n_tiles + 1); w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.tie += B0 * n_tiles;
+            w.sig += B0; w.pool += B0 * (size_t)w.wgs_max * kKcSlab; w.rec += B0 * (size_t)w.rec_levels * w.wgs_max * kKcRecGran;
+            w.first += B0 * (size_t)w.nlev * n_tiles; w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.tie += B0 * n_tiles;
             // (the per-signal strides of `first` / `tflags` follow this call's geometry: nlev levels x n_tiles tiles per signal)
             const double *xl = bases_c ? bases_c + (int64_t)(L0 - 1) * n : pp_c + (int64_t)((L0 - 1) % 3) * e->pp_pitch;
             const int64_t xl_stride = bases_c ? rows_stride : 3 * e->pp_pitch;
-            w.gpre += B0 * n_groups;
             const hipStream_t kst = cst;
             if (phase & 2) {
-            // (timed: the span from the hand-over's begin to the last step's end, taken from the two dispatches' own timestamps)
-            const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
-            if (p_kn >= 0) {
-                KfWs a_w = w; const Tin *a_x = xc; int64_t a_xs = x_stride, a_ls = xl_stride, a_n = n; const double *a_xl = xl;
+                // ONE launch: hand-over and every fused level (timed from its dispatch's own begin / end timestamps)
+                const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
+                KfWs a_w = w; const Tin *a_x = xc; int64_t a_xs = x_stride, a_ls = xl_stride, a_n = n; const double *a_xl = xl; int a_m = M;
                 const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); const SigState *a_st = state;
-                void *args[] = {&a_w, &a_x, &a_xs, &a_xl, &a_ls, &a_n, &a_c, &a_r, &a_st};
-                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_gather<Tin, T>), dim3((n_tiles + 1) / 2, nb), dim3(kWave), args, 0, kst,
-                                              e->ev[2 * (size_t)p_kn], nullptr, 0));
-            } else {
-                k_kf_gather<Tin, T><<<dim3((n_tiles + 1) / 2, nb), kWave, 0, kst>>>(w, xc, x_stride, xl, xl_stride, n, cnt(L0), rec(L0), state);
-            }
-            for (int lev = L0; lev <= M + 1; ++lev) {
-                // the lists shrink ~3x per level; any grid is correct (the blocks take the chunks in turn)
-                const unsigned blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(w.nchunk, (int64_t)768 >> std::min(lev - L0, 6)));
-                k_kf_step_a<T><<<dim3(blocks + 1, nb), kKfChunk, 0, kst>>>(w, lev, n, xl, xl_stride);
-                if (p_kn >= 0 && lev == M + 1) {
-                    KfWs a_w = w; int a_lev = lev, a_m = M;
-                    void *args[] = {&a_w, &a_lev, &a_m};
-                    HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_step_b), dim3(blocks + 1, nb), dim3(kKfChunk), args, 0, kst,
-                                                  nullptr, e->ev[2 * (size_t)p_kn + 1], 0));
-                } else {
-                    k_kf_step_b<<<dim3(blocks + 1, nb), kKfChunk, 0, kst>>>(w, lev, M);
-                }
-            }
+                void *args[] = {&a_w, &a_x, &a_xs, &a_xl, &a_ls, &a_n, &a_m, &a_c, &a_r, &a_st};
+                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_knots<Tin, T>), dim3((unsigned)w.wgs * (unsigned)nb), dim3(kKcThreads), args, 0, kst,
+                                              p_kn >= 0 ? e->ev[2 * (size_t)p_kn] : nullptr, p_kn >= 0 ? e->ev[2 * (size_t)p_kn + 1] : nullptr, 0));
             }
             if (phase & 4) {
+#ifdef ITD_DEBUG_GAP
+                k_debug_gap<<<1, 64, 0, cst>>>((long long)(ITD_DEBUG_GAP) * 100);
+#endif
                 const int pair = time_slot(e, ITD_TIME_KF_APPLY);
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
                 const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
@@ -1202,6 +1198,12 @@ extern "C" int itd_debug_prof_buffer(void *dev_buf)
 {
     unsigned long long *p = static_cast<unsigned long long *>(dev_buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &p, sizeof(p)) == hipSuccess ? ITD_OK : ITD_ERR_HIP;
+}
+// (tools/knots_prof.py): the knot side's workgroups' phase marks
+extern "C" int itd_debug_knots_prof_buffer(void *dev_buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(dev_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_kc_prof), &p, sizeof(p)) == hipSuccess ? ITD_OK : ITD_ERR_HIP;
 }
 #endif
 

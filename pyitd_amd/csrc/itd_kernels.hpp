@@ -1869,43 +1869,18 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restric
                                                                SigState *__restrict__ state,
                                                                SigState *__restrict__ other_state = nullptr,
                                                                int32_t *__restrict__ other_gsum = nullptr, int64_t other_third = 0,
-                                                               int32_t *__restrict__ kf_gpre = nullptr, int32_t *__restrict__ kf_sig = nullptr,
-                                                               int kf_sig_words = 0, unsigned long long *__restrict__ kf_tf = nullptr,
-                                                               size_t kf_tf_words = 0, size_t kf_tf_skip = 0)
+                                                               int32_t *__restrict__ kf_sig = nullptr, int kf_sig_words = 0,
+                                                               int kf_sig_stride = 0)
 {
     __shared__ int s_red[kFinalizeThreads / 64];
     const int sig = blockIdx.y;
-    // in front of the fused sparse levels (itd_knotfirst.hpp): the signal's bookkeeping and the flag words of the levels behind the
-    // first fused one cleared, the exclusive prefix of gsum_last's group sums (the knots in front of every 64-tile group)
+    // in front of the fused sparse levels (itd_knotfirst.hpp): the signal's bookkeeping cleared, its generation counter bumped
     if (kf_sig) {
-        using U2 = unsigned long long __attribute__((ext_vector_type(2)));
-        U2 *tf2 = reinterpret_cast<U2 *>(kf_tf + (size_t)sig * kf_tf_words + kf_tf_skip);     // (16-byte aligned: whole tiles of 64 bytes)
-        const U2 z = {0ull, 0ull};
-        const size_t cnt2 = (kf_tf_words - kf_tf_skip) / 2;
-        for (size_t i = (size_t)blockIdx.x * kFinalizeThreads + threadIdx.x; i < cnt2; i += (size_t)gridDim.x * kFinalizeThreads) tf2[i] = z;
         if (blockIdx.x == 0) {
-            __shared__ int s_part[kFinalizeThreads];
-            const int tid = threadIdx.x, n_groups = groups_of(n_tiles);
-            int32_t *kz = kf_sig + (size_t)sig * kf_sig_words;
-            for (int i = tid; i < kf_sig_words; i += kFinalizeThreads) kz[i] = 0;
-            const int32_t *gs = gsum_last + (size_t)sig * n_groups * kGsumPitch;
-            int32_t *gp = kf_gpre + (size_t)sig * n_groups;
-            int carry = 0;
-            for (int g0 = 0; g0 < n_groups; g0 += kFinalizeThreads) {
-                const int g = g0 + tid;
-                const int v = g < n_groups ? gs[(size_t)g * kGsumPitch] : 0;
-                s_part[tid] = v;
-                __syncthreads();
-                for (int d = 1; d < kFinalizeThreads; d <<= 1) {          // Hillis-Steele inclusive scan
-                    const int a = tid >= d ? s_part[tid - d] : 0;
-                    __syncthreads();
-                    s_part[tid] += a;
-                    __syncthreads();
-                }
-                if (g < n_groups) gp[g] = carry + s_part[tid] - v;
-                carry += s_part[kFinalizeThreads - 1];
-                __syncthreads();
-            }
+            // (kf_sig_words = the words to clear; the word behind them is the generation of the call's boundary records)
+            int32_t *kz = kf_sig + (size_t)sig * kf_sig_stride;
+            for (int i = threadIdx.x; i < kf_sig_words; i += kFinalizeThreads) kz[i] = 0;
+            if (threadIdx.x == 0) kz[kf_sig_words] += 1;
         }
     }
     // the other set of states / group sums (itd_engine.hip): left in its initial state for the decomposition after this one —
