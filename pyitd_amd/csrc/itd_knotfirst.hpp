@@ -44,7 +44,7 @@ constexpr int kKcThreads = 256;                  // threads of a workgroup
 constexpr int kKcTiles = 64;                     // tiles a workgroup owns at most (KfWs::tpw; one thread per 128-sample group of them)
 constexpr int kKcCap = 1024;                     // candidates a workgroup holds (more: the signal is left to the level-by-level engine)
 constexpr int kKcEnt = kKcCap / kKcThreads;      // candidates per thread
-constexpr int kKcRound = 4;                      // workgroups whose records a halo search reads in one polling round
+constexpr int kKcRound = 2;                      // workgroups whose records a halo search's first round reads (the nearest ones, whatever they hold)
 constexpr int kKcSlab = 2 * kKcCap + 128;        // table entries (all fused levels) a workgroup may write
 constexpr int kKcRecGran = 32;                   // 8-byte granules per record slot (20 in use): 256 bytes
 constexpr uint32_t kKcPoison = 0xffffffffu;      // a record of a workgroup that has given up
@@ -108,6 +108,16 @@ __device__ __forceinline__ unsigned long long kc_load(const unsigned long long *
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A workgroup barrier for LDS hand-overs only: __syncthreads() also waits for every global store and atomic the wavefront has in
+// flight (its fence covers global memory: s_waitcnt vmcnt(0)) — here that would put the write-through record stores and the table
+// stores, which no thread of the workgroup ever reads back, on every level's critical path (~1.5 us each).
+__device__ __forceinline__ void kc_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // exclusive prefix of v over the workgroup's threads (in thread order) and the total
 __device__ __forceinline__ int kc_scan(int v, int *s_red, int &total)
 {
@@ -115,9 +125,9 @@ __device__ __forceinline__ int kc_scan(int v, int *s_red, int &total)
     int inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
-    __syncthreads();                                   // (the previous scan's reads of s_red are done)
+    kc_barrier();                                   // (the previous scan's reads of s_red are done)
     if (lane == 63) s_red[wave] = inc;
-    __syncthreads();
+    kc_barrier();
     int wb = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < kKcThreads / 64; ++k) { const int s = s_red[k]; if (k < wave) wb += s; tot += s; }
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                                                          const TileRec *__restrict__ recs, const SigState *__restrict__ state)
 {
     static_assert(TW == 512 && kKcTiles * (TW / 128) == kKcThreads && kKcTiles == 64, "one thread per 128-sample group, one lane per tile");
-    // the candidates (thread t owns entries t * kKcEnt ..): position, the level's values at position - 1, position, position + 1,
+    // the candidates: position, the level's values at position - 1, position, position + 1,
     // flags, and the number of the range's knots at or before the candidate
     __shared__ double c_xl[kKcCap], c_xc[kKcCap], c_xr[kKcCap];
     __shared__ int32_t c_pos[kKcCap];
@@ -178,8 +188,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     __shared__ double k_X[kKcCap + 8], k_B[kKcCap + 8], k_S[kKcCap + 8];
     __shared__ int32_t k_pos[kKcCap + 8];
     __shared__ unsigned long long t_w[kKcTiles * 8];       // the level's knots as the tiles' flag words
-    __shared__ uint32_t s_stage[2][kKcRound][16];
-    __shared__ int s_red[8], s_i[8];
+    __shared__ uint32_t s_stage[2][4][16];
+    __shared__ int s_red[8], s_i[8], s_cnt[kKcEnt * 4];
     __shared__ unsigned long long s_tmask[2];              // tiles of the range whose own / whose next tile's tie flag is set
     __shared__ double s_ends[4];                           // the level's x[0], x[1], x[n-2], x[n-1] (as far as this workgroup needs them)
     constexpr int NT = kKcThreads, ENT = kKcEnt;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     int id = blockIdx.x;
     if (ws.ticketed) {
         if (tid == 0) s_i[0] = atomicAdd(&ws.sig[0].ticket, 1);
-        __syncthreads();
+        kc_barrier();
         id = s_i[0];
     }
     KC_MARK(1);
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
         if (lane == 0) { s_tmask[0] = mo; s_tmask[1] = mo | mn_; }
     }
     if (w == 0 && tid == 0) ks->active = 1;
-    __syncthreads();
+    kc_barrier();
     KC_MARK(2);
     if (tid == 0) {
         const int64_t p = n - 2;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     {
         unsigned long long tm = s_tmask[1];
         if (tm) {
-            __syncthreads();                                                 // (uniform: every thread reads the same mask)
+            kc_barrier();                                                 // (uniform: every thread reads the same mask)
             const Tin *x = x0 + (int64_t)sig * x0_stride;
             while (tm) {
                 const int tt = __builtin_ctzll(tm);
@@ -283,9 +293,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
             }
         }
     }
-    __syncthreads();
+    kc_barrier();
     int c = 0, ck = 0;                                                       // candidates of the range; knots among them
-    int sink = 0;                     // (thread 0) what its additions to the list sizes returned: all of them have arrived when this is used
     {
         const int tt = tid >> 2, g = tid & 3;
         const unsigned long long Ek = t_w[tt * 8 + 2 * g], Ok = t_w[tt * 8 + 2 * g + 1];
@@ -319,26 +328,26 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
             }
         } else if (tid == 0) give_up(kKfFailCapacity);
     }
-    __syncthreads();
+    kc_barrier();
     if (!s_i[1]) {                                                           // the three values around every candidate: one round trip
         double a[ENT], b[ENT], d[ENT];
 #pragma unroll
         for (int i = 0; i < ENT; ++i) {
-            const int j = tid * ENT + i;
+            const int j = i * NT + tid;
             a[i] = b[i] = d[i] = 0.0;
             if (j < c) { const int32_t p = c_pos[j]; a[i] = xs[p - 1]; b[i] = xs[p]; d[i] = xs[p + 1]; }
         }
 #pragma unroll
         for (int i = 0; i < ENT; ++i) {
-            const int j = tid * ENT + i;
+            const int j = i * NT + tid;
             if (j < c) {
                 c_xl[j] = a[i]; c_xc[j] = b[i]; c_xr[j] = d[i];
                 if (c_fl[j] & 1) k_X[c_rk[j] + 1] = b[i];
             }
         }
-        if (tid == 0) sink |= atomicAdd(&ks->mlev[L0], ck) >> 31;
+        if (tid == 192) atomicAdd(&ks->mlev[L0], ck);
     }
-    __syncthreads();
+    kc_barrier();
     KC_MARK(3);
 
     // ---- the levels.  At the top of a level the candidates, the knots' positions and values by rank (k_pos, k_X) and the tiles'
@@ -347,14 +356,16 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     int published = L0 - 1;           // the last level whose record is out
     for (int lev = L0; lev <= M + 1 && !s_i[1]; ++lev) {
         const int li = lev - L0;
-        if (toff + ck + 2 > kKcSlab) { if (tid == 0) give_up(kKfFailCapacity); __syncthreads(); break; }
+        if (toff + ck + 2 > kKcSlab) { if (tid == 0) give_up(kKfFailCapacity); kc_barrier(); break; }
         KC_MARK(4 + 4 * min(li, 12));
         // A. the record for the neighbours (wavefront 2); the tiles' structures of this level for the sample pass (wavefront 3);
         //    the knots around the range from the neighbours' records (wavefront 0: in front, wavefront 1: behind)
         if (wave == 2) {
-            const bool head = w == 0, tail = w == W - 1;
-            kc_publish(rec_slot(lev, w), rec_tag(lev), lane, ck, k_pos, k_X, head ? s_ends[0] : (tail ? s_ends[2] : 0.0),
-                       head ? s_ends[1] : (tail ? s_ends[3] : 0.0), false);
+            if (lev == L0) {                                                 // (the later levels' records leave from the compaction below)
+                const bool head = w == 0, tail = w == W - 1;
+                kc_publish(rec_slot(lev, w), rec_tag(lev), lane, ck, k_pos, k_X, head ? s_ends[0] : (tail ? s_ends[2] : 0.0),
+                           head ? s_ends[1] : (tail ? s_ends[3] : 0.0), false);
+            }
         } else if (wave == 3) {
             int cnt = 0;
             unsigned long long wv[8];
@@ -383,13 +394,15 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                 uint32_t data = 0;
                 const long long t_begin = wall_clock64();
                 for (;;) {
-                    if (!ok) {
-                        const unsigned long long q = kc_load(src);
-                        if ((uint32_t)(q >> 32) == tag) { ok = true; data = (uint32_t)q; }
+                    if (!ok) {                                   // two loads in flight, half a round trip apart: the granule is seen sooner
+                        const unsigned long long q1 = kc_load(src);
+                        __builtin_amdgcn_s_sleep(12);
+                        const unsigned long long q2 = kc_load(src);
+                        if ((uint32_t)(q1 >> 32) == tag) { ok = true; data = (uint32_t)q1; }
+                        else if ((uint32_t)(q2 >> 32) == tag) { ok = true; data = (uint32_t)q2; }
                     }
                     if (__all(ok)) break;
                     if (wall_clock64() - t_begin > ITD_KC_TIMEOUT) { bad = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
                 }
                 bad = __any(bad);
                 return data;
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                 int v0 = -1, v1 = -1, v2 = -1, v3 = -1, nsel = 0;
                 bool reach_edge = false;
                 auto select = [&](int v) { if (nsel == 0) v0 = v; else if (nsel == 1) v1 = v; else if (nsel == 2) v2 = v; else v3 = v; ++nsel; };
-                if (first_round) {                                           // the four nearest, whatever they hold
+                if (first_round) {                                           // the nearest, whatever they hold
                     for (int k = 0; k < kKcRound; ++k) {
                         const int v = nb(dist0 + k);
                         if (v < 0 || v >= W) { reach_edge = true; break; }
@@ -477,8 +490,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                 s_i[2 + side] = have;
             }
         }
-        published = lev;
-        __syncthreads();
+        if (lev == L0) published = lev;
+        kc_barrier();
         if (s_i[1]) break;
         KC_MARK(5 + 4 * min(li, 12));
         // B. knot values (ITD.py:100-110) and slopes (ITD.py:115-116): a thread computes B of its knot and of the next one (no
@@ -511,16 +524,16 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
 #pragma unroll
             for (int q = 0; q < 8; ++q) t_w[tid * 8 + q] = 0ull;
         }
-        __syncthreads();
+        kc_barrier();
         KC_MARK(6 + 4 * min(li, 12));
-        // C. every candidate's three values through the maps of the segments they lie in (ITD.py:114-117); the next level's knots
+        // C. every candidate's three values through the maps of the segments they lie in (ITD.py:114-117); the next level's knots.
+        //    Thread t takes candidates t, t + 256, ...: the lists shrink ~2.6x per level, one candidate per thread from the second level on
         int32_t pos[ENT];
         double yl[ENT], yc[ENT], yr[ENT];
         int nfl[ENT];
-        int nkeep = 0, nknot = 0;
 #pragma unroll
         for (int i = 0; i < ENT; ++i) {
-            const int j = tid * ENT + i;
+            const int j = i * NT + tid;
             nfl[i] = 0; pos[i] = 0; yl[i] = yc[i] = yr[i] = 0.0;
             if (j < c) {
                 const int fl = c_fl[j];
@@ -535,30 +548,73 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                 const bool sticky = (fl & 2) || yl[i] == yc[i] || yc[i] == yr[i];         // an exact tie: rounding may move the knot next time
                 nfl[i] = (knot ? 1 : 0) | (sticky ? 2 : 0);
                 nonfin = nonfin || !(yl[i] - yl[i] == 0.0) || !(yc[i] - yc[i] == 0.0) || !(yr[i] - yr[i] == 0.0);
-                nkeep += nfl[i] ? 1 : 0;
-                nknot += knot ? 1 : 0;
             }
         }
+        if (li == 1) KC_MARK(44);
         if (nonfin) atomicMax(&ks->nf, 64 - lev);
-        // the next level's end samples: workgroup 0 / the last one (ITD.py:101-102 through this level's maps)
+        // the next level's end samples: workgroup 0 / the last one (ITD.py:101-102 through this level's maps).  Thread 192: the
+        // wavefront with the fewest candidates also publishes the record's fixed part below
         double ne0 = 0.0, ne1 = 0.0, ne2 = 0.0;
-        if (tid == 0) {
+        if (tid == 192) {
             if (w == 0) {                                       // dense index 1 is the virtual knot at sample 0
                 ne0 = k_B[1] + k_S[1] * (e0 - e0);
                 ne1 = (2 != d_ve && k_pos[2] == 1) ? k_B[2] + k_S[2] * (e1 - k_X[2]) : k_B[1] + k_S[1] * (e1 - e0);
             }
             if (w == W - 1) ne2 = k_B[ck + 1] + k_S[ck + 1] * (e2 - k_X[ck + 1]);   // sample n-2 lies in the last knot's segment (knots are <= n-2)
         }
-        // the survivors, in order: the next level's candidates, its knots by rank, its tiles' flag words
-        int tot;
-        int o = kc_scan(nkeep | (nknot << 16), s_red, tot);     // (both counts in one scan: each is < 2^15)
-        int r = o >> 16;
-        o &= 0xffff;
-        // (kc_scan's barriers: every read of the old list and of the knot arrays is done)
+        if (li == 1) KC_MARK(45);
+        // the survivors, in order: positions in the next level's list from ballots — per 256-candidate chunk and wavefront the
+        // counts of survivors and of knots among them, one barrier, sixteen sums
+        int pk[ENT], pn[ENT];
+#pragma unroll
+        for (int i = 0; i < ENT; ++i) {
+            const unsigned long long kb = __ballot(nfl[i] != 0), nb = __ballot((nfl[i] & 1) != 0);
+            pk[i] = mbcnt64(kb, 0);
+            pn[i] = mbcnt64(nb, 0);
+            if (lane == 0) s_cnt[i * 4 + wave] = __popcll(kb) | (__popcll(nb) << 16);
+        }
+        kc_barrier();                                           // (also: every read of the old list and of the knot arrays is done)
+        int tot = 0, base[ENT];
+#pragma unroll
+        for (int i = 0; i < ENT; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == wave) base[i] = tot;
+                tot += s_cnt[i * 4 + q];
+            }
+        }
+        if (li == 1) KC_MARK(46);
+        const int ckn = tot >> 16;
+        const bool more = lev < M + 1;                          // the next level's record for the neighbours leaves first, from the registers
+        unsigned long long *slot_n = rec_slot(more ? lev + 1 : lev, w);
+        const uint32_t tag_n = rec_tag(lev + 1);
+        auto publish_knot = [&](int first_granule, int32_t p, double v) {
+            const unsigned long long b = dbits(v);
+            kc_store(slot_n + first_granule, (uint32_t)p, tag_n);
+            kc_store(slot_n + first_granule + 1, (uint32_t)b, tag_n);
+            kc_store(slot_n + first_granule + 2, (uint32_t)(b >> 32), tag_n);
+        };
+        if (more && tid == 192) {
+            kc_store(slot_n, (uint32_t)ckn, tag_n);
+            const double ea = w == 0 ? ne0 : (w == W - 1 ? ne2 : 0.0), eb = w == 0 ? ne1 : 0.0;
+            const unsigned long long ba = dbits(ea), bb = dbits(eb);
+            kc_store(slot_n + 16, (uint32_t)ba, tag_n); kc_store(slot_n + 17, (uint32_t)(ba >> 32), tag_n);
+            kc_store(slot_n + 18, (uint32_t)bb, tag_n); kc_store(slot_n + 19, (uint32_t)(bb >> 32), tag_n);
+            if (ckn < 2) publish_knot(1, 0, 0.0);               // (slots of knots that do not exist carry the tag too: the readers poll them)
+            if (ckn < 1) publish_knot(4, 0, 0.0);
+            for (int h = ckn; h < 3; ++h) publish_knot(7 + 3 * h, 0, 0.0);
+        }
+        if (li == 1) KC_MARK(47);
 #pragma unroll
         for (int i = 0; i < ENT; ++i) {
             if (nfl[i]) {
-                r += nfl[i] & 1;
+                const int o = (base[i] & 0xffff) + pk[i];
+                const int r = (base[i] >> 16) + pn[i] + (nfl[i] & 1);     // knots of the range at or before the candidate
+                if (more && (nfl[i] & 1)) {
+                    if (r <= 3) publish_knot(4 + 3 * r, pos[i], yc[i]);          // the first three: granules 7.., 10.., 13..
+                    if (r == ckn - 1) publish_knot(1, pos[i], yc[i]);            // the second last
+                    if (r == ckn) publish_knot(4, pos[i], yc[i]);                // the last
+                }
                 c_pos[o] = pos[i]; c_xl[o] = yl[i]; c_xc[o] = yc[i]; c_xr[o] = yr[i]; c_fl[o] = (unsigned char)nfl[i]; c_rk[o] = (unsigned short)r;
                 if (nfl[i] & 1) {
                     k_pos[r + 1] = pos[i];
@@ -566,18 +622,19 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                     const int tt = pos[i] / TW - t0, q = pos[i] & (TW - 1);
                     atomicOr(&t_w[tt * 8 + 2 * (q >> 7) + (q & 1)], 1ull << ((q & 127) >> 1));
                 }
-                ++o;
             }
         }
-        if (tid == 0) {
-            sink |= atomicAdd(&ks->mlev[lev + 1], tot >> 16) >> 31;
+        if (li == 1) KC_MARK(48);
+        if (tid == 192) {
+            atomicAdd(&ks->mlev[lev + 1], ckn);
             if (w == 0) { s_ends[0] = ne0; s_ends[1] = ne1; }
             if (w == W - 1) { s_ends[2] = ne2; s_ends[3] = 0.0; }
         }
         toff += ck + 2;
         c = tot & 0xffff;
-        ck = tot >> 16;
-        __syncthreads();
+        ck = ckn;
+        if (more) published = lev + 1;
+        kc_barrier();
         KC_MARK(7 + 4 * min(li, 12));
     }
     // a workgroup that gave up tells everyone who may still wait for it
@@ -587,10 +644,11 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     // the tie flags clean themselves (the fused level-0 launch only ever sets them); the neighbour in front has read this range's
     // first flag before any of its records — which this workgroup has waited for — left
     if (wave == 1 && lane < nt && ((s_tmask[0] >> lane) & 1)) tie[t0 + lane] = 0;
-    // the signal's last workgroup draws the stop rules (ITD.py:400-426) from the list sizes (a workgroup's additions to them have
-    // returned before its arrival is counted: `sink`)
-    if (tid == 0) {
-        if (atomicAdd(&ks->done, 1 + (sink & 1)) == W - 1) {
+    // the signal's last workgroup draws the stop rules (ITD.py:400-426) from the list sizes (a workgroup's additions to them are
+    // complete — the wait below, by the thread that made them — before its arrival is counted)
+    if (tid == 192) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&ks->done, 1) == W - 1) {
             int lend = M + 1, natural = 0;
             for (int lev = L0; lev <= M + 1; ++lev) {
                 if (__hip_atomic_load(&ks->mlev[lev + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) { lend = lev; natural = 1; break; }   // "No more decompositions possible"

@@ -39,6 +39,7 @@ for li in range(M + 2 - 3):
     names += [(4 + 4 * li, "L%d: knots by rank, words" % (3 + li)), (5 + 4 * li, "L%d: halo arrived" % (3 + li)),
               (6 + 4 * li, "L%d: B, S, table" % (3 + li)), (7 + 4 * li, "L%d: map + compaction" % (3 + li))]
 names += [(60, "end")]
+fine = [(6 + 4, "L4: B, S, table"), (44, "  L4 maps done"), (45, "  L4 end samples (thread 0)"), (46, "  L4 scan"), (47, "  L4 record's fixed part (thread 0)"), (48, "  L4 compaction writes"), (7 + 4, "L4: barrier")]
 prev = b[:, 0]
 print("%-44s %9s %9s %9s   %s" % ("mark", "median at", "max at", "d median", "(us since the first workgroup's start)"))
 for k, nm in names:
@@ -48,3 +49,8 @@ for k, nm in names:
         continue
     print("%-44s %9.2f %9.2f %9.2f" % (nm, np.median(us(col[ok])), us(col[ok]).max(), np.median((col - prev)[ok]) / 100.0))
     prev = col
+if (b[:, 44] > 0).any():
+    prev = b[:, fine[0][0]]
+    for k, nm in fine[1:]:
+        print("%-44s %9.2f %9s %9.2f" % (nm, np.median(us(b[:, k])), "", np.median(b[:, k] - prev) / 100.0))
+        prev = b[:, k]
