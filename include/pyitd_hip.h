@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 6
+#define ITD_ABI_VERSION 7
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -91,7 +91,8 @@ int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32
  * baselines_dev  optional [batch][max_iteration+2][n] float64: row j = baseline after extraction j+1
  *                (the reference's `baselines` buffer, ITD.py:385,429); NULL = keep only a ping-pong pair
  *                inside the engine (saves 8 B/sample/level of HBM capacity, same traffic).
- * Everything is enqueued on `stream` with no host synchronisation; call itd_get_summary afterwards.
+ * Everything is enqueued on `stream` with no host synchronisation; call itd_get_summary afterwards — the rows are final once it
+ * has returned (or, for stream-ordered consumers, under itd_set_valid_flags / itd_set_device_repair below).
  * Calls of one engine must be ordered with respect to each other (the same stream, or synchronised by the caller): they share
  * the engine's workspace, and a call's last launch leaves part of it initialised for the next call.  A call that is captured
  * into a graph initialises what it needs itself, so the graph can be replayed any number of times. */
@@ -99,6 +100,25 @@ int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batc
                       int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream);
 int itd_decompose_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
                       int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream);
+
+/* Stream-ordered consumers (a kernel of the caller's enqueued behind the decomposition, a replayed hipGraph).
+ * The engine runs optimistic forms first — the fused sparse levels, the fused level 0, the resident form of short signals — each
+ * of which either delivers the reference's result or REPORTS that it cannot (tied / quantised / very smooth input, non-finite
+ * values); by default itd_get_summary then repeats the call level by level, so rows_dev is final only once the summary has been
+ * read.  Two settings make the result usable without that host round trip:
+ *   itd_set_valid_flags(e, valid_dev)   valid_dev[batch] int32, device memory owned by the caller (NULL = off).  Behind the last
+ *       launch of every later decomposition the engine writes valid_dev[b] = 1 if signal b's rows (and baselines) are final,
+ *       0 if they are not (they will be once itd_get_summary has run).  One short launch.
+ *   itd_set_device_repair(e, 1)          the engine also enqueues the level-by-level repeat itself, guarded on the device: its
+ *       launches return at once for every signal whose first result stands and re-run the others, so that rows_dev is final —
+ *       and valid_dev[b] = 1 — when the stream has drained, with no host synchronisation (graph-capturable).  A call whose
+ *       optimistic forms all delivered pays the guarded launches' boundaries (a dozen empty launches, ~25 us).  The one case left
+ *       to the host is a NaN in the caller's signal under ITD_NAN_INPUT_FOLLOW (valid_dev[b] = 0; itd_get_summary repeats such a
+ *       call the way the reference runs it).  itd_get_summary stays valid after either setting and repeats nothing twice.
+ * Reference behaviour: ITD.itd returns final arrays, ITD.py:404-432. */
+int itd_set_valid_flags(itd_engine *e, int32_t *valid_dev);
+int itd_set_device_repair(itd_engine *e, int32_t on);
+int64_t itd_get_device_repairs(const itd_engine *e);   /* signals the device-side repair has re-run (counted when a summary is read) */
 
 /* Synchronise with the last decomposition and fetch its per-signal summary (any pointer may be NULL):
  *   n_rows       [batch]      rows valid in rows_dev (= shape[0] of the reference's result)
@@ -423,11 +443,18 @@ int itd_stream_status(itd_stream *s, int32_t *status);
 #define ITD_TIME_DECOMPOSE 3      /* first launch .. last launch of one whole decomposition */
 #define ITD_TIME_SCAN0 4          /* k_scan0: the level-0 knot scan of the caller's signal (4 B/sample for float32) */
 #define ITD_TIME_KF_APPLY 5       /* k_kf_apply: the one pass over the samples for all fused levels (8 B read + 8 B per row written) */
-#define ITD_TIME_KF_KNOTS 6       /* the knot side of the fused levels: hand-over + two short launches per level (a span, not a launch) */
+#define ITD_TIME_KF_KNOTS 6       /* k_kf_knots: the knot side of the fused levels (hand-over and every level's step), one launch */
 int itd_set_kernel_timing(itd_engine *e, int max_decompositions);
 /* instrument only every stride-th decomposition (launches with events cost ~2 us more each, the span's marker records ~5 us each) */
 int itd_set_kernel_timing_stride(itd_engine *e, int stride);
 int itd_get_kernel_timing(itd_engine *e, int32_t which, double *ms_total, int32_t *launches);
+/* the individual durations behind that sum (ms), in launch order: at most `cap` are written, *count = how many exist */
+int itd_get_kernel_timing_samples(itd_engine *e, int32_t which, double *ms_out, int32_t cap, int32_t *count);
+/* mode 1: only the level-0 launch of each decomposition carries events (one completion signal per step instead of one per launch);
+ * itd_get_step_periods then gives the time from one decomposition's first launch to the next one's (ms): the per-step period of
+ * back-to-back calls, from the dispatches' own timestamps.  mode 0 (default): every launch class. */
+int itd_set_kernel_timing_mode(itd_engine *e, int32_t mode);
+int itd_get_step_periods(itd_engine *e, double *ms_out, int32_t cap, int32_t *count);
 
 #ifdef __cplusplus
 }

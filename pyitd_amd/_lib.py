@@ -17,7 +17,7 @@ HEADERS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) + glob.glob(os.
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -75,6 +75,12 @@ ABI = {
     "itd_set_level0_mode": (_INT, [_P, _I32]),
     "itd_set_host_keep_baselines": (_INT, [_P, _I32]),
     "itd_get_last_baselines_host": (_INT, [_P, _P, _I64, _I32]),
+    "itd_set_valid_flags": (_INT, [_P, _P]),
+    "itd_set_device_repair": (_INT, [_P, _I32]),
+    "itd_get_device_repairs": (_I64, [_P]),
+    "itd_set_kernel_timing_mode": (_INT, [_P, _I32]),
+    "itd_get_kernel_timing_samples": (_INT, [_P, _I32, _P, _I32, _P]),
+    "itd_get_step_periods": (_INT, [_P, _P, _I32, _P]),
     "itd_set_fuse_mode": (_INT, [_P, _I32]),
     "itd_set_fuse_level": (_INT, [_P, _I32]),
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),

@@ -56,6 +56,68 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
     if (keep_in_nan) st[b].in_nan = in_nan;   // the NaN-input repeat needs to know which signals hold one (k_nan_level0)
 }
 
+// ---- device-visible validity and the device-side repair (itd_set_valid_flags, itd_set_device_repair) ----
+// One thread per signal, behind the last launch of a decomposition: the fused levels' verdict merged into the signal's state (what
+// kf_verdict does on the host when the summary is read), then valid[b] = 1 if the rows in the caller's buffer are final; need[b] = 1
+// if the optimistic forms fell short for this signal (fused levels refused, fused level 0 out of reach, resident form met a
+// non-finite value) and a level-by-level run would repair it.  A NaN in the caller's signal is neither (the host repeats such a
+// call the way the reference runs it): valid = 0, need = 0.
+__global__ void k_verdict(SigState *__restrict__ state, int batch, const KfSig *__restrict__ kf, int L0, int nan_follow,
+                          int32_t *__restrict__ valid, int32_t *__restrict__ need)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    SigState &st = state[b];
+    if (kf) {
+        const KfSig &ks = kf[b];
+        if (!ks.active) { if (ks.fail) st.kf_fail = ks.fail; }
+        else {
+            int fail = ks.fail;
+            const int lend = ks.lend;
+            if (lend < 0) fail |= kKfFailCapacity;
+            // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
+            if (!fail && (ks.natural ? ks.m_exact >= 2 : ks.m_exact < 2)) fail |= kKfFailVerify;
+            if (fail) st.kf_fail = fail;
+            else {
+                for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
+                st.m[lend + 1] = ks.m_exact;
+                st.fin_stopped = ks.natural;
+                st.fin_stop_level = ks.natural ? lend + 1 : -1;
+            }
+        }
+    }
+    const int nan_in = st.in_nan != 0;
+    const int short_fall = !nan_in && (st.kf_fail != 0 || st.l0_fail != 0 || st.res_fail != 0);
+    if (need) need[b] = short_fall;
+    if (valid) valid[b] = (!short_fall && !(nan_in && nan_follow)) ? 1 : 0;
+}
+
+// in front of the repair's launches: the set of states they work on — a signal that needs the repair starts from the initial
+// state, every other one carries a copy of its final state and the skip flag (the repair's launches return at once for it); the
+// set's group sums cleared
+__global__ void k_repair_init(const SigState *__restrict__ from, SigState *__restrict__ to, const int32_t *__restrict__ need, int batch,
+                              int32_t *gsum, int64_t gsum_elems)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < gsum_elems; i += (int64_t)gridDim.x * blockDim.x)
+        gsum[i] = 0;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    if (need[b]) {
+        const int why = (from[b].kf_fail ? 1 : 0) | (from[b].l0_fail ? 2 : 0) | (from[b].res_fail ? 4 : 0);
+        sig_state_reset(to + b);
+        to[b].skip = -why;
+    } else { to[b] = from[b]; to[b].skip = 1; }
+}
+
+// behind the repair: what it repaired is final now (a level-by-level run cannot fall short; a NaN it met in the signal stays the host's)
+__global__ void k_verdict_repaired(const SigState *__restrict__ state, int batch, const int32_t *__restrict__ need, int nan_follow,
+                                   int32_t *__restrict__ valid)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch || !need[b]) return;
+    valid[b] = (state[b].in_nan && nan_follow) ? 0 : 1;
+}
+
 // totals[2b + 1] = signal b holds a NaN (k_compact): OR them into one flag
 __global__ void k_or_nan_flags(const int32_t *__restrict__ totals, int batch, int32_t *__restrict__ flag)
 {
@@ -124,6 +186,13 @@ struct itd_engine {
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
     bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
+    // device-visible validity / device-side repair (itd_set_valid_flags, itd_set_device_repair)
+    int32_t *valid_dev = nullptr;                    // the caller's [batch] words, written behind every decomposition; NULL = none
+    bool device_repair = false;
+    int32_t *d_need = nullptr;                       // [max_batch] which signals the repair's launches work on
+    int32_t *d_valid_own = nullptr;                  // [max_batch] (the repair needs the words even if the caller gave none)
+    bool last_device_repair = false;                 // the last call carried its repair: the summary has nothing to repeat
+    int64_t device_repairs = 0;                      // signals the device-side repair has re-run (counted when a summary is read)
     int64_t kf_resident_wgs = 0;                     // knot-side workgroups the device holds at once (occupancy query at creation of the workspace)
     int32_t fuse_group = 4;                          // chunks of a batch that share one knot side of the fused levels
     int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
@@ -171,6 +240,7 @@ struct itd_engine {
     int span_first = -1, span_last = -1;   // of the decomposition being enqueued: its first / last instrumented launch
     int n_timed = 0;              // pairs recorded since timing was (re)enabled
     bool timing_overflow = false;
+    int timing_mode = 0;          // 0: every launch class; 1: the level-0 launch only (itd_get_step_periods)
     int timing_stride = 1;        // instrument every stride-th decomposition only (event records cost ~5 us each)
     int timing_seq = 0;
     bool timing_now = false;
@@ -204,6 +274,7 @@ inline int64_t tiles_of(int64_t n) { return (n + T - 1) / T; }
 int time_slot(itd_engine *e, int tag)
 {
     if (!e->timing || !e->timing_now) return -1;
+    if (e->timing_mode == 1 && tag != ITD_TIME_EXTRACT_L0) return -1;   // step periods: only the level-0 launch carries events
     if (2 * (size_t)e->n_timed + 1 >= e->ev.size()) { e->timing_overflow = true; return -1; }
     const int k = e->n_timed++;
     e->ev_tag[(size_t)k] = tag;
@@ -283,8 +354,11 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
 
 template <typename Tin>
 int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M,
-                      double *rows, double *bases_user, hipStream_t st, bool fuse0, bool nan_input = false, bool kf = false)
+                      double *rows, double *bases_user, hipStream_t st, bool fuse0, bool nan_input = false, bool kf = false,
+                      const int32_t *repair_need = nullptr)
 {
+    // repair_need: the device-side repair of the call just enqueued (itd_set_device_repair): the same call again, level by level,
+    // whose launches return at once for every signal that is not flagged (SigState::skip, set by k_repair_init)
     // nan_input: the caller's signal holds a NaN (found by the previous, rejected run of this call): level 0 the way the
     // reference runs it — k_nan_level0 writes the mutated signal (NaN -> +inf, ITD.py:50) into the third baseline slot, which
     // nothing touches before level 2, and the level-0 records; the record-driven level-0 extraction then reads that copy
@@ -331,7 +405,12 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     SigState *const other_state = e->d_state + (size_t)(set ^ 1) * e->max_batch;
     int32_t *const other_gsum = e->d_gsum + (size_t)(set ^ 1) * 3 * e->gsum_third;
     const int64_t gs_extent = (int64_t)batch * n_groups * kGsumPitch;
-    if (nan_input || capturing || e->dirty_sig[set] > 0 || e->dirty_gs[set] > 0) {
+    if (repair_need) {
+        const int64_t ge = 3 * e->gsum_third;
+        const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
+        k_repair_init<<<gb, 256, 0, st>>>(other_state, set_state, repair_need, batch, set_gsum, ge);
+        e->dirty_sig[set] = std::max(e->dirty_sig[set], batch);
+    } else if (nan_input || capturing || e->dirty_sig[set] > 0 || e->dirty_gs[set] > 0) {
         const int64_t ge = 3 * e->gsum_third;   // the buffers are small: clear all of them
         const int gb = (int)std::min<int64_t>(std::max<int64_t>((ge + 255) / 256, (batch + 255) / 256), 2048);
         k_init_state<<<gb, 256, 0, st>>>(set_state, batch, set_gsum, ge, nan_input ? 1 : 0);
@@ -649,9 +728,30 @@ template <typename Tin>
 int enqueue_any(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x_stride, int32_t M, double *rows,
                 double *bases_user, hipStream_t st)
 {
-    if (want_resident(e, n)) return enqueue_resident<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
-    const bool f0 = want_fused(e);
-    return enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, f0, false, want_kf(e, n, batch, M, f0));
+    int rc;
+    if (want_resident(e, n)) rc = enqueue_resident<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st);
+    else {
+        const bool f0 = want_fused(e);
+        rc = enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, f0, false, want_kf(e, n, batch, M, f0));
+    }
+    e->last_device_repair = false;
+    if (rc || (!e->valid_dev && !e->device_repair)) return rc;
+    // ---- behind the call's last launch: the verdict on the device (and, if asked for, the repair) ----
+    const int vb = (batch + 63) / 64;
+    SigState *state_a = e->d_state + (size_t)e->cur_set * e->max_batch;
+    int32_t *valid = e->valid_dev ? e->valid_dev : e->d_valid_own;
+    const int follow = e->nan_input_mode == ITD_NAN_INPUT_FOLLOW ? 1 : 0;
+    k_verdict<<<vb, 64, 0, st>>>(state_a, batch, e->last_kf ? e->kf.sig : nullptr, e->last_kf_level, follow, valid, e->device_repair ? e->d_need : nullptr);
+    if (e->device_repair) {
+        // the same call level by level (record-driven level 0: any knot spacing), guarded per signal by d_need: rows_dev is final
+        // when the stream has drained, with no host synchronisation in between
+        rc = enqueue_decompose<Tin>(e, x, n, batch, x_stride, M, rows, bases_user, st, false, false, false, e->d_need);
+        if (rc) return rc;
+        k_verdict_repaired<<<vb, 64, 0, st>>>(e->d_state + (size_t)e->cur_set * e->max_batch, batch, e->d_need, follow, valid);
+        e->last_device_repair = true;
+    }
+    HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
 }
 
 // how the next decomposition's level 0 finds its knots: fused (one pass over the signal) unless the engine was told
@@ -817,6 +917,8 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     alloc((void **)&e->d_hgsum, 3 * (size_t)e->hgsum_third * sizeof(int32_t));
     alloc((void **)&e->d_hstate, sizeof(SigState));
     alloc((void **)&e->d_flag, 64);
+    alloc((void **)&e->d_need, sizeof(int32_t) * (size_t)max_batch);
+    alloc((void **)&e->d_valid_own, sizeof(int32_t) * (size_t)max_batch);
     const size_t st_b = B * sizeof(SigState);
     if (rc == hipSuccess) rc = hipHostMalloc((void **)&e->h_state, st_b);
     if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -838,7 +940,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
-    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); (void)hipFree(e->d_flag);
+    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); (void)hipFree(e->d_flag); (void)hipFree(e->d_need); (void)hipFree(e->d_valid_own);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_kf) (void)hipHostFree(e->h_kf);
@@ -995,6 +1097,19 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     }
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
     if (e->last_kf) kf_verdict(e, B);
+    if (e->last_device_repair) {
+        // the call carried its own repair (itd_set_device_repair): nothing to repeat here; count what it re-ran and let the engine's
+        // next calls start the way that would have delivered (workloads tend to be homogeneous) — as the host-side repeats do
+        int fixed = 0, why = 0;
+        for (int b = 0; b < B; ++b) if (e->h_state[b].skip < 0) { ++fixed; why |= -e->h_state[b].skip; }
+        e->device_repairs += fixed;
+        e->last_device_repair = false;      // (a second summary of the same call counts nothing)
+        if (fixed && (B < 8 || fixed * 8 > B)) {
+            if (why & 1) e->fuse_off_left = 16;
+            if (why & 2) e->l0_records_left = 16;
+            if (why & 4) e->resident_off_left = 16;
+        }
+    }
     auto any_nan_input = [&]() {
         for (int b = 0; b < B; ++b) if (e->h_state[b].in_nan) return true;
         return false;
@@ -1151,6 +1266,22 @@ int itd_set_resident_mode(itd_engine *e, int32_t mode)
 }
 
 int itd_get_resident_repeats(const itd_engine *e) { return e ? e->resident_repeats : -1; }
+
+int itd_set_valid_flags(itd_engine *e, int32_t *valid_dev)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    e->valid_dev = valid_dev;
+    return ITD_OK;
+}
+
+int itd_set_device_repair(itd_engine *e, int32_t on)
+{
+    if (!e) return ITD_ERR_INVALID_ARG;
+    e->device_repair = on != 0;
+    return ITD_OK;
+}
+
+int64_t itd_get_device_repairs(const itd_engine *e) { return e ? e->device_repairs : -1; }
 
 int itd_set_fuse_mode(itd_engine *e, int32_t mode)
 {
@@ -2115,6 +2246,56 @@ int itd_set_kernel_timing_stride(itd_engine *e, int stride)
 {
     if (!e || stride < 1) return ITD_ERR_INVALID_ARG;
     e->timing_stride = stride;
+    return ITD_OK;
+}
+
+int itd_set_kernel_timing_mode(itd_engine *e, int32_t mode)
+{
+    if (!e || mode < 0 || mode > 1) return ITD_ERR_INVALID_ARG;
+    e->timing_mode = mode;
+    return ITD_OK;
+}
+
+int itd_get_kernel_timing_samples(itd_engine *e, int32_t which, double *ms_out, int32_t cap, int32_t *count)
+{
+    if (!e || which < 0 || which > ITD_TIME_KF_KNOTS || cap < 0 || (cap > 0 && !ms_out)) return ITD_ERR_INVALID_ARG;
+    if (!e->ran || !e->timing) return ITD_ERR_NOT_RUN;
+    DevGuard g(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    int cnt = 0;
+    for (int k = 0; k < e->n_timed; ++k) {
+        if (e->ev_tag[(size_t)k] != which) continue;
+        if (cnt < cap) {
+            float ms = 0.f;
+            HIP_TRY(e, hipEventElapsedTime(&ms, e->ev[(size_t)e->ev_from[(size_t)k]], e->ev[(size_t)e->ev_to[(size_t)k]]));
+            ms_out[cnt] = ms;
+        }
+        ++cnt;
+    }
+    if (count) *count = cnt;
+    return ITD_OK;
+}
+
+int itd_get_step_periods(itd_engine *e, double *ms_out, int32_t cap, int32_t *count)
+{
+    if (!e || cap < 0 || (cap > 0 && !ms_out)) return ITD_ERR_INVALID_ARG;
+    if (!e->ran || !e->timing) return ITD_ERR_NOT_RUN;
+    DevGuard g(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->last_stream));
+    int cnt = 0, prev = -1;
+    for (int k = 0; k < e->n_timed; ++k) {
+        if (e->ev_tag[(size_t)k] != ITD_TIME_EXTRACT_L0) continue;
+        if (prev >= 0) {
+            if (cnt < cap) {
+                float ms = 0.f;
+                HIP_TRY(e, hipEventElapsedTime(&ms, e->ev[(size_t)e->ev_from[(size_t)prev]], e->ev[(size_t)e->ev_from[(size_t)k]]));
+                ms_out[cnt] = ms;
+            }
+            ++cnt;
+        }
+        prev = k;
+    }
+    if (count) *count = cnt;
     return ITD_OK;
 }
 

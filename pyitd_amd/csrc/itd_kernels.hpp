@@ -105,6 +105,9 @@ struct SigState {
                              // repeated level by level
     int32_t res_fail;        // written by k_resident only (itd_resident.hpp): the one-workgroup form met a non-finite sample (it
                              // handles finite data only): the call is repeated through the level-by-level engine
+    int32_t skip;            // the device-side repair (itd_set_device_repair): 1 = this signal's result was final before the repair's
+                             // launches, which return at once for it; the state is a copy of the first run's.  < 0: the repair re-ran
+                             // this signal, -(1: the fused levels had refused | 2: fused level 0 out of reach | 4: resident form)
     double ends[2][4];       // [level & 1]: x[0], x[1], x[n-2], x[n-1] of that level's input (ITD.py:101-102)
 };
 
@@ -1064,6 +1067,7 @@ __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, in
     const int t0 = xcd_item(blockIdx.x, gridDim.x) * KT, sig = blockIdx.y;
     const Tin *x = xin + (int64_t)sig * x_stride;
     SigState *st = state + sig;
+    if (st->skip > 0) return;       // (the device-side repair: this signal's first result stands)
     Tin q[KT][G2][2];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -1196,7 +1200,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     // load in front of the wavefront's requests; A/B in profiles/r02_ablation.txt)
     {
         const int sl = st->stop_level;
-        if (sl >= 0 && sl < level) return;
+        if ((sl >= 0 && sl < level) || st->skip > 0) return;
     }
 #endif
 
@@ -1858,6 +1862,7 @@ __device__ __forceinline__ void sig_state_reset(SigState *st)
     st->fin_stop_level = -1;
     st->kf_fail = 0;
     st->res_fail = 0;
+    st->skip = 0;
 }
 
 constexpr int kFinalizeThreads = 256;
@@ -1896,6 +1901,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restric
         }
     }
     SigState *st = state + sig;
+    if (st->skip > 0) return;       // (the device-side repair: this signal's first result, rows and state, stands)
     int stop_level = st->stop_level;
     int stopped = stop_level >= 0;
     if (!stopped) {

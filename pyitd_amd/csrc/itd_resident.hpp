@@ -122,10 +122,10 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
         if (os) { os->m[tid] = -1; os->c_delta[tid] = 0; }
         if (tid == 0) {
             st->stop_level = -1; st->nan_mask = 0; st->in_nan = 0; st->l0_fail = 0;
-            st->fin_stopped = 0; st->fin_stop_level = -1; st->kf_fail = 0; st->res_fail = 0;
+            st->fin_stopped = 0; st->fin_stop_level = -1; st->kf_fail = 0; st->res_fail = 0; st->skip = 0;
             if (os) {
                 os->stop_level = -1; os->nan_mask = 0; os->in_nan = 0; os->l0_fail = 0;
-                os->fin_stopped = 0; os->fin_stop_level = -1; os->kf_fail = 0; os->res_fail = 0;
+                os->fin_stopped = 0; os->fin_stop_level = -1; os->kf_fail = 0; os->res_fail = 0; os->skip = 0;
             }
         }
     }

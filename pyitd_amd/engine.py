@@ -117,6 +117,38 @@ class Engine:
         verification fails is repeated level by level), FUSE_OFF, FUSE_ONLY (never repeat)."""
         self._check(self._L.itd_set_fuse_mode(self._h, int(mode)))
 
+    def set_valid_flags(self, valid_dev_ptr):
+        """valid_dev_ptr: device pointer to int32[batch] (0 / None = off): behind every later decomposition's last launch the engine
+        writes 1 where a signal's rows are final, 0 where `summary()` still has a level-by-level repeat to run (include/pyitd_hip.h)."""
+        self._check(self._L.itd_set_valid_flags(self._h, ctypes.c_void_p(int(valid_dev_ptr or 0))))
+
+    def set_device_repair(self, on=True):
+        """The level-by-level repeat of a refused optimistic form enqueued by the engine itself, guarded per signal on the device:
+        the rows are final when the stream has drained (no `summary()` needed in between; graph-capturable)."""
+        self._check(self._L.itd_set_device_repair(self._h, 1 if on else 0))
+
+    @property
+    def device_repairs(self):
+        return int(self._L.itd_get_device_repairs(self._h))
+
+    def set_timing_mode(self, mode):
+        """0: every launch class carries events; 1: only each decomposition's level-0 launch (step_periods())."""
+        self._check(self._L.itd_set_kernel_timing_mode(self._h, int(mode)))
+
+    def kernel_timing_samples(self, which=TIME_EXTRACT, cap=4096):
+        """The individual durations (ms) of the recorded launches of class `which`, in launch order."""
+        buf = (ctypes.c_double * cap)()
+        cnt = ctypes.c_int32(0)
+        self._check(self._L.itd_get_kernel_timing_samples(self._h, which, buf, cap, ctypes.byref(cnt)))
+        return np.array(buf[: min(cnt.value, cap)], dtype=np.float64)
+
+    def step_periods(self, cap=4096):
+        """ms from one recorded decomposition's first launch to the next one's (set_timing_mode(1), back-to-back calls)."""
+        buf = (ctypes.c_double * cap)()
+        cnt = ctypes.c_int32(0)
+        self._check(self._L.itd_get_step_periods(self._h, buf, cap, ctypes.byref(cnt)))
+        return np.array(buf[: min(cnt.value, cap)], dtype=np.float64)
+
     def set_fuse_level(self, first_fused_level):
         """The first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2 are one launch each)."""
         self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))

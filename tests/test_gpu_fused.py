@@ -310,3 +310,92 @@ def test_host_api_through_the_fused_levels(P, oracle, monkeypatch):
         assert_bits_equal(d.itd(x, m), ref["rows"], name + ": ITD().itd")
         assert d.stop_reason == ref["stop"]
         assert_bits_equal(d.get_baselines(), ref["baselines"], name + ": get_baselines")
+
+
+def test_rows_are_final_on_the_stream_without_a_summary(P, torch, oracle):
+    """itd_set_valid_flags / itd_set_device_repair (include/pyitd_hip.h): a consumer enqueued on the same stream behind the
+    decomposition — here a device-to-device copy of rows_dev — sees the reference's rows with NO itd_get_summary in between, also
+    for signals the optimistic forms refuse (a chirp: ties at its extrema; quantised input; a plateau-led signal).  Without the
+    repair the validity words say which rows are not final yet."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m = 1 << 17, 6
+    lead = np.concatenate([np.zeros(3000), sines_noise(n, seed=11)[3000:].astype(np.float64)]).astype(np.float32)
+    xs = np.stack([sines_noise(n, seed=90), chirp(n).astype(np.float32), sines_noise(n, seed=91),
+                   (np.round(fuzz_signal(np.random.default_rng(12), 0, n) * 3) / 4.0).astype(np.float32), lead])
+    B = len(xs)
+    refs = [oracle.itd(x, m) for x in xs]           # (the full restatement: its knot counts follow the reference's NaN rules)
+    x = torch.from_numpy(xs).cuda()
+    for repair in (False, True):
+        eng = P.Engine(n, B, 0)
+        eng.set_fuse_mode(FUSE_AUTO)
+        eng.set_fuse_min_samples(65536)
+        valid = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        eng.set_valid_flags(valid.data_ptr())
+        eng.set_device_repair(repair)
+        rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        seen = torch.empty_like(rows)
+        s = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, s.cuda_stream)
+            seen.copy_(rows, non_blocking=True)          # the stream-ordered consumer
+            v = valid.clone()
+        s.synchronize()
+        v = v.cpu().numpy()
+        if repair:
+            assert v.tolist() == [1] * B
+        else:
+            assert v[0] == 1 and v[2] == 1 and v[1] == 0, v      # the chirp refuses; the sines deliver
+        for b in range(B):
+            if v[b]:
+                nr = refs[b]["rows"].shape[0]
+                assert_bits_equal(seen[b, :nr].cpu().numpy(), refs[b]["rows"], "repair %s signal %d as the consumer saw it" % (repair, b))
+        summ = eng.summary(B)                            # still valid afterwards, and repeats nothing twice
+        for b in range(B):
+            nr = int(summ["n_rows"][b])
+            assert nr == refs[b]["rows"].shape[0]
+            assert_bits_equal(rows[b, :nr].cpu().numpy(), refs[b]["rows"], "repair %s signal %d after the summary" % (repair, b))
+            kc = [int(k) for k in summ["knot_counts"][b] if k >= 0]
+            assert kc[1: 1 + len(refs[b]["knot_counts"])] == refs[b]["knot_counts"].tolist()
+        if repair:
+            assert eng.device_repairs >= 1 and eng.fuse_repeats == 0 and eng.fuse_signal_repairs == 0
+        eng.close()
+
+
+def test_device_repair_in_a_replayed_graph(P, torch, oracle):
+    """The call with its guarded repair captured into a hipGraph: replays on data the fused form delivers and on data it refuses
+    leave final rows and validity words with no host involvement at all."""
+    from pyitd_amd.engine import FUSE_AUTO
+    B, n, m = 3, 1 << 17, 5
+    eng = P.Engine(n, B, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_min_samples(65536)
+    valid = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    eng.set_valid_flags(valid.data_ptr())
+    eng.set_device_repair(True)
+    x = torch.zeros((B, n), dtype=torch.float32, device="cuda")
+    rows = torch.zeros((B, m + 2, n), dtype=torch.float64, device="cuda")
+    x.copy_(torch.from_numpy(np.stack([sines_noise(n, seed=100 + b) for b in range(B)])))
+    torch.cuda.synchronize()
+    eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)      # (allocates the fused levels' workspace)
+    eng.summary(B)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for seed, odd in ((110, None), (120, "chirp"), (130, None)):
+        y = np.stack([sines_noise(n, seed=seed + b) for b in range(B)])
+        if odd:
+            y[1] = chirp(n)
+        x.copy_(torch.from_numpy(y))
+        rows.fill_(float("nan"))
+        valid.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert valid.cpu().numpy().tolist() == [1] * B
+        for b in range(B):
+            ref = oracle.itd_lean(y[b], m)
+            assert_bits_equal(rows[b, : ref["rows"].shape[0]].cpu().numpy(), ref["rows"], "replay %d signal %d" % (seed, b))
+    eng.close()

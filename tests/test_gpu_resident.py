@@ -280,3 +280,32 @@ def test_resident_call_is_graph_capturable(P, torch, oracle):
         s = eng.summary(B)
         _check_against_oracle(oracle, y_np, m, rows.cpu().numpy(), None, s, "graph replay seed %d" % seed)
     eng.close()
+
+
+def test_resident_call_with_device_side_repair(P, torch, oracle):
+    """itd_set_valid_flags / itd_set_device_repair under the resident form: a batch of short signals of which two lead with a plateau
+    (a NaN baseline) — rows, baselines and validity words are final when the stream has drained, no summary in between; the summary
+    afterwards agrees and repeats nothing."""
+    from pyitd_amd.engine import LEVEL0_AUTO, RESIDENT_AUTO
+    n, m, B = 3000, 6, 12
+    x = np.stack([sines_noise(n, seed=200 + b, dtype=np.float64) for b in range(B)])
+    x[3, :40] = 0.25
+    x[9, :7] = -1.0
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    bases = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    valid = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    eng = P.Engine(n, B, 0)
+    eng.set_level0_mode(LEVEL0_AUTO)
+    eng.set_resident_mode(RESIDENT_AUTO)
+    eng.set_valid_flags(valid.data_ptr())
+    eng.set_device_repair(True)
+    torch.cuda.synchronize()
+    eng.decompose_dev(xd.data_ptr(), np.float64, n, B, n, m, rows.data_ptr(), bases.data_ptr(), None)
+    torch.cuda.synchronize()                      # (the engine's own stream has drained: no summary was read)
+    assert valid.cpu().numpy().tolist() == [1] * B
+    r_np, b_np = rows.cpu().numpy(), bases.cpu().numpy()
+    s = eng.summary(B)
+    assert eng.resident_repeats == 0          # (the resident form runs the reference's NaN rules itself: nothing for either repair to do)
+    _check_against_oracle(oracle, x, m, r_np, b_np, s, "resident + device repair")
+    eng.close()
