@@ -8,9 +8,9 @@ whole level recursion ITD.py:384-432 can run on the knot list alone:
   * a candidate carries the level's values at (e-1, e, e+1);
   * B_k, S_k come from the knots' values and positions (ITD.py:100-116), the three values move to the next level through the
     affine maps of the segments they lie in, the knot predicate (ITD.py:59 on x and -x) on the new triple decides survival;
-  * positions next to an exact tie of the ORIGINAL signal (x0[i] == x0[i+1]) and sample n-2 (its right neighbour is forced to
-    0: baseline[n-1] is never written, ITD.py:112-117) stay candidates for ever ("sticky"), and so does every candidate
-    whose triple shows an exact tie at some level.
+  * positions next to an exact tie of the level the recursion starts from (x[i] == x[i+1]) and sample n-2 (its right neighbour
+    is forced to 0: baseline[n-1] is never written, ITD.py:112-117) stay candidates for ever ("sticky"), and so does every
+    candidate whose triple shows an exact tie at some level.
 The samples then need ONE pass over all fused levels (every sample through its segment's map at each level, rotation rows
 written, nothing else read or written), which also re-derives every level's knots from the actual samples: any difference
 from the knot side's list means the shortcut missed a knot and the result is discarded (the engine repeats level by level).
@@ -30,6 +30,15 @@ def _predicate(yl, yc, yr):
     with np.errstate(invalid="ignore"):
         dp, dn = yc - yl, yr - yc
         return ((dn > 0) & (dp <= 0)) | ((dn < 0) & (dp >= 0))
+
+
+NEAR = 2.0 ** -20
+
+
+def near(a, b):
+    """Two neighbouring values that rounding may make (or has made) equal within the levels to come: |a - b| <= 2^-20 max(|a|, |b|)."""
+    with np.errstate(invalid="ignore"):
+        return np.abs(a - b) <= NEAR * np.maximum(np.abs(a), np.abs(b))
 
 
 def level_tables(n, pos, xc, ends):
@@ -59,14 +68,18 @@ def apply_map(n, e, X, B, S, i, xi):
 
 def knot_side(x_level, x0, n_extract, knots_fn):
     """The recursion on the knot list: `n_extract` extractions starting from the level whose input x_level is given in full.
-    x0: the original signal (for its exact ties).  Returns the per-level tables (dict: pos, e, X, B, S, ends) and the knot list of
+    x0: the original signal (unused since round 4: the sticky candidates come from the exact ties of x_level).  Returns the per-level tables (dict: pos, e, X, B, S, ends) and the knot list of
     the last pending baseline.  Raises NeedFallback on non-finite knot data / too many ties."""
     n = len(x_level)
-    x64 = np.asarray(x0, dtype=np.float64)
-    ties = np.flatnonzero(x64[:-1] == x64[1:])
+    # near ties of the level the recursion starts from — NOT the exact ties of the original signal: quantised input grows ties of its
+    # own at the first levels (adjacent knots: B_k = x[k-1]/4 + x[k]/2 + x[k+1]/4 is exact on a grid and two neighbours can
+    # coincide), a level may break a tie by one ulp and the next one restore it, and neighbours a few thousand ulps apart can
+    # collapse a few levels on (differences shrink geometrically from level to level)
+    x64 = np.asarray(x_level, dtype=np.float64)
+    ties = np.flatnonzero(near(x64[:-1], x64[1:]))
     sticky = np.unique(np.concatenate((ties, ties + 1, [n - 2])))
     sticky = sticky[(sticky >= 1) & (sticky <= n - 2)]
-    if len(sticky) > max(64, n // 4096):
+    if len(sticky) > n // 16:      # (the GPU's limit is a capacity: a workgroup of 64 tiles holds 1024 candidates, knots included)
         raise NeedFallback("too many exact ties in the input (%d)" % len(ties))
     pos = np.asarray(knots_fn(x_level), dtype=np.int64)
     cand = np.unique(np.concatenate((pos, sticky)))
@@ -88,7 +101,7 @@ def knot_side(x_level, x0, n_extract, knots_fn):
         new = apply_map(n, e, X, B, S, idx.ravel(), tri.ravel()).reshape(-1, 3)
         ends = apply_map(n, e, X, B, S, np.array([0, 1, n - 2, n - 1]), ends)
         flag = _predicate(new[:, 0], new[:, 1], new[:, 2])
-        tie = (new[:, 0] == new[:, 1]) | (new[:, 1] == new[:, 2])
+        tie = near(new[:, 0], new[:, 1]) | near(new[:, 1], new[:, 2])
         sticky_set.update(cand[tie].tolist())
         keep = flag | np.isin(cand, np.fromiter(sticky_set, dtype=np.int64, count=len(sticky_set)))
         cand, tri, is_knot = cand[keep], new[keep], flag[keep]

@@ -341,10 +341,10 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
     {   // how many knot-side workgroups are resident at once: a grid within that takes its ids from blockIdx (itd_knotfirst.hpp)
         int per_cu = 0, cus = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_kf_knots<float, T>), kKcThreads, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_kf_knots<T>), kKcThreads, 0) != hipSuccess ||
             hipGetDeviceProperties(&prop, e->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
         else cus = prop.multiProcessorCount;
-        // (the float64 instance has the same footprint.  Should the hardware admit fewer than the API says, the surplus workgroups
+        // (Should the hardware admit fewer than the API says, the surplus workgroups
         //  start in blockIdx order as others finish — observed, not promised; a wait that can never end is given up after
         //  ITD_KC_TIMEOUT and the call repeated level by level)
         e->kf_resident_wgs = (int64_t)per_cu * cus;
@@ -505,7 +505,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         int a_nt = n_tiles, a_b = nb, a_lvl = j, a_keep = 0;                                                               \
         const int32_t *a_ci = cnt(j), *a_gi = gs(j); int32_t *a_co = cnt(j + 1), *a_go = gs(j + 1), *a_gc = gs(j + 2);      \
         const TileRec *a_ri = rec(j); TileRec *a_ro = rec(j + 1); double *a_rot = rot_out, *a_bas = base_out;              \
-        SigState *a_st = state; int32_t *a_tie = (FUSE) ? tie_c : nullptr;                                                 \
+        SigState *a_st = state; int32_t *a_tie = (TIES) ? tie_c : nullptr;                                                 \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
                         &a_bas, &a_bs, &a_st, &a_lvl, &a_keep, &a_tie};                                                    \
         HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, KTW, FUSE, TIES>),              \
@@ -515,11 +515,12 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     } while (0)
             if (j == 0) {   // never the last level: M >= 0
                 if (nan_input) ITD_LAUNCH_EXTRACT(double, false, xm_c, 3 * e->pp_pitch, kRankCap0, false);
-                else if (fuse0 && kf) ITD_LAUNCH_EXTRACT_KT(Tin, false, xc, x_stride, kRankCap0, true, kFuse0TilesPerWave, true);
                 else if (fuse0) ITD_LAUNCH_EXTRACT_KT(Tin, false, xc, x_stride, kRankCap0, true, kFuse0TilesPerWave, false);
                 else ITD_LAUNCH_EXTRACT(Tin, false, xc, x_stride, kRankCap0, false);
             } else {
                 if (final_level) ITD_LAUNCH_EXTRACT(double, true, base_in, base_in_stride, kRankCap, false);
+                // (the launch in front of the fused sparse levels also flags the tiles of its baseline that hold a near tie)
+                else if (kf && j == j_last) ITD_LAUNCH_EXTRACT_KT(double, false, base_in, base_in_stride, kRankCap, false, kTilesPerWave, true);
                 else ITD_LAUNCH_EXTRACT(double, false, base_in, base_in_stride, kRankCap, false);
             }
 #undef ITD_LAUNCH_EXTRACT
@@ -559,10 +560,10 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             if (phase & 2) {
                 // ONE launch: hand-over and every fused level (timed from its dispatch's own begin / end timestamps)
                 const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
-                KfWs a_w = w; const Tin *a_x = xc; int64_t a_xs = x_stride, a_ls = xl_stride, a_n = n; const double *a_xl = xl; int a_m = M;
+                KfWs a_w = w; int64_t a_ls = xl_stride, a_n = n; const double *a_xl = xl; int a_m = M;
                 const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); const SigState *a_st = state;
-                void *args[] = {&a_w, &a_x, &a_xs, &a_xl, &a_ls, &a_n, &a_m, &a_c, &a_r, &a_st};
-                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_knots<Tin, T>), dim3((unsigned)w.wgs * (unsigned)nb), dim3(kKcThreads), args, 0, kst,
+                void *args[] = {&a_w, &a_xl, &a_ls, &a_n, &a_m, &a_c, &a_r, &a_st};
+                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_knots<T>), dim3((unsigned)w.wgs * (unsigned)nb), dim3(kKcThreads), args, 0, kst,
                                               p_kn >= 0 ? e->ev[2 * (size_t)p_kn] : nullptr, p_kn >= 0 ? e->ev[2 * (size_t)p_kn + 1] : nullptr, 0));
             }
             if (phase & 4) {

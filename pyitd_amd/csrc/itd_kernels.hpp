@@ -759,7 +759,16 @@ __device__ __forceinline__ void knot_predicate(const T (&d0)[NG], const T (&d1)[
 // Differences: d0 = even - left, d1 = odd - even, d2 = right - odd (= the next lane's d0): every difference is computed
 // once and shared by the two samples whose predicate uses it (ITD.py:59 on raw differences).
 // ---------------------------------------------------------------------------------------------
-template <int TW, bool COUNT_ONLY = false>
+// Two neighbouring values that rounding may make (or has made) equal within the levels to come: the fused sparse levels
+// (itd_knotfirst.hpp) keep both samples of such a pair as candidates.  |a - b| <= 2^-20 max(|a|, |b|): differences shrink by a few
+// bits per level, a pair 2^-27 apart at level 3 was an exact tie at level 8 (signal 51 of the bench's batch recipe).
+constexpr double kNearTie = 0x1p-20;
+__device__ __forceinline__ bool near_tie(double a, double b)
+{
+    return __builtin_fabs(a - b) <= kNearTie * __builtin_fmax(__builtin_fabs(a), __builtin_fabs(b));
+}
+
+template <int TW, bool COUNT_ONLY = false, bool NEARF = false>
 __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], double x_lo, double x_hi, int64_t s, int nrem,
                                             size_t slot, size_t gsum_index, int32_t *__restrict__ counts_out,
                                             TileRec *__restrict__ recs_out, int32_t *__restrict__ gsum_out,
@@ -788,6 +797,14 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
             d1[g] = xr[g][1] - xr[g][0];
         }
         knot_predicate<double, G2>(d0, d1, x_hi - xr[G2 - 1][1], E, O);
+        if constexpr (NEARF) {   // the launch in front of the fused sparse levels: flag the tile if two of its neighbouring samples (the
+            bool nr = false;     // one in front of the tile included) nearly tie — a superset of near_tie(): the flag only says "look here"
+#pragma unroll
+            for (int g = 0; g < G2; ++g)
+                nr = nr || __builtin_fabs(d0[g]) <= 2.0 * kNearTie * __builtin_fabs(xr[g][0]) || __builtin_fabs(d1[g]) <= 2.0 * kNearTie * __builtin_fabs(xr[g][1]);
+            if (__any(nr) && lane == 0 && tie_slot) *tie_slot = 1;
+            tie_slot = nullptr;
+        }
         if ((s == 0) || (nrem <= TW + 1)) {   // the tile holds sample 0, or sample n-2 or later: the first and the last sample are
             const int lo = s > 0 ? 0 : 1, hi = nrem - 2;   // never knots (ITD.py:70-73), nothing beyond sample n-2
 #pragma unroll
@@ -1791,9 +1808,10 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                 if (own_nan) atomicOr(&st->nan_mask, 1 << level);
             }
         }
-        scan_publish<TW, FINAL>(xr, x_lo, x_hi, s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
-                                counts_out, recs_out, gsum_out, s_rec, s_pos, FUSE0 ? own_c : 0,
-                                (TIES && tie_here) ? tie_out + slot0 + t : nullptr);
+        // TIES on a record-driven launch (the level in front of the fused sparse levels): near ties of the baseline it has just written
+        scan_publish<TW, FINAL, TIES && !FUSE0>(xr, x_lo, x_hi, s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
+                                                counts_out, recs_out, gsum_out, s_rec, s_pos, FUSE0 ? own_c : 0,
+                                                (TIES && (tie_here || !FUSE0)) ? tie_out + slot0 + t : nullptr);
     }
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
     PROF_MARK(7)   // next level's scan + record

@@ -13,9 +13,11 @@
 //               candidate to the next level through the maps of the segments they lie in, and decides with the knot predicate
 //               (ITD.py:59 on x and on -x) which candidates are knots of the next level.  Knots and sticky candidates stay in
 //               the list.  Sticky for ever: sample n-2 (its right neighbour is forced to 0: baseline[n-1] is never written,
-//               ITD.py:112-117), both samples of every exact tie of the caller's signal, and every candidate whose triple ever
-//               shows an exact tie — the places where rounding makes or breaks a plateau and a knot can appear where the
-//               previous level had none.  The stop rules (ITD.py:400-426) are decided here, from the list sizes.
+//               ITD.py:112-117), both samples of every NEAR tie of the first fused level's input (near_tie(): two neighbours
+//               within 2^-20 of their magnitude — exact ties of quantised data, ties that the first levels have grown or broken
+//               by an ulp, neighbours close enough to collapse a few levels on), and every candidate whose triple ever shows a
+//               near tie — the places where rounding makes or breaks a plateau and a knot can appear where the previous level
+//               had none.  The stop rules (ITD.py:400-426) are decided here, from the list sizes.
 //               A workgroup owns kKcTiles consecutive tiles of the signal and keeps its part of the candidate list in LDS from
 //               the hand-over to the last level; all it needs from outside at a level are the two knots in front of its range
 //               and the three behind it, which its neighbours publish as records of data-tagged 8-byte granules (one sc1 store
@@ -171,10 +173,10 @@ __device__ unsigned long long *g_kc_prof;   // [workgroups][64]
 //      starting: a grid that fits the device at once (KfWs::ticketed = 0) takes the id from blockIdx; a larger one hands out
 //      tickets — whoever starts first takes the lowest range, so whatever a resident workgroup waits for has started already
 //      or starts without that workgroup finishing first (dependencies reach a few ranges per level, the device holds hundreds).
-template <typename Tin, int TW>
-__global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__restrict__ x0, int64_t x0_stride, const double *__restrict__ xl,
-                                                         int64_t xl_stride, int64_t n, int max_iteration, const int32_t *__restrict__ counts,
-                                                         const TileRec *__restrict__ recs, const SigState *__restrict__ state)
+template <int TW>
+__global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64_t n, int max_iteration,
+                                                         const int32_t *__restrict__ counts, const TileRec *__restrict__ recs,
+                                                         const SigState *__restrict__ state)
 {
     static_assert(TW == 512 && kKcTiles * (TW / 128) == kKcThreads && kKcTiles == 64, "one thread per 128-sample group, one lane per tile");
     // the candidates: position, the level's values at position - 1, position, position + 1,
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     auto give_up = [&](int code) { s_i[1] = 1; atomicOr(&ks->fail, code); };
 
     // ---- hand-over: the level-L0 knots of the range (flag words of the records the launch for level L0 - 1 left); sticky
-    //      candidates: sample n-2, both samples of every exact tie of the caller's signal (rare: the tile was flagged)
+    //      candidates: sample n-2, both samples of every near tie of the level's input (near_tie(); rare: the launch that wrote
+    //      it flagged the tile)
     unsigned long long *s_w = reinterpret_cast<unsigned long long *>(k_B);   // (sticky words: until the first level needs k_B)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
     }
     if (tid < 4) s_ends[tid] = end_in;
     if (tid == 0) s_i[1] = 0;
-    if (wave == 0) {                                                         // a tie (p-1, p) is flagged in p's tile
+    if (wave == 0) {                                                         // a near tie (p-1, p) is flagged in p's tile
         const unsigned long long mo = __ballot(tie_own != 0), mn_ = __ballot(tie_next != 0);
         if (lane == 0) { s_tmask[0] = mo; s_tmask[1] = mo | mn_; }
     }
@@ -279,15 +282,14 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
         unsigned long long tm = s_tmask[1];
         if (tm) {
             kc_barrier();                                                 // (uniform: every thread reads the same mask)
-            const Tin *x = x0 + (int64_t)sig * x0_stride;
             while (tm) {
                 const int tt = __builtin_ctzll(tm);
                 tm &= tm - 1;
                 for (int i = tid; i < TW; i += NT) {
                     const int64_t p = (int64_t)(t0 + tt) * TW + i;
                     if (p >= 1 && p <= n - 2) {
-                        const Tin a = x[p - 1], b = x[p], c = x[p + 1];
-                        if (a == b || b == c) atomicOr(&s_w[tt * 8 + 2 * (i >> 7) + (i & 1)], 1ull << ((i & 127) >> 1));
+                        const double a = xs[p - 1], b = xs[p], c = xs[p + 1];
+                        if (near_tie(a, b) || near_tie(b, c)) atomicOr(&s_w[tt * 8 + 2 * (i >> 7) + (i & 1)], 1ull << ((i & 127) >> 1));
                     }
                 }
             }
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const Tin *__r
                 yc[i] = k_B[dc] + k_S[dc] * (c_xc[j] - k_X[dc]);
                 yr[i] = (pos[i] + 1 == n1) ? 0.0 : k_B[dr] + k_S[dr] * (c_xr[j] - k_X[dr]);   // baseline[n-1] stays 0, ITD.py:112-117
                 const bool knot = kf_pred(yl[i], yc[i], yr[i]);
-                const bool sticky = (fl & 2) || yl[i] == yc[i] || yc[i] == yr[i];         // an exact tie: rounding may move the knot next time
+                const bool sticky = (fl & 2) || near_tie(yl[i], yc[i]) || near_tie(yc[i], yr[i]);   // a (near) tie: rounding may move the knot
                 nfl[i] = (knot ? 1 : 0) | (sticky ? 2 : 0);
                 nonfin = nonfin || !(yl[i] - yl[i] == 0.0) || !(yc[i] - yc[i] == 0.0) || !(yr[i] - yr[i] == 0.0);
             }

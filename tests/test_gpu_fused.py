@@ -4,7 +4,7 @@ deliver — smooth, quantised, NaN-producing input — they report, after which 
 import numpy as np
 import pytest
 
-from helpers import assert_bits_equal, chirp, fuzz_signal, load_golden, sines_noise
+from helpers import assert_bits_equal, chirp, coarse, fuzz_signal, load_golden, sines_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -99,8 +99,9 @@ def test_full_size_headline_signal(P, torch, oracle):
 
 
 def test_what_the_fused_levels_cannot_deliver_is_reported_and_repeated(P, torch, oracle):
-    """Smooth (float32 chirp: plateaus at its extrema), tiled, quantised and plateau-led (NaN-producing) input: ONLY refuses,
-    AUTO repeats level by level — the result is the oracle's either way — and then starts the next calls level by level."""
+    """Tiled, coarsely quantised and plateau-led (NaN-producing) input: ONLY refuses, AUTO repeats level by level — the result is the
+    oracle's either way — and then starts the next calls level by level.  (A float32 chirp — near ties at its extrema — was refused
+    up to round 3 and is delivered since the near ties' samples are candidates.)"""
     from pyitd_amd import ITDError
     from pyitd_amd.engine import FUSE_AUTO, FUSE_ONLY
     radio = load_golden("radio8000_input")["x"]
@@ -132,15 +133,16 @@ def test_few_knots_stop_before_the_fused_levels(P, torch, oracle):
 
 
 def test_batches_and_the_drop_in_class(P, torch, oracle):
-    """A batch of 2^17-sample signals (the fused levels run per chunk of signals); one signal of the batch is a chirp: just that
-    signal is run again level by level (one in nine) and every signal still equals the oracle.  The drop-in class takes the same path."""
+    """A batch of 2^17-sample signals (the fused levels run per chunk of signals); one signal of the batch is coarsely quantised:
+    just that signal is run again level by level (one in nine) and every signal still equals the oracle.  The drop-in class takes
+    the same path."""
     from pyitd_amd.engine import FUSE_AUTO
     n, m, B = 1 << 17, 6, 9
     xs = np.stack([sines_noise(n, seed=20 + b, fscale=1 + b / 50.0) for b in range(B)])
     for with_chirp in (False, True):
         x = xs.copy()
         if with_chirp:
-            x[4] = chirp(n)
+            x[4] = coarse(xs[4])
         eng = P.Engine(n, B, 0)
         eng.set_fuse_mode(FUSE_AUTO)
         eng.set_fuse_min_samples(65536)
@@ -175,12 +177,17 @@ def test_first_fused_level_is_two_at_least(P):
 
 
 def test_a_few_refusing_signals_of_a_batch_are_rerun_on_their_own(P, torch, oracle):
-    """Signal 51 of the bench's batch recipe (2^20 samples, 8 levels) grows a knot from rounding at level 8 that the knot side cannot
-    know (tests/test_oracle_knotfirst.py's model refuses it too): itd_get_summary re-runs just that signal level by level, the rest
-    of the batch keeps its fused result, the engine stays in the fused form, and a second summary of the same call does no work."""
+    """Signals 40, 51 and 55 of the bench's batch recipe (2^20 samples, 8 levels) grow a knot from rounding at a deep level — two
+    neighbours 2^-27 apart at level 3 are an exact tie at level 8 —, which the fused levels refused up to round 3; with both samples
+    of every near tie kept as candidates they are delivered.  Two members are coarsely quantised here: itd_get_summary re-runs just
+    those level by level, the rest of the batch keeps its fused result, the engine stays in the fused form, and a second summary of
+    the same call does no work."""
     n, M = 1 << 20, 7
     ids = list(range(40, 56))
     xs = np.stack([sines_noise(n, seed=b % 16, fscale=1 + b / 8192.0) for b in ids])
+    odd = (3, 12)
+    for j in odd:
+        xs[j] = coarse(xs[j])
     from pyitd_amd.engine import FUSE_AUTO
     eng = P.Engine(n, len(ids), 0)
     eng.set_fuse_mode(FUSE_AUTO)          # (whatever PYITD_FUSE_MODE says: this test is about the automatic mode's repairs)
@@ -191,19 +198,19 @@ def test_a_few_refusing_signals_of_a_batch_are_rerun_on_their_own(P, torch, orac
         eng.decompose_dev(x.data_ptr(), np.float32, n, len(ids), n, M, rows.data_ptr(), None, None)
         s = eng.summary(len(ids))
         assert eng.fuse_repeats == 0, "the whole call was repeated"
-        assert eng.fuse_signal_repairs >= call + 1, "no signal refused: the recipe changed?"
-        assert eng.fuse_signal_repairs <= 2 * (call + 1)
+        assert eng.fuse_signal_repairs == len(odd) * (call + 1), "exactly the quantised members are re-run (40, 51, 55 deliver)"
         s2 = eng.summary(len(ids))
         assert all(np.array_equal(s[k], s2[k]) for k in s)
         for j, b in enumerate(ids):
-            if call == 1 and b not in (40, 51, 55):
+            if call == 1 and b not in (40, 51, 55) and j not in odd:
                 continue
             ref = oracle.itd_lean(xs[j], M)
             nr = int(s["n_rows"][j])
             assert nr == ref["rows"].shape[0]
             assert_bits_equal(rows[j, :nr].cpu().numpy(), ref["rows"], "call %d signal %d" % (call, b))
             kc = [int(v) for v in s["knot_counts"][j] if v >= 0]
-            assert kc[: len(ref["knot_counts"])] == ref["knot_counts"].tolist(), "signal %d knots per level" % b   # (itd_lean counts every level's input)
+            if j not in odd:      # (itd_lean counts every level's input plainly; plateau-ridden input follows the reference's NaN-rule counts)
+                assert kc[: len(ref["knot_counts"])] == ref["knot_counts"].tolist(), "signal %d knots per level" % b
     eng.close()
 
 
@@ -249,7 +256,7 @@ def test_fused_call_is_graph_capturable(P, torch, oracle):
     for seed, with_chirp in ((50, False), (60, True), (70, False)):
         y_np = np.stack([sines_noise(n, seed=seed + b, fscale=1 + b / 30.0) for b in range(B)])
         if with_chirp:
-            y_np[2] = chirp(n)
+            y_np[2] = coarse(y_np[2])
         x.copy_(torch.from_numpy(y_np))
         rows.fill_(float("nan"))
         g.replay()
@@ -260,7 +267,7 @@ def test_fused_call_is_graph_capturable(P, torch, oracle):
             nr = int(s["n_rows"][b])
             assert nr == ref["rows"].shape[0], "replay seed %d signal %d" % (seed, b)
             assert_bits_equal(rows[b, :nr].cpu().numpy(), ref["rows"], "replay seed %d signal %d" % (seed, b))
-    assert eng.fuse_repeats >= 1          # the chirp replay: one of six signals refused (more than one in eight)
+    assert eng.fuse_repeats >= 1          # the replay with a coarsely quantised member: one of six signals refused (more than one in eight)
     eng.close()
 
 
@@ -272,7 +279,7 @@ def test_fused_batch_with_odd_members(P, torch, oracle):
     n, m, B = (1 << 17) + 333, 6, 10
     xs = np.stack([sines_noise(n, seed=80 + b, fscale=1 + b / 40.0, dtype=np.float64) for b in range(B)])
     xs[6] = np.linspace(-1.0, 1.0, n)
-    xs[7] = chirp(n)
+    xs[7] = coarse(xs[7])
     eng = P.Engine(n, B, 0)
     eng.set_fuse_mode(FUSE_AUTO)
     eng.set_fuse_min_samples(65536)
@@ -345,7 +352,7 @@ def test_rows_are_final_on_the_stream_without_a_summary(P, torch, oracle):
         if repair:
             assert v.tolist() == [1] * B
         else:
-            assert v[0] == 1 and v[2] == 1 and v[1] == 0, v      # the chirp refuses; the sines deliver
+            assert v[0] == 1 and v[2] == 1 and v[3] == 0 and v[4] == 0, v      # the sines deliver; coarse quantisation and the NaN baseline do not
         for b in range(B):
             if v[b]:
                 nr = refs[b]["rows"].shape[0]
