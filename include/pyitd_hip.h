@@ -189,6 +189,11 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
 #define ITD_FUSE_ONLY 2
 int itd_set_fuse_mode(itd_engine *e, int32_t mode);
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
+/* Tiles (of 512 samples) a knot-side workgroup of the fused levels owns: 64, 32 or 16; 0 (default) = automatic: 64 (16 when fused from
+ * level 2), halved for the calls after one in which a workgroup's candidate list (1024 entries: knots and near-tie samples) outgrew
+ * its LDS — dense knots at the first fused level (white noise, alternating data).  Smaller ranges hold denser lists and cost more
+ * workgroups. */
+int itd_set_fuse_range(itd_engine *e, int32_t tiles);
 int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
 /* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot side of the fused levels (default 4: its launches are
  * bound by their boundaries, not by the lists' lengths, so they are amortised over more signals than a level launch takes) */

@@ -81,6 +81,7 @@ ABI = {
     "itd_set_kernel_timing_mode": (_INT, [_P, _I32]),
     "itd_get_kernel_timing_samples": (_INT, [_P, _I32, _P, _I32, _P]),
     "itd_get_step_periods": (_INT, [_P, _P, _I32, _P]),
+    "itd_set_fuse_range": (_INT, [_P, _I32]),
     "itd_set_fuse_mode": (_INT, [_P, _I32]),
     "itd_set_fuse_level": (_INT, [_P, _I32]),
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),

@@ -193,6 +193,8 @@ struct itd_engine {
     int32_t *d_valid_own = nullptr;                  // [max_batch] (the repair needs the words even if the caller gave none)
     bool last_device_repair = false;                 // the last call carried its repair: the summary has nothing to repeat
     int64_t device_repairs = 0;                      // signals the device-side repair has re-run (counted when a summary is read)
+    int32_t fuse_range = 0;                          // tiles per knot-side workgroup: 0 = automatic, or 16 / 32 / 64 (itd_set_fuse_range)
+    int32_t kf_shrink = 0;                           // automatic: how often a list has outgrown a workgroup (each time halves the range, down to 16 tiles)
     int64_t kf_resident_wgs = 0;                     // knot-side workgroups the device holds at once (occupancy query at creation of the workspace)
     int32_t fuse_group = 4;                          // chunks of a batch that share one knot side of the fused levels
     int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
@@ -306,7 +308,12 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 constexpr int kKfLevels = ITD_MAX_ITERATION + 3;
 // tiles per knot-side workgroup: its LDS holds kKcCap candidates — the first fused level's knots of its tiles (typically 0.04 /
 // 0.012 n at levels 2 / 3: 20 / 6 per tile) plus the sticky ones
-inline int kf_tiles_per_wg(int first_fused_level) { return first_fused_level >= 3 ? kKcTiles : kKcTiles / 4; }
+// (typically 0.04 / 0.012 n at levels 2 / 3: 20 / 6 per tile); a call that a list outgrew halves the ranges of the calls after it
+inline int kf_tiles_per_wg(const itd_engine *e, int first_fused_level)
+{
+    if (e->fuse_range) return e->fuse_range;
+    return std::max(kKcTiles / 4, (first_fused_level >= 3 ? kKcTiles : kKcTiles / 4) >> e->kf_shrink);
+}
 int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
 {
     const size_t wgs = (size_t)(e->max_tiles + tpw - 1) / tpw;
@@ -371,7 +378,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
-    const int kf_tpw = kf_tiles_per_wg(L0);
+    const int kf_tpw = kf_tiles_per_wg(e, L0);
     if (kf && capturing && ensure_kf_ws(e, kf_tpw, false) != ITD_OK) kf = false;
     if (kf) {
         const int rc = ensure_kf_ws(e, kf_tpw, true);
@@ -1106,7 +1113,8 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         e->device_repairs += fixed;
         e->last_device_repair = false;      // (a second summary of the same call counts nothing)
         if (fixed && (B < 8 || fixed * 8 > B)) {
-            if (why & 1) e->fuse_off_left = 16;
+            if ((why & 1) && !e->fuse_range && kf_tiles_per_wg(e, 3) > kKcTiles / 4) ++e->kf_shrink;   // (the device does not say why: try smaller ranges first)
+            else if (why & 1) e->fuse_off_left = 16;
             if (why & 2) e->l0_records_left = 16;
             if (why & 4) e->resident_off_left = 16;
         }
@@ -1163,12 +1171,17 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                 snprintf(e->err, sizeof(e->err), "fused sparse levels: not the reference's result (fail bits 0x%x: 1 verification, 2 capacity, 4 non-finite, 8 ties); ITD_FUSE_ONLY forbids the level-by-level repeat", code);
                 return ITD_ERR_HIP;
             }
+            // a list that outgrew its workgroup (dense knots): the calls after this one run with half the tiles per workgroup
+            bool outgrown = false;
+            for (int b = 0; b < B; ++b) outgrown = outgrown || (e->h_state[b].kf_fail & kKfFailCapacity);
+            const bool can_shrink = outgrown && !e->fuse_range && kf_tiles_per_wg(e, e->last_kf_level) > kKcTiles / 4;
+            if (can_shrink) ++e->kf_shrink;
             if (B >= 8 && nfail * 8 <= B) {
                 const int rc = repair_signals(e, B);
                 if (rc) return rc;
             } else {
                 ++e->fuse_repeats;
-                e->fuse_off_left = 16;
+                if (!can_shrink) e->fuse_off_left = 16;
                 const int rc = repeat(want_fused(e), false);
                 if (rc) return rc;
             }
@@ -1283,6 +1296,14 @@ int itd_set_device_repair(itd_engine *e, int32_t on)
 }
 
 int64_t itd_get_device_repairs(const itd_engine *e) { return e ? e->device_repairs : -1; }
+
+int itd_set_fuse_range(itd_engine *e, int32_t tiles)
+{
+    if (!e || (tiles != 0 && tiles != 16 && tiles != 32 && tiles != 64)) return ITD_ERR_INVALID_ARG;
+    e->fuse_range = tiles;
+    e->kf_shrink = 0;
+    return ITD_OK;
+}
 
 int itd_set_fuse_mode(itd_engine *e, int32_t mode)
 {

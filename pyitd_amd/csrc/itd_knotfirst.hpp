@@ -410,10 +410,10 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
                 return data;
             };
             int have = 0, dist0 = 1;
-            bool edge = false, bad = false, first_round = true;
+            bool edge = false, bad = false, first_round = true, ends_read = false;
             while (have < want && !edge && !bad) {
                 // the workgroups whose records this round reads, nearest first (all lanes agree)
-                int v0 = -1, v1 = -1, v2 = -1, v3 = -1, nsel = 0;
+                int v0 = -1, v1 = -1, v2 = -1, v3 = -1, nsel = 0, ends_only = -1;
                 bool reach_edge = false;
                 auto select = [&](int v) { if (nsel == 0) v0 = v; else if (nsel == 1) v1 = v; else if (nsel == 2) v2 = v; else v3 = v; ++nsel; };
                 if (first_round) {                                           // the nearest, whatever they hold
@@ -439,9 +439,11 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
                         select(nb(dist0 + l));
                         pend += min((int)__shfl((int)cnt, l), want - have - pend);
                     }
-                    if (reach_edge && have + pend < want) {                  // the walk will end at the signal's end: its end samples
+                    if (reach_edge && have + pend < want && !ends_read) {    // the walk will end at the signal's end: its end samples
                         const int last = nsel == 0 ? -1 : (nsel == 1 ? v0 : (nsel == 2 ? v1 : v2));
-                        if (last != v_end) select(v_end);
+                        // (not among the workgroups that hold knots: read for the end samples only — if an earlier round has passed
+                        //  it, its knots are in the halo already and so are the end samples)
+                        if (last != v_end) { ends_only = nsel; select(v_end); }
                     }
                     dist0 += 64;
                 }
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
                         if (side == 0 && vv == 0) { s_ends[0] = bits_d(sg[7], sg[8]); s_ends[1] = bits_d(sg[9], sg[10]); }
                         if (side == 1 && vv == W - 1) { s_ends[2] = bits_d(sg[10], sg[11]); s_ends[3] = bits_d(sg[12], sg[13]); }
                     }
-                    const int take = min((int)cnt, want - have);
+                    if (vv == v_end) ends_read = true;
+                    const int take = k == ends_only ? 0 : min((int)cnt, want - have);
                     if (lane == 0) {
                         for (int h = 0; h < take; ++h) {
                             // in front: the neighbour's last knot first (granules 4..6), then its second last (1..3); behind: its first three
@@ -490,6 +493,17 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
                     k_X[d] = side == 0 ? s_ends[0] : s_ends[3];
                 }
                 s_i[2 + side] = have;
+                if (!bad) {
+                    // what the walk has assembled must be knots strictly outside the range, in order (a guard on the exchange
+                    // itself: the sample pass verifies knots, not table values)
+                    const int32_t lo_pos = (int32_t)(t0 * TW), hi_pos = (int32_t)min((int64_t)t1 * TW, n);
+                    bool okh = true;
+                    for (int h = 0; h < have; ++h) {
+                        if (side == 0) { const int d = 1 - h; okh = okh && k_pos[d] >= 1 && k_pos[d] < lo_pos && (h == 0 || k_pos[d] < k_pos[d + 1]); }
+                        else { const int d = ck + 2 + h; okh = okh && k_pos[d] >= hi_pos && k_pos[d] < n1 && (h == 0 || k_pos[d] > k_pos[d - 1]); }
+                    }
+                    if (!okh) give_up(kKfFailVerify);
+                }
             }
         }
         if (lev == L0) published = lev;

@@ -50,6 +50,9 @@ class Engine:
         mode = os.environ.get("PYITD_FUSE_GROUP")       # chunks of a batch per knot side of the fused levels (sweeps)
         if mode:
             self.set_fuse_group(int(mode))
+        mode = os.environ.get("PYITD_FUSE_RANGE")       # tiles per knot-side workgroup of the fused levels (sweeps; 16 / 32 / 64)
+        if mode:
+            self.set_fuse_range(int(mode))
         mode = os.environ.get("PYITD_FUSE_MIN")         # samples per launch sequence from which FUSE_AUTO fuses (tests: 65536)
         if mode:
             self.set_fuse_min_samples(int(mode))
@@ -148,6 +151,10 @@ class Engine:
         cnt = ctypes.c_int32(0)
         self._check(self._L.itd_get_step_periods(self._h, buf, cap, ctypes.byref(cnt)))
         return np.array(buf[: min(cnt.value, cap)], dtype=np.float64)
+
+    def set_fuse_range(self, tiles):
+        """Tiles per knot-side workgroup of the fused levels: 64, 32, 16, or 0 = automatic (halved after a call whose lists outgrew them)."""
+        self._check(self._L.itd_set_fuse_range(self._h, int(tiles)))
 
     def set_fuse_level(self, first_fused_level):
         """The first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2 are one launch each)."""
