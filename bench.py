@@ -92,6 +92,49 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def preflight(args):
+    """N > 1: fail fast, with a message that says what is missing, before any rank allocates — fewer visible devices than ranks;
+    a per-rank footprint (rows + input + workspace) beyond the free HBM of this rank's device.  torch.cuda.device_count() does
+    not initialise HIP on this image, so the plain launcher's parent stays free of the GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible devices, this process sees %d (HIP_VISIBLE_DEVICES=%r, ROCR_VISIBLE_DEVICES=%r): "
+                         "nothing was started.  On a one-GPU box the sharded path is rehearsed with --rehearse-one-gpu.\n"
+                         % (args.gpus, args.gpus, have, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+        print(json.dumps({"error": "needs %d devices, %d visible" % (args.gpus, have), "n_gpus": args.gpus}))
+        return 2
+    if "WORLD_SIZE" in os.environ:          # a rank: its device's free memory against its shard's footprint
+        n = 1 << (args.log2n if args.log2n != LOG2N else 20)
+        need = shard_footprint_bytes(args.batch, n)
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        free, total = torch.cuda.mem_get_info(local)
+        if need > free:
+            sys.stderr.write("bench.py rank %s: the shard of %d x 2^%d signals needs %.1f GB (rows %.1f + input %.1f + workspace %.1f), "
+                             "device %d has %.1f GB free of %.1f: lower --batch\n"
+                             % (os.environ.get("RANK"), args.batch, n.bit_length() - 1, need / 1e9, 8.0 * (MAX_ITERATION + 2) * n * args.batch / 1e9,
+                                4.0 * n * args.batch / 1e9, (need - (8.0 * (MAX_ITERATION + 2) + 4.0) * n * args.batch) / 1e9, local, free / 1e9, total / 1e9))
+            return 3
+    return 0
+
+
+def shard_footprint_bytes(batch, n):
+    """HBM one rank's shard of `batch` signals of n samples takes: float64 rows [batch][M + 2][n], the float32 input, the engine's
+    workspace (three rotating baseline slots = 24 B/sample, tile records ~0.4 B/sample, the fused levels' tables, flag words and
+    first indices ~12 B/sample)."""
+    return int(batch * n * (8.0 * (MAX_ITERATION + 2) + 4.0 + 24.0 + 0.4 + 12.0))
+
+
+def topology_summary():
+    """`rocm-smi --showtopo` in a few lines (link types and hop counts between the visible GPUs), for the N > 1 line's config."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showtopotype", "--showtopohops"], capture_output=True, text=True, timeout=20).stdout
+        keep = [ln.strip() for ln in out.splitlines() if ln.strip() and not set(ln.strip()) <= set("=- ")]
+        return keep[:40] if keep else None
+    except Exception as ex:  # noqa: BLE001
+        return "unavailable: %r" % (ex,)
+
+
 def spawn_ranks(args):
     """The parent of a plain `bench.py --gpus N`: start N rank processes and relay rank 0's JSON line.  This process never
     initialises HIP (fresh children, no exec of a GPU-holding process).  Every rank's stderr is captured and relayed with a
@@ -403,6 +446,8 @@ def run_rank(args):
                         "all-gather of the per-signal summaries only",
             "collective_backend": None if world == 1 else ("nccl (RCCL)" if coll_backend == "nccl" else coll_backend),
             "device": None if stub else device_info(torch, dev),
+            "xgmi_topology": topology_summary() if (world > 1 and not stub and not args.rehearse_one_gpu) else None,
+            "shard_footprint_GB": None if (stub or not sharded) else round(shard_footprint_bytes(per_gpu, n) / 1e9, 1),
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
             "fused_levels_refused_and_retimed_level_by_level": fused_refused,
             "summary_read_every_step": bool(sharded),
@@ -949,6 +994,10 @@ def main():
                                                 "numpy.resize to 2^22, 10 levels): adds config5_audio to the line (also: PYITD_WAV)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the launcher only
     args = ap.parse_args()
+    if args.gpus > 1 and not args.stub and not args.rehearse_one_gpu:
+        rc = preflight(args)
+        if rc:
+            return rc
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
     return run_rank(args)

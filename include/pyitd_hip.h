@@ -83,6 +83,18 @@ int itd_dev_alloc(int device_id, int64_t bytes, void **out);
 int itd_dev_free(int device_id, void *p);
 int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32_t to_device);
 
+/* ---- sharding a batch over the GPUs of a node (one process and one engine per GPU) ----
+ * Signals are independent: rank r of `world` owns the contiguous range [lo, hi) of the batch (the first batch % world ranks get one
+ * signal more) and decomposes it with its own engine; there is NO data-path collective.  itd_shard_range is that arithmetic
+ * (pyitd_amd.distributed.shard_range).  itd_shard_scatter hands every rank its range when the batch lives on ONE rank — the
+ * "trivial batch scatter" of the north star — as one group of ncclSend / ncclRecv over xGMI: `nccl_comm` is the caller's ncclComm_t
+ * (as void *; RCCL is resolved with dlopen at the first call, the library does not link it), x_root_dev the root's [batch][n]
+ * array (ignored elsewhere), x_local_dev this rank's [hi - lo][n] array, elem_bytes 4 or 8; enqueued on `stream`, no host
+ * synchronisation.  world = 1 is a local copy and needs no communicator.  ITD_ERR_NO_DEVICE: no RCCL library on this host. */
+int itd_shard_range(int64_t batch, int32_t world, int32_t rank, int64_t *lo, int64_t *hi);
+int itd_shard_scatter(const void *x_root_dev, void *x_local_dev, int64_t n, int64_t batch, int32_t elem_bytes, int32_t world,
+                      int32_t rank, int32_t root, void *nccl_comm, void *stream);
+
 /* ---- full decomposition, device resident: replaces ITD.itd (ITD.py:351-432) -------------------
  * x_dev          [batch] signals, signal b starts at x_dev + b*x_stride (elements), n samples each
  * rows_dev       [batch][max_iteration+2][n] float64.  On return (after the stream has run) rows

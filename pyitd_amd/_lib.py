@@ -29,6 +29,8 @@ ABI = {
     "itd_engine_destroy": (None, [_P]),
     "itd_engine_workspace_bytes": (_I64, [_P]),
     "itd_engine_device": (_INT, [_P]),
+    "itd_shard_range": (_INT, [_I64, _I32, _I32, _P, _P]),
+    "itd_shard_scatter": (_INT, [_P, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _P]),
     "itd_decompose_f32": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _P, _P]),
     "itd_decompose_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _P, _P]),
     "itd_get_summary": (_INT, [_P, _P, _P, _P, _P, _P]),
@@ -107,7 +109,7 @@ def hipcc_command(out=LIB_PATH, tile=None):
            "-Wall", "-o", out]
     if tile:
         cmd.append("-DITD_TILE=%d" % tile)
-    return cmd + SOURCES
+    return cmd + SOURCES + ["-ldl"]
 
 
 def needs_build():

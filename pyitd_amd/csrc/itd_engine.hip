@@ -14,6 +14,7 @@
 #include <cstring>
 #include <type_traits>
 #include <atomic>
+#include <dlfcn.h>
 #include <memory>
 #include <new>
 #include <thread>
@@ -997,6 +998,76 @@ int itd_dev_copy(int device_id, void *dst, const void *src, int64_t bytes, int32
                ? ITD_OK : ITD_ERR_HIP;
 }
 int itd_engine_device(const itd_engine *e) { return e ? e->device : -1; }
+
+// ---- sharding a batch of independent signals over the GPUs of a node, for hosts without torch.distributed ----
+int itd_shard_range(int64_t batch, int32_t world, int32_t rank, int64_t *lo, int64_t *hi)
+{
+    if (batch < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return ITD_ERR_INVALID_ARG;
+    const int64_t q = batch / world, r = batch % world;
+    *lo = (int64_t)rank * q + std::min<int64_t>(rank, r);
+    *hi = *lo + q + (rank < r ? 1 : 0);
+    return ITD_OK;
+}
+
+namespace {
+// RCCL's point-to-point entry points, resolved at the first scatter (the library does not link against librccl: a single-GPU
+// host never needs it)
+struct RcclApi {
+    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    bool tried = false, ok = false;
+};
+RcclApi g_rccl;
+bool rccl_load()
+{
+    if (g_rccl.tried) return g_rccl.ok;
+    g_rccl.tried = true;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return false;
+    g_rccl.send = reinterpret_cast<decltype(g_rccl.send)>(dlsym(h, "ncclSend"));
+    g_rccl.recv = reinterpret_cast<decltype(g_rccl.recv)>(dlsym(h, "ncclRecv"));
+    g_rccl.group_start = reinterpret_cast<decltype(g_rccl.group_start)>(dlsym(h, "ncclGroupStart"));
+    g_rccl.group_end = reinterpret_cast<decltype(g_rccl.group_end)>(dlsym(h, "ncclGroupEnd"));
+    g_rccl.ok = g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end;
+    return g_rccl.ok;
+}
+}  // namespace
+
+int itd_shard_scatter(const void *x_root_dev, void *x_local_dev, int64_t n, int64_t batch, int32_t elem_bytes, int32_t world,
+                      int32_t rank, int32_t root, void *nccl_comm, void *stream)
+{
+    int64_t lo = 0, hi = 0;
+    if (n < 1 || (elem_bytes != 4 && elem_bytes != 8) || root < 0 || root >= world || itd_shard_range(batch, world, rank, &lo, &hi)) return ITD_ERR_INVALID_ARG;
+    if ((rank == root && !x_root_dev) || (hi > lo && !x_local_dev)) return ITD_ERR_INVALID_ARG;
+    const hipStream_t st = (hipStream_t)stream;
+    const size_t row = (size_t)n * (size_t)elem_bytes;
+    if (rank == root && hi > lo && x_local_dev != static_cast<const char *>(x_root_dev) + (size_t)lo * row)      // the root's own shard: a local copy
+        if (hipMemcpyAsync(x_local_dev, static_cast<const char *>(x_root_dev) + (size_t)lo * row, (size_t)(hi - lo) * row, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return ITD_ERR_HIP;
+    if (world == 1) return ITD_OK;
+    if (!nccl_comm) return ITD_ERR_INVALID_ARG;
+    if (!rccl_load()) return ITD_ERR_NO_DEVICE;            // no RCCL library on this host
+    // one group of point-to-point transfers: every link of the root busy at once (xGMI is point to point), bytes as ncclChar (= 0)
+    if (g_rccl.group_start()) return ITD_ERR_HIP;
+    int rc = 0;
+    if (rank == root) {
+        for (int r = 0; r < world && !rc; ++r) {
+            int64_t l = 0, h = 0;
+            (void)itd_shard_range(batch, world, r, &l, &h);
+            if (r != root && h > l) rc = g_rccl.send(static_cast<const char *>(x_root_dev) + (size_t)l * row, (size_t)(h - l) * row, 0, r, nccl_comm, st);
+        }
+    } else if (hi > lo) {
+        rc = g_rccl.recv(x_local_dev, (size_t)(hi - lo) * row, 0, root, nccl_comm, st);
+    }
+    const int rc_end = g_rccl.group_end();
+    return (rc || rc_end) ? ITD_ERR_HIP : ITD_OK;
+}
 
 int itd_decompose_f32(itd_engine *e, const float *x_dev, int64_t n, int32_t batch, int64_t x_stride,
                       int32_t max_iteration, double *rows_dev, double *baselines_dev, void *stream)

@@ -72,3 +72,21 @@ def test_product_path_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".inc")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower(), "%s mentions the oracle" % os.path.join(dirpath, f)
+
+
+def test_shard_range_of_the_c_abi_is_the_python_one(lib):
+    """itd_shard_range (for hosts without torch.distributed) and pyitd_amd.distributed.shard_range agree; bad requests are refused."""
+    import ctypes
+    from pyitd_amd.distributed import shard_range
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for batch, world in ((8192, 8), (1024, 8), (10, 3), (0, 4), (5, 8), (1, 1), (1000003, 7)):
+        covered = 0
+        for rank in range(world):
+            assert lib.itd_shard_range(batch, world, rank, ctypes.byref(lo), ctypes.byref(hi)) == 0
+            assert (lo.value, hi.value) == shard_range(batch, world, rank)
+            assert lo.value == covered
+            covered = hi.value
+        assert covered == batch
+    assert lib.itd_shard_range(8, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) != 0
+    assert lib.itd_shard_range(8, 4, 4, ctypes.byref(lo), ctypes.byref(hi)) != 0
+    assert lib.itd_shard_scatter(None, None, 16, 8, 4, 1, 0, 0, None, None) != 0      # the root's array is missing

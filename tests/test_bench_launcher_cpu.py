@@ -36,3 +36,17 @@ def test_under_an_external_launcher_the_process_is_one_rank():
     # what the driver does for N > 1: WORLD_SIZE etc. are already set -> no spawning; a 1-rank world runs alone
     d = _run(["--gpus", "1", "--log2n", "10"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert d["n_gpus"] == 1 and d["config"]["signals_in_gathered_table"] is None
+
+
+def test_more_ranks_than_devices_fails_fast_with_a_message():
+    """`bench.py --gpus 8` where fewer devices are visible starts nothing: exit code 2, the reason on stderr and in one JSON line
+    (no rank ever allocates or waits for a rendezvous)."""
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["HIP_VISIBLE_DEVICES"] = ""          # whatever this host has: none visible
+    e["ROCR_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2"], capture_output=True, text=True, timeout=120, env=e)
+    assert p.returncode == 2
+    assert "needs 8 visible devices" in p.stderr and "--rehearse-one-gpu" in p.stderr
+    assert json.loads(p.stdout.strip().splitlines()[-1])["error"].startswith("needs 8 devices")

@@ -79,7 +79,7 @@ def test_config4_sharding_emulated_on_one_gpu(P, torch, oracle):
     (shard_range(8192, 8, rank)) decomposes the first signals of ITS shard (reduced per-rank batch) on this GPU; the
     concatenated summary table and one signal's rows per rank must equal the oracle's."""
     from pyitd_amd.distributed import ShardedBatch, shard_range, pack_summary, unpack_summary
-    G, world, n, m, per_rank = 8192, 8, 1 << 20, 7, 4
+    G, world, n, m, per_rank = 8192, 8, 1 << 20, 7, 16      # (16 signals of every rank's real range: 128 of the 8192)
     R = m + 2
     eng = P.Engine(n, per_rank, 0)
     tables, ids = [], []
