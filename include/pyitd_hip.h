@@ -178,24 +178,26 @@ int itd_set_nan_fallback(itd_engine *e, int enable);
 #define ITD_LEVEL0_RECORDS 1
 #define ITD_LEVEL0_FUSED 2   /* never repeat: itd_get_summary fails with ITD_ERR_HIP if the reach was exceeded (benchmarks) */
 int itd_set_level0_mode(itd_engine *e, int32_t mode);
-/* The sparse levels fused ("knot first", pyitd_amd/csrc/itd_knotfirst.hpp; ABI revision 6).  An extraction maps every sample
- * through an affine function of itself inside its segment (ITD.py:114-117), so the next level's knots sit at this level's knots
- * (apart from places where exact ties let rounding make or break a plateau): from level `first_fused_level` on the level recursion
- * runs on the knot list alone and the samples take ONE pass for all remaining levels — 8 B read + 8 B per row written per sample
- * instead of 24 B per sample and level.  The sample pass re-derives every level's knots from the values it computes; where they
- * differ from the knot side's (or a list outgrows its workspace, or knot data go non-finite, or the input holds too many exact
- * ties: smooth and quantised signals) itd_get_summary repeats the call level by level before it returns (x_dev / rows_dev /
- * baselines_dev must stay valid until then, as before) and the engine's next 16 decompositions start level by level; when
- * only a few signals of a batch are concerned (at most one in eight) just those are run again, each on its own, and the
- * engine stays in the fused form.
+/* The sparse levels fused ("knot first", pyitd_amd/csrc/itd_knotfirst.hpp; ABI revision 6, one knot-side launch since revision 7).
+ * An extraction maps every sample through an affine function of itself inside its segment (ITD.py:114-117), so the next level's
+ * knots sit at this level's knots (apart from places where near ties let rounding make or break a plateau: both samples of every
+ * near tie of the first fused level's input stay candidates): from level `first_fused_level` on the level recursion runs on the
+ * knot list alone — ONE launch, the lists resident in LDS — and the samples take ONE pass for all remaining levels: 8 B read + 8 B
+ * per row written per sample instead of 24 B per sample and level.  The sample pass re-derives every level's knots from the values
+ * it computes; where they differ from the knot side's (or a list outgrows its workgroup, or knot data go non-finite: coarsely
+ * quantised, plateau-ridden or very smooth signals) itd_get_summary repeats the call level by level before it returns (x_dev /
+ * rows_dev / baselines_dev must stay valid until then, as before; or on the device: itd_set_device_repair) and the engine's next 16
+ * decompositions start level by level — after a list outgrew its workgroup they stay fused with half the tiles per workgroup
+ * (itd_set_fuse_range); when only a few signals of a batch are concerned (at most one in eight) just those are run again, each on
+ * its own, and the engine stays in the fused form.
  * Results are bit-identical in every mode: what the fused form cannot deliver it reports.  The fused levels' workspace is allocated
  * by the first call that takes this path; a call being captured into a graph cannot allocate: on an engine that has not fused yet it is
  * captured level by level (run one decomposition before the capture to get the fused form into the graph).
  * ITD_FUSE_AUTO (default): calls whose launch sequences cover at least itd_set_fuse_min_samples samples (signals per chunk x n; default
- * 6 * 2^20: the fused form has more launches — 18 instead of 10 at 8 levels — and pays once they are memory bound: one signal of 2^22
- * samples is 6 % slower fused, one of 2^23 9 % faster), signals of >= 65536 samples; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never
- * repeat (itd_get_summary fails with ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 ..
- * max_iteration (default 3: levels 0, 1, 2 as one launch each; measured on 2^24 samples: 0.499 / 0.482 / 0.501 ms for 2 / 3 / 4). */
+ * 2 * 2^20: one signal of 2^20 / 2^21 / 2^22 / 2^23 samples takes 89 / 115 / 183 / 305 us level by level and 90 / 104 / 149 / 227 us
+ * fused), signals of >= 65536 samples; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never repeat (itd_get_summary fails with
+ * ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2
+ * as one launch each). */
 #define ITD_FUSE_AUTO 0
 #define ITD_FUSE_OFF 1
 #define ITD_FUSE_ONLY 2
@@ -207,8 +209,8 @@ int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
  * workgroups. */
 int itd_set_fuse_range(itd_engine *e, int32_t tiles);
 int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
-/* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot side of the fused levels (default 4: its launches are
- * bound by their boundaries, not by the lists' lengths, so they are amortised over more signals than a level launch takes) */
+/* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot-side launch of the fused levels (default 1; sharing it
+ * paid while the knot side was a dozen launches) */
 int itd_set_fuse_group(itd_engine *e, int32_t chunks);
 /* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);

@@ -197,8 +197,9 @@ struct itd_engine {
     int32_t fuse_range = 0;                          // tiles per knot-side workgroup: 0 = automatic, or 16 / 32 / 64 (itd_set_fuse_range)
     int32_t kf_shrink = 0;                           // automatic: how often a list has outgrown a workgroup (each time halves the range, down to 16 tiles)
     int64_t kf_resident_wgs = 0;                     // knot-side workgroups the device holds at once (occupancy query at creation of the workspace)
-    int32_t fuse_group = 4;                          // chunks of a batch that share one knot side of the fused levels
-    int64_t fuse_min_samples = (int64_t)6 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
+    int32_t fuse_group = 1;                          // chunks of a batch that share one knot side of the fused levels (1 since the knot side is one launch:
+                                                     // sharing it over 2 / 4 chunks measured 25.1 / 26.1 ms against 23.9 on 1024 x 2^20)
+    int64_t fuse_min_samples = (int64_t)2 << 20;   // automatic mode: samples per launch sequence from which the fused form pays
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
     bool last_kf = false;
     int last_kf_level = 0;         // the first fused level of that call
@@ -305,7 +306,7 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 
 // The workspace of the fused sparse levels (itd_knotfirst.hpp), allocated at the first call that takes that path.  Per signal and
 // knot-side workgroup (kKcTiles tiles): a slab of table entries (32 B per knot and level: kKcSlab of them) and one 256-byte
-// boundary record per level; per level and tile the knots' flag words and the tile's first table index; per tile a tie flag.
+// boundary record per level; per level and tile the knots' flag words and the tile's first table index; per tile the near-tie flag words.
 constexpr int kKfLevels = ITD_MAX_ITERATION + 3;
 // tiles per knot-side workgroup: its LDS holds kKcCap candidates — the first fused level's knots of its tiles (typically 0.04 /
 // 0.012 n at levels 2 / 3: 20 / 6 per tile) plus the sticky ones
@@ -329,7 +330,7 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_sig = al(B * sizeof(KfSig)), b_pool = al(B * wgs * kKcSlab * sizeof(KfEntry));
     const size_t b_first = al(B * kKfLevels * (size_t)e->max_tiles * 4), b_tf = al(B * kKfLevels * (size_t)e->max_tiles * 64);
-    const size_t b_tie = al(B * (size_t)e->max_tiles * 4), b_rec = al(B * kKfLevels * wgs * kKcRecGran * 8);
+    const size_t b_tie = al(B * (size_t)e->max_tiles * 64), b_rec = al(B * kKfLevels * wgs * kKcRecGran * 8);
     const size_t total = b_sig + b_pool + b_first + b_tf + b_tie + b_rec;
     const hipError_t rc = hipMalloc(&e->d_kf, total);
     if (rc != hipSuccess) { e->d_kf = nullptr; fail_hip(e, rc, "hipMalloc(fused levels' workspace)"); return rc == hipErrorOutOfMemory ? ITD_ERR_NOMEM : ITD_ERR_HIP; }
@@ -341,10 +342,10 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
     w.pool = (KfEntry *)p; p += b_pool;
     w.first = (int32_t *)p; p += b_first;
     w.tflags = (unsigned long long *)p; p += b_tf;
-    w.tie = (int32_t *)p; p += b_tie;
+    w.nearw = (unsigned long long *)p; p += b_tie;
     w.rec = (unsigned long long *)p;
-    // the tie flags clean themselves from here on; the signals' generation counters start at 0 and no record carries a tag yet
-    if (hipMemset(w.sig, 0, b_sig) != hipSuccess || hipMemset(w.tie, 0, b_tie) != hipSuccess || hipMemset(w.rec, 0, b_rec) != hipSuccess) return ITD_ERR_HIP;
+    // the signals' generation counters start at 0 and no record carries a tag yet
+    if (hipMemset(w.sig, 0, b_sig) != hipSuccess || hipMemset(w.rec, 0, b_rec) != hipSuccess) return ITD_ERR_HIP;
     w.wgs_max = (int32_t)wgs; w.rec_levels = kKfLevels;
     {   // how many knot-side workgroups are resident at once: a grid within that takes its ids from blockIdx (itd_knotfirst.hpp)
         int per_cu = 0, cus = 0;
@@ -485,7 +486,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         }
 
         const int j_last = kf ? L0 - 1 : M + 1;
-        int32_t *tie_c = kf ? e->kf.tie + (size_t)b0 * n_tiles : nullptr;
+        unsigned long long *near_c = kf ? e->kf.nearw + (size_t)b0 * n_tiles * 8 : nullptr;
         for (int j = 0; j <= j_last; ++j) {
             // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
             double *base_out;
@@ -513,7 +514,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         int a_nt = n_tiles, a_b = nb, a_lvl = j, a_keep = 0;                                                               \
         const int32_t *a_ci = cnt(j), *a_gi = gs(j); int32_t *a_co = cnt(j + 1), *a_go = gs(j + 1), *a_gc = gs(j + 2);      \
         const TileRec *a_ri = rec(j); TileRec *a_ro = rec(j + 1); double *a_rot = rot_out, *a_bas = base_out;              \
-        SigState *a_st = state; int32_t *a_tie = (TIES) ? tie_c : nullptr;                                                 \
+        SigState *a_st = state; unsigned long long *a_tie = (TIES) ? near_c : nullptr;                                                 \
         void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_b, &a_ci, &a_co, &a_ri, &a_ro, &a_gi, &a_go, &a_gc, &a_rot, &a_rs,    \
                         &a_bas, &a_bs, &a_st, &a_lvl, &a_keep, &a_tie};                                                    \
         HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_extract<TIN, T, FIN, CAPK, KTW, FUSE, TIES>),              \
@@ -560,7 +561,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             w.ticketed = (int64_t)w.wgs * nb > e->kf_resident_wgs ? 1 : 0;
             const size_t B0 = (size_t)b0;
             w.sig += B0; w.pool += B0 * (size_t)w.wgs_max * kKcSlab; w.rec += B0 * (size_t)w.rec_levels * w.wgs_max * kKcRecGran;
-            w.first += B0 * (size_t)w.nlev * n_tiles; w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.tie += B0 * n_tiles;
+            w.first += B0 * (size_t)w.nlev * n_tiles; w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.nearw += B0 * (size_t)n_tiles * 8;
             // (the per-signal strides of `first` / `tflags` follow this call's geometry: nlev levels x n_tiles tiles per signal)
             const double *xl = bases_c ? bases_c + (int64_t)(L0 - 1) * n : pp_c + (int64_t)((L0 - 1) % 3) * e->pp_pitch;
             const int64_t xl_stride = bases_c ? rows_stride : 3 * e->pp_pitch;

@@ -775,8 +775,8 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
                                             int32_t *s_rec /* sizeof(TileRec) bytes, 16-byte aligned */, int32_t *s_pos /* 8 ints */,
                                             int count_hi = 0 /* added to the int behind the group sum by the same (64-bit) atomic:
                                                                 the fused level-0 launch's own knot count, for m[0] */,
-                                            int32_t *tie_slot = nullptr /* non-null (rare): the tile's input held an exact tie of two
-                                                                neighbouring samples: set its flag for the fused sparse levels */)
+                                            unsigned long long *near_words = nullptr /* NEARF: the tile's 2 TW / 128 words (flag_pos format) that
+                                                                mark both samples of every near tie of the scanned row (itd_knotfirst.hpp) */)
 {
     constexpr int G2 = TW / 128;
     const int lane = lane_id();
@@ -789,21 +789,36 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
         for (int g = 0; g < G2; ++g) { gcount[g] = 0; E[g] = O[g] = 0; }
     } else {
         double d0[G2], d1[G2];
+        unsigned long long nt0[G2], nt1[G2];
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
             const double fill = (g == 0) ? x_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);   // lane 0 <- lane 63 of the previous group
             const double left = wave_dpp<0x138>(fill, xr[g][1]);
+            nt0[g] = nt1[g] = 0ull;
             d0[g] = xr[g][0] - left;
             d1[g] = xr[g][1] - xr[g][0];
+            if constexpr (NEARF) {   // the launch in front of the fused sparse levels: near ties of the row just written
+                nt0[g] = __ballot(__builtin_fabs(d0[g]) <= kNearTie * __builtin_fmax(__builtin_fabs(left), __builtin_fabs(xr[g][0])));      // (left neighbour, even sample)
+                nt1[g] = __ballot(__builtin_fabs(d1[g]) <= kNearTie * __builtin_fmax(__builtin_fabs(xr[g][0]), __builtin_fabs(xr[g][1])));  // (even sample, odd sample)
+            }
         }
         knot_predicate<double, G2>(d0, d1, x_hi - xr[G2 - 1][1], E, O);
-        if constexpr (NEARF) {   // the launch in front of the fused sparse levels: flag the tile if two of its neighbouring samples (the
-            bool nr = false;     // one in front of the tile included) nearly tie — a superset of near_tie(): the flag only says "look here"
+        if constexpr (NEARF) {
+            // both samples of a near pair: an even sample with either neighbour, an odd sample with its even one or with the next
+            // lane's even one (the next group's first / the next tile's first sample for lane 63); positions 1 .. n-2 only
+            const unsigned long long nlast = __ballot(near_tie(xr[G2 - 1][1], x_hi)) & (1ull << 63);
+            unsigned long long mine = 0ull;
 #pragma unroll
-            for (int g = 0; g < G2; ++g)
-                nr = nr || __builtin_fabs(d0[g]) <= 2.0 * kNearTie * __builtin_fabs(xr[g][0]) || __builtin_fabs(d1[g]) <= 2.0 * kNearTie * __builtin_fabs(xr[g][1]);
-            if (__any(nr) && lane == 0 && tie_slot) *tie_slot = 1;
-            tie_slot = nullptr;
+            for (int g = 0; g < G2; ++g) {
+                unsigned long long Es = nt0[g] | nt1[g];
+                unsigned long long Os = nt1[g] | (nt0[g] >> 1) | (g + 1 < G2 ? nt0[g + 1 < G2 ? g + 1 : g] << 63 : nlast);
+                const int lo = s > 0 ? 0 : 1, hi = nrem - 2;
+                Es &= bit_range((lo - 128 * g + 1) >> 1, (hi - 128 * g) >> 1);
+                Os &= bit_range((lo - 128 * g) >> 1, (hi - 128 * g - 1) >> 1);
+                if (lane == 2 * g) mine = Es;
+                if (lane == 2 * g + 1) mine = Os;
+            }
+            if (lane < 2 * G2 && near_words) near_words[lane] = mine;
         }
         if ((s == 0) || (nrem <= TW + 1)) {   // the tile holds sample 0, or sample n-2 or later: the first and the last sample are
             const int lo = s > 0 ? 0 : 1, hi = nrem - 2;   // never knots (ITD.py:70-73), nothing beyond sample n-2
@@ -822,7 +837,6 @@ __device__ __forceinline__ int scan_publish(const double (&xr)[TW / 128][2], dou
     // count and group sum first (a wavefront cannot retire before its last store is acknowledged)
     if (lane == 0) {
         if (!(ITD_ABL_R & 32)) counts_out[slot] = total;
-        if (tie_slot) *tie_slot = 1;
         if (count_hi)   // the group sums are 128 bytes apart: element +1 is free, and 8-byte aligned with element 0
             atomicAdd(reinterpret_cast<unsigned long long *>(&gsum_out[gsum_index]), ((unsigned long long)(unsigned)count_hi << 32) | (unsigned)total);
         else if (total && !(ITD_ABL_R & 16)) atomicAdd(&gsum_out[gsum_index], total);
@@ -1180,8 +1194,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
                                                      SigState *__restrict__ state, int level,
                                                      int keep_nan = 0 /* single-level helper: store the baseline as computed (the NaN -> +inf
                                                                          write, ITD.py:50, belongs to the driver's stop test) */,
-                                                     int32_t *__restrict__ tie_out = nullptr /* FUSE0, optional [batch][n_tiles]: 1 = the tile
-                                                                         holds an exact tie of neighbouring samples (itd_knotfirst.hpp) */)
+                                                     unsigned long long *__restrict__ near_out = nullptr /* TIES, [batch][n_tiles][8]: flag
+                                                                         words of both samples of every near tie of the baseline this launch
+                                                                         writes (the launch in front of the fused sparse levels) */)
 {
     constexpr int G2 = TW / 128;   // 128-sample groups; flag words 2g (even samples) and 2g+1 (odd samples)
     static_assert(TW % 128 == 0 && 2 * G2 <= kMaxGroups, "tile geometry");
@@ -1318,7 +1333,6 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int rem = ni - si;            // samples of the signal from the tile's first on (>= 1)
     const bool full = rem >= TW;
     int nb = 0, nf = 0, own_c = 0;   // real knots found in front (0..2) / behind (0..3); the tile's own knots
-    bool tie_here = false;           // FUSE0: the tile's samples hold an exact tie (wave-uniform; flagged with the tile's count store)
     // the tile's own knots, decoded once: kinfo[g] = ke | bitE << 16 | bitO << 17 with ke = knots of the tile at or before the
     // lane's even sample of group g; gcnt = the groups' knot counts, 8 bits each
     int kinfo[G2];
@@ -1472,12 +1486,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         }
         // window = [s-128, s+TW+128): positions allowed to flag are the signal's 1 .. n-2 (ITD.py:70-73)
         unsigned long long E[G2 + 2], O[G2 + 2];
-        if constexpr (TIES) {   // the launch in front of the fused sparse levels: flag tiles that hold an exact tie
-            unsigned long long zero_any = 0;
-            knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O, &zero_any);
-            tie_here = zero_any != 0;   // (padding zeros beyond the row flag the last tile: harmless)
-        } else
-            knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O);
+        knot_masks<Tin, G2 + 2>(v, max(1, 129 - si), min(TW + 255, rem + 126), E, O);
         PROF_MARK(1)   // the tile has arrived; knot predicate on tile + halo groups
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
@@ -1811,7 +1820,7 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         // TIES on a record-driven launch (the level in front of the fused sparse levels): near ties of the baseline it has just written
         scan_publish<TW, FINAL, TIES && !FUSE0>(xr, x_lo, x_hi, s, nrem, slot0 + t, ((size_t)sig * n_groups + t / kTilesPerGroup) * kGsumPitch,
                                                 counts_out, recs_out, gsum_out, s_rec, s_pos, FUSE0 ? own_c : 0,
-                                                (TIES && (tie_here || !FUSE0)) ? tie_out + slot0 + t : nullptr);
+                                                (TIES && !FUSE0) ? near_out + (slot0 + t) * 8 : nullptr);
     }
     wave_sync();   // the next tile's staging must not overtake this tile's LDS reads
     PROF_MARK(7)   // next level's scan + record

@@ -84,7 +84,8 @@ struct KfWs {
     KfEntry *pool;                // [batch][wgs_max][kKcSlab]       a workgroup's tables, level after level
     int32_t *first;               // [batch][nlev][tiles]            pool index (within the signal) of the table entry in front of the tile's knots
     unsigned long long *tflags;   // [batch][nlev][tiles][8]         the level's knots as flag words (flag_pos format)
-    int32_t *tie;                 // [batch][tiles]                  the fused level-0 launch saw a zero difference in the tile (cleared by the sample pass)
+    unsigned long long *nearw;    // [batch][tiles][8]               both samples of every near tie of the first fused level's input, as flag words (written
+                                  //                                 by the launch that wrote that input: k_extract's TIES form)
     unsigned long long *rec;      // [batch][rec_levels][wgs_max][kKcRecGran]   boundary records
     int32_t wgs_max, rec_levels;  // strides of pool / rec
     int32_t nlev, n_tiles, L0;    // this call's geometry
@@ -192,7 +193,6 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     __shared__ unsigned long long t_w[kKcTiles * 8];       // the level's knots as the tiles' flag words
     __shared__ uint32_t s_stage[2][4][16];
     __shared__ int s_red[8], s_i[8], s_cnt[kKcEnt * 4];
-    __shared__ unsigned long long s_tmask[2];              // tiles of the range whose own / whose next tile's tie flag is set
     __shared__ double s_ends[4];                           // the level's x[0], x[1], x[n-2], x[n-1] (as far as this workgroup needs them)
     constexpr int NT = kKcThreads, ENT = kKcEnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -217,23 +217,23 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     const int tpw = ws.tpw;
     const int t0 = w * tpw, t1 = min(n_tiles, t0 + tpw), nt = t1 - t0;
     const int32_t n1 = (int32_t)(n - 1);
-    int32_t *tie = ws.tie + (size_t)sig * n_tiles;
     // everything the hand-over needs is requested before the first use: one round trip
-    unsigned long long w_in[2];
+    unsigned long long w_in[2], s_in[2];
     int c_in[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int q = tid + r * NT, t = t0 + (q >> 3);
-        w_in[r] = 0ull; c_in[r] = 0;
-        if (t < t1) { c_in[r] = counts[(size_t)sig * n_tiles + t]; w_in[r] = recs[(size_t)sig * n_tiles + t].flags[q & 7]; }
+        w_in[r] = s_in[r] = 0ull; c_in[r] = 0;
+        if (t < t1) {
+            c_in[r] = counts[(size_t)sig * n_tiles + t];
+            w_in[r] = recs[(size_t)sig * n_tiles + t].flags[q & 7];
+            s_in[r] = ws.nearw[((size_t)sig * n_tiles + t) * 8 + (q & 7)];
+        }
     }
-    int tie_own = 0, tie_next = 0;
-    if (tid < nt) { tie_own = tie[t0 + tid]; tie_next = t0 + tid + 1 < n_tiles ? tie[t0 + tid + 1] : 0; }
     const double end_in = st->ends[L0 & 1][tid & 3];
     const uint32_t seq = ks->seq;
     const bool active = !st->fin_stopped && st->nan_mask == 0 && !st->in_nan && !st->l0_fail;
     if (!active) {                                                           // (every workgroup of the signal sees the same)
-        if (tid < nt && tie_own) tie[t0 + tid] = 0;
         if (w == 0 && tid == 0) {
             ks->active = 0;
             ks->lend = -1;
@@ -252,21 +252,17 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     auto give_up = [&](int code) { s_i[1] = 1; atomicOr(&ks->fail, code); };
 
     // ---- hand-over: the level-L0 knots of the range (flag words of the records the launch for level L0 - 1 left); sticky
-    //      candidates: sample n-2, both samples of every near tie of the level's input (near_tie(); rare: the launch that wrote
-    //      it flagged the tile)
+    //      candidates: sample n-2, both samples of every near tie of the level's input (near_tie(): flag words the launch that
+    //      wrote it left)
     unsigned long long *s_w = reinterpret_cast<unsigned long long *>(k_B);   // (sticky words: until the first level needs k_B)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int q = tid + r * NT;
         t_w[q] = c_in[r] > 0 ? w_in[r] : 0ull;                               // (an empty tile's record holds no words)
-        s_w[q] = 0ull;
+        s_w[q] = s_in[r];
     }
     if (tid < 4) s_ends[tid] = end_in;
     if (tid == 0) s_i[1] = 0;
-    if (wave == 0) {                                                         // a near tie (p-1, p) is flagged in p's tile
-        const unsigned long long mo = __ballot(tie_own != 0), mn_ = __ballot(tie_next != 0);
-        if (lane == 0) { s_tmask[0] = mo; s_tmask[1] = mo | mn_; }
-    }
     if (w == 0 && tid == 0) ks->active = 1;
     kc_barrier();
     KC_MARK(2);
@@ -276,23 +272,6 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
         if (p >= 1 && tp >= t0 && tp < t1) {
             const int q = (int)(p - (int64_t)tp * TW);
             s_w[(tp - t0) * 8 + 2 * (q >> 7) + (q & 1)] |= 1ull << ((q & 127) >> 1);
-        }
-    }
-    {
-        unsigned long long tm = s_tmask[1];
-        if (tm) {
-            kc_barrier();                                                 // (uniform: every thread reads the same mask)
-            while (tm) {
-                const int tt = __builtin_ctzll(tm);
-                tm &= tm - 1;
-                for (int i = tid; i < TW; i += NT) {
-                    const int64_t p = (int64_t)(t0 + tt) * TW + i;
-                    if (p >= 1 && p <= n - 2) {
-                        const double a = xs[p - 1], b = xs[p], c = xs[p + 1];
-                        if (near_tie(a, b) || near_tie(b, c)) atomicOr(&s_w[tt * 8 + 2 * (i >> 7) + (i & 1)], 1ull << ((i & 127) >> 1));
-                    }
-                }
-            }
         }
     }
     kc_barrier();
@@ -657,9 +636,6 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     if (s_i[1] && wave == 0) {
         for (int lev = published + 1; lev <= M + 1; ++lev) kc_publish(rec_slot(lev, w), rec_tag(lev), lane, 0, k_pos, k_X, 0.0, 0.0, true);
     }
-    // the tie flags clean themselves (the fused level-0 launch only ever sets them); the neighbour in front has read this range's
-    // first flag before any of its records — which this workgroup has waited for — left
-    if (wave == 1 && lane < nt && ((s_tmask[0] >> lane) & 1)) tie[t0 + lane] = 0;
     // the signal's last workgroup draws the stop rules (ITD.py:400-426) from the list sizes (a workgroup's additions to them are
     // complete — the wait below, by the thread that made them — before its arrival is counted)
     if (tid == 192) {
