@@ -297,9 +297,10 @@ constexpr int32_t kMaxGridY = 65535;   // HIP's limit on gridDim.y
 int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 {
     if (e->chunk > 0) return std::min<int32_t>(std::min<int32_t>(e->chunk, kMaxGridY), batch);
-    // one stream: 2^24 samples per chunk; two or more (the default): 3/4 of that per chunk — two chunks in flight, measured best
-    // on 1024 x 2^20 (chunks of 10-12 signals over 2 streams: 32.5 ms against 35.9 ms with 16 over one, profiles/r02/session2_batch_streams.txt)
-    const int64_t per = e->batch_streams > 1 ? ((int64_t)3 << 22) : ((int64_t)1 << 24);
+    // one stream: 2^24 samples per chunk; two or more (the default): half of that per chunk — two chunks in flight, measured best
+    // on 512 x 2^20 with the fused levels' knot side as one launch (chunks of 8 signals over 2 streams: 12.3 ms against 12.7 with 12
+    // and 13.0 with 16 over one stream; round 2, level by level: 10-12 signals over 2 streams, profiles/r02/session2_batch_streams.txt)
+    const int64_t per = e->batch_streams > 1 ? ((int64_t)1 << 23) : ((int64_t)1 << 24);
     const int64_t c = std::max<int64_t>(1, per / n);
     return (int)std::min<int64_t>(std::min<int64_t>(c, kMaxGridY), batch);   // a chunk's signals are the launches' grid.y
 }

@@ -1229,8 +1229,9 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int32_t *gs = gsum_in + (size_t)sig * n_groups * kGsumPitch;
 #if ITD_EARLY_STOP
     // a signal that stopped at an earlier level streams nothing: the test comes before any load is issued (one scalar
-    // load in front of the wavefront's requests; A/B in profiles/r02_ablation.txt)
-    {
+    // load in front of the wavefront's requests; A/B in profiles/r02_ablation.txt).  Not in the fused level-0 launch: level 0
+    // never stops and is never part of a device-side repair — the round trip in front of its loads bought nothing
+    if constexpr (!FUSE0) {
         const int sl = st->stop_level;
         if ((sl >= 0 && sl < level) || st->skip > 0) return;
     }
@@ -1304,8 +1305,15 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
     const int sl_late = st->stop_level;
 #endif
     // the four end samples of the level's input (ITD.py:101-102): published by the launch that wrote it; FUSE0: the signal's own
-    const double e0 = FUSE0 ? (double)x[0] : st->ends[level & 1][0], e1 = FUSE0 ? (double)x[1] : st->ends[level & 1][1];
-    const double e2 = FUSE0 ? (double)x[n - 2] : st->ends[level & 1][2], e3 = FUSE0 ? (double)x[n - 1] : st->ends[level & 1][3];
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+    if constexpr (FUSE0) {
+        // only a tile within the halo search's reach of an end of the signal (128 + kReach x 510 samples: 9 tiles) can ever use them:
+        // every other wavefront goes on without waiting for four scalar loads from the far ends of the signal
+        const int t_first = launch_item(blockIdx.x, gridDim.x, level) * KT;
+        if (t_first < 12 || t_first + KT + 12 > n_tiles) { e0 = (double)x[0]; e1 = (double)x[1]; e2 = (double)x[n - 2]; e3 = (double)x[n - 1]; }
+    } else {
+        e0 = st->ends[level & 1][0]; e1 = st->ends[level & 1][1]; e2 = st->ends[level & 1][2]; e3 = st->ends[level & 1][3];
+    }
 #if !ITD_EARLY_STOP
     if (sl_late >= 0 && sl_late < level) return;
 #endif
