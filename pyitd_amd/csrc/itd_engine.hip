@@ -536,22 +536,19 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 #undef ITD_LAUNCH_EXTRACT
 #undef ITD_LAUNCH_EXTRACT_KT
         }
-        // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch)
-        {
+        // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch).  With fused sparse levels
+        // the knot side's launch does this for its first level (k_kf_knots: KfFin) — one launch less
+        if (!kf) {
             // blocks per signal: a thread of the row fix-up moves 8 samples (four 16-byte accesses) before the grid is widened
             const int fb = (int)std::min<int64_t>(std::max<int64_t>((n + 8 * kFinalizeThreads - 1) / (8 * kFinalizeThreads), 1), 1024);
             int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
-            const int jf = j_last + 1;      // the level whose input is pending: max_iteration + 2, or the first fused level
-            // fused sparse levels: this launch also clears their per-signal bookkeeping and bumps the signals' record generation
-            int32_t *kf_sig = kf ? reinterpret_cast<int32_t *>(e->kf.sig + b0) : nullptr;
+            const int jf = j_last + 1;      // the level whose input is pending: max_iteration + 2
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
-                                                                       gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
-                                                                       kf_sig, kKfSigZeroWords, (int)(sizeof(KfSig) / 4));
+                                                                       gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
             else
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
-                                                                       e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third,
-                                                                       kf_sig, kKfSigZeroWords, (int)(sizeof(KfSig) / 4));
+                                                                       e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
         }
         }
         if (kf && (phase & 6)) {
@@ -571,8 +568,14 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 // ONE launch: hand-over and every fused level (timed from its dispatch's own begin / end timestamps)
                 const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
                 KfWs a_w = w; int64_t a_ls = xl_stride, a_n = n; const double *a_xl = xl; int a_m = M;
-                const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); const SigState *a_st = state;
-                void *args[] = {&a_w, &a_xl, &a_ls, &a_n, &a_m, &a_c, &a_r, &a_st};
+                const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); SigState *a_st = state;
+                KfFin a_f;      // k_finalize's work for the first fused level (the stop test of its input, the other state set)
+                a_f.rows = rows_c; a_f.rows_stride = rows_stride;
+                a_f.bases = bases_c ? bases_c : pp_c; a_f.bases_stride = bases_c ? rows_stride : 3 * e->pp_pitch;
+                a_f.bases_row_pitch = bases_c ? n : e->pp_pitch; a_f.bases_rotate = bases_c ? 0 : 3;
+                a_f.gsum = gs(L0); a_f.other_state = other_state + b0; a_f.other_gsum = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
+                a_f.other_third = e->gsum_third;
+                void *args[] = {&a_w, &a_f, &a_xl, &a_ls, &a_n, &a_m, &a_c, &a_r, &a_st};
                 HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_knots<T>), dim3((unsigned)w.wgs * (unsigned)nb), dim3(kKcThreads), args, 0, kst,
                                               p_kn >= 0 ? e->ev[2 * (size_t)p_kn] : nullptr, p_kn >= 0 ? e->ev[2 * (size_t)p_kn + 1] : nullptr, 0));
             }

@@ -1908,21 +1908,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_finalize(double *__restric
                                                                int n_tiles, int level_last,
                                                                SigState *__restrict__ state,
                                                                SigState *__restrict__ other_state = nullptr,
-                                                               int32_t *__restrict__ other_gsum = nullptr, int64_t other_third = 0,
-                                                               int32_t *__restrict__ kf_sig = nullptr, int kf_sig_words = 0,
-                                                               int kf_sig_stride = 0)
+                                                               int32_t *__restrict__ other_gsum = nullptr, int64_t other_third = 0)
 {
     __shared__ int s_red[kFinalizeThreads / 64];
     const int sig = blockIdx.y;
-    // in front of the fused sparse levels (itd_knotfirst.hpp): the signal's bookkeeping cleared, its generation counter bumped
-    if (kf_sig) {
-        if (blockIdx.x == 0) {
-            // (kf_sig_words = the words to clear; the word behind them is the generation of the call's boundary records)
-            int32_t *kz = kf_sig + (size_t)sig * kf_sig_stride;
-            for (int i = threadIdx.x; i < kf_sig_words; i += kFinalizeThreads) kz[i] = 0;
-            if (threadIdx.x == 0) kz[kf_sig_words] += 1;
-        }
-    }
     // the other set of states / group sums (itd_engine.hip): left in its initial state for the decomposition after this one —
     // the signal's state, and elements 0 and 1 (all that is ever written) of its group-sum slots in the three rotating buffers
     if (other_state) {

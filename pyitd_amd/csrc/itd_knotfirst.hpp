@@ -61,23 +61,39 @@ static_assert(sizeof(KfEntry) == 32, "table entries are two 16-byte words");
 constexpr int kKfFailVerify = 1, kKfFailCapacity = 2, kKfFailNonFinite = 4, kKfFailTies = 8;
 
 struct KfSig {
-    // ---- the head: what itd_get_summary copies to the host (kKfSigHead bytes); cleared by k_finalize before every call ----
+    // ---- the head: what itd_get_summary copies to the host (kKfSigHead bytes).  Written with plain stores by the signal's last
+    //      knot-side workgroup (workgroup 0 for a signal the fused levels do not run for); the sample pass ORs into `fail` and adds
+    //      to `m_exact` behind that ----
     int32_t fail;
     int32_t active;       // the fused levels run for this signal (it had not stopped before the hand-over, no NaN anywhere)
     int32_t lend;         // the last fused level: rows 0 .. lend are the result (-1: the signal is not active)
     int32_t natural;      // at lend: 1 = natural stop (row lend = the level's input), 0 = "Out of time!" (rotation + baseline)
     int32_t m_exact;      // knots of the last pending baseline, counted by the sample pass
+    int32_t pad0[3];
+    int32_t mlev[kMaxLevels + 2];   // knots of level j's input
+    // ---- the knot side's accumulators: zero between calls (the signal's last workgroup reads and clears them; the workspace starts
+    //      zeroed), so no launch has to prepare them ----
+    int32_t acc_mlev[kMaxLevels + 2];
+    int32_t acc_fail;
     int32_t nf;           // 64 - (the first level whose knot data was not finite); 0 = all finite
     int32_t done;         // workgroups of the signal that have finished
-    int32_t ticket;       // (first signal of a launch) the launch's workgroup tickets
-    int32_t mlev[kMaxLevels + 2];   // knots of level j's input
-    // ---- not cleared ----
-    uint32_t seq;         // bumped by k_finalize: the generation in the tags of this call's records
-    uint32_t pad;
+    int32_t ticket;       // (first signal of a launch that hands out tickets) the launch's workgroup tickets ...
+    int32_t fin;          // ... and its finished workgroups: the last one clears both
+    int32_t pad1;
+    uint32_t seq;         // the generation in the tags of a call's records: bumped by the signal's last workgroup
+    uint32_t pad2;
 };
 constexpr size_t kKfSigHead = (8 + kMaxLevels + 2) * sizeof(int32_t);
-constexpr int kKfSigZeroWords = 8 + kMaxLevels + 2;      // what k_finalize clears (the word behind them is seq)
-static_assert(sizeof(KfSig) == kKfSigHead + 8, "KfSig layout");
+static_assert(offsetof(KfSig, acc_mlev) == kKfSigHead, "KfSig layout");
+
+// what the knot side's launch needs to do k_finalize's work (itd_kernels.hpp) for the hand-over level: the stop test of that level's
+// input with its row fix-up, and the other set of states / group sums left initialised for the call after this one
+struct KfFin {
+    double *rows; int64_t rows_stride;
+    const double *bases; int64_t bases_stride, bases_row_pitch; int32_t bases_rotate;
+    const int32_t *gsum;                 // the hand-over level's group sums
+    SigState *other_state; int32_t *other_gsum; int64_t other_third;
+};
 
 struct KfWs {
     KfSig *sig;                   // [batch]
@@ -175,9 +191,9 @@ __device__ unsigned long long *g_kc_prof;   // [workgroups][64]
 //      tickets — whoever starts first takes the lowest range, so whatever a resident workgroup waits for has started already
 //      or starts without that workgroup finishing first (dependencies reach a few ranges per level, the device holds hundreds).
 template <int TW>
-__global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64_t n, int max_iteration,
+__global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, const double *__restrict__ xl, int64_t xl_stride, int64_t n, int max_iteration,
                                                          const int32_t *__restrict__ counts, const TileRec *__restrict__ recs,
-                                                         const SigState *__restrict__ state)
+                                                         SigState *__restrict__ state)
 {
     static_assert(TW == 512 && kKcTiles * (TW / 128) == kKcThreads && kKcTiles == 64, "one thread per 128-sample group, one lane per tile");
     // the candidates: position, the level's values at position - 1, position, position + 1,
@@ -212,11 +228,15 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     const int sig = id / W, w = id - sig * W;
     if (sig >= ws.nb) return;
     KfSig *ks = ws.sig + sig;
-    const SigState *st = state + sig;
+    SigState *st = state + sig;
     const int n_tiles = ws.n_tiles, L0 = ws.L0, M = max_iteration;
     const int tpw = ws.tpw;
     const int t0 = w * tpw, t1 = min(n_tiles, t0 + tpw), nt = t1 - t0;
     const int32_t n1 = (int32_t)(n - 1);
+    // a launch that hands out tickets counts its finished workgroups: the last one clears both counters for the next call
+    auto launch_done = [&]() {
+        if (ws.ticketed && tid == 192 && atomicAdd(&ws.sig[0].fin, 1) == W * ws.nb - 1) { ws.sig[0].ticket = 0; ws.sig[0].fin = 0; }
+    };
     // everything the hand-over needs is requested before the first use: one round trip
     unsigned long long w_in[2], s_in[2];
     int c_in[2];
@@ -230,15 +250,61 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
             s_in[r] = ws.nearw[((size_t)sig * n_tiles + t) * 8 + (q & 7)];
         }
     }
+    const int n_groups = groups_of(n_tiles);
+    int m_part = 0;                                                          // this level's knots: the launch in front left group sums
+    {
+        const int32_t *gs = fin.gsum + (size_t)sig * n_groups * kGsumPitch;
+        for (int g = tid; g < n_groups; g += NT) m_part += gs[(size_t)g * kGsumPitch];
+    }
     const double end_in = st->ends[L0 & 1][tid & 3];
     const uint32_t seq = ks->seq;
-    const bool active = !st->fin_stopped && st->nan_mask == 0 && !st->in_nan && !st->l0_fail;
-    if (!active) {                                                           // (every workgroup of the signal sees the same)
+    int stop_level = st->stop_level;
+    const int nan_mask = st->nan_mask, c_delta = L0 >= 1 ? st->c_delta[L0 - 1] : 0;
+    const bool odd_input = nan_mask != 0 || st->in_nan || st->l0_fail;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m_part += __shfl_xor(m_part, d);
+    if (lane == 0) s_red[wave] = m_part;
+    if (tid == 0) s_i[1] = 0;
+    kc_barrier();
+    // ---- what k_finalize does behind a level-by-level call (ITD.py:400-416): the stop test of the pending baseline — here the first
+    //      fused level's input —, the residual row of a signal that has stopped, the other set of states left ready for the next call
+    bool stopped = stop_level >= 0;
+    if (!stopped) {
+        int m_last = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (L0 >= 1 && ((nan_mask >> (L0 - 1)) & 1)) m_last += c_delta;     // the baseline held a NaN: counted under the NaN rules (nan_rules)
+        if (m_last < 2) { stopped = true; stop_level = L0; }
+        if (w == 0 && tid == 0) st->m[L0] = m_last;
+    }
+    if (w == 0) {
+        if (tid == 0) { st->fin_stopped = stopped ? 1 : 0; st->fin_stop_level = stop_level; }
+        if (fin.other_state) {
+            if (tid == 0) sig_state_reset(fin.other_state + sig);
+            int32_t *og = fin.other_gsum + (size_t)sig * n_groups * kGsumPitch;
+            for (int k = tid; k < 3 * n_groups; k += NT) {
+                int32_t *slot = og + (size_t)(k / n_groups) * fin.other_third + (size_t)(k % n_groups) * kGsumPitch;
+                slot[0] = 0;
+                slot[1] = 0;
+            }
+        }
+    }
+    if (stopped) {      // row c = stop_level - 1 of the result is baselines[c-1], or zeros when c = 0: this workgroup's samples of it
+        const int c_row = stop_level - 1;
+        double *dst = fin.rows + (int64_t)sig * fin.rows_stride + (int64_t)c_row * n;
+        const double *src = nullptr;
+        if (c_row >= 1) {
+            const int row = fin.bases_rotate ? ((c_row - 1) % fin.bases_rotate) : (c_row - 1);
+            src = fin.bases + (int64_t)sig * fin.bases_stride + (int64_t)row * fin.bases_row_pitch;
+        }
+        const int64_t lo = (int64_t)t0 * TW, hi = min((int64_t)t1 * TW, n);
+        for (int64_t i = lo + tid; i < hi; i += NT) dst[i] = src ? src[i] : 0.0;
+    }
+    if (stopped || odd_input) {                                              // (every workgroup of the signal sees the same)
         if (w == 0 && tid == 0) {
             ks->active = 0;
             ks->lend = -1;
-            if (!st->fin_stopped) ks->fail = kKfFailNonFinite;                // NaN rules / an unfinished level 0: not this path's
+            ks->fail = stopped ? 0 : kKfFailNonFinite;                        // NaN rules / an unfinished level 0: not this path's
         }
+        launch_done();
         return;
     }
     unsigned long long *rec_sig = ws.rec + ((size_t)sig * ws.rec_levels) * ws.wgs_max * kKcRecGran;
@@ -249,7 +315,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     const double *xs = xl + (int64_t)sig * xl_stride;
     auto rec_slot = [&](int lev, int v) { return rec_sig + ((size_t)(lev - L0) * ws.wgs_max + v) * kKcRecGran; };
     auto rec_tag = [&](int lev) { return seq * 64u + (uint32_t)(lev - L0 + 1); };
-    auto give_up = [&](int code) { s_i[1] = 1; atomicOr(&ks->fail, code); };
+    auto give_up = [&](int code) { s_i[1] = 1; atomicOr(&ks->acc_fail, code); };
 
     // ---- hand-over: the level-L0 knots of the range (flag words of the records the launch for level L0 - 1 left); sticky
     //      candidates: sample n-2, both samples of every near tie of the level's input (near_tie(): flag words the launch that
@@ -262,7 +328,6 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
         s_w[q] = s_in[r];
     }
     if (tid < 4) s_ends[tid] = end_in;
-    if (tid == 0) s_i[1] = 0;
     if (w == 0 && tid == 0) ks->active = 1;
     kc_barrier();
     KC_MARK(2);
@@ -326,7 +391,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
                 if (c_fl[j] & 1) k_X[c_rk[j] + 1] = b[i];
             }
         }
-        if (tid == 192) atomicAdd(&ks->mlev[L0], ck);
+        if (tid == 192) atomicAdd(&ks->acc_mlev[L0], ck);
     }
     kc_barrier();
     KC_MARK(3);
@@ -621,7 +686,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
         }
         if (li == 1) KC_MARK(48);
         if (tid == 192) {
-            atomicAdd(&ks->mlev[lev + 1], ckn);
+            atomicAdd(&ks->acc_mlev[lev + 1], ckn);
             if (w == 0) { s_ends[0] = ne0; s_ends[1] = ne1; }
             if (w == W - 1) { s_ends[2] = ne2; s_ends[3] = 0.0; }
         }
@@ -636,21 +701,35 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, const double *
     if (s_i[1] && wave == 0) {
         for (int lev = published + 1; lev <= M + 1; ++lev) kc_publish(rec_slot(lev, w), rec_tag(lev), lane, 0, k_pos, k_X, 0.0, 0.0, true);
     }
-    // the signal's last workgroup draws the stop rules (ITD.py:400-426) from the list sizes (a workgroup's additions to them are
-    // complete — the wait below, by the thread that made them — before its arrival is counted)
+    // the signal's last workgroup draws the stop rules (ITD.py:400-426) from the list sizes, publishes the verdict and leaves the
+    // accumulators cleared for the next call (every workgroup's additions to them are complete — each wavefront's wait below —
+    // before its arrival is counted)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    kc_barrier();
     if (tid == 192) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(&ks->done, 1) == W - 1) {
             int lend = M + 1, natural = 0;
             for (int lev = L0; lev <= M + 1; ++lev) {
-                if (__hip_atomic_load(&ks->mlev[lev + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) { lend = lev; natural = 1; break; }   // "No more decompositions possible"
+                if (__hip_atomic_load(&ks->acc_mlev[lev + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) { lend = lev; natural = 1; break; }   // "No more decompositions possible"
             }
             const int nf = __hip_atomic_load(&ks->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (nf && 64 - nf <= lend) atomicOr(&ks->fail, kKfFailNonFinite);
+            int fail = __hip_atomic_load(&ks->acc_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nf && 64 - nf <= lend) fail |= kKfFailNonFinite;
+            for (int j = 0; j < kMaxLevels + 2; ++j) {
+                ks->mlev[j] = __hip_atomic_load(&ks->acc_mlev[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ks->acc_mlev[j] = 0;
+            }
+            ks->fail = fail;
+            ks->m_exact = 0;
             ks->natural = natural;
             ks->lend = lend;
+            ks->acc_fail = 0;
+            ks->nf = 0;
+            ks->done = 0;
+            ks->seq = seq + 1;
         }
     }
+    launch_done();
 #if ITD_PROF
     KC_MARK(60);
     if (tid == 0 && g_kc_prof) {

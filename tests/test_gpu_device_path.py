@@ -311,6 +311,7 @@ def test_state_sets_survive_changing_geometry(P, torch, oracle):
         B, n = xs.shape
         x = torch.from_numpy(xs).cuda()
         rows = torch.full((B, M + 2, n), -3.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()     # (the fill runs on torch's stream, the engine on its own: unordered, the fill overwrote rows now and then)
         eng.decompose_dev(x.data_ptr(), np.float64, n, B, n, M, rows.data_ptr(), None, None)
         if not read_summary:
             torch.cuda.synchronize()

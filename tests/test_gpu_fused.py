@@ -434,6 +434,7 @@ def test_small_ranges_and_deep_levels_deliver_or_refuse_never_wrong(P, torch, or
         eng.set_fuse_range(tiles)
         xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
         rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
         try:
             eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), None, None)
             s = eng.summary(1)

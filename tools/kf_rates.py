@@ -27,6 +27,7 @@ def one(x, m):
     eng.set_fuse_mode(FUSE_ONLY)
     xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()        # (the fill runs on torch's stream, the engine on its own)
     try:
         for tiles in (64, 32, 16):          # (what the automatic mode does over consecutive calls: a list that outgrew its workgroup halves the ranges)
             eng.set_fuse_range(tiles)
