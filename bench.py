@@ -316,15 +316,17 @@ def run_rank(args):
     if not sharded and not stub:
         eng.set_timing(args.steps, stride=TIMING_STRIDE)      # (allocates the events; re-armed below)
         eng.set_timing(0)
+    # (the summary first: reading it leaves the GPU idle for a few hundred microseconds, and 20 steps timed a millisecond after
+    #  such a gap ran 5-7 % below the rate the same build sustains — 0.423 against 0.396 ms, profiles/r04 — so nothing but steps
+    #  lies between the warm-up below and the timed region)
+    step()
     sync()
+    summ = sb.local_summary()
     t_w = time.perf_counter()
     while not stub and (time.perf_counter() - t_w) * 1e3 < args.warm_ms:
         for _ in range(8):
             step()
         sync()
-    step()
-    sync()
-    summ = sb.local_summary()
     # on every 4th step of the timed region the launches carry their own hipEvent pair (hipExtLaunchKernel: the dispatch's
     # begin/end timestamps, the same thing rocprofv3 reports); such a launch costs ~2 us more, hence the stride
     for _ in range(args.warmup):
