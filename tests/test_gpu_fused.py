@@ -173,6 +173,11 @@ def test_first_fused_level_is_two_at_least(P):
             eng.set_fuse_level(bad)
     eng.set_fuse_level(2)
     eng.set_fuse_level(20)
+    for bad in (1, 8, 48, 128, -16):              # tiles per knot-side workgroup: 0 (automatic), 16, 32 or 64
+        with pytest.raises(ITDError):
+            eng.set_fuse_range(bad)
+    for ok in (16, 32, 64, 0):
+        eng.set_fuse_range(ok)
     eng.close()
 
 
@@ -447,3 +452,50 @@ def test_small_ranges_and_deep_levels_deliver_or_refuse_never_wrong(P, torch, or
         assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "case %d (family %d, n %d, %d levels, %d tiles per workgroup)" % (case, kind, n, m + 1, tiles))
         delivered += 1
     assert delivered >= 4
+
+
+def test_knot_side_with_more_workgroups_than_the_device_holds(P, torch, oracle):
+    """A knot-side launch whose workgroups do not all fit the device at once hands out tickets instead of taking its ids from
+    blockIdx (itd_knotfirst.hpp): one 2^23-sample signal with 16-tile ranges (1024 workgroups), and a batch of 40 signals of 2^19
+    samples in ONE chunk (640 workgroups, several of them for a signal that has stopped) — rows bit-exact, twice in a row (the
+    ticket counters clean themselves)."""
+    from pyitd_amd.engine import FUSE_ONLY, FUSE_AUTO
+    n, m = 1 << 23, 7
+    x = sines_noise(n, seed=77)
+    ref = oracle.itd_lean(x, m)
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_ONLY)
+    eng.set_fuse_range(16)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for call in range(2):
+        rows.fill_(float("nan"))
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+        s = eng.summary(1)
+        nr = int(s["n_rows"][0])
+        assert nr == ref["rows"].shape[0]
+        assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "2^23 samples, 1024 knot-side workgroups, call %d" % call)
+    eng.close()
+    del rows, xd
+    B, n = 40, 1 << 19
+    xs = np.stack([sines_noise(n, seed=300 + b, fscale=1 + b / 64.0) for b in range(B)])
+    xs[7] = np.linspace(-1.0, 1.0, n)            # stops at once: its workgroups return at the hand-over
+    eng = P.Engine(n, B, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_batch_chunk(B)
+    eng.set_batch_streams(1)
+    xd = torch.from_numpy(xs).cuda()
+    rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for call in range(2):
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
+        s = eng.summary(B)
+        assert eng.fuse_repeats == 0
+        for b in (0, 7, 8, 23, 39):
+            rb = oracle.itd_lean(xs[b], m)
+            nr = int(s["n_rows"][b])
+            assert nr == rb["rows"].shape[0], "signal %d" % b
+            assert_bits_equal(rows[b, :nr].cpu().numpy(), rb["rows"], "batch of 40 in one chunk, call %d signal %d" % (call, b))
+    eng.close()

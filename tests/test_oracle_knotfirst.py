@@ -27,6 +27,13 @@ def _levels_of(x, m):
     ("random walk f32", fuzz_signal(np.random.default_rng(2), 1, 50000).astype(np.float32), 9, 3),
     ("alternating", fuzz_signal(np.random.default_rng(3), 6, 30000), 9, 2),
     ("radio clip", load_golden("radio8000_input")["x"], 11, 2),
+    # int16 PCM as float32 (the reference's own domain, PyITD.ipynb cell 2): exact ties in the input, more of them grown at levels
+    # 1-2 (adjacent knots on a grid), ties broken by an ulp and restored: delivered since the near ties of the hand-over level are
+    # candidates (round 3's rule — the exact ties of the original signal — misses knots at level 4 of this very signal)
+    ("sines 2^18 as 16-bit PCM", (np.round(sines_noise(1 << 18, seed=9).astype(np.float64) / np.abs(sines_noise(1 << 18, seed=9)).max() * 32767.0)
+                                  / 32768.0).astype(np.float32), 7, 3),
+    ("sines 2^17 as 12-bit PCM", (np.round(sines_noise(1 << 17, seed=10).astype(np.float64) / np.abs(sines_noise(1 << 17, seed=10)).max() * 2047.0)
+                                  / 2048.0).astype(np.float32), 9, 3),
 ])
 def test_knot_side_recursion_reproduces_the_oracle(name, x, m, L0):
     ref, lv = _levels_of(x, m)
