@@ -499,3 +499,28 @@ def test_knot_side_with_more_workgroups_than_the_device_holds(P, torch, oracle):
             assert nr == rb["rows"].shape[0], "signal %d" % b
             assert_bits_equal(rows[b, :nr].cpu().numpy(), rb["rows"], "batch of 40 in one chunk, call %d signal %d" % (call, b))
     eng.close()
+
+
+def test_a_list_that_outgrows_its_workgroup_halves_the_ranges_of_the_next_calls(P, torch, oracle):
+    """White noise has ~13 knots per tile at level 3: with 64 tiles per knot-side workgroup the candidate lists outgrow the LDS.
+    The automatic mode repeats that call level by level and runs the NEXT ones fused with 32 tiles per workgroup (a reallocation of
+    the fused levels' workspace between two calls): every call equals the oracle, only the first is repeated."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m = 300000, 7
+    x = fuzz_signal(np.random.default_rng(77), 0, n).astype(np.float32)
+    ref = oracle.itd_lean(x, m)
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_min_samples(65536)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    for call in range(3):
+        rows.fill_(float("nan"))
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+        s = eng.summary(1)
+        nr = int(s["n_rows"][0])
+        assert nr == ref["rows"].shape[0]
+        assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "white noise, call %d" % call)
+        assert eng.fuse_repeats == 1, "call %d: only the first call is repeated (then the ranges are halved)" % call
+    eng.close()
