@@ -163,8 +163,6 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
 #define ITD_NAN_INPUT_FOLLOW 0
 #define ITD_NAN_INPUT_REJECT 1
 int itd_set_nan_input_mode(itd_engine *e, int32_t mode);
-/* ABI revision 1 switched a NaN-faithful re-run on and off here; kept as a no-op (always faithful now) */
-int itd_set_nan_fallback(itd_engine *e, int enable);
 /* Level 0 of a decomposition (the caller's signal) finds its knots in one of two ways:
  *   fused    the level-0 extraction launch evaluates the knot predicate itself and takes each tile's neighbouring knots from
  *            the 128 samples either side of the tile (walking on through up to ~4000 samples where those hold too few): the

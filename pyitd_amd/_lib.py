@@ -70,7 +70,6 @@ ABI = {
     "itd_stream_push_host_f64": (_INT, [_P, _P, _P, _P, _P]),
     "itd_stream_flush_host_f64": (_INT, [_P, _P, _P, _P]),
     "itd_stream_status": (_INT, [_P, _P]),
-    "itd_set_nan_fallback": (_INT, [_P, _INT]),
     "itd_set_nan_input_mode": (_INT, [_P, _I32]),
     "itd_set_batch_chunk": (_INT, [_P, _I32]),
     "itd_set_batch_streams": (_INT, [_P, _I32]),

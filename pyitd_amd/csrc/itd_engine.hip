@@ -1306,14 +1306,6 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
     return ITD_OK;
 }
 
-int itd_set_nan_fallback(itd_engine *e, int enable)
-{
-    // kept for ABI compatibility: since ABI revision 2 the extraction kernel itself follows the reference's NaN rules
-    // (nan_rules in itd_kernels.hpp), there is no separate re-run to switch off
-    (void)enable;
-    return e ? ITD_OK : ITD_ERR_INVALID_ARG;
-}
-
 int itd_set_level0_mode(itd_engine *e, int32_t mode)
 {
     if (!e || mode < ITD_LEVEL0_AUTO || mode > ITD_LEVEL0_FUSED) return ITD_ERR_INVALID_ARG;

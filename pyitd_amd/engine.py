@@ -103,10 +103,6 @@ class Engine:
         self._check(self._L.itd_set_kernel_timing_stride(self._h, int(stride)))
         self._check(self._L.itd_set_kernel_timing(self._h, int(max_decompositions)))
 
-    def set_nan_fallback(self, on):
-        """No-op since ABI revision 2 (the extraction kernel follows the reference's NaN rules itself)."""
-        self._check(self._L.itd_set_nan_fallback(self._h, 1 if on else 0))
-
     def set_nan_input_mode(self, mode):
         """NAN_INPUT_FOLLOW (default: a NaN in the input is treated as the reference treats it, ITD.py:46-51) or NAN_INPUT_REJECT."""
         self._check(self._L.itd_set_nan_input_mode(self._h, int(mode)))
