@@ -571,17 +571,22 @@ def run_rank(args):
         # N > 1: every GPU runs its shard as chunks whose launches overlap on two streams, so a single launch's duration is not
         # a rate; the figure is the whole decomposition's algorithmic bytes (188 B/sample) per GPU over the max-over-ranks time.
         # The per-launch figure of the dominant kernel is the N = 1 line's.
-        per_gpu_gbps = algorithmic_bytes_per_sample(LEVELS) * float(n) * per_gpu * args.steps / elapsed / 1e9
+        # own bytes: with levels 3 .. 8 fused (the default) the engine moves 20 + 24 x 2 + (8 + 8 x 6) = 124 B per sample; level by level
+        # (--no-fuse, or a refused and re-timed run) the reference flow's 188
+        ran_fused = not fused_refused and not args.no_fuse
+        own_bytes = 124.0 if ran_fused else float(algorithmic_bytes_per_sample(LEVELS))
+        per_gpu_gbps = own_bytes * float(n) * per_gpu * args.steps / elapsed / 1e9
         out["roofline"] = {
             "bound": "hbm",
-            "kernel": "whole decomposition per GPU: fused level-0 launch + %d x k_extract<double> + final launch + k_finalize per chunk "
-                      "(20 + 24 x %d B/sample); per-launch figure of k_extract<double>: see the N = 1 line" % (LEVELS - 1, LEVELS - 1),
+            "kernel": "whole decomposition per GPU, own bytes (%d B/sample: %s); per-launch figures: the N = 1 line"
+                      % (int(own_bytes), "levels 0-2 one launch each, levels 3-8 fused" if ran_fused else "one launch per level"),
             "achieved": round(per_gpu_gbps, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(per_gpu_gbps / HBM_PEAK_GBPS, 4),
             "traffic": None,
             "per_gpu": True,
+            "reference_flow_equivalent_GBps_per_gpu": round(algorithmic_bytes_per_sample(LEVELS) * float(n) * per_gpu * args.steps / elapsed / 1e9, 1),
         }
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only (the N = 1 line of the same build carries all four CPU legs)
     if world == 1 and not stub and not args.no_cpu_baseline:
