@@ -380,3 +380,24 @@ def test_knot_values_on_device_buffers(P, torch, oracle):
     assert got[0] == -5.0 and got[-1] == -5.0
     assert_bits_equal(got[1:-1], want[1:-1], "knot values on device buffers")
     eng.close()
+
+
+def test_c_abi_shard_scatter_on_one_rank(P, torch):
+    """itd_shard_scatter with a world of one is a stream-ordered local copy (no communicator, RCCL never loaded); with more ranks
+    and no communicator it refuses instead of guessing.  (More than one rank over RCCL: test_two_gpu_ranks_shard_and_gather_over_rccl,
+    where two devices are visible.)"""
+    import ctypes
+    from pyitd_amd import _lib
+    L = _lib.load()
+    B, n = 5, 4099
+    x = torch.randn((B, n), dtype=torch.float32, device="cuda")
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    rc = L.itd_shard_scatter(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), n, B, 4, 1, 0, 0, None, ctypes.c_void_p(s.cuda_stream))
+    assert rc == 0
+    s.synchronize()
+    assert torch.equal(x, y)
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    assert L.itd_shard_range(B, 2, 1, ctypes.byref(lo), ctypes.byref(hi)) == 0 and (lo.value, hi.value) == (3, 5)
+    assert L.itd_shard_scatter(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), n, B, 4, 2, 0, 0, None, None) != 0
