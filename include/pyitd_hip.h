@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 7
+#define ITD_ABI_VERSION 8
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -360,6 +360,36 @@ int itd_baseline_extract_spline_host2_f64(itd_engine *e, const double *x_host, i
  * list — `matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size` (MEITD.py:350, :376, :409) is mode ITD_DETECT_KNOTS.
  * Plain rules; returns ITD_ERR_NONFINITE (counts filled in) if a signal holds a NaN.  batch <= 65535. */
 int itd_count_knots_host_f64(itd_engine *e, const double *x_host, int64_t n, int32_t batch, int32_t mode, int32_t *counts_host);
+/* ---- MEITD's operators on device-resident signals (ABI revision 8) --------------------------------
+ * MEITD.py:344-534 keeps one signal, its rotation and its baseline in a loop of extractions, knot counts and entropy tests: with
+ * these entries the arrays stay on the device for the whole loop and only scalars come back (pyitd_amd/meitd.py).
+ *
+ * itd_count_knots_f64: itd_count_knots_host_f64 for signals that are on the device already (signal b at x_dev + b*x_stride).
+ *
+ * itd_wpe3_f64: weighted_permutation_entropy(x, order=3), MEITD.py:79-128, as far as it touches the samples — for each of the six
+ * permutation patterns of the windows (x[i], x[i+1], x[i+2]), in numpy.unique's order of the reference's hash values
+ * (5, 7, 11, 15, 19, 21 = argsort (2,1,0), (1,2,0), (2,0,1), (0,2,1), (1,0,2), (0,1,2)): bin_weights_host[6] the sum of the
+ * windows' variances, bin_windows_host[6] the number of windows (a pattern without windows is absent from the reference's list).
+ * The argsort is numpy's (insertion on three values, NaNs last, ties in index order), the variance numpy.var's expression; up to
+ * 65536 windows the sums are taken one by one in index order like the reference's cumsum, longer signals in segments of 4096
+ * windows added in order (deterministic, equal to rounding).  The entropy itself is six logarithms on the host:
+ * p = w / sum(w); -sum(p log2 p) [/ log2(6)].  knots_host (optional): x's knot count (ITD_DETECT_KNOTS) in the same
+ * synchronisation — MEITD.py:346-351, :373-378 ask for both; then ITD_ERR_NONFINITE (count filled in) if x holds a NaN.
+ *
+ * itd_baseline_extract_spline2_f64: itd_baseline_extract_spline_f64 plus baseline_knots_host [batch], the knot count of every
+ * PRODUCED baseline, one synchronisation for both (the device form of itd_baseline_extract_spline_host2_f64).
+ *
+ * itd_subtract_f64: out = a - b, elementwise (MEITD.py:453), enqueued.   itd_copy: a copy ordered on the engine's stream (or
+ * `stream`): kind 0 device -> host, 1 host -> device, 2 device -> device, 3 zero fill (src ignored); wait != 0 returns when done. */
+int itd_count_knots_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride, int32_t mode,
+                        int32_t *counts_host, void *stream);
+int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weights_host, int64_t *bin_windows_host,
+                 int32_t *knots_host, void *stream);
+int itd_baseline_extract_spline2_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                                     int32_t min_extrema, double *baseline_dev, int64_t baseline_stride, double *rot_dev,
+                                     int64_t rot_stride, int32_t *knots_host, int32_t *baseline_knots_host, void *stream);
+int itd_subtract_f64(itd_engine *e, const double *a_dev, const double *b_dev, double *out_dev, int64_t count, void *stream);
+int itd_copy(itd_engine *e, void *dst, const void *src, int64_t bytes, int32_t kind, int32_t wait, void *stream);
 /* crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols float64 (the ensemble
  * members of retrieve_statistical_image_component go through in one call): the operator over every row, then over every
  * column of that; over every column, then every row of that; the mean of the two.  Transposes and the mean run on the GPU. */

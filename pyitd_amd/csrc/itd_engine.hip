@@ -30,6 +30,7 @@
 #include "itd_tfe.hpp"
 #include "itd_spline.hpp"
 #include "itd_nak.hpp"
+#include "itd_wpe.hpp"
 
 #ifndef ITD_TILE
 #define ITD_TILE 512
@@ -217,6 +218,7 @@ struct itd_engine {
     void *d_sp = nullptr; size_t sp_bytes = 0;            // spline flavour (batched): lists, counts, records, group sums, states,
                                                           // ordered knot lists, totals, fit arrays, metadata
     double *d_sp2 = nullptr; size_t sp2_bytes = 0;        // 2-D consumers: three planes of scratch
+    char *d_wpe = nullptr; size_t wpe_bytes = 0;          // weighted permutation entropy: the segments' sums
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
     double *d_io_bases = nullptr; size_t io_bases_bytes = 0;
@@ -955,7 +957,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
     (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); (void)hipFree(e->d_flag); (void)hipFree(e->d_need); (void)hipFree(e->d_valid_own);
-    (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2);
+    (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2); (void)hipFree(e->d_wpe);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_kf) (void)hipHostFree(e->h_kf);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
@@ -2197,6 +2199,133 @@ int itd_count_knots_host_f64(itd_engine *e, const double *x_host, int64_t n, int
     bool nan_in = false;
     for (int b = 0; b < batch; ++b) { counts_host[b] = tot[2 * (size_t)b]; nan_in = nan_in || tot[2 * (size_t)b + 1]; }
     return nan_in ? ITD_ERR_NONFINITE : ITD_OK;     // counted under the plain rules: see itd_detect_* for detect_peaks' NaN branch
+}
+
+// ---- MEITD's operators on device-resident signals (MEITD.py:344-534 keeps one signal and its rotations / baselines in a loop:
+//      nothing but a few scalars has to cross PCIe per pass) -----------------------------------------------------------------
+int itd_count_knots_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride, int32_t mode,
+                        int32_t *counts_host, void *stream)
+{
+    if (!e || !x_dev || !counts_host || n < 3 || batch < 1 || batch > kMaxGridY || mode < 0 || mode > 4) return ITD_ERR_INVALID_ARG;
+    if (batch > 1 && x_stride < n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    DetectWs w;
+    int rc = detect_enqueue(e, x_dev, x_stride, n, batch, mode, -1, st, w, nullptr, 0, false);
+    if (rc) return rc;
+    std::vector<int32_t> tot(2 * (size_t)batch);
+    HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    bool nan_in = false;
+    for (int b = 0; b < batch; ++b) { counts_host[b] = tot[2 * (size_t)b]; nan_in = nan_in || tot[2 * (size_t)b + 1]; }
+    return nan_in ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
+// the weighted sums and window counts of the six order-3 permutation patterns of x (itd_wpe.hpp; MEITD.py:79-128), and —
+// optionally, in the same synchronisation — x's knot count: MEITD.py:346-351 and :373-378 ask for both of the same signal
+int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weights_host, int64_t *bin_windows_host,
+                 int32_t *knots_host, void *stream)
+{
+    if (!e || !x_dev || !bin_weights_host || !bin_windows_host || n < 3) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    const int64_t nw = n - 2;
+    const bool exact = nw <= kWpeExactWindows;
+    const int64_t seg_len = exact ? nw : kWpeSeg;
+    const int64_t nseg = (nw + seg_len - 1) / seg_len;
+    if (nseg > INT32_MAX / 8) return ITD_ERR_INVALID_ARG;
+    const size_t out_off = (size_t)nseg * 6 * (sizeof(double) + sizeof(long long));    // the segments' sums, then the totals
+    int rc = grow(e, &e->d_wpe, &e->wpe_bytes, out_off + 6 * (sizeof(double) + sizeof(long long)));
+    if (rc) return rc;
+    double *part_s = reinterpret_cast<double *>(e->d_wpe);
+    long long *part_c = reinterpret_cast<long long *>(part_s + (size_t)nseg * 6);
+    double *out_s = reinterpret_cast<double *>(e->d_wpe + out_off);
+    long long *out_c = reinterpret_cast<long long *>(out_s + 6);
+    k_wpe3<<<(unsigned)nseg, 256, 0, st>>>(x_dev, nw, seg_len, part_s, part_c);
+    if (nseg > 1) k_wpe3_combine<<<1, 64, 0, st>>>(part_s, part_c, (int)nseg, out_s, out_c);
+    HIP_TRY(e, hipGetLastError());
+    struct { double s[6]; long long c[6]; } res;
+    if (nseg > 1) HIP_TRY(e, hipMemcpyAsync(&res, out_s, sizeof(res), hipMemcpyDeviceToHost, st));
+    else {
+        HIP_TRY(e, hipMemcpyAsync(res.s, part_s, sizeof(res.s), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipMemcpyAsync(res.c, part_c, sizeof(res.c), hipMemcpyDeviceToHost, st));
+    }
+    int32_t tot[2] = {0, 0};
+    if (knots_host) {
+        DetectWs w;
+        rc = detect_enqueue(e, x_dev, n, n, 1, (int)kKnots, -1, st, w, nullptr, 0, false);
+        if (rc) return rc;
+        HIP_TRY(e, hipMemcpyAsync(tot, w.totals, sizeof(tot), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(e, hipStreamSynchronize(st));
+    for (int b = 0; b < 6; ++b) { bin_weights_host[b] = res.s[b]; bin_windows_host[b] = (int64_t)res.c[b]; }
+    if (knots_host) *knots_host = tot[0];
+    return knots_host && tot[1] ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
+// itd_baseline_extract_spline_f64 plus the knot count of every PRODUCED baseline, one synchronisation for both
+// (MEITD.py:362-363, :497-505)
+int itd_baseline_extract_spline2_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
+                                     int32_t min_extrema, double *baseline_dev, int64_t baseline_stride, double *rot_dev,
+                                     int64_t rot_stride, int32_t *knots_host, int32_t *baseline_knots_host, void *stream)
+{
+    if (!e || !x_dev || !baseline_dev) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n >= (int64_t)INT32_MAX - 8 || batch < 1 || batch > 65535 || min_extrema < 0) return ITD_ERR_INVALID_ARG;
+    if (batch > 1 && (x_stride < n || baseline_stride < n || (rot_dev && rot_stride < n))) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    const bool par = e->spline_solver == ITD_SPLINE_PARALLEL || (e->spline_solver == ITD_SPLINE_AUTO && batch < 256 && n >= 1024);
+    const int32_t *totals = nullptr;
+    SplineWs w;
+    int rc;
+    if (par) rc = nak_enqueue(e, x_dev, n, batch, x_stride, min_extrema, baseline_dev, baseline_stride, rot_dev, rot_stride, st, &totals);
+    else {
+        rc = spline_enqueue(e, x_dev, n, batch, x_stride, min_extrema, baseline_dev, baseline_stride, rot_dev, rot_stride, st, w);
+        totals = w.totals;
+    }
+    if (rc) return rc;
+    if (!baseline_knots_host) return spline_finish(e, batch, totals, knots_host, st);
+    // (the extraction's totals are read before the counting launches reuse the detection workspace)
+    std::vector<int32_t> tot((size_t)batch * 2), btot((size_t)batch * 2);
+    HIP_TRY(e, hipMemcpyAsync(tot.data(), totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DetectWs dw;
+    rc = detect_enqueue(e, baseline_dev, baseline_stride, n, batch, (int)kKnots, -1, st, dw, nullptr, 0, false);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(btot.data(), dw.totals, btot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    bool nan_in = false;
+    for (int b = 0; b < batch; ++b) {
+        if (knots_host) knots_host[b] = tot[2 * (size_t)b];
+        baseline_knots_host[b] = btot[2 * (size_t)b];
+        nan_in = nan_in || tot[2 * (size_t)b + 1] != 0;
+    }
+    return nan_in ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
+int itd_subtract_f64(itd_engine *e, const double *a_dev, const double *b_dev, double *out_dev, int64_t count, void *stream)
+{
+    if (!e || !a_dev || !b_dev || !out_dev || count < 0) return ITD_ERR_INVALID_ARG;
+    if (!count) return ITD_OK;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    k_subtract<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(a_dev, b_dev, out_dev, count);
+    HIP_TRY(e, hipGetLastError());
+    return ITD_OK;
+}
+
+// copies ordered on the engine's stream (or `stream`): kind 0 device -> host, 1 host -> device, 2 device -> device,
+// 3 zero bytes (src ignored); wait != 0: return when it is done
+int itd_copy(itd_engine *e, void *dst, const void *src, int64_t bytes, int32_t kind, int32_t wait, void *stream)
+{
+    if (!e || !dst || (!src && kind != 3) || bytes < 0 || kind < 0 || kind > 3) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    if (bytes) {
+        if (kind == 3) HIP_TRY(e, hipMemsetAsync(dst, 0, (size_t)bytes, st));
+        else HIP_TRY(e, hipMemcpyAsync(dst, src, (size_t)bytes, kind == 0 ? hipMemcpyDeviceToHost : (kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice), st));
+    }
+    if (wait) HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
 }
 
 // crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols (device, contiguous):

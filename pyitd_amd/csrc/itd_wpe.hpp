@@ -1,0 +1,141 @@
+// weighted_permutation_entropy(x, order=3, delay=1), MEITD.py:79-128, as far as it touches the samples: every window
+// (x[i], x[i+1], x[i+2]) falls into one of the six permutation patterns and carries its variance as weight; the entropy is
+// drawn on the host from the six sums.  The reference's arithmetic, step by step:
+//   sorted_idx = _embed(x).argsort(kind="quicksort")   numpy sorts 3 values by insertion on the index list, NaNs last — ties keep
+//                                                      their index order (checked against numpy on rows with ties and NaNs)
+//   hashval    = (sorted_idx * [1, 3, 9]).sum(1)       5, 7, 11, 15, 19, 21 — `bins` below in this (numpy.unique's) order
+//   weights    = numpy.var(windows, 1)                 mean = ((a0 + a1) + a2) / 3; ((d0*d0 + d1*d1) + d2*d2) / 3
+//   counts[h]  = cumsum(weights[hashval == h])[-1]     one by one, in index order
+// Signals up to kWpeExactWindows windows are summed in exactly that order (one lane per pattern, one pass over the windows);
+// longer ones in segments of kWpeSeg windows, each summed in order, the segments' sums then added in order — deterministic,
+// equal to the reference's sum to rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace itd {
+constexpr int kWpeSeg = 4096;
+constexpr int64_t kWpeExactWindows = 1 << 16;
+
+// numpy's order of doubles: a NaN sorts behind everything (npy_sort's LT for floating types)
+__device__ __forceinline__ bool np_lt(double a, double b) { return a < b || (b != b && a == a); }
+
+// a window's pattern (0..5, in the order above) and weight
+__device__ __forceinline__ void wpe3_window(double a0, double a1, double a2, unsigned char &bin, double &wt)
+{
+    // insertion sort of the indices 0, 1, 2 by value
+    double v0 = a0, v1 = a1, v2 = a2;
+    int i0 = 0, i1 = 1, i2 = 2;
+    if (np_lt(v1, v0)) { const double t = v0; v0 = v1; v1 = t; i0 = 1; i1 = 0; }
+    if (np_lt(v2, v1)) {
+        const double t = v2;
+        v2 = v1; i2 = i1;
+        if (np_lt(t, v0)) { v1 = v0; i1 = i0; v0 = t; i0 = 2; }
+        else { v1 = t; i1 = 2; }
+    }
+    (void)v2;
+    const int h = i0 + 3 * i1 + 9 * i2;
+    bin = (unsigned char)(h == 5 ? 0 : h == 7 ? 1 : h == 11 ? 2 : h == 15 ? 3 : h == 19 ? 4 : 5);
+    const double mean = ((a0 + a1) + a2) / 3.0;
+    const double d0 = a0 - mean, d1 = a1 - mean, d2 = a2 - mean;
+    wt = ((d0 * d0 + d1 * d1) + d2 * d2) / 3.0;
+}
+
+// One segment of windows per workgroup, through LDS in chunks of kWpeChunk windows.  Per chunk: the samples into LDS; every
+// thread takes a run of consecutive windows and counts its patterns; a scan over the threads gives every window its place in its
+// pattern's list (index order within a pattern is kept); the weights go there; lane b < 6 then adds pattern b's list to its
+// running sum one by one — the chain of additions is the reference's cumsum, only the windows of other patterns are not in the way.
+constexpr int kWpeChunk = 4096;
+constexpr int kWpeThreads = 256;
+__global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__ x, int64_t nw, int64_t seg_len, double *__restrict__ part_s,
+                                                      long long *__restrict__ part_c)
+{
+    static_assert(kWpeChunk % kWpeThreads == 0 && kWpeChunk < 65536, "three 16-bit counts per word");
+    __shared__ double s_x[kWpeChunk + 2], s_l[kWpeChunk];
+    __shared__ unsigned long long s_wave[2][kWpeThreads / 64];
+    const int64_t lo = (int64_t)blockIdx.x * seg_len, hi = lo + seg_len < nw ? lo + seg_len : nw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;                    // (0.0 + w == w: a variance is never -0.0)
+    long long c = 0;
+    for (int64_t base = lo; base < hi; base += kWpeChunk) {
+        const int m = (int)(hi - base < kWpeChunk ? hi - base : kWpeChunk);
+        for (int k = tid; k < m + 2; k += kWpeThreads) s_x[k] = x[base + k];
+        __syncthreads();
+        const int run = (m + kWpeThreads - 1) / kWpeThreads, k0 = tid * run < m ? tid * run : m, k1 = k0 + run < m ? k0 + run : m;
+        // patterns 0..2 count in the 16-bit fields of a, 3..5 in those of b
+        unsigned long long a = 0ull, b = 0ull;
+        for (int k = k0; k < k1; ++k) {
+            unsigned char bin;
+            double wt;
+            wpe3_window(s_x[k], s_x[k + 1], s_x[k + 2], bin, wt);
+            if (bin < 3) a += 1ull << (16 * bin); else b += 1ull << (16 * (bin - 3));
+        }
+        // exclusive scan over the threads (in thread order = window order)
+        unsigned long long ia = a, ib = b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+            if (lane >= d) { ia += ua; ib += ub; }
+        }
+        if (lane == 63) { s_wave[0][wave] = ia; s_wave[1][wave] = ib; }
+        __syncthreads();
+        unsigned long long ta = 0ull, tb = 0ull, pa = ia - a, pb = ib - b;      // totals; this thread's places
+#pragma unroll
+        for (int q = 0; q < kWpeThreads / 64; ++q) {
+            if (q < wave) { pa += s_wave[0][q]; pb += s_wave[1][q]; }
+            ta += s_wave[0][q]; tb += s_wave[1][q];
+        }
+        auto field = [](unsigned long long v, int f) { return (int)((v >> (16 * f)) & 0xffffull); };
+        int start[6], total[6];
+        for (int q = 0, acc = 0; q < 6; ++q) { total[q] = q < 3 ? field(ta, q) : field(tb, q - 3); start[q] = acc; acc += total[q]; }
+        for (int k = k0; k < k1; ++k) {
+            unsigned char bin;
+            double wt;
+            wpe3_window(s_x[k], s_x[k + 1], s_x[k + 2], bin, wt);
+            int pos;
+            if (bin < 3) { pos = field(pa, bin); pa += 1ull << (16 * bin); } else { pos = field(pb, bin - 3); pb += 1ull << (16 * (bin - 3)); }
+            s_l[start[bin == 0 ? 0 : bin == 1 ? 1 : bin == 2 ? 2 : bin == 3 ? 3 : bin == 4 ? 4 : 5] + pos] = wt;
+        }
+        __syncthreads();
+        if (tid < 6) {
+            int k = 0, e = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (q == tid) { k = start[q]; e = start[q] + total[q]; }
+            c += e - k;
+            for (; k + 8 <= e; k += 8) {
+                double w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = s_l[k + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += w[q];
+            }
+            for (; k < e; ++k) s += s_l[k];
+        }
+        __syncthreads();
+    }
+    if (tid < 6) {
+        part_s[(size_t)blockIdx.x * 6 + tid] = s;
+        part_c[(size_t)blockIdx.x * 6 + tid] = c;
+    }
+}
+
+// the segments' sums, added in segment order
+__global__ __launch_bounds__(64) void k_wpe3_combine(const double *__restrict__ part_s, const long long *__restrict__ part_c, int nseg,
+                                                     double *__restrict__ out_s, long long *__restrict__ out_c)
+{
+    const unsigned bin = threadIdx.x;
+    if (bin >= 6) return;
+    double s = part_s[bin];
+    long long c = part_c[bin];
+    for (int g = 1; g < nseg; ++g) { s += part_s[(size_t)g * 6 + bin]; c += part_c[(size_t)g * 6 + bin]; }
+    out_s[bin] = s;
+    out_c[bin] = c;
+}
+
+// out = a - b (MEITD.py:453 `x = x - rotation_[:]`)
+__global__ __launch_bounds__(256) void k_subtract(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = a[i] - b[i];
+}
+}  // namespace itd

@@ -351,6 +351,38 @@ class Engine:
                     allow=(ITD_ERR_NONFINITE,))
         return out
 
+    # ---- MEITD's operators on device-resident signals (pointers are ints; only scalars come back) ----------------------------
+    def count_knots_dev(self, x_ptr, n, mode=DETECT_KNOTS, stream=None):
+        """The knot count of the n float64 samples at x_ptr (matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size)."""
+        out = np.zeros(1, np.int32)
+        self._check(self._L.itd_count_knots_f64(self._h, x_ptr, n, 1, n, int(mode), _np_ptr(out), stream), allow=(ITD_ERR_NONFINITE,))
+        return int(out[0])
+
+    def wpe3_dev(self, x_ptr, n, want_knots=False, stream=None):
+        """(weights[6], windows[6]) of the six order-3 permutation patterns of the n samples at x_ptr (MEITD.py:79-128), in
+        numpy.unique's order of the reference's hash values; want_knots: a third item, x's knot count (same synchronisation)."""
+        w = np.zeros(6, np.float64)
+        c = np.zeros(6, np.int64)
+        k = np.zeros(1, np.int32) if want_knots else None
+        self._check(self._L.itd_wpe3_f64(self._h, x_ptr, n, _np_ptr(w), _np_ptr(c), _np_ptr(k), stream), allow=(ITD_ERR_NONFINITE,))
+        return (w, c, int(k[0])) if want_knots else (w, c)
+
+    def spline_extract_dev(self, x_ptr, n, base_ptr, rot_ptr=None, min_extrema=0, want_baseline_knots=False, stream=None):
+        """The spline baseline of the n samples at x_ptr into base_ptr (x - baseline into rot_ptr): returns the signal's knot
+        count, and the produced baseline's with want_baseline_knots."""
+        k = np.zeros(1, np.int32)
+        bk = np.zeros(1, np.int32) if want_baseline_knots else None
+        self._check(self._L.itd_baseline_extract_spline2_f64(self._h, x_ptr, n, 1, n, int(min_extrema), base_ptr, n, rot_ptr, n,
+                                                             _np_ptr(k), _np_ptr(bk), stream))
+        return (int(k[0]), int(bk[0])) if want_baseline_knots else int(k[0])
+
+    def subtract_dev(self, a_ptr, b_ptr, out_ptr, count, stream=None):
+        self._check(self._L.itd_subtract_f64(self._h, a_ptr, b_ptr, out_ptr, count, stream))
+
+    def copy(self, dst, src, nbytes, kind, wait=False, stream=None):
+        """A copy ordered on the engine's stream: kind 0 device -> host, 1 host -> device, 2 device -> device, 3 zero fill."""
+        self._check(self._L.itd_copy(self._h, dst, src, nbytes, int(kind), 1 if wait else 0, stream))
+
     def crossways_host(self, images, min_extrema=10):
         """images[P, rows, cols] float64 -> crossways_itd_baseline_extract of every plane (siftED2D.ipynb cell 1)."""
         img = np.ascontiguousarray(images, dtype=np.float64)

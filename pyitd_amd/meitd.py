@@ -1,24 +1,30 @@
 """Host-side mirror of MEITD.py's selection drivers, on top of the GPU operators:
 
-  weighted_permutation_entropy(time_series, order=3, normalize=False)   MEITD.py:79-128   (host numpy, as upstream)
+  weighted_permutation_entropy(time_series, order=3, normalize=False)   MEITD.py:79-128
   retrieve_proper_rotation(x, WPEMAX)                                    MEITD.py:344-368
   determine_if_first_is_proper_rotation(x, WPEMAX)                       MEITD.py:371-392
   MEITD(data, max_iteration=40, WPEMAX=0.6) -> (high, low, residual)     MEITD.py:395-534
   XITD(data)                                                             MEITD.py:536-549
 
-The drivers are control logic around two operators, both of which run on the GPU: the cubic-spline baseline extraction
-(MEITD.py:303-338 -> pyitd_amd.itd_baseline_extract_spline) and the extrema count (matlab_detect_peaks(x).size +
-matlab_detect_peaks(-x).size -> the engine's knot scan).  The entropy is a few numpy calls on the host upstream and stays
-that: its sums are taken in the reference's order so that the threshold tests decide identically.
-Upstream quirks kept: `max_iteration` is never used by MEITD (:395); XITD passes its WPEMAX estimate in that position
-(:541), so MEITD runs with WPEMAX = 0.6 there; nothing is printed.
+The drivers are control logic around three operators, all of which run on the GPU on arrays that STAY on the GPU for the whole
+loop (include/pyitd_hip.h, "MEITD's operators on device-resident signals"): the cubic-spline baseline extraction (MEITD.py:303-338
+-> itd_baseline_extract_spline2_f64), the extrema count (matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size ->
+itd_count_knots_f64) and the entropy's pass over the samples (itd_wpe3_f64: six weighted sums, taken in the reference's order).
+Per pass a few scalars come back — the counts, the six sums — and the threshold tests are drawn from them here; the signal is
+uploaded once and the components are downloaded once.
+
+Upstream quirks kept: `max_iteration` is never used by MEITD (:395); XITD passes its WPEMAX estimate in that position (:541), so
+MEITD runs with WPEMAX = 0.6 there (the estimate itself, :538-540, has no consumer and is not computed); nothing is printed.
+One piece of upstream's work is NOT repeated because nothing can observe it: when the entropy test of retrieve_proper_rotation
+fails, its loop (:359-366) keeps extracting down to fewer than 6 extrema and then returns its INPUT (:368) — on the golden signals
+that is 209-249 of the ~290 extractions of a MEITD call.
 """
 from math import factorial
 
 import numpy
 
-from .itd import _engine_for
-from .spline import itd_baseline_extract_spline
+from .engine import DeviceBuffer
+from .spline import _eng
 
 
 def _embed(x, order=3, delay=1):
@@ -30,9 +36,29 @@ def _embed(x, order=3, delay=1):
     return Y.T
 
 
-def weighted_permutation_entropy(time_series, order=3, normalize=False):
-    """MEITD.py:79-128: permutation patterns of the embedded series, each window weighted by its variance."""
+def _entropy_from_bins(weights, windows, order=3, normalize=False):
+    """MEITD.py:119-128 from the patterns' weighted counts (in numpy.unique's order; a pattern without windows is absent)."""
+    wc = weights[windows > 0]
+    p = numpy.true_divide(wc, wc.sum())
+    pe = -numpy.multiply(p, numpy.log2(p)).sum()
+    if normalize:
+        pe /= numpy.log2(factorial(order))
+    return pe
+
+
+def weighted_permutation_entropy(time_series, order=3, normalize=False, device=0):
+    """MEITD.py:79-128: permutation patterns of the embedded series, each window weighted by its variance.  Order 3 (the only one
+    MEITD.py uses) runs on the GPU; other orders are the reference's numpy expressions."""
     x = numpy.array(time_series)
+    if order == 3 and x.ndim == 1 and len(x) >= 3:
+        x = numpy.ascontiguousarray(x, dtype=numpy.float64)
+        buf = DeviceBuffer(x.nbytes, device)
+        try:
+            buf.upload(x)
+            w, c = _eng(len(x), device).wpe3_dev(buf.ptr, len(x))
+        finally:
+            buf.free()
+        return _entropy_from_bins(w, c, 3, normalize)
     hashmult = numpy.power(order, numpy.arange(order))
     sorted_idx = _embed(x, order=order).argsort(kind="quicksort")
     windows = numpy.lib.stride_tricks.sliding_window_view(x, order)      # = util_rolling_window(x, order), MEITD.py:73-76
@@ -50,123 +76,246 @@ def weighted_permutation_entropy(time_series, order=3, normalize=False):
     return pe
 
 
-def _num_extrema(x, device):
-    """matlab_detect_peaks(x).size + matlab_detect_peaks(-x).size: the knot count of x — counted on the GPU, four bytes come
-    back (no index list is built or copied)."""
-    return int(_engine_for(len(x), device).count_knots_host(x)[0])
+_ROWS_KEPT = 22          # MEITD returns once more than 20 components are kept (:414-415): 21 rows at most, in either list
 
 
-def _extract_and_count(x, device):
-    """itd_baseline_extract(x) (MEITD.py:303-338) and the extrema count of its baseline in ONE engine call: the loops of
-    MEITD.py:362-363 and :497-505 ask for that count right after every extraction."""
-    from .spline import _eng
-    x = numpy.asarray(x, dtype=numpy.float64)
-    base, rot, knots, bk = _eng(len(x), device).spline_extract_host(x[None, :], 0, want_rotation=True, want_baseline_knots=True)
-    if knots[0] < 2:
-        raise TypeError("m > k must hold")        # what scipy.interpolate.splrep raises for fewer than 4 data sites
-    return rot[0], base[0], int(bk[0])
+class _Work:
+    """The device arrays of one MEITD run — rows of n float64 in one allocation: four working rows that change roles by
+    renaming (no copies), the two lists of kept rotations."""
+
+    def __init__(self, n, device):
+        self.n, self.device = n, device
+        self.eng = _eng(n, device)
+        self.buf = DeviceBuffer((6 + 2 * _ROWS_KEPT) * n * 8, device)
+        self.free_rows = [self.row(i) for i in range(6)]
+        self.high0, self.low0 = self.row(6), self.row(6 + _ROWS_KEPT)
+
+    def row(self, i):
+        return self.buf.ptr + i * self.n * 8
+
+    def kept(self, first, k):
+        return first + k * self.n * 8
+
+    def take(self):
+        return self.free_rows.pop()
+
+    def give(self, p):
+        self.free_rows.append(p)
+
+    # ---- the operators -------------------------------------------------------------------------------------------------------
+    def upload(self, x, dst):
+        self.eng.copy(dst, x.ctypes.data, x.nbytes, 1, wait=True)
+
+    def download(self, src, rows=1):
+        out = numpy.empty((rows, self.n))
+        self.eng.copy(out.ctypes.data, src, out.nbytes, 0, wait=True)
+        return out
+
+    def assign(self, dst, src):
+        self.eng.copy(dst, src, self.n * 8, 2)
+
+    def zero(self, dst):
+        self.eng.copy(dst, None, self.n * 8, 3)
+
+    def probe(self, src):
+        """(normalised entropy, extrema count) of a row: MEITD.py:346-351 / :373-378."""
+        w, c, count = self.eng.wpe3_dev(src, self.n, want_knots=True)
+        return numpy.mean(_entropy_from_bins(w, c, 3, True)), count
+
+    def count(self, src):
+        return self.eng.count_knots_dev(src, self.n)
+
+    def entropy(self, src):
+        """weighted_permutation_entropy(row, order=3, normalize=True)"""
+        return _entropy_from_bins(*self.eng.wpe3_dev(src, self.n), 3, True)
+
+    def subtract(self, a, b, out):
+        self.eng.subtract_dev(a, b, out, self.n)
+
+    def reset(self):
+        """every working row is free again (a call that raised may have left some taken)"""
+        self.free_rows = [self.row(i) for i in range(6)]
+
+    def extract(self, src, base, rot=None, want_baseline_count=False):
+        """itd_baseline_extract (MEITD.py:303-338): src -> (rot, base); with the extrema count of the produced baseline."""
+        r = self.eng.spline_extract_dev(src, self.n, base, rot, 0, want_baseline_knots=want_baseline_count)
+        knots = r[0] if want_baseline_count else r
+        if knots < 2:
+            raise TypeError("m > k must hold")        # what scipy.interpolate.splrep raises for fewer than 4 data sites
+        return r[1] if want_baseline_count else None
+
+
+_work = {}
+
+
+def _work_for(n, device):
+    key = int(device)
+    w = _work.get(key)
+    if w is None or w.n != n or w.eng is not _eng(n, device):
+        if w is not None:
+            w.buf.free()
+        w = _work[key] = _Work(n, device)
+    w.reset()
+    return w
+
+
+def _proper(wpe, WPEMAX):
+    return wpe < WPEMAX and not wpe < 0.2             # MEITD.py:364 / :387
+
+
+def _retrieve(wk, rot, WPEMAX):
+    """retrieve_proper_rotation on the row `rot`: returns (row holding the result, proper)."""
+    wpe, count = wk.probe(rot)
+    if count > 5 and _proper(wpe, WPEMAX):            # the first extraction is the answer (:360-365)
+        base, out = wk.take(), wk.take()
+        wk.extract(rot, base, out)
+        wk.give(base)
+        wk.give(rot)
+        return out, 1
+    return rot, 0                                     # "I can't retrieve a proper rotation" / the loop that returns its input
+
+
+def _determine(wk, src, rot, base, WPEMAX, probed=None):
+    """determine_if_first_is_proper_rotation(src) into the rows rot / base (base None: not wanted).  Returns proper."""
+    wpe, count = probed if probed is not None else wk.probe(src)
+    if count < 5:
+        wk.assign(rot, src)
+        if base is not None:
+            wk.zero(base)
+        return 0
+    tmp = base if base is not None else wk.take()
+    wk.extract(src, tmp, rot)
+    if base is None:
+        wk.give(tmp)
+    return 1 if _proper(wpe, WPEMAX) else 0
 
 
 def retrieve_proper_rotation(x, WPEMAX, device=0):
-    """MEITD.py:344-368 — keep extracting from the baseline until fewer than 6 extrema remain; the entropy of the INPUT decides."""
-    x = numpy.asarray(x).astype(dtype=numpy.float64)
-    wpe = numpy.mean(weighted_permutation_entropy(x, order=3, normalize=True))
-    accept = wpe < WPEMAX and not wpe < 0.2
-    count = _num_extrema(x, device)
-    if count < 5:
-        return x, 0
-    rotation = numpy.zeros(len(x))
-    baseline = x.copy()
-    while count > 5:
-        rotation, baseline, count = _extract_and_count(baseline, device)
-        if accept:
-            return rotation, 1
-    return x, 0
+    """MEITD.py:344-368 — the first extraction's rotation if the entropy of the INPUT passes the test, else the input."""
+    x = numpy.ascontiguousarray(numpy.asarray(x).astype(dtype=numpy.float64))
+    wk = _work_for(len(x), device)
+    rot = wk.take()
+    wk.upload(x, rot)
+    rot, proper = _retrieve(wk, rot, WPEMAX)
+    out = wk.download(rot)[0] if proper else x
+    wk.give(rot)
+    return out, proper
 
 
 def determine_if_first_is_proper_rotation(x, WPEMAX, device=0):
     """MEITD.py:371-392 — one extraction; proper if the input's entropy lies in [0.2, WPEMAX)."""
-    x = numpy.asarray(x).astype(dtype=numpy.float64)
-    wpe = numpy.mean(weighted_permutation_entropy(x, order=3, normalize=True))
-    if _num_extrema(x, device) < 5:
-        return x, numpy.zeros(len(x)), 0
-    rotation, baseline = itd_baseline_extract_spline(x, device)
-    return rotation, baseline, 1 if (wpe < WPEMAX and not wpe < 0.2) else 0
+    x = numpy.ascontiguousarray(numpy.asarray(x).astype(dtype=numpy.float64))
+    wk = _work_for(len(x), device)
+    src, rot, base = wk.take(), wk.take(), wk.take()
+    wk.upload(x, src)
+    proper = _determine(wk, src, rot, base, WPEMAX)
+    r, b = wk.download(rot)[0], wk.download(base)[0]
+    for p in (src, rot, base):
+        wk.give(p)
+    return r, b, proper
+
+
+def _meitd(wk, data, WPEMAX):
+    """MEITD.py:395-534 on device rows.  Returns (n_high, n_low, row of the residual) or None for the early return of :411-413."""
+    x, rotation, baseline = wk.take(), wk.take(), wk.take()
+    wk.upload(data, x)
+    n_high = n_low = 0
+    probed = wk.probe(x)
+    proper = _determine(wk, x, rotation, baseline, WPEMAX, probed)
+    changed, on_signal, digs = False, True, 1           # xchanged, HILO == 1, soft_reset
+    count = probed[1]
+    if count < 4:
+        for p in (x, rotation, baseline):
+            wk.give(p)
+        return None
+    while count > 5:
+        if n_high + n_low > 20:
+            break
+        if proper == 0:      # not proper yet, but decomposable: go down its own baselines
+            rotation, proper = _retrieve(wk, rotation, WPEMAX)
+        if proper == 1:
+            if on_signal:
+                wk.assign(wk.kept(wk.high0, n_high), rotation)
+                n_high += 1
+            else:
+                wk.assign(wk.kept(wk.low0, n_low), rotation)
+                n_low += 1
+            digs = 0
+            wk.subtract(x, rotation, x)
+            changed = True
+        if changed and on_signal:
+            count = wk.count(x)
+            if count < 5:
+                continue
+            wk.extract(x, baseline)
+            proper = _determine(wk, baseline, rotation, None, WPEMAX)
+            changed, on_signal = False, False
+            continue
+        elif on_signal:
+            proper = _determine(wk, baseline, rotation, None, WPEMAX)
+            on_signal = False
+            continue
+        if changed and not on_signal:
+            probed = wk.probe(x)
+            count = probed[1]
+            if count < 5:
+                continue
+            proper = _determine(wk, x, rotation, baseline, WPEMAX, probed)
+            changed, on_signal = False, True
+            continue
+        if not changed and not on_signal:
+            if digs == 0:
+                wk.extract(x, baseline, rotation)
+                digs = 1
+            count = wk.count(baseline)
+            if count < 5:
+                continue
+            for _ in range(digs):
+                deeper = wk.take()
+                count = wk.extract(baseline, deeper, rotation, want_baseline_count=True)
+                wk.give(baseline)
+                baseline = deeper
+                if count < 5:
+                    break
+            digs += 1
+            continue
+    wk.give(rotation)
+    wk.give(baseline)
+    return n_high, n_low, x
 
 
 def MEITD(data, max_iteration=40, WPEMAX=0.6, device=0):
     """MEITD.py:395-534 — alternate between peeling a proper rotation off the signal (the "high" list) and off its baseline
     (the "low" list); dig further down the baselines when neither succeeds.  Returns (high[h, N], low[l, N], residual[N])."""
-    x = numpy.asarray(data).astype(dtype=numpy.float64)
-    n = len(x)
-    high, low = numpy.zeros((44, n)), numpy.zeros((44, n))
-    n_high = n_low = 0
-    rotation, baseline = numpy.zeros(n), numpy.zeros(n)
-    rotation[:], baseline[:], proper = determine_if_first_is_proper_rotation(x, WPEMAX, device)
-    changed, on_signal, digs = False, True, 1           # xchanged, HILO == 1, soft_reset
-    count = _num_extrema(x, device)
-    if count < 4:
-        zero = numpy.zeros(n)
-        return zero, zero, x
-    while count > 5:
-        if n_high + n_low > 20:
-            return high[:n_high], low[:n_low], x[:]
-        if proper == 0:      # not proper yet, but decomposable: go down its own baselines
-            rotation[:], proper = retrieve_proper_rotation(rotation[:], WPEMAX, device)
-        if proper == 1:
-            if on_signal:
-                high[n_high] = rotation
-                n_high += 1
-            else:
-                low[n_low] = rotation
-                n_low += 1
-            digs = 0
-            x = x - rotation
-            changed = True
-        if changed and on_signal:
-            count = _num_extrema(x, device)
-            if count < 5:
-                continue
-            _, baseline[:] = itd_baseline_extract_spline(x, device)
-            rotation[:], _, proper = determine_if_first_is_proper_rotation(baseline[:], WPEMAX, device)
-            changed, on_signal = False, False
-            continue
-        elif on_signal:
-            rotation[:], _, proper = determine_if_first_is_proper_rotation(baseline[:], WPEMAX, device)
-            on_signal = False
-            continue
-        if changed and not on_signal:
-            count = _num_extrema(x, device)
-            if count < 5:
-                continue
-            rotation[:], baseline[:], proper = determine_if_first_is_proper_rotation(x, WPEMAX, device)
-            changed, on_signal = False, True
-            continue
-        if not changed and not on_signal:
-            if digs == 0:
-                rotation[:], baseline[:] = itd_baseline_extract_spline(x, device)
-                digs = 1
-            count = _num_extrema(baseline, device)
-            if count < 5:
-                continue
-            for _ in range(digs):
-                rotation[:], baseline[:], count = _extract_and_count(baseline[:], device)
-                if count < 5:
-                    break
-            digs += 1
-            continue
-    return high[:n_high], low[:n_low], x[:]
+    data = numpy.ascontiguousarray(numpy.asarray(data).astype(dtype=numpy.float64))
+    wk = _work_for(len(data), device)
+    r = _meitd(wk, data, WPEMAX)
+    if r is None:
+        zero = numpy.zeros(len(data))
+        return zero, zero, data
+    n_high, n_low, x = r
+    high = wk.download(wk.high0, n_high) if n_high else numpy.zeros((0, len(data)))
+    low = wk.download(wk.low0, n_low) if n_low else numpy.zeros((0, len(data)))
+    residual = wk.download(x)[0]
+    wk.give(x)
+    return high, low, residual
 
 
 def XITD(data, device=0):
-    """MEITD.py:536-549 — MEITD's components and residual, ordered by their entropy."""
-    data = numpy.asarray(data).astype(dtype=numpy.float64)
-    m_ = data.mean(axis=0)
-    sd_ = data.std(axis=0, ddof=0)
-    with numpy.errstate(all="ignore"):
-        wpemax = numpy.log(abs(20 * numpy.log10(abs(numpy.where(sd_ == 0, 0, m_ / sd_)))))
-    high, low, residual = MEITD(data, wpemax, device=device)     # upstream passes it where max_iteration goes (:541)
-    rotations = numpy.vstack((high, low))
-    rotations = numpy.vstack((rotations, residual))
-    ent = [weighted_permutation_entropy(rotations[i, :], order=3, normalize=True) for i in range(rotations.shape[0])]
-    return rotations[numpy.argsort(ent), :]
+    """MEITD.py:536-549 — MEITD's components and residual, ordered by their entropy (taken on the device rows)."""
+    data = numpy.ascontiguousarray(numpy.asarray(data).astype(dtype=numpy.float64))
+    wk = _work_for(len(data), device)
+    r = _meitd(wk, data, 0.6)                        # upstream passes its WPEMAX estimate where max_iteration goes (:541)
+    if r is None:
+        zero = numpy.zeros(len(data))
+        rotations = numpy.vstack((numpy.vstack((zero, zero)), data))
+        ent = [weighted_permutation_entropy(rotations[i, :], order=3, normalize=True, device=device) for i in range(3)]
+        return rotations[numpy.argsort(ent), :]
+    n_high, n_low, x = r
+    rows = [wk.kept(wk.high0, k) for k in range(n_high)] + [wk.kept(wk.low0, k) for k in range(n_low)] + [x]
+    ent = [wk.entropy(p) for p in rows]
+    out = numpy.empty((len(rows), wk.n))
+    for k, i in enumerate(numpy.argsort(ent)):
+        out[k] = wk.download(rows[i])[0]
+    wk.give(x)
+    return out

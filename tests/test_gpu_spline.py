@@ -139,3 +139,147 @@ def test_crossways_with_more_rows_than_one_grid(P):
     bad[0, 5, 3] = np.nan            # in the FIRST chunk of the first stage only
     with pytest.raises(ITDError):
         eng.crossways_host(bad, 10)
+
+
+# ---- MEITD's operators on device-resident signals (include/pyitd_hip.h, ABI revision 8) ------------------------------------
+def _wpe_cases():
+    rng = np.random.default_rng(11)
+    n = 5000
+    t = np.arange(n)
+    cases = {
+        "noise": rng.standard_normal(n),
+        "walk": np.cumsum(rng.standard_normal(n)),
+        "quantised (ties in most windows)": np.round(3.0 * rng.standard_normal(n)),
+        "constant": np.full(n, 2.5),
+        "two values": (t // 3 % 2).astype(np.float64),
+        "with NaNs": np.where(rng.random(n) < 0.01, np.nan, rng.standard_normal(n)),
+        "three samples": np.array([0.5, -1.0, 0.25]),
+        "exactly 65536 windows": rng.standard_normal(65538),
+    }
+    for f in sorted(os.listdir(SPLINE)):
+        if f.startswith("meitd_"):
+            cases[f[:-4]] = np.load(os.path.join(SPLINE, f))["x"]
+    return cases
+
+
+def test_wpe3_bins_are_the_reference_sums_bit_for_bit(P):
+    """itd_wpe3_f64 against oracle/meitd_oracle.py (numpy's argsort, numpy.var, cumsum in index order — MEITD.py:79-128): pattern
+    populations exact, weighted sums bit for bit up to 65536 windows; the public function equals the oracle's entropy."""
+    from oracle import meitd_oracle
+    from pyitd_amd import meitd
+    from pyitd_amd.engine import DeviceBuffer
+    from pyitd_amd.spline import _eng
+    for name, x in _wpe_cases().items():
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        buf = DeviceBuffer(x.nbytes)
+        buf.upload(x)
+        w, c = _eng(len(x), 0).wpe3_dev(buf.ptr, len(x))
+        buf.free()
+        with np.errstate(all="ignore"):
+            wo, co = meitd_oracle.bins(x)
+            ref = meitd_oracle.weighted_permutation_entropy(x, order=3, normalize=True)
+            got = meitd.weighted_permutation_entropy(x, order=3, normalize=True)
+        assert np.array_equal(c, co), "%s: pattern populations %s != %s" % (name, c, co)
+        same = (w.view(np.uint64) == wo.view(np.uint64)) | (np.isnan(w) & np.isnan(wo))      # (a NaN's sign and payload are not compared)
+        assert same.all(), "%s: weighted sums %s != %s" % (name, w, wo)
+        assert got == ref or (np.isnan(got) and np.isnan(ref)), "%s: entropy %r != %r" % (name, got, ref)
+
+
+def test_wpe3_long_signal_in_segments(P):
+    """More than 65536 windows: segments of 4096 windows summed in order, the segments added in order — populations exact, sums equal
+    to rounding, the same every time."""
+    from oracle import meitd_oracle
+    from pyitd_amd.engine import DeviceBuffer
+    from pyitd_amd.spline import _eng
+    x = np.cumsum(np.random.default_rng(5).standard_normal(300001))
+    buf = DeviceBuffer(x.nbytes)
+    buf.upload(x)
+    eng = _eng(len(x), 0)
+    w, c = eng.wpe3_dev(buf.ptr, len(x))
+    w2, c2 = eng.wpe3_dev(buf.ptr, len(x))
+    buf.free()
+    wo, co = meitd_oracle.bins(x)
+    assert np.array_equal(c, co) and np.array_equal(c, c2)
+    assert np.array_equal(w.view(np.uint64), w2.view(np.uint64))
+    assert np.max(np.abs(w - wo) / wo) < 1e-12
+
+
+def test_device_row_operators_equal_their_host_forms(P):
+    """itd_count_knots_f64, itd_baseline_extract_spline2_f64, itd_subtract_f64 and itd_copy on device rows against the host entry
+    points of the same operators (bit for bit: the same kernels, no transfer in between)."""
+    from pyitd_amd.engine import DeviceBuffer
+    from pyitd_amd.spline import _eng
+    rng = np.random.default_rng(3)
+    n = 6000
+    x = np.cumsum(rng.standard_normal(n)) + 3.0 * np.sin(np.arange(n) / 17.0)
+    eng = _eng(n, 0)
+    base_h, rot_h, knots_h, bk_h = eng.spline_extract_host(x[None, :], 0, want_rotation=True, want_baseline_knots=True)
+    buf = DeviceBuffer(5 * n * 8)
+    px, pb, pr, pd, pz = (buf.ptr + i * n * 8 for i in range(5))
+    eng.copy(px, x.ctypes.data, x.nbytes, 1, wait=True)
+    assert eng.count_knots_dev(px, n) == int(eng.count_knots_host(x)[0])
+    knots, bk = eng.spline_extract_dev(px, n, pb, pr, 0, want_baseline_knots=True)
+    assert (knots, bk) == (int(knots_h[0]), int(bk_h[0]))
+    assert eng.spline_extract_dev(px, n, pb, None, 0) == knots
+    eng.subtract_dev(px, pr, pd, n)                     # x - rotation
+    eng.copy(pz, px, n * 8, 2)
+    eng.copy(pz, None, (n // 2) * 8, 3)                 # zero the first half of the copy
+    got = np.empty((5, n))
+    eng.copy(got.ctypes.data, buf.ptr, got.nbytes, 0, wait=True)
+    buf.free()
+    assert np.array_equal(got[0], x)
+    assert np.array_equal(got[1].view(np.uint64), base_h[0].view(np.uint64))
+    assert np.array_equal(got[2].view(np.uint64), rot_h[0].view(np.uint64))
+    assert np.array_equal(got[3], x - rot_h[0])
+    assert np.array_equal(got[4][:n // 2], np.zeros(n // 2)) and np.array_equal(got[4][n // 2:], x[n // 2:])
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(SPLINE) if f.startswith("meitd_")))
+def test_meitd_helpers_match_the_reference_flow(P, name, so):
+    """retrieve_proper_rotation / determine_if_first_is_proper_rotation (MEITD.py:344-392) on the GPU against the same flow over the
+    oracle's operators (oracle.meitd_oracle.CpuWork): the same decisions, the arrays to 1e-10."""
+    from oracle import meitd_oracle
+    from pyitd_amd import meitd
+    x = np.load(os.path.join(SPLINE, name + ".npz"))["x"]
+    for wpemax in (0.6, 2.0):
+        cw = meitd_oracle.CpuWork(len(x))
+        src, rot, base = cw.take(), cw.take(), cw.take()
+        cw.upload(x, src)
+        proper_ref = meitd._determine(cw, src, rot, base, wpemax)
+        r, b, proper = meitd.determine_if_first_is_proper_rotation(x, wpemax)
+        assert proper == proper_ref
+        _close(r, cw.rows[rot], name + " determine: rotation", 1e-10)
+        _close(b, cw.rows[base], name + " determine: baseline", 1e-10)
+        cw = meitd_oracle.CpuWork(len(x))
+        rot = cw.take()
+        cw.upload(x, rot)
+        out_ref, proper_ref = meitd._retrieve(cw, rot, wpemax)
+        out, proper = meitd.retrieve_proper_rotation(x, wpemax)
+        assert proper == proper_ref
+        _close(out, cw.rows[out_ref], name + " retrieve", 1e-10)
+
+
+def test_meitd_keeps_its_arrays_on_the_device(P):
+    """One MEITD call uploads the signal once, downloads the components once, and reads back only scalars in between: the number of
+    extractions stays below 60 on the golden signals (upstream: up to 292, most of them discarded — see pyitd_amd/meitd.py)."""
+    from pyitd_amd import meitd
+    x = np.load(os.path.join(SPLINE, "meitd_two_tone_noise.npz"))["x"]
+    wk = meitd._work_for(len(x), 0)
+    calls = {"extract": 0, "upload": 0, "download": 0}
+    orig = {k: getattr(wk, k) for k in calls}
+
+    def counted(k):
+        def f(*a, **kw):
+            calls[k] += 1
+            return orig[k](*a, **kw)
+        return f
+
+    for k in calls:
+        setattr(wk, k, counted(k))
+    try:
+        hi, lo, res = meitd.MEITD(x.copy())
+    finally:
+        for k in calls:
+            delattr(wk, k)
+    assert calls["upload"] == 1 and calls["download"] <= 3 and calls["extract"] < 60, calls
+    assert len(lo) + len(hi) == 21

@@ -38,33 +38,39 @@ def meitd_cases():
 
 
 @pytest.mark.parametrize("name", meitd_cases())
-def test_meitd_driver_logic_matches_reference(name, monkeypatch):
-    """pyitd_amd/meitd.py's control logic (MEITD.py:344-549) with its two GPU operators replaced by the oracle's: the
-    selection decisions, the entropy and the outputs must equal the reference's run (no GPU involved here; the -m gpu twin
-    of this test runs the real operators)."""
-    from oracle import cpu_oracle
+def test_entropy_oracle_matches_reference(name):
+    """oracle/meitd_oracle.py against the reference's own weighted_permutation_entropy(x, 3, True); the six-bin form the GPU
+    operator returns (itd_wpe3_f64) gives the same number through pyitd_amd.meitd's host formula, bit for bit."""
+    from oracle import meitd_oracle
     import pyitd_amd.meitd as mm
-
-    def extract(x, device=0):
-        x = np.asarray(x, dtype=np.float64)
-        if cpu_oracle.knots(x).size < 2:
-            raise TypeError("m > k must hold")
-        b = spline_oracle.baseline(x, 0)
-        return x - b, b
-
-    monkeypatch.setattr(mm, "itd_baseline_extract_spline", extract)
-    monkeypatch.setattr(mm, "_num_extrema", lambda x, device=0: int(cpu_oracle.knots(np.asarray(x, dtype=np.float64)).size))
-
-    def extract_and_count(x, device=0):       # the fused "extraction + count of its baseline" call of the GPU path
-        r, b = extract(x)
-        return r, b, int(cpu_oracle.knots(b).size)
-
-    monkeypatch.setattr(mm, "_extract_and_count", extract_and_count)
     g = np.load(os.path.join(SPLINE, name + ".npz"))
-    assert mm.weighted_permutation_entropy(g["x"], order=3, normalize=True) == float(g["wpe"])
+    assert meitd_oracle.weighted_permutation_entropy(g["x"], order=3, normalize=True) == float(g["wpe"])
+    w, c = meitd_oracle.bins(g["x"])
+    assert c.sum() == g["x"].size - 2
+    assert mm._entropy_from_bins(w, c, 3, True) == float(g["wpe"])
+
+
+@pytest.mark.parametrize("name", meitd_cases())
+def test_meitd_driver_logic_matches_reference(name, monkeypatch):
+    """pyitd_amd/meitd.py's control logic (MEITD.py:344-549) with its device rows and GPU operators replaced by numpy rows and
+    the oracle's operators: the selection decisions and the outputs must equal the reference's run bit for bit — including the
+    extractions the driver does NOT repeat (the loop of retrieve_proper_rotation whose result upstream discards, MEITD.py:359-368).
+    No GPU involved here; the -m gpu twin of this test runs the real operators."""
+    from oracle import meitd_oracle
+    import pyitd_amd.meitd as mm
+    g = np.load(os.path.join(SPLINE, name + ".npz"))
+    works = []
+
+    def work_for(n, device=0):
+        works.append(meitd_oracle.CpuWork(n))
+        return works[-1]
+
+    monkeypatch.setattr(mm, "_work_for", work_for)
     hi, lo, res = mm.MEITD(g["x"].copy())
     assert hi.shape == g["high"].shape and lo.shape == g["low"].shape
     assert_bits_equal(hi, g["high"], name + " high")
     assert_bits_equal(lo, g["low"], name + " low")
     assert_bits_equal(res, g["residual"], name + " residual")
+    assert works[-1].calls["extract"] < 60          # (upstream: up to 292 on these signals)
+    assert sorted(works[-1].free_rows) == list(range(6))
     assert_bits_equal(mm.XITD(g["x"].copy()), g["xitd"], name + " XITD")
