@@ -28,8 +28,10 @@ batch legs and the N > 1 path read the summary inside every step.
 The headline has an untimed warm-up of its own (--warm-ms of its own steps, then the W warm-up steps), so it does not depend on any
 other leg.  At N = 1 the line also carries, all timed AFTER the headline and skipped by --no-extra: "config3_batch" (BASELINE
 configs[2], 1024 x 2^20 signals), "short_signal_batches" (4096 x 4096 and 60 000 x 256 samples through the resident form and level by
-level), "f_rows" (the SURVEY 8f operators: cubic baseline at 2^24, instantaneous step, totalextract2d on 512 x 512 beside the reference's
-recorded 10.1457 s, block-wise microseconds per block) and, with --wav PATH, "config5_audio" (BASELINE configs[4] on that file).
+level), "mid_size_signals" (single signals of 2^16 .. 2^20 samples, BASELINE configs[0]'s chirp among them), "f_rows" (the SURVEY 8f
+operators: cubic baseline at 2^24, instantaneous step, totalextract2d on 512 x 512 beside the reference's recorded 10.1457 s, MEITD on a
+golden signal, block-wise microseconds per block), "config5_audio" (BASELINE configs[4] on --wav PATH or the substitute clip) and
+"headline_on_quantised_2p24".
 """
 import argparse
 import json
@@ -596,7 +598,7 @@ def run_rank(args):
         del rows, x
         torch.cuda.empty_cache()
         for key, leg in (("config3_batch", lambda: batch_leg(torch, dev)), ("short_signal_batches", lambda: short_signal_leg(torch, dev)),
-                         ("f_rows", lambda: f_rows_leg(torch, dev))):
+                         ("mid_size_signals", lambda: mid_size_leg(torch, dev)), ("f_rows", lambda: f_rows_leg(torch, dev))):
             try:
                 out[key] = leg()
             except Exception as ex:  # noqa: BLE001
@@ -795,6 +797,18 @@ def f_rows_leg(torch, dev):
     dt = time.perf_counter() - t0
     out["totalextract2d_512x512"] = {"ms": round(dt * 1e3, 3), "reference_recorded_s": 10.1457, "reference_source": "siftED2D.ipynb cell 3 (author's machine, numba)",
                                      "note": "host arrays in and out, host noise generation included"}
+    # MEITD (MEITD.py:395-534) on the golden two-tone + noise signal (3000 samples): the arrays stay on the GPU, scalars come back
+    try:
+        from pyitd_amd import meitd
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "spline", "meitd_two_tone_noise.npz"))
+        meitd.MEITD(g["x"].copy())
+        dt = timed(lambda: meitd.MEITD(g["x"].copy()), 5)
+        hi, lo, _ = meitd.MEITD(g["x"].copy())
+        out["meitd_two_tone_noise_3000"] = {"ms": round(dt * 1e3, 3), "components": [int(len(hi)), int(len(lo))],
+                                            "same_selection_as_reference": bool(hi.shape == g["high"].shape and lo.shape == g["low"].shape),
+                                            "form": "signal uploaded once, components downloaded once; extraction, extrema count and the entropy's sums on the GPU"}
+    except Exception as ex:  # noqa: BLE001
+        out["meitd_two_tone_noise_3000"] = {"error": repr(ex)[:200]}
     # block-wise operation (itd.cpp:31-44): microseconds per pushed 4096-sample block, device form
     Lb, nb = 4096, 64
     xs = torch.from_numpy(np.cumsum(np.random.default_rng(1).standard_normal(Lb * nb)) * 0.05).to(dev)[None].contiguous()
@@ -903,6 +917,40 @@ def short_signal_leg(torch, dev, steps=10):
         del x, rows
     return {"workload": "float32 sines + noise, max_iteration=%d, device resident, %d timed calls per figure" % (MAX_ITERATION, steps),
             "batches": out}
+
+
+def mid_size_leg(torch, dev, calls=200):
+    """Single signals between the one-workgroup form (<= 8192 samples) and the sizes whose launches are memory bound (>= 2^21):
+    BASELINE configs[0]'s signal (a 2^16-sample float32 chirp, 4 levels) and the headline recipe at 2^16 / 2^18 / 2^20 samples, 8 levels,
+    device resident, one call after the other on one stream.  Every launch here is bound by its ~6.5 us boundary:
+    informational, with the fraction of the HBM peak on the result's own bytes (input once, every produced row once)."""
+    import pyitd_amd
+    out = []
+    t = np.arange(1 << 16, dtype=np.float64) / 48000.0
+    chirp = np.sin(2 * np.pi * (200.0 * t + 0.5 * 6000.0 * t * t)).astype(np.float32)      # 200 Hz -> 8.4 kHz over 1.37 s
+    for name, x_host, M in (("configs[0]: chirp, 2^16 samples, 4 levels", chirp, 3), ("sines + noise, 2^16 samples, 8 levels", sines_noise(1 << 16), 7),
+                            ("sines + noise, 2^18 samples, 8 levels", sines_noise(1 << 18), 7), ("sines + noise, 2^20 samples, 8 levels", sines_noise(1 << 20), 7)):
+        n = len(x_host)
+        x = torch.from_numpy(x_host).to(dev)
+        rows = torch.empty((M + 2, n), dtype=torch.float64, device=dev)
+        eng = pyitd_amd.Engine(n, 1, dev.index or 0)
+        torch.cuda.synchronize()
+        for _ in range(20):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, None)
+        s = eng.summary(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / calls
+        s = eng.summary(1)
+        own = 4.0 * n + 8.0 * n * float(s["n_rows"][0])
+        out.append({"signal": name, "us_per_decomposition": round(dt * 1e6, 2), "Msamples_per_s": round(n / dt / 1e6, 1), "rows": int(s["n_rows"][0]),
+                    "own_bytes_frac_of_peak": round(own / dt / 1e9 / HBM_PEAK_GBPS, 4)})
+        eng.close()
+        del x, rows
+    return {"workload": "one signal per call, device resident, %d calls per figure" % calls, "signals": out}
 
 
 def cpu_legs(x_host, n, M, summ, rows, args):
