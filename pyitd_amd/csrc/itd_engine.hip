@@ -2073,7 +2073,7 @@ int nak_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_
     if (rc) return rc;
     const int64_t L = n + 2;
     const size_t jobs_b = (((size_t)batch * sizeof(CubicJob)) + 255) & ~(size_t)255;
-    rc = grow(e, &e->d_cub, &e->cub_bytes, jobs_b + 4 * (size_t)batch * (size_t)L * sizeof(double));
+    rc = grow(e, &e->d_cub, &e->cub_bytes, jobs_b + 6 * (size_t)batch * (size_t)L * sizeof(double));
     if (rc) return rc;
     CubicJob *jobs = (CubicJob *)e->d_cub;
     double *arr = (double *)((char *)e->d_cub + jobs_b);
@@ -2082,11 +2082,12 @@ int nak_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_
     A.e = w.kidx; A.e_stride = w.kidx_stride;
     A.jobs = jobs; A.job_stride = 1;
     A.K = arr; A.bf = arr + (size_t)batch * L; A.b = arr + 2 * (size_t)batch * L; A.a_stride = L;
-    double *cp = arr + 3 * (size_t)batch * L;
+    double *cp = arr + 3 * (size_t)batch * L, *sub = arr + 4 * (size_t)batch * L, *rhs = arr + 5 * (size_t)batch * L;
     k_nak_jobs<<<(batch + 255) / 256, 256, 0, st>>>(jobs, batch, w.totals, min_extrema);
     k_nak_values<<<dim3((unsigned)((n + 255) / 256), batch), 256, 0, st>>>(A);
+    k_nak_rows<<<dim3((unsigned)((n + 255) / 256), batch), 256, 0, st>>>(A, sub, rhs);
     const unsigned runs = (unsigned)((n + kNakRun - 1) / kNakRun);
-    k_nak_forward<<<dim3((runs + 63) / 64, batch), 64, 0, st>>>(A, cp);
+    k_nak_forward<<<dim3((runs + 63) / 64, batch), 64, 0, st>>>(A, cp, sub, rhs);
     k_nak_backward<<<dim3((runs + 63) / 64, batch), 64, 0, st>>>(A, cp);
     k_cubic_eval<T, true><<<dim3((unsigned)tiles_of(n), batch), kWave, 0, st>>>(A, 0, n, base, base_stride, 1, rot, rot_stride);
     HIP_TRY(e, hipGetLastError());

@@ -74,9 +74,25 @@ __device__ __forceinline__ NakRow nak_row(const int32_t *__restrict__ e, const d
     return r;
 }
 
+// the rows of the system, one thread per row, once: every row is met by kNakWarm / kNakRun + 1 = 5 forward runs, and a row costs
+// five divisions.  sub and rhs are stored; sup = 1 - sub and diag = 2 except in the two end rows, which the runs rebuild
+__global__ __launch_bounds__(256) void k_nak_rows(CubicArgs A, double *__restrict__ sub_ws, double *__restrict__ rhs_ws)
+{
+    const int sig = blockIdx.y;
+    const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
+    if (!job.valid) return;
+    const int m = job.idx + 1;
+    const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > m - 2) return;
+    const NakRow r = nak_row(A.e + (int64_t)sig * A.e_stride, A.K + (int64_t)sig * A.a_stride, m, j);
+    sub_ws[(int64_t)sig * A.a_stride + j] = r.sub;
+    rhs_ws[(int64_t)sig * A.a_stride + j] = r.rhs;
+}
+
 // forward elimination of a run of kNakRun rows per thread: cp_j = sup / den, dp_j = (rhs - sub dp_{j-1}) / den,
 // den = diag - sub cp_{j-1}; into A.bf (dp) and A.b (cp, overwritten by the back substitution's M afterwards: separate array)
-__global__ __launch_bounds__(64) void k_nak_forward(CubicArgs A, double *__restrict__ cp_ws)
+__global__ __launch_bounds__(64) void k_nak_forward(CubicArgs A, double *__restrict__ cp_ws, const double *__restrict__ sub_ws,
+                                                    const double *__restrict__ rhs_ws)
 {
     const int sig = blockIdx.y;
     const CubicJob job = A.jobs[(size_t)sig * A.job_stride];
@@ -86,11 +102,14 @@ __global__ __launch_bounds__(64) void k_nak_forward(CubicArgs A, double *__restr
     if (s > m - 2) return;
     const int32_t *e = A.e + (int64_t)sig * A.e_stride;
     const double *S = A.K + (int64_t)sig * A.a_stride;
+    const double *subv = sub_ws + (int64_t)sig * A.a_stride, *rhsv = rhs_ws + (int64_t)sig * A.a_stride;
     double *dpv = A.bf + (int64_t)sig * A.a_stride, *cpv = cp_ws + (int64_t)sig * A.a_stride;
     const int last = min(s + kNakRun - 1, m - 2);
     double cp = 0.0, dp = 0.0;
     for (int j = max(1, s - kNakWarm); j <= last; ++j) {
-        const NakRow r = nak_row(e, S, m, j);
+        NakRow r;
+        if (j == 1 || j == m - 2) r = nak_row(e, S, m, j);       // (the not-a-knot rows: their own diag / sup)
+        else { r.sub = subv[j]; r.rhs = rhsv[j]; r.sup = 1 - r.sub; r.diag = 2; }
         const double den = r.diag - r.sub * cp;
         cp = r.sup / den;
         dp = (r.rhs - r.sub * dp) / den;
