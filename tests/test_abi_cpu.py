@@ -90,3 +90,28 @@ def test_shard_range_of_the_c_abi_is_the_python_one(lib):
     assert lib.itd_shard_range(8, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) != 0
     assert lib.itd_shard_range(8, 4, 4, ctypes.byref(lo), ctypes.byref(hi)) != 0
     assert lib.itd_shard_scatter(None, None, 16, 8, 4, 1, 0, 0, None, None) != 0      # the root's array is missing
+
+
+def test_meitd_entry_points_reject_bad_arguments_before_touching_a_device(lib):
+    """ABI revision 8's device-row operators: a NULL engine or pointer is ITD_ERR_INVALID_ARG (1), decided before any HIP call."""
+    w = (ctypes.c_double * 6)()
+    c = (ctypes.c_int64 * 6)()
+    k = ctypes.c_int32()
+    assert lib.itd_wpe3_f64(None, None, 100, w, c, ctypes.byref(k), None) == 1
+    assert lib.itd_count_knots_f64(None, None, 100, 1, 100, 0, ctypes.byref(k), None) == 1
+    assert lib.itd_baseline_extract_spline2_f64(None, None, 100, 1, 100, 0, None, 100, None, 100, None, None, None) == 1
+    assert lib.itd_subtract_f64(None, None, None, None, 10, None) == 1
+    assert lib.itd_copy(None, None, None, 8, 0, 0, None) == 1
+
+
+def test_meitd_mirror_keeps_the_reference_surface():
+    """pyitd_amd.meitd's public functions take what MEITD.py's take (MEITD.py:79, :344, :371, :395, :536)."""
+    import inspect
+    from pyitd_amd import meitd
+    assert list(inspect.signature(meitd.weighted_permutation_entropy).parameters)[:3] == ["time_series", "order", "normalize"]
+    assert inspect.signature(meitd.weighted_permutation_entropy).parameters["order"].default == 3
+    assert list(inspect.signature(meitd.retrieve_proper_rotation).parameters)[:2] == ["x", "WPEMAX"]
+    assert list(inspect.signature(meitd.determine_if_first_is_proper_rotation).parameters)[:2] == ["x", "WPEMAX"]
+    p = inspect.signature(meitd.MEITD).parameters
+    assert list(p)[:3] == ["data", "max_iteration", "WPEMAX"] and p["max_iteration"].default == 40 and p["WPEMAX"].default == 0.6
+    assert list(inspect.signature(meitd.XITD).parameters)[:1] == ["data"]
