@@ -926,8 +926,8 @@ def mid_size_leg(torch, dev, calls=200):
     informational, with the fraction of the HBM peak on the result's own bytes (input once, every produced row once)."""
     import pyitd_amd
     out = []
-    t = np.arange(1 << 16, dtype=np.float64) / 48000.0
-    chirp = np.sin(2 * np.pi * (200.0 * t + 0.5 * 6000.0 * t * t)).astype(np.float32)      # 200 Hz -> 8.4 kHz over 1.37 s
+    t = np.arange(1 << 16, dtype=np.float64) / float(1 << 16)
+    chirp = np.sin(2 * np.pi * (50.0 * t + 0.5 * (8000.0 - 50.0) * t * t)).astype(np.float32)   # SURVEY 8d, config 1 (8050 / 3884 / 1997 / 800 knots)
     for name, x_host, M in (("configs[0]: chirp, 2^16 samples, 4 levels", chirp, 3), ("sines + noise, 2^16 samples, 8 levels", sines_noise(1 << 16), 7),
                             ("sines + noise, 2^18 samples, 8 levels", sines_noise(1 << 18), 7), ("sines + noise, 2^20 samples, 8 levels", sines_noise(1 << 20), 7)):
         n = len(x_host)
