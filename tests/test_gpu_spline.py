@@ -283,3 +283,28 @@ def test_meitd_keeps_its_arrays_on_the_device(P):
             delattr(wk, k)
     assert calls["upload"] == 1 and calls["download"] <= 3 and calls["extract"] < 60, calls
     assert len(lo) + len(hi) == 21
+
+
+@pytest.mark.parametrize("n, seed", [(500, 1), (2048, 2), (20000, 3), (70000, 4)])
+def test_meitd_on_other_signals_matches_the_flow_over_the_oracles_operators(P, n, seed):
+    """MEITD on signals the goldens do not cover (lengths from 500 samples to beyond the entropy's exact-order limit of 65536 windows):
+    the GPU run and the same control flow over the oracle's operators (oracle.meitd_oracle.CpuWork) keep the same components, to 1e-9."""
+    from oracle import meitd_oracle
+    from pyitd_amd import meitd
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 1000.0
+    x = np.sin(2 * np.pi * 3.0 * t) * (1.0 + 0.5 * np.sin(2 * np.pi * 0.4 * t)) + 0.3 * np.sin(2 * np.pi * 41.0 * t + 1.0) + 0.1 * rng.standard_normal(n)
+    hi, lo, res = meitd.MEITD(x.copy())
+    saved = meitd._work_for
+    meitd._work_for = lambda nn, device=0: meitd_oracle.CpuWork(nn)
+    try:
+        hi2, lo2, res2 = meitd.MEITD(x.copy())
+    finally:
+        meitd._work_for = saved
+    assert hi.shape == hi2.shape and lo.shape == lo2.shape, "components %s + %s against %s + %s" % (hi.shape, lo.shape, hi2.shape, lo2.shape)
+    if hi.size:
+        _close(hi, hi2, "high", 1e-9)
+    if lo.size:
+        _close(lo, lo2, "low", 1e-9)
+    _close(res, res2, "residual", 1e-9)
+    assert np.max(np.abs(hi.sum(0) + lo.sum(0) + res - x)) < 1e-9 * max(1.0, np.max(np.abs(x)))     # the components add up to the signal
