@@ -373,8 +373,9 @@ int itd_count_knots_host_f64(itd_engine *e, const double *x_host, int64_t n, int
  * The argsort is numpy's (insertion on three values, NaNs last, ties in index order), the variance numpy.var's expression; up to
  * 65536 windows the sums are taken one by one in index order like the reference's cumsum, longer signals in segments of 4096
  * windows added in order (deterministic, equal to rounding).  The entropy itself is six logarithms on the host:
- * p = w / sum(w); -sum(p log2 p) [/ log2(6)].  knots_host (optional): x's knot count (ITD_DETECT_KNOTS) in the same
- * synchronisation — MEITD.py:346-351, :373-378 ask for both; then ITD_ERR_NONFINITE (count filled in) if x holds a NaN.
+ * p = w / sum(w); -sum(p log2 p) [/ log2(6)].  knots_host (optional): x's knot count (ITD_DETECT_KNOTS, plain rules) from the same
+ * launch — a window's middle sample is a knot or not; MEITD.py:346-351, :373-378 ask for both; then ITD_ERR_NONFINITE (count filled
+ * in) if x holds a NaN.
  *
  * itd_baseline_extract_spline2_f64: itd_baseline_extract_spline_f64 plus baseline_knots_host [batch], the knot count of every
  * PRODUCED baseline, one synchronisation for both (the device form of itd_baseline_extract_spline_host2_f64).

@@ -2235,33 +2235,27 @@ int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weig
     const int64_t seg_len = exact ? nw : kWpeSeg;
     const int64_t nseg = (nw + seg_len - 1) / seg_len;
     if (nseg > INT32_MAX / 8) return ITD_ERR_INVALID_ARG;
-    const size_t out_off = (size_t)nseg * 6 * (sizeof(double) + sizeof(long long));    // the segments' sums, then the totals
-    int rc = grow(e, &e->d_wpe, &e->wpe_bytes, out_off + 6 * (sizeof(double) + sizeof(long long)));
+    const size_t out_off = (size_t)nseg * (6 * (sizeof(double) + sizeof(long long)) + 2 * sizeof(int));    // the segments' sums, then the totals
+    int rc = grow(e, &e->d_wpe, &e->wpe_bytes, out_off + 6 * (sizeof(double) + sizeof(long long)) + 2 * sizeof(int));
     if (rc) return rc;
     double *part_s = reinterpret_cast<double *>(e->d_wpe);
     long long *part_c = reinterpret_cast<long long *>(part_s + (size_t)nseg * 6);
+    int *part_k = reinterpret_cast<int *>(part_c + (size_t)nseg * 6);
     double *out_s = reinterpret_cast<double *>(e->d_wpe + out_off);
     long long *out_c = reinterpret_cast<long long *>(out_s + 6);
-    k_wpe3<<<(unsigned)nseg, 256, 0, st>>>(x_dev, nw, seg_len, part_s, part_c);
-    if (nseg > 1) k_wpe3_combine<<<1, 64, 0, st>>>(part_s, part_c, (int)nseg, out_s, out_c);
+    int *out_k = reinterpret_cast<int *>(out_c + 6);
+    // (the knot count of x rides along: a window's middle sample is a knot or not — MEITD.py:346-351, :373-378 ask for both)
+    k_wpe3<<<(unsigned)nseg, kWpeThreads, 0, st>>>(x_dev, nw, seg_len, part_s, part_c, knots_host ? part_k : nullptr);
+    if (nseg > 1) k_wpe3_combine<<<1, 64, 0, st>>>(part_s, part_c, (int)nseg, out_s, out_c, knots_host ? part_k : nullptr, out_k);
     HIP_TRY(e, hipGetLastError());
-    struct { double s[6]; long long c[6]; } res;
-    if (nseg > 1) HIP_TRY(e, hipMemcpyAsync(&res, out_s, sizeof(res), hipMemcpyDeviceToHost, st));
-    else {
-        HIP_TRY(e, hipMemcpyAsync(res.s, part_s, sizeof(res.s), hipMemcpyDeviceToHost, st));
-        HIP_TRY(e, hipMemcpyAsync(res.c, part_c, sizeof(res.c), hipMemcpyDeviceToHost, st));
-    }
-    int32_t tot[2] = {0, 0};
-    if (knots_host) {
-        DetectWs w;
-        rc = detect_enqueue(e, x_dev, n, n, 1, (int)kKnots, -1, st, w, nullptr, 0, false);
-        if (rc) return rc;
-        HIP_TRY(e, hipMemcpyAsync(tot, w.totals, sizeof(tot), hipMemcpyDeviceToHost, st));
-    }
+    struct { double s[6]; long long c[6]; int k[2]; } res;
+    res.k[0] = res.k[1] = 0;
+    if (nseg > 1) HIP_TRY(e, hipMemcpyAsync(&res, out_s, 6 * (sizeof(double) + sizeof(long long)) + (knots_host ? 2 * sizeof(int) : 0), hipMemcpyDeviceToHost, st));
+    else HIP_TRY(e, hipMemcpyAsync(&res, part_s, 6 * (sizeof(double) + sizeof(long long)) + (knots_host ? 2 * sizeof(int) : 0), hipMemcpyDeviceToHost, st));
     HIP_TRY(e, hipStreamSynchronize(st));
     for (int b = 0; b < 6; ++b) { bin_weights_host[b] = res.s[b]; bin_windows_host[b] = (int64_t)res.c[b]; }
-    if (knots_host) *knots_host = tot[0];
-    return knots_host && tot[1] ? ITD_ERR_NONFINITE : ITD_OK;
+    if (knots_host) *knots_host = res.k[0];
+    return knots_host && res.k[1] ? ITD_ERR_NONFINITE : ITD_OK;
 }
 
 // itd_baseline_extract_spline_f64 plus the knot count of every PRODUCED baseline, one synchronisation for both

@@ -47,12 +47,17 @@ __device__ __forceinline__ void wpe3_window(double a0, double a1, double a2, uns
 // running sum one by one — the chain of additions is the reference's cumsum, only the windows of other patterns are not in the way.
 constexpr int kWpeChunk = 4096;
 constexpr int kWpeThreads = 256;
+// part_k (optional): per segment, the number of windows whose MIDDLE sample is a knot of x (ITD.py:59 on x and on -x, raw
+// differences: what the count-only detection counts for samples 1 .. n-2) and whether a sample of the segment's windows is a NaN
 __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__ x, int64_t nw, int64_t seg_len, double *__restrict__ part_s,
-                                                      long long *__restrict__ part_c)
+                                                      long long *__restrict__ part_c, int *__restrict__ part_k)
 {
     static_assert(kWpeChunk % kWpeThreads == 0 && kWpeChunk < 65536, "three 16-bit counts per word");
     __shared__ double s_x[kWpeChunk + 2], s_l[kWpeChunk];
     __shared__ unsigned long long s_wave[2][kWpeThreads / 64];
+    __shared__ int s_kn[2];
+    if (threadIdx.x < 2) s_kn[threadIdx.x] = 0;
+    int kn = 0, nanf = 0;
     const int64_t lo = (int64_t)blockIdx.x * seg_len, hi = lo + seg_len < nw ? lo + seg_len : nw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;                    // (0.0 + w == w: a variance is never -0.0)
@@ -67,8 +72,12 @@ __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__
         for (int k = k0; k < k1; ++k) {
             unsigned char bin;
             double wt;
-            wpe3_window(s_x[k], s_x[k + 1], s_x[k + 2], bin, wt);
+            const double a0 = s_x[k], a1 = s_x[k + 1], a2 = s_x[k + 2];
+            wpe3_window(a0, a1, a2, bin, wt);
             if (bin < 3) a += 1ull << (16 * bin); else b += 1ull << (16 * (bin - 3));
+            const double d0 = a1 - a0, d1 = a2 - a1;
+            kn += ((d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0)) ? 1 : 0;
+            nanf |= (a0 != a0 || a1 != a1 || a2 != a2) ? 1 : 0;
         }
         // exclusive scan over the threads (in thread order = window order)
         unsigned long long ia = a, ib = b;
@@ -117,13 +126,25 @@ __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__
         part_s[(size_t)blockIdx.x * 6 + tid] = s;
         part_c[(size_t)blockIdx.x * 6 + tid] = c;
     }
+    if (part_k) {
+        if (kn) atomicAdd(&s_kn[0], kn);
+        if (nanf) s_kn[1] = 1;
+        __syncthreads();
+        if (tid < 2) part_k[(size_t)blockIdx.x * 2 + tid] = s_kn[tid];
+    }
 }
 
 // the segments' sums, added in segment order
 __global__ __launch_bounds__(64) void k_wpe3_combine(const double *__restrict__ part_s, const long long *__restrict__ part_c, int nseg,
-                                                     double *__restrict__ out_s, long long *__restrict__ out_c)
+                                                     double *__restrict__ out_s, long long *__restrict__ out_c, const int *__restrict__ part_k,
+                                                     int *__restrict__ out_k)
 {
     const unsigned bin = threadIdx.x;
+    if (part_k && (bin == 6 || bin == 7)) {          // knots: a sum; NaN seen: an or
+        int v = 0;
+        for (int g = 0; g < nseg; ++g) v = bin == 6 ? v + part_k[(size_t)g * 2] : (v | part_k[(size_t)g * 2 + 1]);
+        out_k[bin - 6] = v;
+    }
     if (bin >= 6) return;
     double s = part_s[bin];
     long long c = part_c[bin];

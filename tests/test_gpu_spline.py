@@ -154,6 +154,7 @@ def _wpe_cases():
         "two values": (t // 3 % 2).astype(np.float64),
         "with NaNs": np.where(rng.random(n) < 0.01, np.nan, rng.standard_normal(n)),
         "three samples": np.array([0.5, -1.0, 0.25]),
+        "with infinities": np.where(rng.random(n) < 0.01, np.inf, rng.standard_normal(n)) * np.where(rng.random(n) < 0.5, 1.0, -1.0),
         "exactly 65536 windows": rng.standard_normal(65538),
     }
     for f in sorted(os.listdir(SPLINE)):
@@ -173,7 +174,11 @@ def test_wpe3_bins_are_the_reference_sums_bit_for_bit(P):
         x = np.ascontiguousarray(x, dtype=np.float64)
         buf = DeviceBuffer(x.nbytes)
         buf.upload(x)
-        w, c = _eng(len(x), 0).wpe3_dev(buf.ptr, len(x))
+        eng = _eng(len(x), 0)
+        w, c = eng.wpe3_dev(buf.ptr, len(x))
+        w2, c2, knots = eng.wpe3_dev(buf.ptr, len(x), want_knots=True)       # the knot count rides along in the same launch
+        assert knots == eng.count_knots_dev(buf.ptr, len(x)), "%s: knot count %d" % (name, knots)
+        assert np.array_equal(c, c2) and (np.array_equal(w.view(np.uint64), w2.view(np.uint64)) or np.isnan(w).any())
         buf.free()
         with np.errstate(all="ignore"):
             wo, co = meitd_oracle.bins(x)
@@ -196,7 +201,8 @@ def test_wpe3_long_signal_in_segments(P):
     buf.upload(x)
     eng = _eng(len(x), 0)
     w, c = eng.wpe3_dev(buf.ptr, len(x))
-    w2, c2 = eng.wpe3_dev(buf.ptr, len(x))
+    w2, c2, knots = eng.wpe3_dev(buf.ptr, len(x), want_knots=True)
+    assert knots == eng.count_knots_dev(buf.ptr, len(x))
     buf.free()
     wo, co = meitd_oracle.bins(x)
     assert np.array_equal(c, co) and np.array_equal(c, c2)
