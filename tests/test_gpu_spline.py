@@ -314,3 +314,33 @@ def test_meitd_on_other_signals_matches_the_flow_over_the_oracles_operators(P, n
         _close(lo, lo2, "low", 1e-9)
     _close(res, res2, "residual", 1e-9)
     assert np.max(np.abs(hi.sum(0) + lo.sum(0) + res - x)) < 1e-9 * max(1.0, np.max(np.abs(x)))     # the components add up to the signal
+
+
+def test_meitd_early_returns(P):
+    """Signals with fewer than 4 extrema (MEITD.py:411-413: zeros, zeros, the signal itself), a short random one, and XITD of both:
+    the GPU run equals the flow over the oracle's operators."""
+    from oracle import meitd_oracle
+    from pyitd_amd import meitd
+    rng = np.random.default_rng(9)
+    for name, x in (("constant", np.full(100, 1.5)), ("ramp", np.linspace(-1.0, 2.0, 300)), ("one bump", np.exp(-np.linspace(-3, 3, 200) ** 2)),
+                    ("50 random samples", rng.standard_normal(50))):
+        with np.errstate(all="ignore"):
+            got = meitd.MEITD(x.copy())
+            gx = meitd.XITD(x.copy())
+            saved = meitd._work_for
+            meitd._work_for = lambda nn, device=0: meitd_oracle.CpuWork(nn)
+            saved_wpe = meitd.weighted_permutation_entropy
+            meitd.weighted_permutation_entropy = lambda ts, order=3, normalize=False, device=0: meitd_oracle.weighted_permutation_entropy(ts, order, normalize)
+            try:
+                ref = meitd.MEITD(x.copy())
+                rx = meitd.XITD(x.copy())
+            finally:
+                meitd._work_for = saved
+                meitd.weighted_permutation_entropy = saved_wpe
+        for a, b, what in zip(got, ref, ("high", "low", "residual")):
+            assert np.shape(a) == np.shape(b), "%s: %s" % (name, what)
+            if np.size(a):
+                _close(a, b, name + " " + what, 1e-9)
+        assert gx.shape == rx.shape, name
+        ok = np.isfinite(rx)
+        assert np.array_equal(np.isfinite(gx), ok) and np.max(np.abs(gx[ok] - rx[ok]), initial=0.0) < 1e-9, name
