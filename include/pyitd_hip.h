@@ -377,6 +377,11 @@ int itd_count_knots_host_f64(itd_engine *e, const double *x_host, int64_t n, int
  * launch — a window's middle sample is a knot or not; MEITD.py:346-351, :373-378 ask for both; then ITD_ERR_NONFINITE (count filled
  * in) if x holds a NaN.
  *
+ * itd_wpe_f64: the same pass for any `order` 2 .. 5 (MEITD.py:79 takes the order; MEITD itself only passes 3): sums_host and
+ * windows_host have order^order entries, indexed by the reference's hash value sum(argsort[k] * order^k); the entropy is drawn from
+ * the entries with windows, in ascending hash order (numpy.unique's).  Sums in index order per hash up to 65536 windows, in
+ * segments of 16384 beyond.  A side path: its work grows with order^order x windows.
+ *
  * itd_baseline_extract_spline2_f64: itd_baseline_extract_spline_f64 plus baseline_knots_host [batch], the knot count of every
  * PRODUCED baseline, one synchronisation for both (the device form of itd_baseline_extract_spline_host2_f64).
  *
@@ -386,6 +391,7 @@ int itd_count_knots_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t b
                         int32_t *counts_host, void *stream);
 int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weights_host, int64_t *bin_windows_host,
                  int32_t *knots_host, void *stream);
+int itd_wpe_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t order, double *sums_host, int64_t *windows_host, void *stream);
 int itd_baseline_extract_spline2_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,
                                      int32_t min_extrema, double *baseline_dev, int64_t baseline_stride, double *rot_dev,
                                      int64_t rot_stride, int32_t *knots_host, int32_t *baseline_knots_host, void *stream);

@@ -21,11 +21,13 @@ def _embed(x, order=3, delay=1):
     return Y.T
 
 
-def weighted_permutation_entropy(time_series, order=3, normalize=False):
-    """MEITD.py:79-128, expression by expression."""
+def weighted_permutation_entropy(time_series, order=3, normalize=False, sort_kind="quicksort"):
+    """MEITD.py:79-128, expression by expression.  sort_kind: the reference asks numpy for "quicksort"; on rows of 3 values that is
+    numpy's insertion sort (ties keep their index order) on every build — on rows of 4 or more an AVX-512 build of numpy sorts with
+    x86-simd-sort's networks, whose order of tied values is its own: "stable" is the build-independent reading (tests of orders != 3)."""
     x = numpy.array(time_series)
     hashmult = numpy.power(order, numpy.arange(order))
-    sorted_idx = _embed(x, order=order).argsort(kind="quicksort")
+    sorted_idx = _embed(x, order=order).argsort(kind=sort_kind)
     windows = numpy.lib.stride_tricks.sliding_window_view(x, order)      # = util_rolling_window(x, order), MEITD.py:73-76
     weights = numpy.var(windows, 1)
     hashval = (numpy.multiply(sorted_idx, hashmult)).sum(1)

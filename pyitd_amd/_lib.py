@@ -55,6 +55,7 @@ ABI = {
     "itd_count_knots_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P]),
     "itd_count_knots_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _P]),
     "itd_wpe3_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P]),
+    "itd_wpe_f64": (_INT, [_P, _P, _I64, _I32, _P, _P, _P]),
     "itd_baseline_extract_spline2_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_subtract_f64": (_INT, [_P, _P, _P, _P, _I64, _P]),
     "itd_copy": (_INT, [_P, _P, _P, _I64, _I32, _I32, _P]),

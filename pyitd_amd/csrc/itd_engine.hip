@@ -2258,6 +2258,48 @@ int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weig
     return knots_host && res.k[1] ? ITD_ERR_NONFINITE : ITD_OK;
 }
 
+// weighted_permutation_entropy's pass over the samples for any order 2 .. 5: sums_host / windows_host [order^order], indexed by the
+// reference's hash value (a hash without windows is absent from its list)
+int itd_wpe_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t order, double *sums_host, int64_t *windows_host, void *stream)
+{
+    if (!e || !x_dev || !sums_host || !windows_host || order < 2 || order > kWpeMaxOrder || n < order) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    const int64_t nw = n - order + 1;
+    int nh = 1;
+    for (int k = 0; k < order; ++k) nh *= order;
+    const int64_t seg_len = nw <= kWpeExactWindows ? nw : kWpeSeg * 4;
+    const int64_t nseg = (nw + seg_len - 1) / seg_len;
+    if (nseg > 65535) return ITD_ERR_INVALID_ARG;
+    const size_t wts_off = ((size_t)nw * sizeof(unsigned short) + 255) / 256 * 256;
+    const size_t part_off = wts_off + (size_t)nw * sizeof(double);
+    const size_t out_off = part_off + (size_t)nseg * nh * (sizeof(double) + sizeof(long long));
+    int rc = grow(e, &e->d_wpe, &e->wpe_bytes, out_off + (size_t)nh * (sizeof(double) + sizeof(long long)));
+    if (rc) return rc;
+    unsigned short *hashes = reinterpret_cast<unsigned short *>(e->d_wpe);
+    double *wts = reinterpret_cast<double *>(e->d_wpe + wts_off);
+    double *part_s = reinterpret_cast<double *>(e->d_wpe + part_off);
+    long long *part_c = reinterpret_cast<long long *>(part_s + (size_t)nseg * nh);
+    double *out_s = reinterpret_cast<double *>(e->d_wpe + out_off);
+    long long *out_c = reinterpret_cast<long long *>(out_s + nh);
+    const unsigned gb = (unsigned)((nw + 255) / 256);
+    switch (order) {
+    case 2: k_wpe_eval<2><<<gb, 256, 0, st>>>(x_dev, nw, hashes, wts); break;
+    case 3: k_wpe_eval<3><<<gb, 256, 0, st>>>(x_dev, nw, hashes, wts); break;
+    case 4: k_wpe_eval<4><<<gb, 256, 0, st>>>(x_dev, nw, hashes, wts); break;
+    default: k_wpe_eval<5><<<gb, 256, 0, st>>>(x_dev, nw, hashes, wts); break;
+    }
+    k_wpe_sum<<<dim3((unsigned)((nh + 255) / 256), (unsigned)nseg), 256, 0, st>>>(hashes, wts, nw, seg_len, nh, part_s, part_c);
+    if (nseg > 1) k_wpe_combine<<<(unsigned)((nh + 255) / 256), 256, 0, st>>>(part_s, part_c, (int)nseg, nh, out_s, out_c);
+    HIP_TRY(e, hipGetLastError());
+    std::vector<long long> cnt((size_t)nh);
+    HIP_TRY(e, hipMemcpyAsync(sums_host, nseg > 1 ? out_s : part_s, (size_t)nh * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipMemcpyAsync(cnt.data(), nseg > 1 ? out_c : part_c, (size_t)nh * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    for (int h = 0; h < nh; ++h) windows_host[h] = (int64_t)cnt[(size_t)h];
+    return ITD_OK;
+}
+
 // itd_baseline_extract_spline_f64 plus the knot count of every PRODUCED baseline, one synchronisation for both
 // (MEITD.py:362-363, :497-505)
 int itd_baseline_extract_spline2_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t batch, int64_t x_stride,

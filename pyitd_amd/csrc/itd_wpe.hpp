@@ -153,6 +153,93 @@ __global__ __launch_bounds__(64) void k_wpe3_combine(const double *__restrict__ 
     out_c[bin] = c;
 }
 
+// ---- any order 2 .. 5 (MEITD.py:79-128 takes `order`; MEITD itself only ever passes 3: the kernels above) ---------------------
+// A window's hash is sum(sorted_idx[k] * order^k) < order^order (at most 3125); its weight numpy.var of its `order` values.  One thread
+// per (hash value, segment) adds the weights of the segment's windows with that hash one by one in index order; the segments are added
+// in order (k_wpe_combine).  Work grows with order^order x windows: a side path, not a fast one.
+constexpr int kWpeMaxOrder = 5;
+template <int ORDER>
+__device__ __forceinline__ void wpe_window(const double *__restrict__ a, unsigned short &hash, double &wt)
+{
+    int idx[ORDER];
+    double v[ORDER];
+#pragma unroll
+    for (int k = 0; k < ORDER; ++k) { idx[k] = k; v[k] = a[k]; }
+#pragma unroll
+    for (int i = 1; i < ORDER; ++i) {                // numpy's insertion sort of the index list (npy_sort, n <= 16): stable, NaNs last
+        const double vi = v[i];
+        const int ii = idx[i];
+        int j = i;
+#pragma unroll
+        for (int t = 0; t < ORDER; ++t) {
+            if (j > 0 && np_lt(vi, v[j > 0 ? j - 1 : 0])) { v[j] = v[j - 1]; idx[j] = idx[j - 1]; --j; }
+        }
+        v[j] = vi;
+        idx[j] = ii;
+    }
+    int h = 0, mul = 1;
+#pragma unroll
+    for (int k = 0; k < ORDER; ++k) { h += idx[k] * mul; mul *= ORDER; }
+    hash = (unsigned short)h;
+    double sum = a[0];
+#pragma unroll
+    for (int k = 1; k < ORDER; ++k) sum += a[k];
+    const double mean = sum / (double)ORDER;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < ORDER; ++k) { const double d = a[k] - mean; acc = k == 0 ? d * d : acc + d * d; }
+    wt = acc / (double)ORDER;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_wpe_eval(const double *__restrict__ x, int64_t nw, unsigned short *__restrict__ hashes,
+                                                  double *__restrict__ wts)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nw) return;
+    double a[ORDER];
+#pragma unroll
+    for (int k = 0; k < ORDER; ++k) a[k] = x[i + k];
+    wpe_window<ORDER>(a, hashes[i], wts[i]);
+}
+
+// grid = (ceil(nh / 256), segments): thread = one hash value over one segment of windows
+__global__ __launch_bounds__(256) void k_wpe_sum(const unsigned short *__restrict__ hashes, const double *__restrict__ wts, int64_t nw,
+                                                 int64_t seg_len, int nh, double *__restrict__ part_s, long long *__restrict__ part_c)
+{
+    __shared__ unsigned short s_h[1024];
+    __shared__ double s_w[1024];
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    const int64_t lo = (int64_t)blockIdx.y * seg_len, hi = lo + seg_len < nw ? lo + seg_len : nw;
+    double s = 0.0;
+    long long c = 0;
+    for (int64_t base = lo; base < hi; base += 1024) {
+        const int m = (int)(hi - base < 1024 ? hi - base : 1024);
+        for (int k = threadIdx.x; k < m; k += 256) { s_h[k] = hashes[base + k]; s_w[k] = wts[base + k]; }
+        __syncthreads();
+        if (h < nh)
+            for (int k = 0; k < m; ++k)
+                if (s_h[k] == (unsigned short)h) { s += s_w[k]; ++c; }
+        __syncthreads();
+    }
+    if (h < nh) {
+        part_s[(size_t)blockIdx.y * nh + h] = s;
+        part_c[(size_t)blockIdx.y * nh + h] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wpe_combine(const double *__restrict__ part_s, const long long *__restrict__ part_c, int nseg, int nh,
+                                                     double *__restrict__ out_s, long long *__restrict__ out_c)
+{
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= nh) return;
+    double s = part_s[h];
+    long long c = part_c[h];
+    for (int g = 1; g < nseg; ++g) { s += part_s[(size_t)g * nh + h]; c += part_c[(size_t)g * nh + h]; }
+    out_s[h] = s;
+    out_c[h] = c;
+}
+
 // out = a - b (MEITD.py:453 `x = x - rotation_[:]`)
 __global__ __launch_bounds__(256) void k_subtract(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, int64_t count)
 {

@@ -367,6 +367,14 @@ class Engine:
         self._check(self._L.itd_wpe3_f64(self._h, x_ptr, n, _np_ptr(w), _np_ptr(c), _np_ptr(k), stream), allow=(ITD_ERR_NONFINITE,))
         return (w, c, int(k[0])) if want_knots else (w, c)
 
+    def wpe_dev(self, x_ptr, n, order, stream=None):
+        """(sums[order^order], windows[order^order]) by the reference's hash value, for any order 2 .. 5 (MEITD.py:79-128)."""
+        nh = int(order) ** int(order)
+        w = np.zeros(nh, np.float64)
+        c = np.zeros(nh, np.int64)
+        self._check(self._L.itd_wpe_f64(self._h, x_ptr, n, int(order), _np_ptr(w), _np_ptr(c), stream))
+        return w, c
+
     def spline_extract_dev(self, x_ptr, n, base_ptr, rot_ptr=None, min_extrema=0, want_baseline_knots=False, stream=None):
         """The spline baseline of the n samples at x_ptr into base_ptr (x - baseline into rot_ptr): returns the signal's knot
         count, and the produced baseline's with want_baseline_knots."""

@@ -1,6 +1,6 @@
 """Host-side mirror of MEITD.py's selection drivers, on top of the GPU operators:
 
-  weighted_permutation_entropy(time_series, order=3, normalize=False)   MEITD.py:79-128
+  weighted_permutation_entropy(time_series, order=3, normalize=False)   MEITD.py:79-128   (orders 2 .. 5)
   retrieve_proper_rotation(x, WPEMAX)                                    MEITD.py:344-368
   determine_if_first_is_proper_rotation(x, WPEMAX)                       MEITD.py:371-392
   MEITD(data, max_iteration=40, WPEMAX=0.6) -> (high, low, residual)     MEITD.py:395-534
@@ -27,15 +27,6 @@ from .engine import DeviceBuffer
 from .spline import _eng
 
 
-def _embed(x, order=3, delay=1):
-    """MEITD.py:48-70"""
-    N = len(x)
-    Y = numpy.empty((order, N - (order - 1) * delay))
-    for i in range(order):
-        Y[i] = x[i * delay:i * delay + Y.shape[1]]
-    return Y.T
-
-
 def _entropy_from_bins(weights, windows, order=3, normalize=False):
     """MEITD.py:119-128 from the patterns' weighted counts (in numpy.unique's order; a pattern without windows is absent)."""
     wc = weights[windows > 0]
@@ -47,33 +38,21 @@ def _entropy_from_bins(weights, windows, order=3, normalize=False):
 
 
 def weighted_permutation_entropy(time_series, order=3, normalize=False, device=0):
-    """MEITD.py:79-128: permutation patterns of the embedded series, each window weighted by its variance.  Order 3 (the only one
-    MEITD.py uses) runs on the GPU; other orders are the reference's numpy expressions."""
-    x = numpy.array(time_series)
-    if order == 3 and x.ndim == 1 and len(x) >= 3:
-        x = numpy.ascontiguousarray(x, dtype=numpy.float64)
-        buf = DeviceBuffer(x.nbytes, device)
-        try:
-            buf.upload(x)
-            w, c = _eng(len(x), device).wpe3_dev(buf.ptr, len(x))
-        finally:
-            buf.free()
-        return _entropy_from_bins(w, c, 3, normalize)
-    hashmult = numpy.power(order, numpy.arange(order))
-    sorted_idx = _embed(x, order=order).argsort(kind="quicksort")
-    windows = numpy.lib.stride_tricks.sliding_window_view(x, order)      # = util_rolling_window(x, order), MEITD.py:73-76
-    weights = numpy.var(windows, 1)
-    hashval = (numpy.multiply(sorted_idx, hashmult)).sum(1)
-    counts = []
-    for h in numpy.unique(hashval):
-        w = weights[numpy.where(hashval == h)[0]]
-        counts.append(numpy.cumsum(w)[-1] if w.size else 0.0)            # the reference adds them one by one, in index order
-    wc = numpy.array(counts)
-    p = numpy.true_divide(wc, wc.sum())
-    pe = -numpy.multiply(p, numpy.log2(p)).sum()
-    if normalize:
-        pe /= numpy.log2(factorial(order))
-    return pe
+    """MEITD.py:79-128: permutation patterns of the embedded series, each window weighted by its variance.  The pass over the samples
+    runs on the GPU (order 3, the only one MEITD.py itself uses: itd_wpe3_f64; orders 2, 4, 5: itd_wpe_f64); the entropy is drawn
+    here from the patterns' weighted counts.  Orders above 5 are refused (order^order hash values: the operator is not built for
+    them)."""
+    x = numpy.ascontiguousarray(numpy.array(time_series), dtype=numpy.float64)
+    if x.ndim != 1 or not 2 <= int(order) <= 5 or len(x) < int(order):
+        raise ValueError("weighted_permutation_entropy: a 1-D series of at least `order` samples, order 2 .. 5")
+    buf = DeviceBuffer(x.nbytes, device)
+    try:
+        buf.upload(x)
+        eng = _eng(len(x), device)
+        w, c = eng.wpe3_dev(buf.ptr, len(x)) if int(order) == 3 else eng.wpe_dev(buf.ptr, len(x), int(order))
+    finally:
+        buf.free()
+    return _entropy_from_bins(w, c, int(order), normalize)
 
 
 _ROWS_KEPT = 22          # MEITD returns once more than 20 components are kept (:414-415): 21 rows at most, in either list

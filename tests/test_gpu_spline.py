@@ -344,3 +344,51 @@ def test_meitd_early_returns(P):
         assert gx.shape == rx.shape, name
         ok = np.isfinite(rx)
         assert np.array_equal(np.isfinite(gx), ok) and np.max(np.abs(gx[ok] - rx[ok]), initial=0.0) < 1e-9, name
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_entropy_of_other_orders_matches_the_reference_expressions(P, order):
+    """weighted_permutation_entropy(x, order) for the orders the GPU operators take (itd_wpe3_f64 / itd_wpe_f64) against the
+    reference's numpy expressions (oracle/meitd_oracle.py, MEITD.py:79-128): hash populations exact, weighted sums bit for bit (index
+    order per hash, up to 65536 windows), the entropy equal.  Tied values within a window keep their index order (numpy's insertion
+    sort; an AVX-512 numpy orders ties of rows of 4 or more by its sorting networks: the oracle is asked for the stable order there)."""
+    kind = "quicksort" if order <= 3 else "stable"
+    from oracle import meitd_oracle
+    from pyitd_amd import meitd
+    from pyitd_amd.engine import DeviceBuffer
+    from pyitd_amd.spline import _eng
+    rng = np.random.default_rng(100 + order)
+    cases = {"noise": rng.standard_normal(4000), "quantised": np.round(2.0 * rng.standard_normal(4000)), "walk": np.cumsum(rng.standard_normal(9000)),
+             "with NaNs": np.where(rng.random(3000) < 0.01, np.nan, rng.standard_normal(3000)), "shortest": rng.standard_normal(order)}
+    for name, x in cases.items():
+        with np.errstate(all="ignore"):
+            ref = meitd_oracle.weighted_permutation_entropy(x, order=order, normalize=True, sort_kind=kind)
+            got = meitd.weighted_permutation_entropy(x, order=order, normalize=True)
+        assert got == ref or (np.isnan(got) and np.isnan(ref)), "%s, order %d: %r != %r" % (name, order, got, ref)
+        if order != 3:
+            # the operator's raw output against the reference's per-hash sums
+            buf = DeviceBuffer(x.nbytes)
+            buf.upload(np.ascontiguousarray(x))
+            w, c = _eng(len(x), 0).wpe_dev(buf.ptr, len(x), order)
+            buf.free()
+            sorted_idx = meitd_oracle._embed(x, order=order).argsort(kind=kind)
+            hashval = (sorted_idx * np.power(order, np.arange(order))).sum(1)
+            with np.errstate(all="ignore"):
+                weights = np.var(np.lib.stride_tricks.sliding_window_view(x, order), 1)
+            for h in range(order ** order):
+                sel = weights[hashval == h]
+                assert c[h] == sel.size, "%s, order %d, hash %d" % (name, order, h)
+                if sel.size:
+                    r = np.cumsum(sel)[-1]
+                    assert w[h] == r or (np.isnan(w[h]) and np.isnan(r)), "%s, order %d, hash %d: %r != %r" % (name, order, h, w[h], r)
+    with pytest.raises(ValueError):
+        meitd.weighted_permutation_entropy(np.arange(10.0), order=6)
+
+
+def test_entropy_of_order_4_long_signal_in_segments(P):
+    from oracle import meitd_oracle
+    from pyitd_amd import meitd
+    x = np.cumsum(np.random.default_rng(8).standard_normal(150000))
+    ref = meitd_oracle.weighted_permutation_entropy(x, order=4, normalize=True)
+    got = meitd.weighted_permutation_entropy(x, order=4, normalize=True)
+    assert abs(got - ref) < 1e-12 and meitd.weighted_permutation_entropy(x, order=4, normalize=True) == got
