@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 8
+#define ITD_ABI_VERSION 9
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -190,7 +190,9 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * its own, and the engine stays in the fused form.
  * Results are bit-identical in every mode: what the fused form cannot deliver it reports.  The fused levels' workspace is allocated
  * by the first call that takes this path; a call being captured into a graph cannot allocate: on an engine that has not fused yet it is
- * captured level by level (run one decomposition before the capture to get the fused form into the graph).
+ * captured level by level (run one decomposition before the capture to get the fused form into the graph).  A graph that holds a fused
+ * call stays replayable whatever the engine does afterwards: when later calls need a larger workspace (smaller ranges after a capacity
+ * refusal, itd_set_fuse_range, itd_set_fuse_level) the one the graph refers to is kept until itd_engine_destroy, never freed.
  * ITD_FUSE_AUTO (default): calls whose launch sequences cover at least itd_set_fuse_min_samples samples (signals per chunk x n; default
  * 2 * 2^20: one signal of 2^20 / 2^21 / 2^22 / 2^23 samples takes 89 / 115 / 183 / 305 us level by level and 90 / 104 / 149 / 227 us
  * fused), signals of >= 65536 samples; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never repeat (itd_get_summary fails with
@@ -210,6 +212,17 @@ int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
 /* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot-side launch of the fused levels (default 1; sharing it
  * paid while the knot side was a dozen launches) */
 int itd_set_fuse_group(itd_engine *e, int32_t chunks);
+/* Tests only (ABI revision 9): arm ONE fault in what the fused levels' knot side hands to their sample pass, applied to signal 0 of
+ * every following fused call of this engine until disarmed (kind < 0).  The sample pass verifies everything it takes from the knot
+ * side (itd_knotfirst.hpp: V0 .. V3); a fault in a field it uses must end in a refusal (ITD_FUSE_ONLY: itd_get_summary fails;
+ * otherwise the call is repeated level by level, itd_get_fuse_repeats counts it) — tests/test_gpu_fused.py holds that for thousands.
+ *   kind 0 / 1 / 2  delta ulps added to X / B / S of table entry `slot` (mod the run's length) of tile `where`'s run at `level`;
+ *   kind 3          delta added to that entry's knot position;     kind 4   delta added to the run's start index first[level][where];
+ *   kind 5          bit (delta & 63) of flag word (slot & 7) of tile `where` at `level` flipped;
+ *   kind 6 / 7      the value (delta ulps) / position (delta) of halo knot `slot` (0, 1: the two in front, 2 .. 4: the three behind) as
+ *                   knot-side workgroup `where` receives it from its neighbours at `level`.
+ * `level` is the absolute level (first fused level .. max_iteration + 1). */
+int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta);
 /* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);
 /* ... and how many single signals of batches it has re-run on their own (the rest of their batch kept the fused result) */

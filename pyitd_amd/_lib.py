@@ -17,7 +17,7 @@ HEADERS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) + glob.glob(os.
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -93,6 +93,7 @@ ABI = {
     "itd_set_fuse_level": (_INT, [_P, _I32]),
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),
     "itd_set_fuse_group": (_INT, [_P, _I32]),
+    "itd_debug_kf_fault": (_INT, [_P, _I32, _I32, _I32, _I32, _I32]),
     "itd_get_fuse_repeats": (_INT, [_P]),
     "itd_get_fuse_signal_repairs": (_I64, [_P]),
     "itd_set_resident_mode": (_INT, [_P, _I32]),

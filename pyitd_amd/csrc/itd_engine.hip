@@ -185,6 +185,7 @@ struct itd_engine {
     int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
     // the fused sparse levels (itd_knotfirst.hpp): workspace (allocated at first use), mode, first fused level
     void *d_kf = nullptr; size_t kf_bytes = 0;
+    std::vector<void *> kf_retired;  // earlier, smaller workspaces: a captured graph may still hold their pointers — kept until the engine is destroyed
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
     bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
@@ -204,6 +205,8 @@ struct itd_engine {
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
     bool last_kf = false;
     int last_kf_level = 0;         // the first fused level of that call
+    // fault injection into the fused levels' workspace (itd_debug_kf_fault; tests only): kind < 0 = none
+    int32_t fault_kind = -1, fault_level = 0, fault_where = 0, fault_slot = 0, fault_delta = 0;
     int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
@@ -324,10 +327,13 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
     const size_t wgs = (size_t)(e->max_tiles + tpw - 1) / tpw;
     if (e->d_kf && (size_t)e->kf.wgs_max >= wgs) return ITD_OK;
     if (!may_allocate) return ITD_ERR_NOMEM;
-    if (e->d_kf) {                        // the first fused level was lowered: more, smaller workgroups per signal
-        if (hipDeviceSynchronize() != hipSuccess || hipFree(e->d_kf) != hipSuccess) return ITD_ERR_HIP;
+    if (e->d_kf) {
+        // smaller ranges (a list outgrew its workgroup, itd_set_fuse_range, a lower first fused level): more workgroups per signal need
+        // a larger workspace.  The old one is NOT freed: a hipGraph captured on this engine has its pointers baked into the fused
+        // levels' launches and may be replayed at any time (its launches stay self-consistent: geometry and pointers travel
+        // together as kernel arguments) — it is retired until itd_engine_destroy; its bytes stay counted
+        e->kf_retired.push_back(e->d_kf);
         e->d_kf = nullptr;
-        e->ws_bytes -= (int64_t)e->kf_bytes;
     }
     const size_t B = (size_t)e->max_batch;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -559,6 +565,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             w.n_tiles = n_tiles; w.L0 = L0; w.nlev = M + 3 - L0;
             w.tpw = kf_tpw; w.wgs = (n_tiles + kf_tpw - 1) / kf_tpw; w.nb = nb;
             w.ticketed = (int64_t)w.wgs * nb > e->kf_resident_wgs ? 1 : 0;
+            w.dbg_kind = e->fault_kind; w.dbg_lev = e->fault_level; w.dbg_wg = e->fault_where; w.dbg_slot = e->fault_slot; w.dbg_delta = e->fault_delta;
             const size_t B0 = (size_t)b0;
             w.sig += B0; w.pool += B0 * (size_t)w.wgs_max * kKcSlab; w.rec += B0 * (size_t)w.rec_levels * w.wgs_max * kKcRecGran;
             w.first += B0 * (size_t)w.nlev * n_tiles; w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.nearw += B0 * (size_t)n_tiles * 8;
@@ -585,6 +592,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 #ifdef ITD_DEBUG_GAP
                 k_debug_gap<<<1, 64, 0, cst>>>((long long)(ITD_DEBUG_GAP) * 100);
 #endif
+                if (e->fault_kind >= 0 && e->fault_kind <= 5 && e->fault_level >= L0 && e->fault_level - L0 < w.nlev && e->fault_where >= 0 &&
+                    e->fault_where < n_tiles)      // (tests only) one field of what the sample pass is about to read, perturbed
+                    k_kf_fault<<<1, 64, 0, cst>>>(w, e->fault_kind, e->fault_level - L0, e->fault_where, e->fault_slot & 0xffff, e->fault_delta);
                 const int pair = time_slot(e, ITD_TIME_KF_APPLY);
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
                 const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
@@ -956,7 +966,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
     (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
-    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); (void)hipFree(e->d_flag); (void)hipFree(e->d_need); (void)hipFree(e->d_valid_own);
+    (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); for (void *q : e->kf_retired) (void)hipFree(q); (void)hipFree(e->d_flag); (void)hipFree(e->d_need); (void)hipFree(e->d_valid_own);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2); (void)hipFree(e->d_wpe);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_kf) (void)hipHostFree(e->h_kf);
@@ -1402,6 +1412,15 @@ int itd_set_fuse_min_samples(itd_engine *e, int64_t samples)
 {
     if (!e || samples < 0) return ITD_ERR_INVALID_ARG;
     e->fuse_min_samples = samples;
+    return ITD_OK;
+}
+
+int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta)
+{
+    if (!e || kind > 7 || (kind >= 0 && (level < 2 || level > ITD_MAX_ITERATION + 1 || where < 0 || slot < 0))) return ITD_ERR_INVALID_ARG;
+    if (kind >= 6 && slot > 4) return ITD_ERR_INVALID_ARG;
+    e->fault_kind = kind < 0 ? -1 : kind;
+    e->fault_level = level; e->fault_where = where; e->fault_slot = slot; e->fault_delta = delta;
     return ITD_OK;
 }
 

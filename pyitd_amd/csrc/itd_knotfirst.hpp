@@ -108,6 +108,9 @@ struct KfWs {
     int32_t wgs, nb;              // workgroups per signal, signals of the launch
     int32_t tpw;                  // tiles per workgroup (<= kKcTiles; fewer where the first fused level's knots are dense)
     int32_t ticketed;             // 1: the grid may not fit the device at once: workgroup ids are tickets (KfSig::ticket), not blockIdx
+    // fault injection (itd_debug_kf_fault, tests only): kind 6 / 7 = a halo knot's value / position as this launch's workgroup `wg`
+    // receives it at level `lev` is perturbed (kinds 0 .. 5 are applied to the workspace by k_kf_fault between the two launches)
+    int32_t dbg_kind, dbg_lev, dbg_wg, dbg_slot, dbg_delta;
 };
 
 __device__ __forceinline__ bool kf_pred(double yl, double yc, double yr)
@@ -420,6 +423,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             int inc = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+            // (the level's knot count — what the stop rules are drawn from — is the population of the words the sample pass verifies)
+            if (lane == nt - 1 && inc != ck) give_up(kKfFailVerify);
             if (lane < nt) {
                 first_sig[(size_t)li * n_tiles + t0 + lane] = slab_off + toff + inc - cnt;
                 using U2 = unsigned long long __attribute__((ext_vector_type(2)));
@@ -553,6 +558,14 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         if (lev == L0) published = lev;
         kc_barrier();
         if (s_i[1]) break;
+        if (ws.dbg_kind >= 6 && lev == ws.dbg_lev && w == ws.dbg_wg && sig == 0) {   // fault injection (tests): a halo knot as received
+            if (tid == 0) {
+                const int d = ws.dbg_slot < 2 ? ws.dbg_slot : ck + ws.dbg_slot;     // slots 0, 1: in front; 2 .. 4: behind
+                if (ws.dbg_kind == 6) k_X[d] = __builtin_bit_cast(double, dbits(k_X[d]) + (unsigned long long)(long long)ws.dbg_delta);
+                else k_pos[d] += ws.dbg_delta;
+            }
+            kc_barrier();
+        }
         KC_MARK(5 + 4 * min(li, 12));
         // B. knot values (ITD.py:100-110) and slopes (ITD.py:115-116): a thread computes B of its knot and of the next one (no
         //    exchange in between), the level's table entry leaves at once
@@ -742,8 +755,34 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
 }
 
 // ---- the sample pass: every fused level of a tile in registers.  grid = (tiles, batch), 64 threads. -----------------------
+// What it takes from the knot side it VERIFIES, every level, so that a delivered row is the reference's by construction (induction
+// over the levels: the level's input in the registers is exact — the first fused level's comes from the level-by-level launches):
+//   V0  the level's knots (flag words) = the exact predicate on the level's input: the first fused level's here, every later
+//       level's on the values the level before has just computed;
+//   V1  table entries 1 .. kn of the tile's run ARE the tile's knots: position and value equal the owner lane's own sample, bit
+//       for bit; tile 0 owns the virtual knot at sample 0, the last tile the one at sample n-1 (ITD.py:96,98,101-102);
+//   V2  B of entries 1 .. kn recomputed from the positions and values of entries r-1, r, r+1 in the association of ITD.py:107-110,
+//       S of entries 0 .. kn from B and X of entries r, r+1 (ITD.py:115-116), compared bit for bit;
+//   V3  the runs chain: inside a knot-side workgroup's slab the next tile's run starts where this one's knots end
+//       (first[t+1] == first[t] + kn), so entry 0 / kn+1 of a run is physically the entry its owner tile verifies — the nearest
+//       knot in front of / behind the tile; across two slabs the last tile of a range compares the next slab's copy of the knot
+//       in front (its own entry kn) and its own copy of the knot behind (the next slab's entry 1) bit for bit, all four fields.
+// Every field of every entry a tile uses is thereby checked by its owner or equals, through a chain of bitwise equalities, an
+// entry that is; any mismatch refuses the signal (kKfFailVerify).  tests/test_gpu_fused.py injects faults into every one of
+// these (itd_debug_kf_fault) and requires the refusal.
+// != 0 <=> the bit patterns differ — as integer arithmetic on the vector unit (compares would go through lane masks in scalar
+// registers, which the sample pass has none to spare of)
+__device__ __forceinline__ int ne_d(double a, double b)
+{
+    const unsigned long long x = dbits(a) ^ dbits(b);
+    return (int)((unsigned)x | (unsigned)(x >> 32));
+}
+__device__ __forceinline__ int ne_i(int32_t a, int32_t b) { return a ^ b; }
 #ifndef ITD_KF_APPLY_WAVES
-#define ITD_KF_APPLY_WAVES 0      // A/B builds: wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice: 6)
+#define ITD_KF_APPLY_WAVES 6      // wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice: 5 with 81 VGPRs; 6 costs no spill)
+#endif
+#ifndef ITD_KF_VERIFY
+#define ITD_KF_VERIFY 15          // timing-only A/B builds: bit k = check Vk is compiled in (the shipped build: all four)
 #endif
 template <int TW, int CAP>
 __global__ __launch_bounds__(kWave)
@@ -757,6 +796,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     constexpr int G2 = TW / 128;
     __shared__ double s_X[CAP + 2], s_B[CAP + 2], s_S[CAP + 2];
     __shared__ int32_t s_P[CAP + 2];
+    __shared__ double s_e[2];                                       // the last tile: the level's x[n-2], x[n-1]
     const int sig = blockIdx.y, lane = lane_id();
     KfSig *ks = ws.sig + sig;
     const int n_tiles = ws.n_tiles;
@@ -781,17 +821,63 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     double *rows_s = rows + (int64_t)sig * rows_stride + si;
     double *bases_s = bases ? bases + (int64_t)sig * bases_stride + si : nullptr;
     unsigned long long wcur = lane < 2 * G2 ? tf[(size_t)t * 8 + lane] : 0ull;       // this level's flag words, lane j holds word j
-    bool bad = false;
-    for (int lev = ws.L0; lev <= lend; ++lev) {
+    const bool has_next = t + 1 < n_tiles;
+    const bool range_last = has_next && (t + 1) % ws.tpw == 0;     // tile t+1 starts another knot-side workgroup's slab
+    bool bad = false;            // wave-uniform findings
+    int vbad = 0;                // per-lane findings
+    // the knots of the values in the registers (x_lo / x_hi: the samples next to the tile): the exact predicate, ITD.py:59 on x and -x
+    auto knots_of = [&](double lo_v, double hi_v, unsigned long long (&E2)[G2], unsigned long long (&O2)[G2]) {
+        double d0[G2], d1[G2];
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+            const double fill = (g == 0) ? lo_v : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);
+            const double left = wave_dpp<0x138>(fill, xr[g][1]);
+            d0[g] = xr[g][0] - left;
+            d1[g] = xr[g][1] - xr[g][0];
+        }
+        knot_predicate<double, G2>(d0, d1, hi_v - xr[G2 - 1][1], E2, O2);
+        if (si == 0 || nrem <= TW + 1) {       // first and last sample are never knots (ITD.py:70-73), nothing beyond n-2
+            const int lo = si > 0 ? 0 : 1, hi = nrem - 2;
+#pragma unroll
+            for (int g = 0; g < G2; ++g) {
+                E2[g] &= bit_range((lo - 128 * g + 1) >> 1, (hi - 128 * g) >> 1);
+                O2[g] &= bit_range((lo - 128 * g) >> 1, (hi - 128 * g - 1) >> 1);
+            }
+        }
+    };
+    // Loop over the fused levels.  At the top of a level the level's input is in the registers (xr, x_lo, x_hi) and its flag words
+    // in wcur: V0 first — the exact predicate on those values must reproduce the words — then the level's map.  The pass after the
+    // last level only counts the pending baseline's knots (the stop test, ITD.py:400-404).
+    for (int lev = ws.L0; ; ++lev) {
         const int li = lev - ws.L0;
         const bool last = lev == lend;
+        {
+            unsigned long long E2[G2], O2[G2];
+            knots_of(x_lo, x_hi, E2, O2);
+            if (lev > lend) {
+                int tot = 0;
+#pragma unroll
+                for (int g = 0; g < G2; ++g) tot += __popcll(E2[g]) + __popcll(O2[g]);
+                if (lane == 0 && tot) atomicAdd(&ks->m_exact, tot);
+                break;
+            }
+            if ((ITD_KF_VERIFY & 1) || lev > ws.L0) {
+                WaveMasks wc;
+                wc.lo = (unsigned)wcur; wc.hi = (unsigned)(wcur >> 32);
+#pragma unroll
+                for (int g = 0; g < G2; ++g) bad = bad || (wc.get(2 * g) != E2[g]) || (wc.get(2 * g + 1) != O2[g]);
+            }
+        }
         const int kfst = first[(size_t)li * n_tiles + t];        // the table entry of the knot in front of the tile
+        const int knext = (has_next && (ITD_KF_VERIFY & 8)) ? first[(size_t)li * n_tiles + t + 1] : 0;
         WaveMasks wm;
         wm.lo = (unsigned)wcur; wm.hi = (unsigned)(wcur >> 32);
         int kn = 0;                                                // the tile's knots at this level
 #pragma unroll
         for (int q = 0; q < 2 * G2; ++q) kn += __popcll(wm.get(q));
         if (kn > CAP) { if (lane == 0) atomicOr(&ks->fail, kKfFailCapacity); return; }
+        if (kfst < 0 || kfst + kn + 2 > ws.wgs_max * kKcSlab) { if (lane == 0) atomicOr(&ks->fail, kKfFailVerify); return; }   // (never read beyond the pool)
+        if ((ITD_KF_VERIFY & 8) && has_next && !range_last) bad = bad || knext != kfst + kn;   // V3 inside a slab: the runs chain
         // the next level's flag words (what the values computed below must reproduce)
         const unsigned long long wnext = (!last && lane < 2 * G2) ? tf[((size_t)(li + 1) * n_tiles + t) * 8 + lane] : 0ull;
         const KfEntry *tab = pool + kfst;
@@ -805,16 +891,39 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc32(bases_s ? bases_s + (int64_t)lev * n : row, (bases_s && !last) ? rem : 0, 8);
         int gbase = 0;
         bool nonfin = false;
+        if (ITD_KF_VERIFY & 2) {           // V1 for the two tiles that own a virtual knot (rare paths, kept out of the groups' loop)
+            if (t == 0 && lane == 0)      // the virtual knot at sample 0: x[0], mean(x[:2]) (ITD.py:96,101)
+                vbad |= ne_i(s_P[0], 0) | ne_d(s_X[0], xr[0][0]) | ne_d(s_B[0], (xr[0][0] + xr[0][1]) / 2.0);
+            if (rem <= TW) {              // the last tile: the level's x[n-2], x[n-1] for the virtual knot at sample n-1
+                if (rem == 1 && lane == 0) s_e[0] = x_lo;                            // (sample n-2 is the previous tile's last)
+#pragma unroll
+                for (int g = 0; g < G2; ++g) {
+                    const int p = 128 * g + 2 * lane;
+                    if (p == nrem - 2) s_e[0] = xr[g][0];
+                    if (p + 1 == nrem - 2) s_e[0] = xr[g][1];
+                    if (p == nrem - 1) s_e[1] = xr[g][0];
+                    if (p + 1 == nrem - 1) s_e[1] = xr[g][1];
+                }
+            }
+        }
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
+            __builtin_amdgcn_sched_barrier(0);   // one group's by-rank reads in flight at a time: registers, not latency, are scarce
             const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
             const int bE = lane_bit(E), bO = lane_bit(O);
             const int Le = mbcnt64(O, mbcnt64(E, gbase)) + bE;      // knots of the tile at or before the even sample = its slot
             const int Lo = Le + bO;
-            const int p = 128 * g + 2 * lane;
+            int p = 128 * g + 2 * lane;
+            asm volatile("" : "+v"(p));          // opaque: nothing derived from the position is kept across the levels' loop
             const double xe = xr[g][0], xo = xr[g][1];
-            double be = s_B[Le] + s_S[Le] * (xe - s_X[Le]);          // ITD.py:114-117
-            double bo = s_B[Lo] + s_S[Lo] * (xo - s_X[Lo]);
+            const double Xe = s_X[Le], Xo = s_X[Lo];
+            if (ITD_KF_VERIFY & 2) {                                 // V1: a knot's entry is the owner lane's own sample
+                vbad |= -bE & (ne_i(s_P[Le], si + p) | ne_d(Xe, xe));
+                vbad |= -bO & (ne_i(s_P[Lo], si + p + 1) | ne_d(Xo, xo));
+                asm volatile("" : "+v"(vbad));                       // (decided here: the operands do not stay alive until the tile's verdict)
+            }
+            double be = s_B[Le] + s_S[Le] * (xe - Xe);               // ITD.py:114-117
+            double bo = s_B[Lo] + s_S[Lo] * (xo - Xo);
             if (rem <= TW) {                                         // baseline[n-1] is never written (stays 0), ITD.py:112-117
                 if (p >= nrem - 1) be = 0.0;
                 if (p + 1 >= nrem - 1) bo = 0.0;
@@ -831,6 +940,48 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             gbase += __popcll(E) + __popcll(O);
         }
         if (__any(nonfin)) { if (lane == 0) atomicOr(&ks->fail, kKfFailNonFinite); return; }
+        // V2: the run's knot values and slopes recomputed from its positions and values (the stores above are in flight meanwhile)
+        __builtin_amdgcn_sched_barrier(0);
+        if ((ITD_KF_VERIFY & 4) && (kn > 0 || t == 0)) {
+            for (int r = lane; r <= kn; r += kWave) {      // (one division at a time: registers, not latency, are scarce here)
+                {
+                    const double Sv = (s_B[r + 1] - s_B[r]) / (s_X[r + 1] - s_X[r]);     // ITD.py:115-116
+                    vbad |= ne_d(Sv, s_S[r]);
+                    asm volatile("" : "+v"(vbad));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (r >= 1) {
+                    const int32_t k0 = s_P[r - 1];
+                    const double frac = (double)(s_P[r] - k0) / (double)(s_P[r + 1] - k0);
+                    const double Xm = s_X[r - 1];
+                    const double tt = frac * (s_X[r + 1] - Xm);
+                    const double u = Xm + tt;
+                    const double Bv = 0.5 * u + 0.5 * s_X[r];                        // ITD.py:107-110
+                    vbad |= ne_d(Bv, s_B[r]);
+                    asm volatile("" : "+v"(vbad));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ITD_KF_VERIFY & 8) {                                     // V3
+            if (range_last) {          // across two slabs (one tile in ws.tpw): the next slab's entries 0 — its copy of the knot in front
+                if (lane < 2) {        // of it: this run's entry kn — and 1 — the first knot at or behind its first sample: this run's kn+1
+                    const KfEntry *nx = pool + knext + lane;                          // (field by field: registers are scarce)
+                    const int r = kn + lane;
+                    vbad |= ne_d(nx->X, s_X[r]) | ne_d(nx->B, s_B[r]);
+                    asm volatile("" : "+v"(vbad));
+                    __builtin_amdgcn_sched_barrier(0);
+                    vbad |= ne_d(nx->S, s_S[r]) | ne_i(nx->pos, s_P[r]);
+                    asm volatile("" : "+v"(vbad));
+                }
+            }
+        }
+        if ((ITD_KF_VERIFY & 2) && rem <= TW) {                       // the virtual knot at sample n-1: x[n-1], mean(x[-2:]), no segment (ITD.py:98,102)
+            wave_sync();
+            if (lane == 0)
+                vbad |= ne_i(s_P[kn + 1], ni - 1) | ne_d(s_X[kn + 1], s_e[1]) | ne_d(s_B[kn + 1], (s_e[0] + s_e[1]) / 2.0) | ne_d(s_S[kn + 1], 0.0);
+        }
         // the samples next to the tile, through the same maps
         double n_lo = 0.0, n_hi = 0.0;
         if (t > 0) n_lo = s_B[0] + s_S[0] * (x_lo - s_X[0]);
@@ -839,43 +990,32 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             n_hi = (si + TW == ni - 1) ? 0.0 : s_B[Lh] + s_S[Lh] * (x_hi - s_X[Lh]);
         }
         wave_sync();
-        // the next level's knots from the values just computed: the exact predicate on the actual samples
-        unsigned long long E2[G2], O2[G2];
-        {
-            double d0[G2], d1[G2];
-#pragma unroll
-            for (int g = 0; g < G2; ++g) {
-                const double fill = (g == 0) ? n_lo : wave_dpp<0x13C>(0.0, xr[g > 0 ? g - 1 : 0][1]);
-                const double left = wave_dpp<0x138>(fill, xr[g][1]);
-                d0[g] = xr[g][0] - left;
-                d1[g] = xr[g][1] - xr[g][0];
-            }
-            knot_predicate<double, G2>(d0, d1, n_hi - xr[G2 - 1][1], E2, O2);
-            if (si == 0 || nrem <= TW + 1) {       // first and last sample are never knots (ITD.py:70-73), nothing beyond n-2
-                const int lo = si > 0 ? 0 : 1, hi = nrem - 2;
-#pragma unroll
-                for (int g = 0; g < G2; ++g) {
-                    E2[g] &= bit_range((lo - 128 * g + 1) >> 1, (hi - 128 * g) >> 1);
-                    O2[g] &= bit_range((lo - 128 * g) >> 1, (hi - 128 * g - 1) >> 1);
-                }
-            }
-        }
-        if (!last) {
-            WaveMasks wn;
-            wn.lo = (unsigned)wnext; wn.hi = (unsigned)(wnext >> 32);
-#pragma unroll
-            for (int g = 0; g < G2; ++g) bad = bad || (wn.get(2 * g) != E2[g]) || (wn.get(2 * g + 1) != O2[g]);
-        } else {
-            int tot = 0;
-#pragma unroll
-            for (int g = 0; g < G2; ++g) tot += __popcll(E2[g]) + __popcll(O2[g]);
-            if (lane == 0 && tot) atomicAdd(&ks->m_exact, tot);
-        }
         x_lo = n_lo;
         x_hi = n_hi;
         wcur = wnext;
     }
-    if (bad && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+    if ((bad || __any(vbad != 0)) && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+}
+
+// fault injection for the tests (itd_debug_kf_fault): ONE field of the workspace the sample pass is about to read is perturbed,
+// between the knot side's launch and the sample pass.  kind 0 / 1 / 2: X / B / S of entry `slot` (mod the run's length) of tile
+// `tile`'s run at fused level index `li` (delta added to the bit pattern: ulps); 3: its position; 4: first[li][tile]; 5: bit
+// (delta & 63) of flag word `slot` & 7 of the tile flipped.
+__global__ void k_kf_fault(KfWs ws, int kind, int li, int tile, int slot, int delta)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const int n_tiles = ws.n_tiles;
+    int32_t *first = ws.first + (size_t)li * n_tiles;
+    unsigned long long *tf = ws.tflags + ((size_t)li * n_tiles + tile) * 8;
+    if (kind == 4) { first[tile] += delta; return; }
+    if (kind == 5) { tf[slot & 7] ^= 1ull << (delta & 63); return; }
+    int kn = 0;
+    for (int q = 0; q < 8; ++q) kn += __popcll(tf[q]);
+    KfEntry *en = ws.pool + first[tile] + slot % (kn + 2);
+    if (kind == 0) en->X = __builtin_bit_cast(double, dbits(en->X) + (unsigned long long)(long long)delta);
+    if (kind == 1) en->B = __builtin_bit_cast(double, dbits(en->B) + (unsigned long long)(long long)delta);
+    if (kind == 2) en->S = __builtin_bit_cast(double, dbits(en->S) + (unsigned long long)(long long)delta);
+    if (kind == 3) en->pos += delta;
 }
 
 // The verdict of the fused levels — what k_kf_finish did as a launch of its own — is drawn on the host by itd_get_summary from

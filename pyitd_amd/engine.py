@@ -152,6 +152,11 @@ class Engine:
         """Tiles per knot-side workgroup of the fused levels: 64, 32, 16, or 0 = automatic (halved after a call whose lists outgrew them)."""
         self._check(self._L.itd_set_fuse_range(self._h, int(tiles)))
 
+    def debug_kf_fault(self, kind, level=3, where=0, slot=0, delta=1):
+        """Tests only: arm one fault in what the fused levels' knot side hands to their sample pass (include/pyitd_hip.h:
+        itd_debug_kf_fault); kind < 0 disarms."""
+        self._check(self._L.itd_debug_kf_fault(self._h, int(kind), int(level), int(where), int(slot), int(delta)))
+
     def set_fuse_level(self, first_fused_level):
         """The first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2 are one launch each)."""
         self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))

@@ -525,3 +525,125 @@ def test_a_list_that_outgrows_its_workgroup_halves_the_ranges_of_the_next_calls(
         assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "white noise, call %d" % call)
         assert eng.fuse_repeats == 1, "call %d: only the first call is repeated (then the ranges are halved)" % call
     eng.close()
+
+
+def test_every_injected_fault_is_refused(P, torch, oracle):
+    """The sample pass takes nothing from the knot side on trust (itd_knotfirst.hpp, V0 .. V3): every table entry it uses is checked
+    against the tile's own samples (position, value), recomputed (B, S) or tied by bitwise equality to an entry that is; the runs'
+    start indices chain; every level's flag words are the exact predicate of the values in the registers.  So ONE perturbed field —
+    a value or slope off by an ulp, a position or a start index off by one, a flipped flag bit —, at any fused level (3 .. 8), in an
+    interior tile or at a workgroup's range boundary, with ranges of 16 / 32 / 64 tiles, must end in a refusal: > 1000 of them, none
+    delivered.  Faults in what a knot-side workgroup RECEIVES from its neighbours (a halo knot's value or position) change what it
+    computes: refused too, or — where rounding swallows the perturbation — still the reference's rows, never anything else.  The
+    automatic mode then repeats level by level and delivers the oracle's result."""
+    from pyitd_amd import ITDError
+    from pyitd_amd.engine import FUSE_AUTO, FUSE_ONLY
+    n, m, L0 = 1 << 18, 7, 3
+    x = sines_noise(n, seed=77)
+    ref = oracle.itd_lean(x, m)
+    assert ref["rows"].shape[0] == m + 2 and ref["stop"] == "timeout"     # levels 3 .. 8 all run fused
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.zeros((m + 2, n), dtype=torch.float64, device="cuda")
+    n_tiles = n // 512
+    rng = np.random.default_rng(2025)
+    injected = refused = halo_refused = halo_exact = 0
+    for tpw in (16, 32, 64):
+        eng = P.Engine(n, 1, 0)
+        eng.set_fuse_level(L0)
+        eng.set_fuse_range(tpw)
+        eng.set_fuse_min_samples(65536)
+        eng.set_fuse_mode(FUSE_ONLY)
+
+        def run():
+            rows.zero_()
+            torch.cuda.synchronize()                           # (the engine runs on a stream of its own)
+            eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+            return eng.summary(1)
+
+        run()                                                  # no fault: delivered
+        assert_bits_equal(rows.cpu().numpy(), ref["rows"], "no fault, %d-tile ranges" % tpw)
+        for k in range(420):
+            kind = int(rng.integers(0, 6))
+            level = int(rng.integers(L0, m + 2))               # 3 .. 8
+            where = k % 3                                      # a range's first tile, its last tile, an interior tile
+            w = int(rng.integers(0, n_tiles // tpw))
+            tile = w * tpw + (0 if where == 0 else tpw - 1 if where == 1 else int(rng.integers(1, tpw - 1)))
+            slot = int(rng.integers(0, 64))                    # (taken modulo the run's length / the tile's flag words)
+            delta = int(rng.choice([1, -1, 2, -3, 1 << 20, -(1 << 30)])) if kind <= 2 else int(rng.choice([1, -1])) if kind <= 4 else int(rng.integers(0, 64))
+            eng.debug_kf_fault(kind, level, tile, slot, delta)
+            injected += 1
+            try:
+                run()
+            except ITDError as err:
+                assert "fused sparse levels" in str(err) and "fail bits" in str(err), str(err)
+                refused += 1
+                continue
+            raise AssertionError("fault not refused: kind %d level %d tile %d (range of %d) slot %d delta %d" % (kind, level, tile, tpw, slot, delta))
+        for k in range(60):                                    # what a workgroup receives from its neighbours
+            kind, level = 6 + k % 2, int(rng.integers(L0, m + 2))
+            w, slot = int(rng.integers(0, n_tiles // tpw)), int(rng.integers(0, 5))
+            eng.debug_kf_fault(kind, level, w, slot, int(rng.choice([1, -1, 1 << 25])) if kind == 6 else int(rng.choice([1, -1])))
+            try:
+                run()
+            except ITDError as err:
+                assert "fused sparse levels" in str(err), str(err)
+                halo_refused += 1
+                continue
+            assert_bits_equal(rows.cpu().numpy(), ref["rows"], "halo fault delivered: kind %d level %d workgroup %d slot %d" % (kind, level, w, slot))
+            halo_exact += 1
+        # the automatic mode: the refused call is repeated level by level, the result is the oracle's
+        eng.set_fuse_mode(FUSE_AUTO)
+        eng.debug_kf_fault(1, 5, n_tiles // 2, 1, 1)
+        rep = eng.fuse_repeats
+        run()
+        assert eng.fuse_repeats == rep + 1
+        assert_bits_equal(rows.cpu().numpy(), ref["rows"], "repeated level by level")
+        eng.debug_kf_fault(-1)
+        eng.set_fuse_mode(FUSE_ONLY)
+        run()                                                  # disarmed: delivered again
+        assert_bits_equal(rows.cpu().numpy(), ref["rows"], "disarmed")
+        eng.close()
+    assert injected == refused >= 1000
+    assert halo_refused + halo_exact == 180 and halo_refused >= 100
+
+
+def test_a_captured_fused_call_survives_a_workspace_change(P, torch, oracle):
+    """A hipGraph that holds a fused call has the fused levels' workspace pointers baked into its launches.  When later calls of the
+    same engine need a larger workspace (smaller ranges: itd_set_fuse_range, or the automatic halving after a capacity refusal) the
+    old one is retired, not freed: the graph replays correctly afterwards, and so do direct calls."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m = 1 << 18, 7
+    x_np = sines_noise(n, seed=91)
+    x = torch.from_numpy(x_np).cuda()
+    rows = torch.zeros((m + 2, n), dtype=torch.float64, device="cuda")
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_min_samples(65536)
+    eng.set_fuse_range(64)
+    torch.cuda.synchronize()
+    eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)      # allocates the 64-tile workspace
+    eng.summary(1)
+    ws0 = eng.workspace_bytes
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    eng.set_fuse_range(16)                                      # four times the workgroups: a new, larger workspace
+    rows.fill_(float("nan"))
+    eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+    eng.summary(1)
+    assert eng.workspace_bytes > ws0 and eng.fuse_repeats == 0
+    ref = oracle.itd_lean(x_np, m)
+    assert_bits_equal(rows.cpu().numpy(), ref["rows"], "direct call with 16-tile ranges")
+    for seed in (92, 93):                                       # the graph still refers to the retired workspace
+        y_np = sines_noise(n, seed=seed)
+        x.copy_(torch.from_numpy(y_np))
+        rows.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        s = eng.summary(1)
+        assert eng.fuse_repeats == 0
+        assert_bits_equal(rows[: int(s["n_rows"][0])].cpu().numpy(), oracle.itd_lean(y_np, m)["rows"], "replay after the change, seed %d" % seed)
+    eng.close()
