@@ -761,12 +761,14 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
 //       level's on the values the level before has just computed;
 //   V1  table entries 1 .. kn of the tile's run ARE the tile's knots: position and value equal the owner lane's own sample, bit
 //       for bit; tile 0 owns the virtual knot at sample 0, the last tile the one at sample n-1 (ITD.py:96,98,101-102);
-//   V2  B of entries 1 .. kn recomputed from the positions and values of entries r-1, r, r+1 in the association of ITD.py:107-110,
-//       S of entries 0 .. kn from B and X of entries r, r+1 (ITD.py:115-116), compared bit for bit;
-//   V3  the runs chain: inside a knot-side workgroup's slab the next tile's run starts where this one's knots end
-//       (first[t+1] == first[t] + kn), so entry 0 / kn+1 of a run is physically the entry its owner tile verifies — the nearest
-//       knot in front of / behind the tile; across two slabs the last tile of a range compares the next slab's copy of the knot
-//       in front (its own entry kn) and its own copy of the knot behind (the next slab's entry 1) bit for bit, all four fields.
+//   V2  B of every knot's entry recomputed from the positions and values of entries r-1, r, r+1 in the association of
+//       ITD.py:107-110, S from B and X of entries r, r+1 (ITD.py:115-116), compared bit for bit — by wavefronts of their own at the
+//       end of the grid, one per level and slab, a knot per lane (in the tiles' wavefronts the two divisions ran on a handful of
+//       lanes: 180 us against 144 without any check);
+//   V3  the runs chain (the check wavefronts): inside a knot-side workgroup's slab the next tile's run starts where this one's knots
+//       end (first[t+1] == first[t] + kn), so entry 0 / kn+1 of a run is physically the entry its owner tile verifies — the nearest
+//       knot in front of / behind the tile; across two slabs the next slab's copy of the knot in front of it and this slab's copy
+//       of the knot behind it are compared with the owners' entries bit for bit, all four fields (the check wavefronts).
 // Every field of every entry a tile uses is thereby checked by its owner or equals, through a chain of bitwise equalities, an
 // entry that is; any mismatch refuses the signal (kKfFailVerify).  tests/test_gpu_fused.py injects faults into every one of
 // these (itd_debug_kf_fault) and requires the refusal.
@@ -778,8 +780,14 @@ __device__ __forceinline__ int ne_d(double a, double b)
     return (int)((unsigned)x | (unsigned)(x >> 32));
 }
 __device__ __forceinline__ int ne_i(int32_t a, int32_t b) { return a ^ b; }
+// workgroups of the sample pass's grid that verify the tables (V2, V3), in front of the tiles': one per knot-side workgroup,
+// padded to a multiple of 8 so that a tile's workgroup lands on the same XCD as in every other launch (xcd_item)
+__host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 7) & ~7; }
 #ifndef ITD_KF_APPLY_WAVES
-#define ITD_KF_APPLY_WAVES 6      // wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice: 5 with 81 VGPRs; 6 costs no spill)
+#define ITD_KF_APPLY_WAVES 7      // wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice; 7: 72 VGPRs, no spill; measured 152 us against 157 at 6)
+#endif
+#ifndef ITD_KF_FASTGROUP
+#define ITD_KF_FASTGROUP 1        // A/B builds: 0 = every 128-sample group takes the by-rank path
 #endif
 #ifndef ITD_KF_VERIFY
 #define ITD_KF_VERIFY 15          // timing-only A/B builds: bit k = check Vk is compiled in (the shipped build: all four)
@@ -796,14 +804,76 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     constexpr int G2 = TW / 128;
     __shared__ double s_X[CAP + 2], s_B[CAP + 2], s_S[CAP + 2];
     __shared__ int32_t s_P[CAP + 2];
-    __shared__ double s_e[2];                                       // the last tile: the level's x[n-2], x[n-1]
     const int sig = blockIdx.y, lane = lane_id();
     KfSig *ks = ws.sig + sig;
     const int n_tiles = ws.n_tiles;
-    const int t = xcd_item(blockIdx.x, n_tiles);
     if (!ks->active || ks->fail) return;
     const int lend = ks->lend, natural = ks->natural;
     if (lend < 0) return;
+    const int n_chk = kf_check_blocks(ws.wgs);   // (the grid's FIRST workgroups: they overlap the tiles' instead of trailing them)
+    if ((int)blockIdx.x < n_chk) {
+        // ---- one wavefront per knot-side workgroup, level after level: what can be verified on the tables themselves, a knot (or a tile) per
+        //      lane instead of a handful of lanes in every tile's wavefront.  Entries 1 .. cnt of the slab's table are the range's
+        //      knots, 0 and cnt + 1 the copies of the knots around the range.
+        //      V3 inside   first[t + 1] == first[t] + (population of tile t's flag words) for the range's tiles: the runs chain;
+        //      V2          B of entries 1 .. cnt from the positions and values of entries r-1, r, r+1 (ITD.py:107-110), S of entries
+        //                  0 .. cnt from B and X of entries r, r+1 (ITD.py:115-116), bit for bit;
+        //      V3 across   the next slab's entry 0 (its copy of the knot in front of it) equals this slab's entry cnt, its entry 1
+        //      two slabs   (the first knot at or behind its first sample) this slab's entry cnt + 1: all four fields, bit for bit.
+        if (!(ITD_KF_VERIFY & 12)) return;
+        const int w = (int)blockIdx.x;
+        if (w >= ws.wgs) return;                                 // (the blocks that only pad the count to a multiple of 8)
+        const int t0 = w * ws.tpw, t1 = min(n_tiles, t0 + ws.tpw);
+        const KfEntry *pool = ws.pool + (size_t)sig * ws.wgs_max * kKcSlab;
+        const int pool_n = ws.wgs_max * kKcSlab;
+        int vb = 0;
+        for (int li = 0; li <= lend - ws.L0; ++li) {             // (one workgroup per slab, all its levels: every workgroup of this grid
+        const int32_t *firstl = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;          // costs dispatch time — 3072 of them, one
+        const unsigned long long *tfl = ws.tflags + ((size_t)sig * ws.nlev + li) * n_tiles * 8;   // per level and slab, cost 6 us)
+        const int start = firstl[t0];
+        const int f_next = t1 < n_tiles ? firstl[t1] : -1;
+        int cnt = 0;
+        for (int tb = t0; tb < t1; tb += kWave) {                // a tile per lane: the chain of the runs; the range's knot count
+            const int tt = tb + lane;
+            int f = 0, fn = 0, kt = 0;
+            if (tt < t1) {
+                using U2 = unsigned long long __attribute__((ext_vector_type(2)));
+                const U2 *wp = reinterpret_cast<const U2 *>(tfl + (size_t)tt * 8);
+                f = firstl[tt];
+                fn = tt + 1 < t1 ? firstl[tt + 1] : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const U2 v = wp[q]; kt += __popcll(v.x) + __popcll(v.y); }
+                if ((ITD_KF_VERIFY & 8) && tt + 1 < t1) vb |= ne_i(fn, f + kt);
+            }
+            const int l_last = t1 - 1 - tb;                      // the lane of the range's last tile, if it is in this round
+            if (l_last < kWave) cnt = __shfl(f + kt, l_last) - start;
+        }
+        if (start < 0 || cnt < 0 || start + cnt + 2 > pool_n || (t1 < n_tiles && (f_next < 0 || f_next + 2 > pool_n))) vb = 1;
+        else if (ITD_KF_VERIFY & 4) {
+            const KfEntry *e = pool + start;
+            for (int r = lane; r <= cnt; r += kWave) {
+                const KfEntry e0 = e[r], e1 = e[r + 1];
+                const double Sv = (e1.B - e0.B) / (e1.X - e0.X);                         // ITD.py:115-116
+                vb |= ne_d(Sv, e0.S);
+                if (r >= 1) {
+                    const KfEntry em = e[r - 1];
+                    const double frac = (double)(e0.pos - em.pos) / (double)(e1.pos - em.pos);
+                    const double tt = frac * (e1.X - em.X);
+                    const double u = em.X + tt;
+                    const double Bv = 0.5 * u + 0.5 * e0.X;                              // ITD.py:107-110
+                    vb |= ne_d(Bv, e0.B);
+                }
+            }
+            if (t1 < n_tiles && lane < 2) {
+                const KfEntry a = pool[f_next + lane], o = e[cnt + lane];
+                vb |= ne_i(a.pos, o.pos) | ne_d(a.X, o.X) | ne_d(a.B, o.B) | ne_d(a.S, o.S);
+            }
+        }
+        }
+        if (__any(vb != 0) && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+        return;
+    }
+    const int t = xcd_item((int)blockIdx.x - n_chk, n_tiles);
     const int ni = (int)n, si = t * TW, rem = ni - si;
     const double *xs = xl + (int64_t)sig * xl_stride;
     const __amdgpu_buffer_rsrc_t rx = tile_rsrc32(xs + si, rem, 8);
@@ -821,8 +891,6 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     double *rows_s = rows + (int64_t)sig * rows_stride + si;
     double *bases_s = bases ? bases + (int64_t)sig * bases_stride + si : nullptr;
     unsigned long long wcur = lane < 2 * G2 ? tf[(size_t)t * 8 + lane] : 0ull;       // this level's flag words, lane j holds word j
-    const bool has_next = t + 1 < n_tiles;
-    const bool range_last = has_next && (t + 1) % ws.tpw == 0;     // tile t+1 starts another knot-side workgroup's slab
     bool bad = false;            // wave-uniform findings
     int vbad = 0;                // per-lane findings
     // the knots of the values in the registers (x_lo / x_hi: the samples next to the tile): the exact predicate, ITD.py:59 on x and -x
@@ -869,7 +937,6 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             }
         }
         const int kfst = first[(size_t)li * n_tiles + t];        // the table entry of the knot in front of the tile
-        const int knext = (has_next && (ITD_KF_VERIFY & 8)) ? first[(size_t)li * n_tiles + t + 1] : 0;
         WaveMasks wm;
         wm.lo = (unsigned)wcur; wm.hi = (unsigned)(wcur >> 32);
         int kn = 0;                                                // the tile's knots at this level
@@ -877,7 +944,6 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         for (int q = 0; q < 2 * G2; ++q) kn += __popcll(wm.get(q));
         if (kn > CAP) { if (lane == 0) atomicOr(&ks->fail, kKfFailCapacity); return; }
         if (kfst < 0 || kfst + kn + 2 > ws.wgs_max * kKcSlab) { if (lane == 0) atomicOr(&ks->fail, kKfFailVerify); return; }   // (never read beyond the pool)
-        if ((ITD_KF_VERIFY & 8) && has_next && !range_last) bad = bad || knext != kfst + kn;   // V3 inside a slab: the runs chain
         // the next level's flag words (what the values computed below must reproduce)
         const unsigned long long wnext = (!last && lane < 2 * G2) ? tf[((size_t)(li + 1) * n_tiles + t) * 8 + lane] : 0ull;
         const KfEntry *tab = pool + kfst;
@@ -894,36 +960,52 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         if (ITD_KF_VERIFY & 2) {           // V1 for the two tiles that own a virtual knot (rare paths, kept out of the groups' loop)
             if (t == 0 && lane == 0)      // the virtual knot at sample 0: x[0], mean(x[:2]) (ITD.py:96,101)
                 vbad |= ne_i(s_P[0], 0) | ne_d(s_X[0], xr[0][0]) | ne_d(s_B[0], (xr[0][0] + xr[0][1]) / 2.0);
-            if (rem <= TW) {              // the last tile: the level's x[n-2], x[n-1] for the virtual knot at sample n-1
-                if (rem == 1 && lane == 0) s_e[0] = x_lo;                            // (sample n-2 is the previous tile's last)
+            if (rem <= TW) {              // the last tile: the virtual knot at sample n-1: x[n-1], mean(x[-2:]), no segment (ITD.py:98,102)
+                auto pick = [&](int q) {  // the level's input at tile position q (wave-uniform): every group's candidates through
+                    const int gq = q >> 7, lq = (q & 127) >> 1, par = q & 1;   // v_readlane, the choice on the scalar unit (registers
+                    unsigned lo = 0, hi = 0;                                     // indexed by a variable would move the tile to scratch)
 #pragma unroll
-                for (int g = 0; g < G2; ++g) {
-                    const int p = 128 * g + 2 * lane;
-                    if (p == nrem - 2) s_e[0] = xr[g][0];
-                    if (p + 1 == nrem - 2) s_e[0] = xr[g][1];
-                    if (p == nrem - 1) s_e[1] = xr[g][0];
-                    if (p + 1 == nrem - 1) s_e[1] = xr[g][1];
-                }
+                    for (int g = 0; g < G2; ++g) {
+                        const unsigned long long ve = dbits(xr[g][0]), vo = dbits(xr[g][1]);
+                        const unsigned le = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ve, lq), he = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(ve >> 32), lq);
+                        const unsigned lo_ = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)vo, lq), ho = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(vo >> 32), lq);
+                        if (gq == g) { lo = par ? lo_ : le; hi = par ? ho : he; }
+                    }
+                    return bits_d(lo, hi);
+                };
+                const double x_n1 = pick(nrem - 1), x_n2 = nrem >= 2 ? pick(nrem - 2) : x_lo;   // (rem == 1: sample n-2 is the previous tile's last)
+                if (lane == 0)
+                    vbad |= ne_i(s_P[kn + 1], ni - 1) | ne_d(s_X[kn + 1], x_n1) | ne_d(s_B[kn + 1], (x_n2 + x_n1) / 2.0) | ne_d(s_S[kn + 1], 0.0);
             }
+            asm volatile("" : "+v"(vbad));
         }
 #pragma unroll
         for (int g = 0; g < G2; ++g) {
             __builtin_amdgcn_sched_barrier(0);   // one group's by-rank reads in flight at a time: registers, not latency, are scarce
             const unsigned long long E = wm.get(2 * g), O = wm.get(2 * g + 1);
-            const int bE = lane_bit(E), bO = lane_bit(O);
-            const int Le = mbcnt64(O, mbcnt64(E, gbase)) + bE;      // knots of the tile at or before the even sample = its slot
-            const int Lo = Le + bO;
             int p = 128 * g + 2 * lane;
             asm volatile("" : "+v"(p));          // opaque: nothing derived from the position is kept across the levels' loop
             const double xe = xr[g][0], xo = xr[g][1];
-            const double Xe = s_X[Le], Xo = s_X[Lo];
-            if (ITD_KF_VERIFY & 2) {                                 // V1: a knot's entry is the owner lane's own sample
-                vbad |= -bE & (ne_i(s_P[Le], si + p) | ne_d(Xe, xe));
-                vbad |= -bO & (ne_i(s_P[Lo], si + p + 1) | ne_d(Xo, xo));
-                asm volatile("" : "+v"(vbad));                       // (decided here: the operands do not stay alive until the tile's verdict)
+            double be, bo;
+            if (ITD_KF_FASTGROUP && (E | O) == 0ull) {
+                // no knot among the group's 128 samples (most groups from the third fused level on): one segment, one table entry
+                // for every lane, nothing to verify
+                const double Xs = s_X[gbase], Bs = s_B[gbase], Ss = s_S[gbase];
+                be = Bs + Ss * (xe - Xs);                            // ITD.py:114-117
+                bo = Bs + Ss * (xo - Xs);
+            } else {
+                const int bE = lane_bit(E), bO = lane_bit(O);
+                const int Le = mbcnt64(O, mbcnt64(E, gbase)) + bE;  // knots of the tile at or before the even sample = its slot
+                const int Lo = Le + bO;
+                const double Xe = s_X[Le], Xo = s_X[Lo];
+                if (ITD_KF_VERIFY & 2) {                             // V1: a knot's entry is the owner lane's own sample
+                    vbad |= -bE & (ne_i(s_P[Le], si + p) | ne_d(Xe, xe));
+                    vbad |= -bO & (ne_i(s_P[Lo], si + p + 1) | ne_d(Xo, xo));
+                    asm volatile("" : "+v"(vbad));                   // (decided here: the operands do not stay alive until the tile's verdict)
+                }
+                be = s_B[Le] + s_S[Le] * (xe - Xe);                  // ITD.py:114-117
+                bo = s_B[Lo] + s_S[Lo] * (xo - Xo);
             }
-            double be = s_B[Le] + s_S[Le] * (xe - Xe);               // ITD.py:114-117
-            double bo = s_B[Lo] + s_S[Lo] * (xo - Xo);
             if (rem <= TW) {                                         // baseline[n-1] is never written (stays 0), ITD.py:112-117
                 if (p >= nrem - 1) be = 0.0;
                 if (p + 1 >= nrem - 1) bo = 0.0;
@@ -940,48 +1022,6 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             gbase += __popcll(E) + __popcll(O);
         }
         if (__any(nonfin)) { if (lane == 0) atomicOr(&ks->fail, kKfFailNonFinite); return; }
-        // V2: the run's knot values and slopes recomputed from its positions and values (the stores above are in flight meanwhile)
-        __builtin_amdgcn_sched_barrier(0);
-        if ((ITD_KF_VERIFY & 4) && (kn > 0 || t == 0)) {
-            for (int r = lane; r <= kn; r += kWave) {      // (one division at a time: registers, not latency, are scarce here)
-                {
-                    const double Sv = (s_B[r + 1] - s_B[r]) / (s_X[r + 1] - s_X[r]);     // ITD.py:115-116
-                    vbad |= ne_d(Sv, s_S[r]);
-                    asm volatile("" : "+v"(vbad));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (r >= 1) {
-                    const int32_t k0 = s_P[r - 1];
-                    const double frac = (double)(s_P[r] - k0) / (double)(s_P[r + 1] - k0);
-                    const double Xm = s_X[r - 1];
-                    const double tt = frac * (s_X[r + 1] - Xm);
-                    const double u = Xm + tt;
-                    const double Bv = 0.5 * u + 0.5 * s_X[r];                        // ITD.py:107-110
-                    vbad |= ne_d(Bv, s_B[r]);
-                    asm volatile("" : "+v"(vbad));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (ITD_KF_VERIFY & 8) {                                     // V3
-            if (range_last) {          // across two slabs (one tile in ws.tpw): the next slab's entries 0 — its copy of the knot in front
-                if (lane < 2) {        // of it: this run's entry kn — and 1 — the first knot at or behind its first sample: this run's kn+1
-                    const KfEntry *nx = pool + knext + lane;                          // (field by field: registers are scarce)
-                    const int r = kn + lane;
-                    vbad |= ne_d(nx->X, s_X[r]) | ne_d(nx->B, s_B[r]);
-                    asm volatile("" : "+v"(vbad));
-                    __builtin_amdgcn_sched_barrier(0);
-                    vbad |= ne_d(nx->S, s_S[r]) | ne_i(nx->pos, s_P[r]);
-                    asm volatile("" : "+v"(vbad));
-                }
-            }
-        }
-        if ((ITD_KF_VERIFY & 2) && rem <= TW) {                       // the virtual knot at sample n-1: x[n-1], mean(x[-2:]), no segment (ITD.py:98,102)
-            wave_sync();
-            if (lane == 0)
-                vbad |= ne_i(s_P[kn + 1], ni - 1) | ne_d(s_X[kn + 1], s_e[1]) | ne_d(s_B[kn + 1], (s_e[0] + s_e[1]) / 2.0) | ne_d(s_S[kn + 1], 0.0);
-        }
         // the samples next to the tile, through the same maps
         double n_lo = 0.0, n_hi = 0.0;
         if (t > 0) n_lo = s_B[0] + s_S[0] * (x_lo - s_X[0]);
