@@ -196,17 +196,18 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * ITD_FUSE_AUTO (default): calls whose launch sequences cover at least itd_set_fuse_min_samples samples (signals per chunk x n; default
  * 2 * 2^20: one signal of 2^20 / 2^21 / 2^22 / 2^23 samples takes 89 / 115 / 183 / 305 us level by level and 90 / 104 / 149 / 227 us
  * fused), signals of >= 65536 samples; ITD_FUSE_OFF: never; ITD_FUSE_ONLY: always, never repeat (itd_get_summary fails with
- * ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2
- * as one launch each). */
+ * ITD_ERR_HIP instead: tests, benchmarks).  itd_set_fuse_level: the first fused level, 2 .. max_iteration, or 0 (default) = automatic:
+ * level 2 where a launch sequence covers at least 2^22 samples (levels 0 and 1 as one launch each; 377 against 404 us at 2^24), else
+ * level 3; a level-2 candidate list that outgrows its workgroup moves the engine's later calls to level 3 before the ranges are halved. */
 #define ITD_FUSE_AUTO 0
 #define ITD_FUSE_OFF 1
 #define ITD_FUSE_ONLY 2
 int itd_set_fuse_mode(itd_engine *e, int32_t mode);
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
-/* Tiles (of 512 samples) a knot-side workgroup of the fused levels owns: 64, 32 or 16; 0 (default) = automatic: 64 (16 when fused from
- * level 2), halved for the calls after one in which a workgroup's candidate list (1024 entries: knots and near-tie samples) outgrew
- * its LDS — dense knots at the first fused level (white noise, alternating data).  Smaller ranges hold denser lists and cost more
- * workgroups. */
+/* Tiles (of 512 samples) a knot-side workgroup of the fused levels owns: 64, 32 or 16; 0 (default) = automatic: 64, halved for the
+ * calls after one in which a workgroup's candidate list (1720 entries at the first fused level, 1024 from the next on: knots and
+ * near-tie samples) outgrew its LDS — dense knots at the first fused level (white noise from level 2, alternating data).  Smaller
+ * ranges hold denser lists and cost more workgroups. */
 int itd_set_fuse_range(itd_engine *e, int32_t tiles);
 int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
 /* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot-side launch of the fused levels (default 1; sharing it

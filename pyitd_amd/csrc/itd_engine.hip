@@ -105,7 +105,9 @@ __global__ void k_repair_init(const SigState *__restrict__ from, SigState *__res
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     if (need[b]) {
-        const int why = (from[b].kf_fail ? 1 : 0) | (from[b].l0_fail ? 2 : 0) | (from[b].res_fail ? 4 : 0);
+        // (bits 0 .. 2: which optimistic form fell short; from bit 3 on the fused levels' own failure bits, so that the host's back-offs
+        //  — smaller ranges only for a list that outgrew its workgroup — see the reason as they do without the device-side repair)
+        const int why = (from[b].kf_fail ? 1 : 0) | (from[b].l0_fail ? 2 : 0) | (from[b].res_fail ? 4 : 0) | ((from[b].kf_fail & 31) << 3);
         sig_state_reset(to + b);
         to[b].skip = -why;
     } else { to[b] = from[b]; to[b].skip = 1; }
@@ -187,7 +189,9 @@ struct itd_engine {
     void *d_kf = nullptr; size_t kf_bytes = 0;
     std::vector<void *> kf_retired;  // earlier, smaller workspaces: a captured graph may still hold their pointers — kept until the engine is destroyed
     KfWs kf{};                       // pointers into d_kf, for signal 0
-    int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 3, fuse_off_left = 0, fuse_repeats = 0;
+    int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 0, fuse_off_left = 0, fuse_repeats = 0;   // fuse_level 0: automatic (kf_first_level)
+    bool kf_force_tickets = false;                   // a halo wait was given up on this engine (kKfFailWait): workgroup ids are tickets from then on
+    bool fuse_level2_off = false;                    // automatic first fused level: a level-2 list has outgrown its workgroup, level 3 from then on
     bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
     // device-visible validity / device-side repair (itd_set_valid_flags, itd_set_device_repair)
     int32_t *valid_dev = nullptr;                    // the caller's [batch] words, written behind every decomposition; NULL = none
@@ -314,13 +318,40 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
 // knot-side workgroup (kKcTiles tiles): a slab of table entries (32 B per knot and level: kKcSlab of them) and one 256-byte
 // boundary record per level; per level and tile the knots' flag words and the tile's first table index; per tile the near-tie flag words.
 constexpr int kKfLevels = ITD_MAX_ITERATION + 3;
-// tiles per knot-side workgroup: its LDS holds kKcCap candidates — the first fused level's knots of its tiles (typically 0.04 /
-// 0.012 n at levels 2 / 3: 20 / 6 per tile) plus the sticky ones
-// (typically 0.04 / 0.012 n at levels 2 / 3: 20 / 6 per tile); a call that a list outgrew halves the ranges of the calls after it
+// tiles per knot-side workgroup: its LDS holds kKcCapH candidates at the hand-over level — the first fused level's knots of its tiles
+// (typically 0.036 / 0.012 n at levels 2 / 3: 18 / 6 per tile, 1180 / 400 per 64-tile range) plus the sticky ones — and kKcCap from
+// the level after it; a call that a list outgrew halves the ranges of the calls after it
 inline int kf_tiles_per_wg(const itd_engine *e, int first_fused_level)
 {
+    (void)first_fused_level;
     if (e->fuse_range) return e->fuse_range;
-    return std::max(kKcTiles / 4, (first_fused_level >= 3 ? kKcTiles : kKcTiles / 4) >> e->kf_shrink);
+    return std::max(kKcTiles / 4, kKcTiles >> e->kf_shrink);
+}
+// The first fused level.  Automatic: level 2 where a launch sequence covers at least 2^22 samples — one level launch less (-63 us
+// at 2^24) for a sample pass that writes one more row (+22) and a knot side that starts on a 2.6 x longer list (+14): one signal of
+// 2^22 / 2^23 / 2^24 samples 153 / 225 / 377 us against 160 / 243 / 404 from level 3, but 102 against 98 at 2^20
+// (profiles/r05/fuse_level_probe.txt) — unless a level-2 list has outgrown its workgroup on this engine (denser knots than the
+// hand-over layout's 1720 per 64 tiles): level 3 then, before the ranges are halved.
+inline int kf_first_level(const itd_engine *e, int64_t n, int32_t batch)
+{
+    if (e->fuse_level) return e->fuse_level;
+    const int64_t seq = (int64_t)std::min<int32_t>(chunk_of(e, n, batch), batch) * n;
+    return (seq >= ((int64_t)1 << 22) && !e->fuse_level2_off) ? 2 : 3;
+}
+// What the engine's NEXT calls do after fused levels refused with the failure bits `bits` (host-side repeat and device-side repair
+// alike).  A list that outgrew its workgroup: the automatic first fused level goes from 2 to 3, after that the ranges are halved
+// (down to 16 tiles) — the calls stay fused: returns true.  A halo wait given up with nothing else wrong (the grid was not resident
+// at once after all: other work on the device): tickets from now on.  Anything else (verification, non-finite knot data): false —
+// the caller lets the next calls run level by level for a while.
+bool kf_back_off(itd_engine *e, int bits, int level)
+{
+    if (bits & kKfFailCapacity) {
+        if (!e->fuse_level && level == 2 && !e->fuse_level2_off) { e->fuse_level2_off = true; return true; }
+        if (!e->fuse_range && kf_tiles_per_wg(e, level) > kKcTiles / 4) { ++e->kf_shrink; return true; }
+        return false;
+    }
+    if (bits == kKfFailWait && !e->kf_force_tickets) { e->kf_force_tickets = true; return true; }
+    return false;
 }
 int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
 {
@@ -382,7 +413,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // nothing touches before level 2, and the level-0 records; the record-driven level-0 extraction then reads that copy
     if (nan_input) fuse0 = false;
     // kf: levels L0 .. max_iteration + 1 run fused (itd_knotfirst.hpp): one launch per level only for levels 0 .. L0 - 1
-    const int L0 = e->fuse_level;
+    int L0 = kf_first_level(e, n, batch);
+    if (!e->fuse_level && L0 > M) L0 = 2;               // (automatic: few levels asked for)
     kf = kf && fuse0 && L0 >= 2 && L0 <= M && n < ((int64_t)1 << 31) - 65536;
     // a call that is being captured into a graph must be complete in itself (the graph may be replayed any number of times) and
     // cannot allocate: a captured call on an engine whose fused workspace does not exist yet runs level by level
@@ -564,7 +596,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             KfWs w = e->kf;
             w.n_tiles = n_tiles; w.L0 = L0; w.nlev = M + 3 - L0;
             w.tpw = kf_tpw; w.wgs = (n_tiles + kf_tpw - 1) / kf_tpw; w.nb = nb;
-            w.ticketed = (int64_t)w.wgs * nb > e->kf_resident_wgs ? 1 : 0;
+            // (ids from blockIdx only where the whole grid is resident at once — with S streams in flight each launch may count on
+            //  its share of the device only)
+            w.ticketed = ((int64_t)w.wgs * nb * S > e->kf_resident_wgs || e->kf_force_tickets) ? 1 : 0;
             w.dbg_kind = e->fault_kind; w.dbg_lev = e->fault_level; w.dbg_wg = e->fault_where; w.dbg_slot = e->fault_slot; w.dbg_delta = e->fault_delta;
             const size_t B0 = (size_t)b0;
             w.sig += B0; w.pool += B0 * (size_t)w.wgs_max * kKcSlab; w.rec += B0 * (size_t)w.rec_levels * w.wgs_max * kKcRecGran;
@@ -742,7 +776,7 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
 // keeps failing the verification: workloads tend to be homogeneous).
 bool want_kf(itd_engine *e, int64_t n, int32_t batch, int32_t M, bool fuse0)
 {
-    if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || e->fuse_level < 2 || e->fuse_level > M) return false;
+    if (e->fuse_mode == ITD_FUSE_OFF || !fuse0 || M < 2 || (e->fuse_level && e->fuse_level > M)) return false;
     if (e->fuse_mode == ITD_FUSE_ONLY) return true;
     if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO || e->fuse_no_memory) return false;
     if ((int64_t)std::min<int32_t>(chunk_of(e, n, batch), batch) * n < e->fuse_min_samples) return false;
@@ -1201,8 +1235,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         e->device_repairs += fixed;
         e->last_device_repair = false;      // (a second summary of the same call counts nothing)
         if (fixed && (B < 8 || fixed * 8 > B)) {
-            if ((why & 1) && !e->fuse_range && kf_tiles_per_wg(e, 3) > kKcTiles / 4) ++e->kf_shrink;   // (the device does not say why: try smaller ranges first)
-            else if (why & 1) e->fuse_off_left = 16;
+            if ((why & 1) && !kf_back_off(e, (why >> 3) & 31, e->last_kf_level)) e->fuse_off_left = 16;
             if (why & 2) e->l0_records_left = 16;
             if (why & 4) e->resident_off_left = 16;
         }
@@ -1259,11 +1292,11 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                 snprintf(e->err, sizeof(e->err), "fused sparse levels: not the reference's result (fail bits 0x%x: 1 verification, 2 capacity, 4 non-finite, 8 ties); ITD_FUSE_ONLY forbids the level-by-level repeat", code);
                 return ITD_ERR_HIP;
             }
-            // a list that outgrew its workgroup (dense knots): the calls after this one run with half the tiles per workgroup
-            bool outgrown = false;
-            for (int b = 0; b < B; ++b) outgrown = outgrown || (e->h_state[b].kf_fail & kKfFailCapacity);
-            const bool can_shrink = outgrown && !e->fuse_range && kf_tiles_per_wg(e, e->last_kf_level) > kKcTiles / 4;
-            if (can_shrink) ++e->kf_shrink;
+            // a list that outgrew its workgroup (dense knots): the calls after this one hand over a level later or run with half the
+            // tiles per workgroup (kf_back_off)
+            int bits = 0;
+            for (int b = 0; b < B; ++b) bits |= e->h_state[b].kf_fail;
+            const bool can_shrink = kf_back_off(e, bits, e->last_kf_level);
             if (B >= 8 && nfail * 8 <= B) {
                 const int rc = repair_signals(e, B);
                 if (rc) return rc;
@@ -1396,8 +1429,9 @@ int itd_set_fuse_mode(itd_engine *e, int32_t mode)
 int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level)
 {
     // (level 1's launch completes the signal's own knot count, and a level-1 list would not fit the workspace: 2 at least)
-    if (!e || first_fused_level < 2 || first_fused_level > ITD_MAX_ITERATION) return ITD_ERR_INVALID_ARG;
+    if (!e || (first_fused_level != 0 && (first_fused_level < 2 || first_fused_level > ITD_MAX_ITERATION))) return ITD_ERR_INVALID_ARG;
     e->fuse_level = first_fused_level;
+    e->fuse_level2_off = false;
     return ITD_OK;
 }
 

@@ -44,10 +44,40 @@ constexpr int kKfCap = 128;        // knots of one tile and level the sample pas
 // ---- geometry of the knot side's launch ----
 constexpr int kKcThreads = 256;                  // threads of a workgroup
 constexpr int kKcTiles = 64;                     // tiles a workgroup owns at most (KfWs::tpw; one thread per 128-sample group of them)
-constexpr int kKcCap = 1024;                     // candidates a workgroup holds (more: the signal is left to the level-by-level engine)
+constexpr int kKcCap = 1024;                     // candidates a workgroup holds from the second fused level on (more: the signal is left to the level-by-level engine)
+constexpr int kKcCapH = 1720;                    // ... and at the hand-over level, whose candidates' triples stay in registers (KcLay)
 constexpr int kKcEnt = kKcCap / kKcThreads;      // candidates per thread
+constexpr int kKcEntH = (kKcCapH + kKcThreads - 1) / kKcThreads;
 constexpr int kKcRound = 2;                      // workgroups whose records a halo search's first round reads (the nearest ones, whatever they hold)
-constexpr int kKcSlab = 2 * kKcCap + 128;        // table entries (all fused levels) a workgroup may write
+constexpr int kKcSlab = 3200;                    // table entries (all fused levels) a workgroup may write: ~1.7 x the hand-over level's knots
+// The workgroup's LDS, two layouts over the same bytes.  From the second fused level on (H = false) a candidate is its position, its
+// triple of values, flags and rank (31 B), a knot by rank its position, value, B and S (28 B): 59 B x kKcCap.  The hand-over level is the
+// densest by a factor of ~2.6 and its candidates' triples come straight from the level's input in memory: they stay in the registers of
+// the threads that fetched them until that level's maps have used them — the hand-over layout (H = true) has no triples and holds
+// kKcCapH candidates in the same 60 KB.  (A level's step reads the old lists into registers, crosses a barrier and only then writes the
+// next lists: the change of layout happens at that barrier.)
+template <bool H>
+struct KcLay {
+    static constexpr int cap = H ? kKcCapH : kKcCap;
+    static constexpr int o_xl = 0, o_xc = 8 * kKcCap, o_xr = 16 * kKcCap;       // (H: none)
+    static constexpr int o_kX = H ? 0 : 24 * kKcCap;
+    static constexpr int o_kB = o_kX + 8 * (cap + 8), o_kS = o_kB + 8 * (cap + 8), o_kpos = o_kS + 8 * (cap + 8);
+    static constexpr int o_cpos = o_kpos + 4 * (cap + 8), o_crk = o_cpos + 4 * cap, o_cfl = o_crk + 2 * cap;
+    static constexpr int end = o_cfl + cap;
+    unsigned char *base;
+    __device__ __forceinline__ double *c_xl() const { return reinterpret_cast<double *>(base + o_xl); }
+    __device__ __forceinline__ double *c_xc() const { return reinterpret_cast<double *>(base + o_xc); }
+    __device__ __forceinline__ double *c_xr() const { return reinterpret_cast<double *>(base + o_xr); }
+    __device__ __forceinline__ double *k_X() const { return reinterpret_cast<double *>(base + o_kX); }
+    __device__ __forceinline__ double *k_B() const { return reinterpret_cast<double *>(base + o_kB); }
+    __device__ __forceinline__ double *k_S() const { return reinterpret_cast<double *>(base + o_kS); }
+    __device__ __forceinline__ int32_t *k_pos() const { return reinterpret_cast<int32_t *>(base + o_kpos); }
+    __device__ __forceinline__ int32_t *c_pos() const { return reinterpret_cast<int32_t *>(base + o_cpos); }
+    __device__ __forceinline__ unsigned short *c_rk() const { return reinterpret_cast<unsigned short *>(base + o_crk); }
+    __device__ __forceinline__ unsigned char *c_fl() const { return base + o_cfl; }
+};
+constexpr int kKcLds = ((KcLay<true>::end > KcLay<false>::end ? KcLay<true>::end : KcLay<false>::end) + 15) & ~15;
+static_assert(KcLay<true>::o_kB - KcLay<true>::o_kX >= kKcTiles * 8 * 8, "the sticky words fit the hand-over layout's k_B");
 constexpr int kKcRecGran = 32;                   // 8-byte granules per record slot (20 in use): 256 bytes
 constexpr uint32_t kKcPoison = 0xffffffffu;      // a record of a workgroup that has given up
 #ifndef ITD_KC_TIMEOUT
@@ -59,6 +89,7 @@ static_assert(sizeof(KfEntry) == 32, "table entries are two 16-byte words");
 
 // failure bits (KfSig::fail, SigState::kf_fail)
 constexpr int kKfFailVerify = 1, kKfFailCapacity = 2, kKfFailNonFinite = 4, kKfFailTies = 8;
+constexpr int kKfFailWait = 16;   // a halo wait was given up (a neighbour that never became resident within ITD_KC_TIMEOUT) or met a neighbour that had given up
 
 struct KfSig {
     // ---- the head: what itd_get_summary copies to the host (kKfSigHead bytes).  Written with plain stores by the signal's last
@@ -201,19 +232,16 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     static_assert(TW == 512 && kKcTiles * (TW / 128) == kKcThreads && kKcTiles == 64, "one thread per 128-sample group, one lane per tile");
     // the candidates: position, the level's values at position - 1, position, position + 1,
     // flags, and the number of the range's knots at or before the candidate
-    __shared__ double c_xl[kKcCap], c_xc[kKcCap], c_xr[kKcCap];
-    __shared__ int32_t c_pos[kKcCap];
-    __shared__ unsigned short c_rk[kKcCap];
-    __shared__ unsigned char c_fl[kKcCap];                 // 1 = a knot of the level, 2 = sticky
-    // the level's knots by rank, dense index = rank + 1: ranks -1, 0 the two knots in front of the range, 1 .. ck its own,
-    // ck + 1 .. ck + 3 the three behind it
-    __shared__ double k_X[kKcCap + 8], k_B[kKcCap + 8], k_S[kKcCap + 8];
-    __shared__ int32_t k_pos[kKcCap + 8];
+    // (c_fl: 1 = a knot of the level, 2 = sticky.  The level's knots by rank, dense index = rank + 1: ranks -1, 0 the two knots in
+    //  front of the range, 1 .. ck its own, ck + 1 .. ck + 3 the three behind it)
+    __shared__ __attribute__((aligned(16))) unsigned char s_lds[kKcLds];
     __shared__ unsigned long long t_w[kKcTiles * 8];       // the level's knots as the tiles' flag words
     __shared__ uint32_t s_stage[2][4][16];
-    __shared__ int s_red[8], s_i[8], s_cnt[kKcEnt * 4];
+    __shared__ int s_red[8], s_i[8], s_cnt[kKcEntH * 4];
+    const KcLay<true> LH{s_lds};
+    const KcLay<false> LN{s_lds};
     __shared__ double s_ends[4];                           // the level's x[0], x[1], x[n-2], x[n-1] (as far as this workgroup needs them)
-    constexpr int NT = kKcThreads, ENT = kKcEnt;
+    constexpr int NT = kKcThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if ITD_PROF
     unsigned long long kc_marks[64];
@@ -323,7 +351,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     // ---- hand-over: the level-L0 knots of the range (flag words of the records the launch for level L0 - 1 left); sticky
     //      candidates: sample n-2, both samples of every near tie of the level's input (near_tie(): flag words the launch that
     //      wrote it left)
-    unsigned long long *s_w = reinterpret_cast<unsigned long long *>(k_B);   // (sticky words: until the first level needs k_B)
+    unsigned long long *s_w = reinterpret_cast<unsigned long long *>(LH.k_B());   // (sticky words: until the first level needs k_B)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int q = tid + r * NT;
@@ -354,7 +382,10 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         c = tot & 0xffff; ck = tot >> 16;
         int r = o >> 16;                                                     // knots in front of the thread's group
         o &= 0xffff;
-        if (c <= kKcCap) {
+        if (c <= kKcCapH) {
+            int32_t *c_pos = LH.c_pos(), *k_pos = LH.k_pos();
+            unsigned char *c_fl = LH.c_fl();
+            unsigned short *c_rk = LH.c_rk();
             const int32_t s = (int32_t)((t0 + tt) * TW + 128 * g);
             while (E | O) {                                                  // within a group the candidates run E_0, O_0, E_1, O_1, ...
                 const int l = __builtin_ctzll(E | O);
@@ -378,21 +409,20 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         } else if (tid == 0) give_up(kKfFailCapacity);
     }
     kc_barrier();
-    if (!s_i[1]) {                                                           // the three values around every candidate: one round trip
-        double a[ENT], b[ENT], d[ENT];
+    // the three values around every candidate, one round trip; they stay in these registers until the first level's maps have used them
+    double va[kKcEntH], vb[kKcEntH], vd[kKcEntH];
 #pragma unroll
-        for (int i = 0; i < ENT; ++i) {
+    for (int i = 0; i < kKcEntH; ++i) va[i] = vb[i] = vd[i] = 0.0;
+    if (!s_i[1]) {
+#pragma unroll
+        for (int i = 0; i < kKcEntH; ++i) {
             const int j = i * NT + tid;
-            a[i] = b[i] = d[i] = 0.0;
-            if (j < c) { const int32_t p = c_pos[j]; a[i] = xs[p - 1]; b[i] = xs[p]; d[i] = xs[p + 1]; }
+            if (j < c) { const int32_t p = LH.c_pos()[j]; va[i] = xs[p - 1]; vb[i] = xs[p]; vd[i] = xs[p + 1]; }
         }
 #pragma unroll
-        for (int i = 0; i < ENT; ++i) {
+        for (int i = 0; i < kKcEntH; ++i) {
             const int j = i * NT + tid;
-            if (j < c) {
-                c_xl[j] = a[i]; c_xc[j] = b[i]; c_xr[j] = d[i];
-                if (c_fl[j] & 1) k_X[c_rk[j] + 1] = b[i];
-            }
+            if (j < c && (LH.c_fl()[j] & 1)) LH.k_X()[LH.c_rk()[j] + 1] = vb[i];
         }
         if (tid == 192) atomicAdd(&ks->acc_mlev[L0], ck);
     }
@@ -403,9 +433,18 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     //      flag words (t_w) are in place: the hand-over's for the first level, the previous level's compaction for the others.
     int toff = 0;                     // table entries this workgroup has written
     int published = L0 - 1;           // the last level whose record is out
-    for (int lev = L0; lev <= M + 1 && !s_i[1]; ++lev) {
+    // one level; `lay`: the layout its lists are in (the hand-over's for the first, whose triples are va / vb / vd).  false = given up
+    auto level = [&](auto lay, const int lev) -> bool {
+        using Lay = decltype(lay);
+        constexpr bool FIRST = Lay::cap == kKcCapH;
+        constexpr int ENT = FIRST ? kKcEntH : kKcEnt;
+        double *const k_X = lay.k_X(), *const k_B = lay.k_B(), *const k_S = lay.k_S();
+        int32_t *const k_pos = lay.k_pos();
+        const int32_t *const c_pos = lay.c_pos();
+        const unsigned short *const c_rk = lay.c_rk();
+        const unsigned char *const c_fl = lay.c_fl();
         const int li = lev - L0;
-        if (toff + ck + 2 > kKcSlab) { if (tid == 0) give_up(kKfFailCapacity); kc_barrier(); break; }
+        if (toff + ck + 2 > kKcSlab) { if (tid == 0) give_up(kKfFailCapacity); kc_barrier(); return false; }
         KC_MARK(4 + 4 * min(li, 12));
         // A. the record for the neighbours (wavefront 2); the tiles' structures of this level for the sample pass (wavefront 3);
         //    the knots around the range from the neighbours' records (wavefront 0: in front, wavefront 1: behind)
@@ -462,9 +501,12 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             bool edge = false, bad = false, first_round = true, ends_read = false;
             while (have < want && !edge && !bad) {
                 // the workgroups whose records this round reads, nearest first (all lanes agree)
-                int v0 = -1, v1 = -1, v2 = -1, v3 = -1, nsel = 0, ends_only = -1;
+                // (lane k of vsel = the k-th workgroup selected, wave-uniform values, read with v_readlane — as four variables chosen
+                //  by nsel the compiler kept them as an array in scratch memory)
+                int vsel = -1, nsel = 0, ends_only = -1;
                 bool reach_edge = false;
-                auto select = [&](int v) { if (nsel == 0) v0 = v; else if (nsel == 1) v1 = v; else if (nsel == 2) v2 = v; else v3 = v; ++nsel; };
+                auto select = [&](int v) { vsel = lane == nsel ? v : vsel; ++nsel; };
+                auto sel = [&](int k) { return __builtin_amdgcn_readlane(vsel, k); };
                 if (first_round) {                                           // the nearest, whatever they hold
                     for (int k = 0; k < kKcRound; ++k) {
                         const int v = nb(dist0 + k);
@@ -489,7 +531,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                         pend += min((int)__shfl((int)cnt, l), want - have - pend);
                     }
                     if (reach_edge && have + pend < want && !ends_read) {    // the walk will end at the signal's end: its end samples
-                        const int last = nsel == 0 ? -1 : (nsel == 1 ? v0 : (nsel == 2 ? v1 : v2));
+                        const int last = nsel == 0 ? -1 : sel(nsel - 1);
                         // (not among the workgroups that hold knots: read for the end samples only — if an earlier round has passed
                         //  it, its knots are in the halo already and so are the end samples)
                         if (last != v_end) { ends_only = nsel; select(v_end); }
@@ -498,7 +540,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                 }
                 // their granules: 16 lanes per workgroup
                 {
-                    const int v = a == 0 ? v0 : (a == 1 ? v1 : (a == 2 ? v2 : v3));
+                    const int v = __shfl(vsel, a);
                     int gi = -1;
                     if (g == 0) gi = 0;
                     else if (side == 0) { if (g <= 6) gi = g; else if (g <= 10 && v == 0) gi = 16 + (g - 7); }
@@ -510,7 +552,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                 }
                 wave_sync();
                 for (int k = 0; k < nsel && have < want; ++k) {              // (every lane follows the walk; lane 0 writes)
-                    const int vv = k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
+                    const int vv = sel(k);
                     const uint32_t *sg = s_stage[side][k];
                     const uint32_t cnt = sg[0];
                     if (cnt == kKcPoison) { bad = true; break; }
@@ -535,7 +577,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                 if (reach_edge && have < want) edge = true;
             }
             if (lane == 0) {
-                if (bad) give_up(kKfFailCapacity);
+                if (bad) give_up(kKfFailWait);
                 else if (have < want) {                                      // the signal's end: the virtual knot at sample 0 / n-1 (ITD.py:96,98)
                     const int d = side == 0 ? 1 - have : ck + 2 + have;
                     k_pos[d] = side == 0 ? 0 : n1;
@@ -557,7 +599,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         }
         if (lev == L0) published = lev;
         kc_barrier();
-        if (s_i[1]) break;
+        if (s_i[1]) return false;
         if (ws.dbg_kind >= 6 && lev == ws.dbg_lev && w == ws.dbg_wg && sig == 0) {   // fault injection (tests): a halo knot as received
             if (tid == 0) {
                 const int d = ws.dbg_slot < 2 ? ws.dbg_slot : ck + ws.dbg_slot;     // slots 0, 1: in front; 2 .. 4: behind
@@ -614,9 +656,12 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                 const int dc = c_rk[j] + 1;                     // the segment of the candidate's own sample
                 const int dl = dc - (fl & 1);                   // of the sample in front of it: a knot's left neighbour lies in the previous segment
                 const int dr = (k_pos[dc + 1] == pos[i] + 1) ? dc + 1 : dc;
-                yl[i] = k_B[dl] + k_S[dl] * (c_xl[j] - k_X[dl]);
-                yc[i] = k_B[dc] + k_S[dc] * (c_xc[j] - k_X[dc]);
-                yr[i] = (pos[i] + 1 == n1) ? 0.0 : k_B[dr] + k_S[dr] * (c_xr[j] - k_X[dr]);   // baseline[n-1] stays 0, ITD.py:112-117
+                double xl_, xc_, xr_;                           // the candidate's triple at this level
+                if constexpr (FIRST) { xl_ = va[i]; xc_ = vb[i]; xr_ = vd[i]; }
+                else { xl_ = LN.c_xl()[j]; xc_ = LN.c_xc()[j]; xr_ = LN.c_xr()[j]; }
+                yl[i] = k_B[dl] + k_S[dl] * (xl_ - k_X[dl]);
+                yc[i] = k_B[dc] + k_S[dc] * (xc_ - k_X[dc]);
+                yr[i] = (pos[i] + 1 == n1) ? 0.0 : k_B[dr] + k_S[dr] * (xr_ - k_X[dr]);   // baseline[n-1] stays 0, ITD.py:112-117
                 const bool knot = kf_pred(yl[i], yc[i], yr[i]);
                 const bool sticky = (fl & 2) || near_tie(yl[i], yc[i]) || near_tie(yc[i], yr[i]);   // a (near) tie: rounding may move the knot
                 nfl[i] = (knot ? 1 : 0) | (sticky ? 2 : 0);
@@ -658,6 +703,11 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         }
         if (li == 1) KC_MARK(46);
         const int ckn = tot >> 16;
+        if ((tot & 0xffff) > kKcCap) {                          // (only behind the hand-over level: its list may be longer than the later layout holds)
+            if (tid == 0) give_up(kKfFailCapacity);
+            kc_barrier();
+            return false;
+        }
         const bool more = lev < M + 1;                          // the next level's record for the neighbours leaves first, from the registers
         unsigned long long *slot_n = rec_slot(more ? lev + 1 : lev, w);
         const uint32_t tag_n = rec_tag(lev + 1);
@@ -688,10 +738,11 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                     if (r == ckn - 1) publish_knot(1, pos[i], yc[i]);            // the second last
                     if (r == ckn) publish_knot(4, pos[i], yc[i]);                // the last
                 }
-                c_pos[o] = pos[i]; c_xl[o] = yl[i]; c_xc[o] = yc[i]; c_xr[o] = yr[i]; c_fl[o] = (unsigned char)nfl[i]; c_rk[o] = (unsigned short)r;
+                // (the next level's lists: always the later layout)
+                LN.c_pos()[o] = pos[i]; LN.c_xl()[o] = yl[i]; LN.c_xc()[o] = yc[i]; LN.c_xr()[o] = yr[i]; LN.c_fl()[o] = (unsigned char)nfl[i]; LN.c_rk()[o] = (unsigned short)r;
                 if (nfl[i] & 1) {
-                    k_pos[r + 1] = pos[i];
-                    k_X[r + 1] = yc[i];
+                    LN.k_pos()[r + 1] = pos[i];
+                    LN.k_X()[r + 1] = yc[i];
                     const int tt = pos[i] / TW - t0, q = pos[i] & (TW - 1);
                     atomicOr(&t_w[tt * 8 + 2 * (q >> 7) + (q & 1)], 1ull << ((q & 127) >> 1));
                 }
@@ -709,10 +760,14 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         if (more) published = lev + 1;
         kc_barrier();
         KC_MARK(7 + 4 * min(li, 12));
-    }
+        return true;
+    };
+    if (!s_i[1] && level(LH, L0))
+        for (int lev = L0 + 1; lev <= M + 1; ++lev)
+            if (!level(LN, lev)) break;
     // a workgroup that gave up tells everyone who may still wait for it
     if (s_i[1] && wave == 0) {
-        for (int lev = published + 1; lev <= M + 1; ++lev) kc_publish(rec_slot(lev, w), rec_tag(lev), lane, 0, k_pos, k_X, 0.0, 0.0, true);
+        for (int lev = published + 1; lev <= M + 1; ++lev) kc_publish(rec_slot(lev, w), rec_tag(lev), lane, 0, LN.k_pos(), LN.k_X(), 0.0, 0.0, true);
     }
     // the signal's last workgroup draws the stop rules (ITD.py:400-426) from the list sizes, publishes the verdict and leaves the
     // accumulators cleared for the next call (every workgroup's additions to them are complete — each wavefront's wait below —

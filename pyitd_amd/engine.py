@@ -158,7 +158,7 @@ class Engine:
         self._check(self._L.itd_debug_kf_fault(self._h, int(kind), int(level), int(where), int(slot), int(delta)))
 
     def set_fuse_level(self, first_fused_level):
-        """The first fused level, 2 .. max_iteration (default 3: levels 0, 1, 2 are one launch each)."""
+        """The first fused level, 2 .. max_iteration, or 0 (default) = automatic: 2 where a launch sequence covers >= 2^22 samples, else 3."""
         self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))
 
     def set_fuse_min_samples(self, samples):

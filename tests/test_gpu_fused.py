@@ -168,9 +168,10 @@ def test_first_fused_level_is_two_at_least(P):
     """Level 1's launch completes the signal's own knot count and a level-1 list does not fit the workspace: 2 .. max."""
     from pyitd_amd import ITDError
     eng = P.Engine(1 << 16, 1, 0)
-    for bad in (0, 1, 21):
+    for bad in (-1, 1, 21):
         with pytest.raises(ITDError):
             eng.set_fuse_level(bad)
+    eng.set_fuse_level(0)                         # automatic (the default)
     eng.set_fuse_level(2)
     eng.set_fuse_level(20)
     for bad in (1, 8, 48, 128, -16):              # tiles per knot-side workgroup: 0 (automatic), 16, 32 or 64
@@ -502,9 +503,11 @@ def test_knot_side_with_more_workgroups_than_the_device_holds(P, torch, oracle):
 
 
 def test_a_list_that_outgrows_its_workgroup_halves_the_ranges_of_the_next_calls(P, torch, oracle):
-    """White noise has ~13 knots per tile at level 3: with 64 tiles per knot-side workgroup the candidate lists outgrow the LDS.
-    The automatic mode repeats that call level by level and runs the NEXT ones fused with 32 tiles per workgroup (a reallocation of
-    the fused levels' workspace between two calls): every call equals the oracle, only the first is repeated."""
+    """White noise has ~13 knots per tile at level 3 (830 per 64-tile range: delivered since the hand-over level's layout holds 1720
+    candidates) and ~45 at level 2: fused from level 2, with 64 tiles per knot-side workgroup, the candidate lists outgrow the LDS.
+    The automatic mode repeats that call level by level and runs the NEXT ones fused with half the tiles per workgroup (a larger
+    workspace between two calls; 32-tile ranges hold 1680 knots + the sticky candidates here: at the limit, 16 are safe): every call
+    equals the oracle, at most the first two are repeated."""
     from pyitd_amd.engine import FUSE_AUTO
     n, m = 300000, 7
     x = fuzz_signal(np.random.default_rng(77), 0, n).astype(np.float32)
@@ -513,9 +516,11 @@ def test_a_list_that_outgrows_its_workgroup_halves_the_ranges_of_the_next_calls(
     eng.set_fuse_mode(FUSE_AUTO)
     eng.set_fuse_min_samples(65536)
     eng.set_fuse_range(0)          # the automatic ranges (a suite run under PYITD_FUSE_RANGE pins them for every other engine)
+    eng.set_fuse_level(2)
     xd = torch.from_numpy(x).cuda()
     rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
-    for call in range(3):
+    reps = []
+    for call in range(4):
         rows.fill_(float("nan"))
         torch.cuda.synchronize()
         eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
@@ -523,7 +528,8 @@ def test_a_list_that_outgrows_its_workgroup_halves_the_ranges_of_the_next_calls(
         nr = int(s["n_rows"][0])
         assert nr == ref["rows"].shape[0]
         assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "white noise, call %d" % call)
-        assert eng.fuse_repeats == 1, "call %d: only the first call is repeated (then the ranges are halved)" % call
+        reps.append(eng.fuse_repeats)
+    assert reps[0] == 1 and reps[1] <= 2 and reps[2] == reps[3] == reps[1], "the first call is repeated, then the ranges are halved: %r" % reps
     eng.close()
 
 

@@ -8,11 +8,11 @@ from pyitd_amd.engine import FUSE_ONLY
 import bench
 M = 7
 dev = torch.device("cuda:0")
-for k in (22, 23):
+for k in [int(a) for a in sys.argv[1:]] or (20, 22, 23, 24):
     n = 1 << k
     x = bench.batch_signals_device(torch, dev, 0, 1, n)
     rows = torch.empty((1, M + 2, n), dtype=torch.float64, device=dev)
-    for L0, rng in ((3, 64), (3, 32), (2, 32), (2, 16)):
+    for L0, rng in ((3, 64), (2, 64), (3, 32), (2, 32)):
         eng = pyitd_amd.Engine(n, 1, 0)
         eng.set_fuse_mode(FUSE_ONLY)
         eng.set_fuse_level(L0)
