@@ -88,6 +88,27 @@ def algorithmic_bytes_per_sample(levels):
     return 20 + 24 * (levels - 1)
 
 
+def own_bytes_per_sample(rows, first_fused_level):
+    """What the engine itself moves per sample for a `rows`-row result: level 0 (20 B) and every level below the first fused one
+    (24 B) as one launch each, then ONE pass for the fused levels: 8 B read + 8 B per row written.  first_fused_level 0 = one launch per
+    level throughout (the reference's flow: the last level writes one row)."""
+    if not first_fused_level:
+        return 20.0 + 24.0 * (rows - 2) + 16.0 if rows >= 2 else 20.0
+    L0 = int(first_fused_level)
+    return 20.0 + 24.0 * (L0 - 1) + 8.0 + 8.0 * (rows - L0)
+
+
+def library_build_id():
+    """sha256 (first 16 hex digits) of the libpyitd_hip.so this process loads: tools/traffic.sh stamps its PMC figures with it, so a line
+    can say whether profiles/traffic.json was measured on the build that is being timed."""
+    import hashlib
+    from pyitd_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -108,6 +129,8 @@ def preflight(args):
         return 2
     if "WORLD_SIZE" in os.environ:          # a rank: its device's free memory against its shard's footprint
         n = 1 << (args.log2n if args.log2n != LOG2N else 20)
+        if args.total_batch:                # strong scaling: the largest shard of the fixed batch
+            args.batch = -(-args.total_batch // max(1, int(os.environ.get("WORLD_SIZE", "1"))))
         need = shard_footprint_bytes(args.batch, n)
         local = int(os.environ.get("LOCAL_RANK", "0"))
         free, total = torch.cuda.mem_get_info(local)
@@ -270,8 +293,15 @@ def run_rank(args):
         n = 1 << args.log2n
         per_gpu = 1
     batch = per_gpu * world
+    strong = bool(sharded and args.total_batch)
+    if strong:
+        # SURVEY 8d config 4 / BASELINE.md section 3: strong scaling at a FIXED batch (8192 signals over 8 GPUs; 2 and 4 GPUs take the
+        # same batch in larger shards) — contiguous balanced shards (shard_range: the first batch % world ranks own one signal more)
+        batch = args.total_batch
+        per_gpu = -(-batch // world)
     if stub:
-        lo, hi = rank * per_gpu, (rank + 1) * per_gpu
+        from pyitd_amd.distributed import shard_range
+        lo, hi = shard_range(batch, world, rank)
         sb = ShardedBatch(batch, n, M, world, rank, engine=_StubEngine(lo, hi, R))
         x = rows = None
         x_ptr = rows_ptr = sp = 0
@@ -374,8 +404,21 @@ def run_rank(args):
         per_rank_ms = [float(p.item()) / args.steps * 1e3 for p in parts]
         elapsed = max(float(p.item()) for p in parts)
 
-    # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal), all-gathered
-    table = sb.gather(group=group, device=coll_dev) if dist.is_initialized() else None
+    # the only inter-GPU traffic of the path: the per-signal summaries (a few hundred bytes per signal), all-gathered — timed on its
+    # own, apart from the compute (a second gather: the first one pays the collective's set-up)
+    table, gather_ms, repairs_by_rank = None, None, None
+    if dist.is_initialized():
+        table = sb.gather(group=group, device=coll_dev)
+        barrier()
+        tg = time.perf_counter()
+        table = sb.gather(group=group, device=coll_dev)
+        sync()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        mine = torch.tensor([0.0 if stub else (eng.fuse_signal_repairs - fix0) / max(args.steps, 1), 0.0 if stub else float(eng.fuse_repeats - rep0),
+                             gather_ms], dtype=torch.float64, device=coll_dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        repairs_by_rank = [[round(float(v), 3) for v in p.tolist()] for p in parts]
 
     if not sharded and not stub:
         from pyitd_amd.engine import (TIME_DECOMPOSE, TIME_EXTRACT, TIME_EXTRACT_FINAL, TIME_EXTRACT_L0, TIME_KF_APPLY, TIME_KF_KNOTS,
@@ -417,13 +460,14 @@ def run_rank(args):
             dist.destroy_process_group()
         return 0
 
-    samples_per_step = n * batch
+    samples_per_step = n * batch          # (strong scaling: the fixed batch; weak: per_gpu x world)
     value = samples_per_step * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     if sharded:
-        workload = ("batch of %d x %d signals x 2^%d float32 samples (sines+noise, draw b mod 16, f*(1+b/8192)), %d ITD levels "
-                    "(max_iteration=%d, %d rows), contiguous shards of %d signals per GPU, device resident"
-                    % (world, per_gpu, n.bit_length() - 1, LEVELS, M, R, per_gpu))
+        workload = ("batch of %s signals x 2^%d float32 samples (sines+noise, draw b mod 16, f*(1+b/8192)), %d ITD levels "
+                    "(max_iteration=%d, %d rows), contiguous shards of %s%d signals per GPU, device resident"
+                    % (("%d (fixed: strong scaling)" % batch) if strong else ("%d x %d" % (world, per_gpu)), n.bit_length() - 1, LEVELS, M, R,
+                       "at most " if strong else "", per_gpu))
     else:
         workload = ("single 2^%d-sample float32 sum-of-sines+noise, %d ITD levels (max_iteration=%d, %d rows), device resident"
                     % (args.log2n, LEVELS, M, R))
@@ -436,7 +480,7 @@ def run_rank(args):
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -456,12 +500,14 @@ def run_rank(args):
             "fused_levels_refused_and_retimed_level_by_level": fused_refused,
             "summary_read_every_step": bool(sharded),
             "signals_rerun_on_their_own_per_step_rank0": None if (stub or not sharded) else round((eng.fuse_signal_repairs - fix0) / max(args.steps, 1), 2),
+            "summary_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "per_rank_signals_rerun_per_step__whole_call_repeats__allgather_ms": repairs_by_rank,
             "rows_all_ranks": None if table is None else sorted(set(int(v) for v in table["n_rows"])),
             "signals_in_gathered_table": None if table is None else int(len(table["n_rows"])),
         },
         # the reference's level-by-level data flow (20 + 24 x 7 = 188 B/sample) over the measured time: an EQUIVALENT rate —
         # what a level-by-level engine would have to sustain to match this time — not bytes this engine moves (with levels 3..8 fused
-        # it moves 124 B/sample: roofline.per_kernel_frac carries that figure)
+        # it moves 108 B/sample fused from level 2, 124 from level 3: roofline.per_kernel_frac carries that figure)
         "hbm_reference_flow_equivalent_GBps": round(algorithmic_bytes_per_sample(LEVELS) * samples_per_step * args.steps / elapsed / 1e9, 1),
     }
     if args.rehearse_one_gpu:
@@ -476,14 +522,16 @@ def run_rank(args):
         ext_cnt = timing["ext"][1]
         ext_us = avg_us("ext")
         achieved = 24.0 * n / (ext_us * 1e-6) / 1e9 if ext_cnt else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("k_extract_f64_bytes_per_launch")
+                traffic_stale = tj.get("library_build_id") != library_build_id()
                 traffic_src = "profiles/traffic.json (%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction; " \
-                              "a recorded measurement of the same build, not of this run)" % tj.get("round")
+                              "a recorded measurement of %s, not of this run)" % (
+                                  tj.get("round"), "an OLDER build of the library (traffic_stale)" if traffic_stale else "this very build of the library (build ids equal)")
             except Exception:
                 traffic = None
 
@@ -513,7 +561,13 @@ def run_rank(args):
                 "frac": frac(apply_bytes, apply_us),
                 "traffic": traffic_a,
                 "traffic_source": traffic_src if traffic_a else None,
+                "traffic_stale": traffic_stale if traffic_a else None,
+                "library_build_id": library_build_id(),
                 "algorithmic_bytes_per_sample": apply_bytes,
+                # SURVEY 8d asks for both fractions: the bytes the launch READS over the peak (8 B/sample: the first fused level's input)
+                # and all its bytes (frac).  The north star's ">= 40 % of the HBM-read roofline" is out of reach for a pass that writes
+                # 8 B per row for every 8 B it reads; frac is the figure to read.
+                "read_frac": frac(8.0, apply_us),
                 "avg_launch_us": round(apply_us, 2),
                 "launches_timed": timing["kfa"][1],
                 "reference_flow_bytes_per_sample": 24.0 * (rows_out - L0),
@@ -546,6 +600,8 @@ def run_rank(args):
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_stale": traffic_stale if traffic else None,
+                "library_build_id": library_build_id(),
                 "avg_launch_us": round(ext_us, 2),
                 "launches_timed": ext_cnt,
                 "read_frac": frac(8.0, ext_us) if ext_cnt else 0.0,
@@ -573,22 +629,23 @@ def run_rank(args):
         # N > 1: every GPU runs its shard as chunks whose launches overlap on two streams, so a single launch's duration is not
         # a rate; the figure is the whole decomposition's algorithmic bytes (188 B/sample) per GPU over the max-over-ranks time.
         # The per-launch figure of the dominant kernel is the N = 1 line's.
-        # own bytes: with levels 3 .. 8 fused (the default) the engine moves 20 + 24 x 2 + (8 + 8 x 6) = 124 B per sample; level by level
+        # own bytes: fused from level 2 (the default for these shards) the engine moves 20 + 24 + (8 + 8 x 7) = 108 B per sample; level by level
         # (--no-fuse, or a refused and re-timed run) the reference flow's 188
         ran_fused = not fused_refused and not args.no_fuse
-        own_bytes = 124.0 if ran_fused else float(algorithmic_bytes_per_sample(LEVELS))
-        per_gpu_gbps = own_bytes * float(n) * per_gpu * args.steps / elapsed / 1e9
+        lvl = eng.last_fuse_level if ran_fused else 0
+        own_bytes = own_bytes_per_sample(R, lvl)
+        per_gpu_gbps = own_bytes * float(n) * sb.n_local * args.steps / elapsed / 1e9     # (rank 0's shard: the largest one)
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "whole decomposition per GPU, own bytes (%d B/sample: %s); per-launch figures: the N = 1 line"
-                      % (int(own_bytes), "levels 0-2 one launch each, levels 3-8 fused" if ran_fused else "one launch per level"),
+                      % (int(own_bytes), ("levels 0-%d one launch each, levels %d-8 fused" % (lvl - 1, lvl)) if lvl else "one launch per level"),
             "achieved": round(per_gpu_gbps, 1),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(per_gpu_gbps / HBM_PEAK_GBPS, 4),
             "traffic": None,
             "per_gpu": True,
-            "reference_flow_equivalent_GBps_per_gpu": round(algorithmic_bytes_per_sample(LEVELS) * float(n) * per_gpu * args.steps / elapsed / 1e9, 1),
+            "reference_flow_equivalent_GBps_per_gpu": round(algorithmic_bytes_per_sample(LEVELS) * float(n) * sb.n_local * args.steps / elapsed / 1e9, 1),
         }
         out["cpu_baseline"] = None   # timed on rank 0 at N = 1 only (the N = 1 line of the same build carries all four CPU legs)
     if world == 1 and not stub and not args.no_cpu_baseline:
@@ -598,7 +655,8 @@ def run_rank(args):
         del rows, x
         torch.cuda.empty_cache()
         for key, leg in (("config3_batch", lambda: batch_leg(torch, dev)), ("short_signal_batches", lambda: short_signal_leg(torch, dev)),
-                         ("mid_size_signals", lambda: mid_size_leg(torch, dev)), ("f_rows", lambda: f_rows_leg(torch, dev))):
+                         ("mid_size_signals", lambda: mid_size_leg(torch, dev)), ("many_mid_size_signals", lambda: many_mid_size_leg(torch, dev)),
+                         ("f_rows", lambda: f_rows_leg(torch, dev))):
             try:
                 out[key] = leg()
             except Exception as ex:  # noqa: BLE001
@@ -616,6 +674,10 @@ def run_rank(args):
             out["headline_on_quantised_2p24"] = quantised_leg(torch, dev, x_host, n, M)
         except Exception as ex:  # noqa: BLE001
             out["headline_on_quantised_2p24"] = {"error": repr(ex)[:200]}
+        try:
+            out["headline_with_valid_flags"] = valid_flags_leg(torch, dev, x_host, n, M)
+        except Exception as ex:  # noqa: BLE001
+            out["headline_with_valid_flags"] = {"error": repr(ex)[:200]}
     print(json.dumps(out))
     sys.stdout.flush()
     if dist.is_initialized():
@@ -694,6 +756,118 @@ def quantised_leg(torch, dev, x_host, n, M, calls=20):
                     "rows": int(s["n_rows"][0])}
         eng.close()
     return out
+
+
+def valid_flags_leg(torch, dev, x_host, n, M, calls=40):
+    """The headline signal the way a stream-ordered consumer runs it: itd_set_valid_flags alone — behind every decomposition one short
+    launch (k_verdict) writes valid_dev[0], nobody reads a summary between the calls.  What such a consumer pays when nothing refuses
+    (the headline's own timed region reads no summary either, but carries no verdict launch)."""
+    import pyitd_amd
+    x = torch.from_numpy(x_host).to(dev)
+    rows = torch.empty((M + 2, n), dtype=torch.float64, device=dev)
+    valid = torch.zeros((1,), dtype=torch.int32, device=dev)
+    eng = pyitd_amd.Engine(n, 1, dev.index or 0)
+    eng.set_valid_flags(valid.data_ptr())
+    torch.cuda.synchronize()
+    for _ in range(10):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, None)
+    eng.summary(1)
+    for _ in range(60):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        eng.decompose_dev(x.data_ptr(), np.float32, n, 1, n, M, rows.data_ptr(), None, None)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / calls
+    ok = int(valid.item())
+    s = eng.summary(1)
+    out = {"workload": "the headline's signal, itd_set_valid_flags only (no summary between the calls), %d calls" % calls,
+           "ms_per_decomposition": round(dt * 1e3, 4), "Msamples_per_s": round(n / dt / 1e6, 1), "valid_flag": ok,
+           "fuse_repeats": eng.fuse_repeats, "rows": int(s["n_rows"][0]), "first_fused_level": eng.last_fuse_level}
+    eng.close()
+    return out
+
+
+def many_mid_size_leg(torch, dev, M=MAX_ITERATION):
+    """MANY independent mid-size signals in flight (the north star's one-signal-per-stream; siftED2D.ipynb cell 1 runs rows under
+    prange): 64 and 256 signals of 2^16 / 2^18 samples, 8 levels, (i) as ONE batch call (the engine's chunks over its own streams:
+    default geometry, and the best of a sweep over itd_set_batch_streams x itd_set_batch_chunk), (ii) one signal per call over a pool
+    of 4 / 8 / 16 engines, each with a stream of its own, driven by host threads.  Gsamples/s and the fraction of the HBM peak on the
+    result's own bytes (input once, every produced row once: 4 + 8 x rows B/sample)."""
+    import pyitd_amd
+    from concurrent.futures import ThreadPoolExecutor
+    out = []
+    for batch, log2n in ((64, 16), (256, 16), (64, 18), (256, 18)):
+        n = 1 << log2n
+        x = batch_signals_device(torch, dev, 0, batch, n)
+        rows = torch.empty((batch, M + 2, n), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        item = {"signals": batch, "samples_per_signal": n}
+        own = None
+
+        def time_batch(streams, chunk, reps=10):
+            eng = pyitd_amd.Engine(n, batch, dev.index or 0)
+            if streams:
+                eng.set_batch_streams(streams)
+            if chunk:
+                eng.set_batch_chunk(chunk)
+            for _ in range(3):
+                eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, M, rows.data_ptr(), None, None)
+            s = eng.summary(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, M, rows.data_ptr(), None, None)
+            s = eng.summary(batch)
+            dt = (time.perf_counter() - t0) / reps
+            lvl, rep = eng.last_fuse_level, eng.fuse_repeats + eng.fuse_signal_repairs
+            eng.close()
+            return dt, s, lvl, rep
+        dt, s, lvl, rep = time_batch(0, 0)
+        own = (4.0 * n * batch + 8.0 * n * float(s["n_rows"].sum()))
+        item["one_batch_call_default"] = {"us": round(dt * 1e6, 1), "Gsamples_per_s": round(batch * n / dt / 1e9, 2),
+                                          "own_bytes_frac_of_peak": round(own / dt / 1e9 / HBM_PEAK_GBPS, 4), "first_fused_level": lvl,
+                                          "repeats_or_repairs": rep}
+        best = None
+        sweep = {}
+        for streams in (1, 2, 3, 4):
+            for chunk in sorted(set(c for c in (max(1, batch // 16), max(1, batch // 8), max(1, batch // 4), max(1, batch // 2), batch))):
+                d2, _, l2, _ = time_batch(streams, chunk, reps=6)
+                sweep["%d streams x %d signals per sequence" % (streams, chunk)] = round(d2 * 1e6, 1)
+                if best is None or d2 < best[0]:
+                    best = (d2, streams, chunk, l2)
+        item["one_batch_call_best_of_sweep"] = {"us": round(best[0] * 1e6, 1), "streams": best[1], "signals_per_sequence": best[2],
+                                                "Gsamples_per_s": round(batch * n / best[0] / 1e9, 2),
+                                                "own_bytes_frac_of_peak": round(own / best[0] / 1e9 / HBM_PEAK_GBPS, 4), "first_fused_level": best[3]}
+        item["sweep_us"] = sweep
+        pools = {}
+        for P in (4, 8, 16):
+            engs = [pyitd_amd.Engine(n, 1, dev.index or 0) for _ in range(P)]
+
+            def work(k):
+                e = engs[k]
+                for b in range(k, batch, P):
+                    e.decompose_dev(x[b].data_ptr(), np.float32, n, 1, n, M, rows[b].data_ptr(), None, None)
+                return k
+            with ThreadPoolExecutor(max_workers=P) as ex:
+                list(ex.map(work, range(P)))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    list(ex.map(work, range(P)))
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 3
+            for e in engs:
+                e.summary(1)
+                e.close()
+            pools["%d engines" % P] = {"us": round(dt * 1e6, 1), "Gsamples_per_s": round(batch * n / dt / 1e9, 2),
+                                       "own_bytes_frac_of_peak": round(own / dt / 1e9 / HBM_PEAK_GBPS, 4)}
+        item["one_signal_per_call_engine_pool"] = pools
+        out.append(item)
+        del x, rows
+    return {"workload": "independent float32 signals (the batch recipe), %d levels, device resident; every figure = all signals once" % (M + 1),
+            "shapes": out}
 
 
 def audio_leg(torch, dev, path, log2n=22, max_iteration=9):
@@ -863,13 +1037,17 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
         dt = timed()
         s = eng.summary(batch)
     alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
+    lvl = 0 if refused else eng.last_fuse_level
+    own = own_bytes_per_sample(MAX_ITERATION + 2, lvl)
     out = {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
             "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
             "hbm_reference_flow_equivalent_GBps": round(alg, 1),
             "bytes_note": "equivalent = the reference flow's 20 + 24 x 7 = 188 B/sample (SURVEY 8d) over the measured time: what a "
                           "level-by-level engine would have to sustain, not a measured traffic (it may exceed what the memory system "
-                          "delivers); with levels 3..8 fused the engine itself moves 124 B/sample: frac_of_peak_own_bytes",
-            "frac_of_peak_own_bytes": None if refused else round(124.0 * batch * n / dt / 1e9 / HBM_PEAK_GBPS, 4),
+                          "delivers); the engine itself moves own_bytes_per_sample (first_fused_level: the levels from there on take one "
+                          "pass over the samples): frac_of_peak_own_bytes",
+            "first_fused_level": lvl, "own_bytes_per_sample": own,
+            "frac_of_peak_own_bytes": round(own * batch * n / dt / 1e9 / HBM_PEAK_GBPS, 4),
             "rows_per_signal": sorted(set(int(v) for v in s["n_rows"])),
             "fused_levels_refused_and_retimed_level_by_level": refused,
             "signals_rerun_on_their_own_per_step": repaired, "summary_read_every_step": True, "order": "timed after the headline"}
@@ -1032,7 +1210,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=LOG2N, help="N = 1: samples of the single signal (24); N > 1: samples per signal (20)")
-    ap.add_argument("--batch", type=int, default=1024, help="N > 1: signals per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="N > 1: signals per GPU (weak scaling: the batch grows with N)")
+    ap.add_argument("--total-batch", type=int, default=0, help="N > 1: a FIXED batch over all GPUs instead (strong scaling; SURVEY 8d config 4: 8192), "
+                                                              "balanced contiguous shards; `scaling` = \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational BASELINE configs[2] leg (1024 x 2^20 signals)")
     ap.add_argument("--try-rccl", action="store_true",

@@ -226,6 +226,9 @@ int itd_set_fuse_group(itd_engine *e, int32_t chunks);
 int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta);
 /* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);
+/* the first fused level of the last decomposition as it was enqueued (2, 3, ...), 0 if it ran one launch per level throughout
+ * (too short, ITD_FUSE_OFF, a back-off) or in the resident form: what a benchmark's byte model needs (ABI revision 9) */
+int itd_get_last_fuse_level(const itd_engine *e);
 /* ... and how many single signals of batches it has re-run on their own (the rest of their batch kept the fused result) */
 int64_t itd_get_fuse_signal_repairs(const itd_engine *e);
 /* Short signals (n <= 8192 samples): the resident form — ONE launch, one workgroup per signal, the signal and its knot arrays

@@ -95,6 +95,7 @@ ABI = {
     "itd_set_fuse_group": (_INT, [_P, _I32]),
     "itd_debug_kf_fault": (_INT, [_P, _I32, _I32, _I32, _I32, _I32]),
     "itd_get_fuse_repeats": (_INT, [_P]),
+    "itd_get_last_fuse_level": (_INT, [_P]),
     "itd_get_fuse_signal_repairs": (_I64, [_P]),
     "itd_set_resident_mode": (_INT, [_P, _I32]),
     "itd_get_resident_repeats": (_INT, [_P]),

@@ -209,6 +209,7 @@ struct itd_engine {
     int64_t fuse_signal_repairs = 0;   // signals itd_get_summary has re-run on their own (a few of a batch refused the fused form)
     bool last_kf = false;
     int last_kf_level = 0;         // the first fused level of that call
+    int last_kf_form = 0;          // ... as enqueued (itd_get_last_fuse_level): stays when a summary has drawn the verdict (last_kf = false then)
     // fault injection into the fused levels' workspace (itd_debug_kf_fault; tests only): kind < 0 = none
     int32_t fault_kind = -1, fault_level = 0, fault_where = 0, fault_slot = 0, fault_delta = 0;
     int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
@@ -309,6 +310,9 @@ int chunk_of(const itd_engine *e, int64_t n, int32_t batch)
     // one stream: 2^24 samples per chunk; two or more (the default): half of that per chunk — two chunks in flight, measured best
     // on 512 x 2^20 with the fused levels' knot side as one launch (chunks of 8 signals over 2 streams: 12.3 ms against 12.7 with 12
     // and 13.0 with 16 over one stream; round 2, level by level: 10-12 signals over 2 streams, profiles/r02/session2_batch_streams.txt)
+    // a batch of up to 2^24 samples in all is ONE sequence (64 signals of 2^18 samples: 393 us as one sequence against 466 as two chunks
+    // of 32 over two streams; 256 x 2^16: 416 against 436 — profiles/r05/bench_default_form.json, many_mid_size_signals)
+    if ((int64_t)batch * n <= ((int64_t)1 << 24) && batch <= kMaxGridY) return batch;
     const int64_t per = e->batch_streams > 1 ? ((int64_t)1 << 23) : ((int64_t)1 << 24);
     const int64_t c = std::max<int64_t>(1, per / n);
     return (int)std::min<int64_t>(std::min<int64_t>(c, kMaxGridY), batch);   // a chunk's signals are the launches' grid.y
@@ -682,6 +686,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_nan_input = nan_input;
     e->last_kf = kf;
     e->last_kf_level = L0;
+    if (!repair_need) e->last_kf_form = kf ? L0 : 0;
     return ITD_OK;
 }
 
@@ -764,6 +769,7 @@ int enqueue_resident(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int6
     e->last_fused = false;
     e->last_resident = true;
     e->last_kf = false;
+    e->last_kf_form = 0;
     e->last_nan_input = false;
     return ITD_OK;
 }
@@ -1148,7 +1154,7 @@ int repair_signals(itd_engine *e, int B)
     const auto keep_batch = e->last_batch; const auto keep_m = e->last_m; const auto keep_n = e->last_n; const auto keep_stream = e->last_stream;
     const void *keep_x = e->last_x; const bool keep_f32 = e->last_x_f32; const auto keep_xs = e->last_x_stride;
     double *keep_rows = e->last_rows, *keep_bases = e->last_bases;
-    const bool keep_fused = e->last_fused; const int keep_kfl = e->last_kf_level;
+    const bool keep_fused = e->last_fused; const int keep_kfl = e->last_kf_level, keep_form = e->last_kf_form;
     const bool keep_timing = e->timing;
     const int main_set = e->cur_set;
     const int64_t main_gs = e->dirty_gs[main_set];
@@ -1182,7 +1188,7 @@ int repair_signals(itd_engine *e, int B)
     e->dirty_gs[main_set ^ 1] = std::max<int64_t>(e->dirty_gs[main_set ^ 1], (int64_t)groups_of((int)tiles_of(keep_n)) * kGsumPitch);
     e->last_batch = keep_batch; e->last_m = keep_m; e->last_n = keep_n; e->last_stream = keep_stream; e->last_x = keep_x; e->last_x_f32 = keep_f32;
     e->last_x_stride = keep_xs; e->last_rows = keep_rows; e->last_bases = keep_bases; e->last_fused = keep_fused; e->last_kf = false;
-    e->last_kf_level = keep_kfl; e->last_resident = false; e->last_nan_input = false;
+    e->last_kf_level = keep_kfl; e->last_kf_form = keep_form; e->last_resident = false; e->last_nan_input = false;
     return rc;
 }
 
@@ -1459,6 +1465,7 @@ int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where
 }
 
 int itd_get_fuse_repeats(const itd_engine *e) { return e ? e->fuse_repeats : -1; }
+int itd_get_last_fuse_level(const itd_engine *e) { return !e ? -1 : (e->ran && e->last_kf_form ? e->last_kf_form : 0); }
 int64_t itd_get_fuse_signal_repairs(const itd_engine *e) { return e ? e->fuse_signal_repairs : -1; }
 
 int itd_set_resident_window(itd_engine *e, int32_t segments)

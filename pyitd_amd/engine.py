@@ -176,6 +176,11 @@ class Engine:
         return self._L.itd_get_fuse_repeats(self._h)
 
     @property
+    def last_fuse_level(self):
+        """The first fused level of the last decomposition as enqueued (2, 3, ...), 0 = one launch per level / resident form."""
+        return self._L.itd_get_last_fuse_level(self._h)
+
+    @property
     def fuse_signal_repairs(self):
         """Single signals of batches that itd_get_summary re-ran on their own (at most one in eight of a batch refused the fused
         form: the rest of the batch kept its fused result)."""

@@ -50,3 +50,15 @@ def test_more_ranks_than_devices_fails_fast_with_a_message():
     assert p.returncode == 2
     assert "needs 8 visible devices" in p.stderr and "--rehearse-one-gpu" in p.stderr
     assert json.loads(p.stdout.strip().splitlines()[-1])["error"].startswith("needs 8 devices")
+
+
+def test_total_batch_is_strong_scaling_with_balanced_shards():
+    """`--total-batch T`: a FIXED batch over all ranks (SURVEY 8d config 4's strong-scaling form): balanced contiguous shards (the
+    first T % N ranks own one signal more), `scaling` = "strong", the gathered table in batch order, the all-gather timed on its own
+    and every rank's repair counts in the line."""
+    d = _run(["--gpus", "2", "--total-batch", "7", "--log2n", "10"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["signals_in_gathered_table"] == 7 and d["config"]["table_signal_ids"] == list(range(7))
+    assert d["config"]["signals_per_gpu"] == 4 and "7 (fixed: strong scaling)" in d["config"]["workload"]
+    assert d["config"]["summary_allgather_ms"] is not None and len(d["config"]["per_rank_signals_rerun_per_step__whole_call_repeats__allgather_ms"]) == 2
+    assert d["value"] > 0

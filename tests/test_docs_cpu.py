@@ -54,3 +54,16 @@ def test_no_profile_claims_more_than_the_peak():
                 if float(m.group(1)) > 1.0:
                     bad.append("%s: %s" % (f, m.group(0)))
     assert not bad, "\n".join(bad[:20])
+
+
+def test_no_profile_is_a_crashed_run():
+    """An evidence file that holds a Python traceback (round 4 shipped one: a diagnostic library that no longer matched the ABI) is
+    not evidence: whatever writes into profiles/ must have run to the end."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "profiles")):
+        for f in files:
+            if f.endswith((".txt", ".json", ".log", ".csv", ".md")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if "Traceback (most recent call last)" in text or "undefined symbol" in text:
+                    bad.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert not bad, "crashed runs kept as evidence: " + ", ".join(bad)

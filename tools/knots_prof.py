@@ -34,12 +34,14 @@ t0 = b[:, 0].min()
 us = lambda v: (v - t0) / 100.0
 print("n = 2^%d: %d workgroups; launch span (first start .. last end) %.2f us" % (lg, len(b), us(b[:, 60].max())))
 print("start skew: last workgroup starts at %.2f us" % us(b[:, 0].max()))
+L0 = eng.last_fuse_level
+print("first fused level %d" % L0)
 names = [(1, "ticket"), (2, "state + words + tie flags loaded"), (3, "expansion + values (hand-over done)")]
-for li in range(M + 2 - 3):
-    names += [(4 + 4 * li, "L%d: knots by rank, words" % (3 + li)), (5 + 4 * li, "L%d: halo arrived" % (3 + li)),
-              (6 + 4 * li, "L%d: B, S, table" % (3 + li)), (7 + 4 * li, "L%d: map + compaction" % (3 + li))]
+for li in range(M + 2 - L0):
+    names += [(4 + 4 * li, "L%d: knots by rank, words" % (L0 + li)), (5 + 4 * li, "L%d: halo arrived" % (L0 + li)),
+              (6 + 4 * li, "L%d: B, S, table" % (L0 + li)), (7 + 4 * li, "L%d: map + compaction" % (L0 + li))]
 names += [(60, "end")]
-fine = [(6 + 4, "L4: B, S, table"), (44, "  L4 maps done"), (45, "  L4 end samples (thread 0)"), (46, "  L4 scan"), (47, "  L4 record's fixed part (thread 0)"), (48, "  L4 compaction writes"), (7 + 4, "L4: barrier")]
+fine = [(6 + 4, "second fused level: B, S, table"), (44, "  maps done"), (45, "  end samples (thread 0)"), (46, "  scan"), (47, "  record's fixed part (thread 0)"), (48, "  compaction writes"), (7 + 4, "  barrier")]
 prev = b[:, 0]
 print("%-44s %9s %9s %9s   %s" % ("mark", "median at", "max at", "d median", "(us since the first workgroup's start)"))
 for k, nm in names:
