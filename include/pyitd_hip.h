@@ -185,9 +185,11 @@ int itd_set_level0_mode(itd_engine *e, int32_t mode);
  * it computes; where they differ from the knot side's (or a list outgrows its workgroup, or knot data go non-finite: coarsely
  * quantised, plateau-ridden or very smooth signals) itd_get_summary repeats the call level by level before it returns (x_dev /
  * rows_dev / baselines_dev must stay valid until then, as before; or on the device: itd_set_device_repair) and the engine's next 16
- * decompositions start level by level — after a list outgrew its workgroup they stay fused with half the tiles per workgroup
- * (itd_set_fuse_range); when only a few signals of a batch are concerned (at most one in eight) just those are run again, each on
- * its own, and the engine stays in the fused form.
+ * decompositions start level by level (32, 64, ... 1024 when the fused attempt that follows such a pause refuses again: a workload
+ * the fused form cannot deliver pays one wasted attempt in ever more calls; a delivered call starts over at 16) — after a list
+ * outgrew its workgroup they stay fused, handing over a level later or with half the tiles per workgroup (itd_set_fuse_range); when
+ * only a few signals of a batch are concerned (at most one in eight) just those are run again, each on its own, and the engine stays
+ * in the fused form.
  * Results are bit-identical in every mode: what the fused form cannot deliver it reports.  The fused levels' workspace is allocated
  * by the first call that takes this path; a call being captured into a graph cannot allocate: on an engine that has not fused yet it is
  * captured level by level (run one decomposition before the capture to get the fused form into the graph).  A graph that holds a fused
@@ -224,6 +226,11 @@ int itd_set_fuse_group(itd_engine *e, int32_t chunks);
  *                   knot-side workgroup `where` receives it from its neighbours at `level`.
  * `level` is the absolute level (first fused level .. max_iteration + 1). */
 int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta);
+/* Tests only (ABI revision 9): the kernels form the knot spacings' ratio (k1 - k0) / (k2 - k0) of ITD.py:107 with the division's own
+ * instruction sequence minus its range scaling and special-case fix-up, which do nothing for exact small integers (itd_kernels.hpp:
+ * int_ratio).  This runs that sequence against the compiler's full float64 division on the device for EVERY pair 0 <= a <= b <= max_den
+ * and for 2^30 pseudo-random pairs below 2^31: *mismatches = pairs whose results differ in any bit (must be 0). */
+int itd_debug_int_ratio_check(int device, int32_t max_den, int64_t *mismatches);
 /* how many whole calls of this engine itd_get_summary has had to repeat level by level because the fused levels reported a failure */
 int itd_get_fuse_repeats(const itd_engine *e);
 /* the first fused level of the last decomposition as it was enqueued (2, 3, ...), 0 if it ran one launch per level throughout

@@ -94,6 +94,7 @@ ABI = {
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),
     "itd_set_fuse_group": (_INT, [_P, _I32]),
     "itd_debug_kf_fault": (_INT, [_P, _I32, _I32, _I32, _I32, _I32]),
+    "itd_debug_int_ratio_check": (_INT, [_INT, _I32, ctypes.POINTER(_I64)]),
     "itd_get_fuse_repeats": (_INT, [_P]),
     "itd_get_last_fuse_level": (_INT, [_P]),
     "itd_get_fuse_signal_repairs": (_I64, [_P]),

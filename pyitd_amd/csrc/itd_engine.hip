@@ -122,6 +122,27 @@ __global__ void k_verdict_repaired(const SigState *__restrict__ state, int batch
     valid[b] = (state[b].in_nan && nan_follow) ? 0 : 1;
 }
 
+// itd_debug_int_ratio_check: int_ratio(a, b) against the compiler's full division for every pair 0 <= a <= b <= max_den (b >= 1) and
+// for pseudo-random pairs up to 2^31 - 1: the number of pairs whose bit patterns differ
+__global__ void k_int_ratio_check(int max_den, unsigned long long *bad)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long long)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (long long b = 1 + tid; b <= max_den; b += nthreads)
+        for (int a = 0; a <= (int)b; ++a) {
+            volatile double x = (double)a, y = (double)(int)b;          // (volatile: the reference stays the emitted division)
+            mine += dbits(int_ratio(a, (int)b)) != dbits(x / y);
+        }
+    unsigned long long h = 0x9e3779b97f4a7c15ull * (unsigned long long)(tid + 1);
+    for (int k = 0; k < 4096; ++k) {
+        h ^= h << 13; h ^= h >> 7; h ^= h << 17;
+        const int b = (int)((h >> 1) & 0x7fffffff) | 1, a = (int)((h >> 33) & 0x7fffffff) % b;
+        volatile double x = (double)a, y = (double)b;
+        mine += dbits(int_ratio(a, b)) != dbits(x / y);
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
 // totals[2b + 1] = signal b holds a NaN (k_compact): OR them into one flag
 __global__ void k_or_nan_flags(const int32_t *__restrict__ totals, int batch, int32_t *__restrict__ flag)
 {
@@ -190,6 +211,10 @@ struct itd_engine {
     std::vector<void *> kf_retired;  // earlier, smaller workspaces: a captured graph may still hold their pointers — kept until the engine is destroyed
     KfWs kf{};                       // pointers into d_kf, for signal 0
     int32_t fuse_mode = ITD_FUSE_AUTO, fuse_level = 0, fuse_off_left = 0, fuse_repeats = 0;   // fuse_level 0: automatic (kf_first_level)
+    int32_t fuse_off_span = 16;                      // calls that run level by level after the next whole-call refusal: doubles with every refusal that
+                                                     // follows a back-off directly (a workload the fused form cannot deliver — periodic, collapsing input —
+                                                     // pays one wasted attempt in 17, then 33, ... 1025 calls), back to 16 after a delivered call
+    bool fuse_probe = false;                         // the call being summarised was the first fused attempt after a back-off
     bool kf_force_tickets = false;                   // a halo wait was given up on this engine (kKfFailWait): workgroup ids are tickets from then on
     bool fuse_level2_off = false;                    // automatic first fused level: a level-2 list has outgrown its workgroup, level 3 from then on
     bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
@@ -356,6 +381,14 @@ bool kf_back_off(itd_engine *e, int bits, int level)
     }
     if (bits == kKfFailWait && !e->kf_force_tickets) { e->kf_force_tickets = true; return true; }
     return false;
+}
+// the engine's next calls run level by level: 16 of them after a first refusal, twice as many after every refusal of the probing
+// call that follows a back-off (up to 1024)
+void kf_levels_off(itd_engine *e)
+{
+    if (e->fuse_probe) e->fuse_off_span = std::min(e->fuse_off_span * 2, 1024);
+    e->fuse_off_left = e->fuse_off_span;
+    e->fuse_probe = false;
 }
 int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
 {
@@ -786,7 +819,7 @@ bool want_kf(itd_engine *e, int64_t n, int32_t batch, int32_t M, bool fuse0)
     if (e->fuse_mode == ITD_FUSE_ONLY) return true;
     if (n < 65536 || e->l0_mode != ITD_LEVEL0_AUTO || e->fuse_no_memory) return false;
     if ((int64_t)std::min<int32_t>(chunk_of(e, n, batch), batch) * n < e->fuse_min_samples) return false;
-    if (e->fuse_off_left > 0) { --e->fuse_off_left; return false; }
+    if (e->fuse_off_left > 0) { if (--e->fuse_off_left == 0) e->fuse_probe = true; return false; }
     return true;
 }
 
@@ -1241,7 +1274,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         e->device_repairs += fixed;
         e->last_device_repair = false;      // (a second summary of the same call counts nothing)
         if (fixed && (B < 8 || fixed * 8 > B)) {
-            if ((why & 1) && !kf_back_off(e, (why >> 3) & 31, e->last_kf_level)) e->fuse_off_left = 16;
+            if ((why & 1) && !kf_back_off(e, (why >> 3) & 31, e->last_kf_level)) kf_levels_off(e);
             if (why & 2) e->l0_records_left = 16;
             if (why & 4) e->resident_off_left = 16;
         }
@@ -1291,11 +1324,12 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         // repeated level by level and the engine's next decompositions start that way.
         int nfail = 0;
         for (int b = 0; b < B; ++b) nfail += e->h_state[b].kf_fail != 0;
+        if (!nfail) { e->fuse_off_span = 16; e->fuse_probe = false; }      // delivered: the back-off starts over
         if (nfail) {
             if (e->fuse_mode == ITD_FUSE_ONLY) {
                 int code = 0;
                 for (int b = 0; b < B; ++b) code |= e->h_state[b].kf_fail;
-                snprintf(e->err, sizeof(e->err), "fused sparse levels: not the reference's result (fail bits 0x%x: 1 verification, 2 capacity, 4 non-finite, 8 ties); ITD_FUSE_ONLY forbids the level-by-level repeat", code);
+                snprintf(e->err, sizeof(e->err), "fused sparse levels: not the reference's result (fail bits 0x%x: 1 verification, 2 capacity, 4 non-finite, 8 ties, 16 halo wait); ITD_FUSE_ONLY forbids the level-by-level repeat", code);
                 return ITD_ERR_HIP;
             }
             // a list that outgrew its workgroup (dense knots): the calls after this one hand over a level later or run with half the
@@ -1308,7 +1342,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                 if (rc) return rc;
             } else {
                 ++e->fuse_repeats;
-                if (!can_shrink) e->fuse_off_left = 16;
+                if (!can_shrink) kf_levels_off(e);
                 const int rc = repeat(want_fused(e), false);
                 if (rc) return rc;
             }
@@ -1429,6 +1463,8 @@ int itd_set_fuse_mode(itd_engine *e, int32_t mode)
     if (!e || mode < ITD_FUSE_AUTO || mode > ITD_FUSE_ONLY) return ITD_ERR_INVALID_ARG;
     e->fuse_mode = mode;
     e->fuse_off_left = 0;
+    e->fuse_off_span = 16;
+    e->fuse_probe = false;
     return ITD_OK;
 }
 
@@ -1453,6 +1489,19 @@ int itd_set_fuse_min_samples(itd_engine *e, int64_t samples)
     if (!e || samples < 0) return ITD_ERR_INVALID_ARG;
     e->fuse_min_samples = samples;
     return ITD_OK;
+}
+
+int itd_debug_int_ratio_check(int device, int32_t max_den, int64_t *mismatches)
+{
+    if (!mismatches || max_den < 1) return ITD_ERR_INVALID_ARG;
+    DevGuard g(device);
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc(&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess) { (void)hipFree(d); return ITD_ERR_HIP; }
+    k_int_ratio_check<<<1024, 256>>>(max_den, d);
+    const bool ok = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    *mismatches = (int64_t)h;
+    return ok ? ITD_OK : ITD_ERR_HIP;
 }
 
 int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta)

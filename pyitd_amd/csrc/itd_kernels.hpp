@@ -52,6 +52,9 @@
 #ifndef ITD_EARLY_STOP
 #define ITD_EARLY_STOP 1
 #endif
+#ifndef ITD_BS_SWEEP
+#define ITD_BS_SWEEP 1   // knot values and slopes in one sweep over the slots (0: round 4's two loops, for A/B builds)
+#endif
 namespace itd {
 
 constexpr int kWave = 64;              // one wavefront per tile, one tile per workgroup
@@ -659,6 +662,23 @@ __device__ __forceinline__ unsigned long long dbits(double v) { return __builtin
 __device__ __forceinline__ double bits_d(unsigned lo, unsigned hi)
 {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// RN(a / b) for integers 0 <= a, 0 < b < 2^31 — the knot spacings' ratio of ITD.py:107 (int64 differences, true-divided in float64).
+// This IS the division the compiler emits (reciprocal estimate, two Newton steps, quotient, residual, correction: correctly rounded)
+// without its range scaling and special-case fix-up (v_div_scale x 2, v_div_fmas' scale, v_div_fixup), which do nothing for operands
+// that are exact small integers: four vector instructions less per ratio.  Held equal to the full division, bit for bit, over every
+// pair with b <= 2048 and random larger ones by tests/test_gpu_parity.py (itd_debug_int_ratio_check).
+__device__ __forceinline__ double int_ratio(int32_t a, int32_t b)
+{
+    const double x = (double)a, y = (double)b;
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    const double res = __builtin_fma(-y, q, x);
+    return __builtin_fma(res, r, q);
 }
 // DPP wavefront shifts (gfx9): CTRL 0x138 wave_shr:1 (lane l <- l-1), 0x130 wave_shl:1 (l <- l+1),
 // 0x13C wave_ror:1 (shr with lane 0 <- lane 63), 0x134 wave_rol:1 (shl with lane 63 <- lane 0).
@@ -1699,30 +1719,63 @@ __global__ __launch_bounds__(kWave) void k_extract(const Tin *__restrict__ xin, 
         wave_sync();
         PROF_MARK(3)   // knots by rank into LDS
         if (g1 < G2 && lane < 2) { s_hX[5 + lane] = s_X[m + lane]; s_hI[5 + lane] = s_gi[m + lane]; }   // ranks rb+m-2, rb+m-1 (before the slopes reuse gi's bytes)
-        // ---- knot values, ITD.py:100-110 -------------------------------------------------------------------------
+#if ITD_BS_SWEEP
+        // ---- knot values, ITD.py:100-110, and per-segment slopes (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116, in ONE sweep over
+        //      the slots, highest first: a slot's slope needs the next slot's B — the next lane's (a DPP shift), for lane 63 the first
+        //      lane's of the round before (carried on the scalar unit); positions, values and B stay in registers in between.  (The
+        //      slopes overwrite the positions' bytes: a round's s_S[L] covers s_gi[2L], s_gi[2L+1], beyond what the lower rounds read.)
+        {
+            double b_carry = 0.0;
+            for (int base = 1 + ((m + 2) & ~63); base >= 1; base -= kWave) {
+                const int L = base + lane;
+                const bool act = L <= m + 3;
+                const int Lr = act ? L : 1;                                      // (lanes beyond the pass read slot 1 and write nothing)
+                const int32_t k0 = s_gi[Lr - 1], k1 = s_gi[Lr], k2 = s_gi[Lr + 1];
+                const double x0 = s_X[Lr - 1], x1 = s_X[Lr], x2 = s_X[Lr + 1];
+                const double frac = int_ratio(k1 - k0, k2 - k0);
+                const double tt = frac * (x2 - x0);
+                const double u = x0 + tt;
+                double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
+                bool endn = false;
+                if (has_ends) {   // wave-uniform: only next to the signal's ends is a slot of the pass one of the two end knots
+                    const bool end0 = (L == 1) && (rb == 0) && (nb == 0);         // e[0]   = sample 0
+                    endn = (L >= m + 2) && (L - (m + 2) >= nfp);                  // e[m+1] = sample n-1 (starts no segment)
+                    Bv = end0 ? m0 : (endn ? mn : Bv);
+                }
+                const double Bn = wave_dpp<0x130>(b_carry, Bv);                  // lane l <- lane l + 1; lane 63 keeps the carry
+                const double sl = (Bn - Bv) / (x2 - x1);
+                wave_sync();                                                     // (the round's position reads are done before its slopes land on them)
+                if (act) s_B[L] = Bv;
+                if (L <= m + 2 && !endn) s_S[L] = sl;
+                b_carry = bits_d((unsigned)__builtin_amdgcn_readlane((int)(unsigned)dbits(Bv), 0), (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(dbits(Bv) >> 32), 0));
+            }
+        }
+        wave_sync();
+#else
+        // (A/B builds, -DITD_BS_SWEEP=0: round 4's two loops — knot values, a round trip through LDS, slopes)
         for (int L = 1 + lane; L <= m + 3; L += kWave) {
             const int32_t k0 = s_gi[L - 1], k1 = s_gi[L], k2 = s_gi[L + 1];
             const double x0 = s_X[L - 1], x1 = s_X[L], x2 = s_X[L + 1];
             const double frac = (double)(k1 - k0) / (double)(k2 - k0);
             const double tt = frac * (x2 - x0);
             const double u = x0 + tt;
-            double Bv = 0.5 * u + 0.5 * x1;                                  // ITD.py:107-110
-            if (has_ends) {   // wave-uniform: only next to the signal's ends is a slot of the pass one of the two end knots
-                const bool end0 = (L == 1) && (rb == 0) && (nb == 0);         // e[0]   = sample 0
-                const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);       // e[m+1] = sample n-1
+            double Bv = 0.5 * u + 0.5 * x1;
+            if (has_ends) {
+                const bool end0 = (L == 1) && (rb == 0) && (nb == 0);
+                const bool endn = (L >= m + 2) && (L - (m + 2) >= nfp);
                 Bv = end0 ? m0 : (endn ? mn : Bv);
             }
             s_B[L] = Bv;
         }
         wave_sync();
-        PROF_MARK(4)   // knot values
-        // ---- per-segment slope (B_{k+1}-B_k)/(x[e_{k+1}]-x[e_k]), ITD.py:115-116 --------------------------------
         for (int L = 1 + lane; L <= m + 2; L += kWave) {
             const double sl = (s_B[L + 1] - s_B[L]) / (s_X[L + 1] - s_X[L]);
-            const bool endn = has_ends && (L >= m + 2) && (L - (m + 2) >= nfp);   // sample n-1 starts no segment
+            const bool endn = has_ends && (L >= m + 2) && (L - (m + 2) >= nfp);
             if (!endn) s_S[L] = sl;
         }
         wave_sync();
+#endif
+        PROF_MARK(4)   // knot values
         PROF_MARK(5)   // slopes
       }
         // ---- baseline at the two samples next to the tile (lane 0) -------------------------------------------------

@@ -80,6 +80,12 @@ constexpr int kKcLds = ((KcLay<true>::end > KcLay<false>::end ? KcLay<true>::end
 static_assert(KcLay<true>::o_kB - KcLay<true>::o_kX >= kKcTiles * 8 * 8, "the sticky words fit the hand-over layout's k_B");
 constexpr int kKcRecGran = 32;                   // 8-byte granules per record slot (20 in use): 256 bytes
 constexpr uint32_t kKcPoison = 0xffffffffu;      // a record of a workgroup that has given up
+#ifndef ITD_KC_GATHER_ORDER
+#define ITD_KC_GATHER_ORDER 1     // A/B builds: 0 = the hand-over's gathers in candidate order
+#endif
+#ifndef ITD_KF_CHECK_STEP
+#define ITD_KF_CHECK_STEP 2       // A/B builds: 1 = one table entry per lane and round in the check wavefronts
+#endif
 #ifndef ITD_KC_TIMEOUT
 #define ITD_KC_TIMEOUT 4000000ll                 // ticks of the 100 MHz wall clock a halo search waits at most (40 ms)
 #endif
@@ -413,12 +419,22 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     double va[kKcEntH], vb[kKcEntH], vd[kKcEntH];
 #pragma unroll
     for (int i = 0; i < kKcEntH; ++i) va[i] = vb[i] = vd[i] = 0.0;
-    if (!s_i[1]) {
+    if (!s_i[1] && c > 0) {
+        // (every load unconditional — a thread without a candidate in a round repeats the list's last one — so that the compiler counts
+        //  them: the knots' values by rank, which the first level's knot values need, wait for the middle samples only; the outer two
+        //  arrive while the halo exchange runs.  At level 2 these gathers touch about half of the input's lines.)
+        int32_t pp[kKcEntH];
 #pragma unroll
-        for (int i = 0; i < kKcEntH; ++i) {
-            const int j = i * NT + tid;
-            if (j < c) { const int32_t p = LH.c_pos()[j]; va[i] = xs[p - 1]; vb[i] = xs[p]; vd[i] = xs[p + 1]; }
-        }
+        for (int i = 0; i < kKcEntH; ++i) pp[i] = LH.c_pos()[min(i * NT + tid, c - 1)];
+#if ITD_KC_GATHER_ORDER
+#pragma unroll
+        for (int i = 0; i < kKcEntH; ++i) vb[i] = xs[pp[i]];
+#pragma unroll
+        for (int i = 0; i < kKcEntH; ++i) { va[i] = xs[pp[i] - 1]; vd[i] = xs[pp[i] + 1]; }
+#else       // (A/B builds: the three samples of a candidate together, as up to round 4)
+#pragma unroll
+        for (int i = 0; i < kKcEntH; ++i) { va[i] = xs[pp[i] - 1]; vb[i] = xs[pp[i]]; vd[i] = xs[pp[i] + 1]; }
+#endif
 #pragma unroll
         for (int i = 0; i < kKcEntH; ++i) {
             const int j = i * NT + tid;
@@ -619,7 +635,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         auto knot_value = [&](int d) {
             if (d == d_vs) return m0;
             if (d == d_ve) return mn;
-            const double frac = (double)(k_pos[d] - k_pos[d - 1]) / (double)(k_pos[d + 1] - k_pos[d - 1]);
+            const double frac = int_ratio(k_pos[d] - k_pos[d - 1], k_pos[d + 1] - k_pos[d - 1]);   // (the check wavefronts divide in full)
             const double tt = frac * (k_X[d + 1] - k_X[d - 1]);
             const double u = k_X[d - 1] + tt;
             return 0.5 * u + 0.5 * k_X[d];                                                // ITD.py:107-110
@@ -906,18 +922,22 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         if (start < 0 || cnt < 0 || start + cnt + 2 > pool_n || (t1 < n_tiles && (f_next < 0 || f_next + 2 > pool_n))) vb = 1;
         else if (ITD_KF_VERIFY & 4) {
             const KfEntry *e = pool + start;
-            for (int r = lane; r <= cnt; r += kWave) {
-                const KfEntry e0 = e[r], e1 = e[r + 1];
+            auto check = [&](const KfEntry &em, const KfEntry &e0, const KfEntry &e1, bool with_b) {
                 const double Sv = (e1.B - e0.B) / (e1.X - e0.X);                         // ITD.py:115-116
-                vb |= ne_d(Sv, e0.S);
-                if (r >= 1) {
-                    const KfEntry em = e[r - 1];
-                    const double frac = (double)(e0.pos - em.pos) / (double)(e1.pos - em.pos);
-                    const double tt = frac * (e1.X - em.X);
-                    const double u = em.X + tt;
-                    const double Bv = 0.5 * u + 0.5 * e0.X;                              // ITD.py:107-110
-                    vb |= ne_d(Bv, e0.B);
-                }
+                int bad_ = ne_d(Sv, e0.S);
+                const double frac = (double)(e0.pos - em.pos) / (double)(e1.pos - em.pos);
+                const double tt = frac * (e1.X - em.X);
+                const double u = em.X + tt;
+                const double Bv = 0.5 * u + 0.5 * e0.X;                                  // ITD.py:107-110
+                if (with_b) bad_ |= ne_d(Bv, e0.B);
+                return bad_;
+            };
+            for (int r = lane; r <= cnt; r += ITD_KF_CHECK_STEP * kWave) {       // two entries per lane and round: their loads fly together
+                const int r2 = r + kWave, q2 = min(r2, cnt);     // (beyond the slab's entries: the last one again, not counted)
+                const KfEntry a0 = e[r], a1 = e[r + 1], am = e[max(r - 1, 0)];
+                const KfEntry b0 = e[q2], b1 = e[q2 + 1], bm = e[q2 - 1 < 0 ? 0 : q2 - 1];
+                vb |= check(am, a0, a1, r >= 1);
+                if (ITD_KF_CHECK_STEP == 2 && r2 <= cnt) vb |= check(bm, b0, b1, true);
             }
             if (t1 < n_tiles && lane < 2) {
                 const KfEntry a = pool[f_next + lane], o = e[cnt + lane];

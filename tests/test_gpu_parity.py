@@ -373,3 +373,15 @@ def test_baselines_stay_on_the_device_until_asked_for(P, oracle):
     a.baselines = None
     with pytest.raises(ValueError):
         a.get_baselines()
+
+
+def test_integer_ratio_equals_the_full_division_bit_for_bit():
+    """The knot spacings' ratio of ITD.py:107 — two int64 differences true-divided in float64 — is formed on the GPU by the division's
+    own instruction sequence without its range scaling and special-case fix-up (itd_kernels.hpp: int_ratio).  Exhaustively equal to
+    the compiler's full division for every pair up to 2048 and for 2^30 random pairs below 2^31."""
+    import ctypes
+    from pyitd_amd import _lib
+    L = _lib.load()
+    bad = ctypes.c_int64(-1)
+    assert L.itd_debug_int_ratio_check(0, 2048, ctypes.byref(bad)) == 0
+    assert bad.value == 0

@@ -1,6 +1,6 @@
 """How often do the fused sparse levels (itd_set_fuse_mode) deliver, per signal family?  ITD_FUSE_ONLY on random draws: a case
 either equals the C oracle bit for bit ("delivered") or the engine reports that the fused form cannot deliver it ("refused",
-with the failure bits: 1 verification, 2 capacity, 4 non-finite, 8 ties) — a third outcome would be a bug and is counted as
+with the failure bits: 1 verification, 2 capacity, 4 non-finite, 8 ties, 16 a halo wait given up / a neighbour that gave up) — a third outcome would be a bug and is counted as
 WRONG.  usage (GPU box): python tools/kf_rates.py [cases per family] [seed]"""
 import os, sys, re
 import numpy as np
@@ -37,7 +37,7 @@ def one(x, m):
             except ITDError as ex:
                 mm = re.search(r"fail bits (0x[0-9a-f]+)", str(ex))
                 code = mm.group(1) if mm else "?"
-                if code == "0x2" and tiles > 16:
+                if code != "?" and (int(code, 16) & 2) and tiles > 16:      # capacity (+ 16: neighbours that met the workgroup that gave up)
                     continue
                 return "refused " + code
             nr = int(s["n_rows"][0])
