@@ -315,7 +315,7 @@ def run_rank(args):
         else:
             x_host = sines_noise(n, seed=0)
             x = torch.from_numpy(x_host).to(dev)[None]
-        rows = torch.empty((sb.n_local, R, n), dtype=torch.float64, device=dev)
+        rows = torch.empty((sb.n_local, R, n + int(os.environ.get("BENCH_ROW_PAD", "0"))), dtype=torch.float64, device=dev)   # (experiment builds: -DITD_ROW_PAD)
         stream = torch.cuda.Stream(device=dev)
         sp = stream.cuda_stream
         x_ptr, rows_ptr = x.data_ptr(), rows.data_ptr()

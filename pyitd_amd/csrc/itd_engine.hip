@@ -205,6 +205,7 @@ struct itd_engine {
     int32_t resident_off_left = 0;  // automatic mode: decompositions still to run level by level after a resident call met a non-finite value
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
     bool resident_attr[12] = {};
+    bool nak_small_attr = false;    // hipFuncSetAttribute done for k_nak_small<true>
     int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
     // the fused sparse levels (itd_knotfirst.hpp): workspace (allocated at first use), mode, first fused level
     void *d_kf = nullptr; size_t kf_bytes = 0;
@@ -473,7 +474,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     const int n_tiles = (int)tiles_of(n);
     const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
-    const int64_t rows_stride = R * n;
+    const int64_t rows_stride = R * (n + ITD_ROW_PAD);
     const dim3 blk(kWave);
 
     // instrument every timing_stride-th decomposition only: a launch that carries events needs a completion signal of its own
@@ -580,7 +581,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 base_stride = 3 * e->pp_pitch;
                 if (j >= 1) { base_in = pp_c + (int64_t)((j - 1) % 3) * e->pp_pitch; base_in_stride = 3 * e->pp_pitch; }
             }
-            double *rot_out = rows_c + (int64_t)j * n;
+            double *rot_out = rows_c + (int64_t)j * (n + ITD_ROW_PAD);
             const bool final_level = !kf && (j == M + 1);
             const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
             // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
@@ -2204,6 +2205,37 @@ int nak_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_
     return ITD_OK;
 }
 
+// ONE signal of at most kNakSmallMax samples through the parallel-in-knots form: one launch, one workgroup (itd_nak.hpp: k_nak_small),
+// one 16-byte copy back — knots, NaN flag, validity, and (want_bcount) the knot count of the produced baseline.  Synchronous.
+int nak_small(itd_engine *e, const double *x, int64_t n, int min_extrema, double *base, double *rot, hipStream_t st,
+              int32_t *knots_host, int32_t *baseline_knots_host)
+{
+    const int64_t L = n + 2;
+    const size_t idx_b = (((size_t)L * sizeof(int32_t)) + 255) & ~(size_t)255, out_b = 256;
+    int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + 6 * (size_t)L * sizeof(double));
+    if (rc) return rc;
+    int32_t *out = (int32_t *)e->d_cub;
+    int32_t *idx = (int32_t *)((char *)e->d_cub + out_b);
+    double *arr = (double *)((char *)e->d_cub + out_b + idx_b);
+    const size_t lds = 4 * (size_t)L * sizeof(double);
+    if (lds <= kNakSmallLdsMax) {                          // the sweeps' arrays in LDS (more than 64 KB of dynamic LDS has to be asked for)
+        if (!e->nak_small_attr) {
+            HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nak_small<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNakSmallLdsMax));
+            e->nak_small_attr = true;
+        }
+        k_nak_small<true><<<1, kNakSmallThreads, lds, st>>>(x, (int)n, min_extrema, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
+                                                             base, rot, baseline_knots_host ? 1 : 0, out);
+    } else
+        k_nak_small<false><<<1, kNakSmallThreads, 0, st>>>(x, (int)n, min_extrema, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
+                                                            base, rot, baseline_knots_host ? 1 : 0, out);
+    int32_t h[4] = {0, 0, 0, 0};
+    HIP_TRY(e, hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    if (knots_host) knots_host[0] = h[0];
+    if (baseline_knots_host) baseline_knots_host[0] = h[3];
+    return h[1] ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
 // after spline_enqueue / nak_enqueue: synchronise, fetch the per-signal knot counts, report NaN input
 int spline_finish(itd_engine *e, int batch, const int32_t *totals, int32_t *knots_host, hipStream_t st)
 {
@@ -2231,6 +2263,7 @@ int itd_baseline_extract_spline_f64(itd_engine *e, const double *x_dev, int64_t 
     hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
     // few long signals: parallel in the knots; many short rows: one thread per signal, FITPACK's own sweep (bit-level)
     const bool par = e->spline_solver == ITD_SPLINE_PARALLEL || (e->spline_solver == ITD_SPLINE_AUTO && batch < 256 && n >= 1024);
+    if (par && batch == 1 && n <= kNakSmallMax) return nak_small(e, x_dev, n, min_extrema, baseline_dev, rot_dev, st, knots_host, nullptr);
     const int32_t *totals = nullptr;
     SplineWs w;
     int rc;
@@ -2421,6 +2454,7 @@ int itd_baseline_extract_spline2_f64(itd_engine *e, const double *x_dev, int64_t
     DevGuard g(e->device);
     hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
     const bool par = e->spline_solver == ITD_SPLINE_PARALLEL || (e->spline_solver == ITD_SPLINE_AUTO && batch < 256 && n >= 1024);
+    if (par && batch == 1 && n <= kNakSmallMax) return nak_small(e, x_dev, n, min_extrema, baseline_dev, rot_dev, st, knots_host, baseline_knots_host);
     const int32_t *totals = nullptr;
     SplineWs w;
     int rc;

@@ -80,6 +80,9 @@ constexpr int kKcLds = ((KcLay<true>::end > KcLay<false>::end ? KcLay<true>::end
 static_assert(KcLay<true>::o_kB - KcLay<true>::o_kX >= kKcTiles * 8 * 8, "the sticky words fit the hand-over layout's k_B");
 constexpr int kKcRecGran = 32;                   // 8-byte granules per record slot (20 in use): 256 bytes
 constexpr uint32_t kKcPoison = 0xffffffffu;      // a record of a workgroup that has given up
+#ifndef ITD_ROW_PAD
+#define ITD_ROW_PAD 0             // experiment builds only (profiles/r05/experiments): the result's rows ITD_ROW_PAD elements further apart than n
+#endif
 #ifndef ITD_KC_GATHER_ORDER
 #define ITD_KC_GATHER_ORDER 1     // A/B builds: 0 = the hand-over's gathers in candidate order
 #endif
@@ -1027,7 +1030,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             s_X[r] = en.X; s_B[r] = en.B; s_S[r] = en.S; s_P[r] = en.pos;
         }
         wave_sync();
-        double *row = rows_s + (int64_t)lev * n;
+        double *row = rows_s + (int64_t)lev * (n + ITD_ROW_PAD);
         const __amdgpu_buffer_rsrc_t r_row = tile_rsrc32(row, rem, 8);
         const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc32(bases_s ? bases_s + (int64_t)lev * n : row, (bases_s && !last) ? rem : 0, 8);
         int gbase = 0;

@@ -148,4 +148,149 @@ __global__ __launch_bounds__(64) void k_nak_backward(CubicArgs A, const double *
     }
 }
 
+// ---- ONE signal of up to kNakSmallMax samples: the whole operator in ONE launch, one workgroup ---------------------------------
+// MEITD / XITD (MEITD.py:344-549) call the operator on one short signal after the other, every call waiting for the host's
+// decision on the previous one: as the batch form's nine launches (knots, compaction, jobs, values, rows, forward, backward,
+// evaluation, + the produced baseline's knot count) an extraction of a 3000-sample signal took ~130 us, all of it launch boundaries.
+// Here the same phases — the same expressions in the same order, hence the same bits as the launches above — run behind one another
+// in one workgroup with a barrier in between (the arrays are global memory, a few ten KB: L2): knots + ordered compaction (a thread
+// owns a run of consecutive samples, one block scan), knot values, rows, the forward and backward runs, evaluation, and the
+// knot count of the baseline it has just written.
+// LDS = true: the rows of the system and the forward sweep's two arrays (4 x (n + 2) doubles) live in dynamic LDS — the two serial
+// recurrences (160 dependent steps per thread) then wait for LDS, not for L2, in every step: 104 -> ~45 us per extraction of a
+// 3000-sample signal; signals whose worst case does not fit (n > ~4900) keep them in global memory.
+constexpr int kNakSmallMax = 8192, kNakSmallThreads = 1024, kNakSmallPer = kNakSmallMax / kNakSmallThreads;
+constexpr size_t kNakSmallLdsMax = 156 * 1024;
+template <bool LDS>
+__global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__restrict__ x, int n, int min_extrema, int32_t *__restrict__ e,
+                                                               double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
+                                                               double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
+                                                               double *__restrict__ base, double *__restrict__ rot, int want_bcount,
+                                                               int32_t *__restrict__ out /* knots, NaN flag, valid, knots of the produced baseline */)
+{
+    extern __shared__ double s_dyn[];
+    double *const subv = LDS ? s_dyn : subg, *const rhsv = LDS ? s_dyn + (n + 2) : rhsg;
+    double *const cpv = LDS ? s_dyn + 2 * (n + 2) : cpg, *const dpv = LDS ? s_dyn + 3 * (n + 2) : dpg;
+    __shared__ int s_wave[kNakSmallThreads / 64], s_flag[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + kNakSmallThreads - 1) / kNakSmallThreads;          // consecutive samples a thread owns (<= kNakSmallPer)
+    const int lo = tid * per, hi = min(n, lo + per);
+    if (tid < 4) s_flag[tid] = 0;
+    __syncthreads();
+    // the knots of a row held in global memory: ITD.py:59 on x and on -x (raw differences), never the first or the last sample
+    auto knot_mask = [&](const double *__restrict__ v, bool &has_nan) {
+        unsigned mask = 0;
+        for (int i = lo; i < hi; ++i) {
+            const double x0 = v[i];
+            has_nan = has_nan || x0 != x0;
+            if (i >= 1 && i <= n - 2) {
+                const double vil = v[i + 1] - x0, vix = x0 - v[i - 1];
+                if (((vil > 0.0) && (vix <= 0.0)) || ((vil < 0.0) && (vix >= 0.0))) mask |= 1u << (i - lo);
+            }
+        }
+        return mask;
+    };
+    // exclusive prefix of c over the workgroup's threads and the total
+    auto block_scan = [&](int c, int &total) {
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int wb = 0, tot = 0;
+        for (int k = 0; k < kNakSmallThreads / 64; ++k) { const int v = s_wave[k]; if (k < wave) wb += v; tot += v; }
+        total = tot;
+        return wb + inc - c;
+    };
+    bool has_nan = false;
+    const unsigned mask = knot_mask(x, has_nan);
+    if (has_nan) s_flag[0] = 1;
+    int knots;
+    const int off = block_scan(__popc(mask), knots);
+    {
+        int k = 1 + off;
+        for (unsigned mm = mask; mm; mm &= mm - 1) e[k++] = lo + __builtin_ctz(mm);
+        if (tid == 0) { e[0] = 0; e[knots + 1] = n - 1; }
+    }
+    __syncthreads();                                      // (also: s_flag[0] is complete)
+    const int m = knots + 2;
+    const bool valid = knots >= min_extrema && knots >= 2;
+    if (tid == 0) { out[0] = knots; out[1] = s_flag[0]; out[2] = valid ? 1 : 0; out[3] = 0; }
+    if (!valid) {                                         // fewer knots than the operator needs: the signal is its own baseline
+        for (int i = lo; i < hi; ++i) { base[i] = x[i]; if (rot) rot[i] = 0.0; }
+        if (want_bcount && tid == 0) out[3] = knots;      // (the baseline IS the signal)
+        return;
+    }
+    for (int k = tid; k < m; k += kNakSmallThreads) K[k] = spline_knot_value(x, n, e, m, k);
+    __syncthreads();
+    for (int j = 1 + tid; j <= m - 2; j += kNakSmallThreads) { const NakRow r = nak_row(e, K, m, j); subv[j] = r.sub; rhsv[j] = r.rhs; }
+    __syncthreads();
+    for (int s = 1 + tid * kNakRun; s <= m - 2; s += kNakSmallThreads * kNakRun) {          // k_nak_forward's run
+        const int last = min(s + kNakRun - 1, m - 2), j0 = max(1, s - kNakWarm);
+        double cp = 0.0, dp = 0.0;
+        double sub_n = subv[j0], rhs_n = rhsv[j0];        // (a step's row is fetched while the step before it divides)
+        for (int j = j0; j <= last; ++j) {
+            NakRow r;
+            r.sub = sub_n; r.rhs = rhs_n; r.sup = 1 - r.sub; r.diag = 2;
+            const int jn = min(j + 1, last);
+            sub_n = subv[jn]; rhs_n = rhsv[jn];
+            if (j == 1 || j == m - 2) r = nak_row(e, K, m, j);
+            const double den = r.diag - r.sub * cp;
+            cp = r.sup / den;
+            dp = (r.rhs - r.sub * dp) / den;
+            if (j >= s) { cpv[j] = cp; dpv[j] = dp; }
+        }
+    }
+    __syncthreads();
+    for (int s = 1 + tid * kNakRun; s <= m - 2; s += kNakSmallThreads * kNakRun) {          // k_nak_backward's run
+        const int top = min(s + kNakRun - 1, m - 2), jt = min(m - 2, top + kNakWarm);
+        double y = 0.0, y_next = 0.0;
+        double dp_n = dpv[jt], cp_n = cpv[jt];
+        for (int j = jt; j >= s; --j) {
+            const double dpj = dp_n, cpj = cp_n;
+            const int jn = max(j - 1, s);
+            dp_n = dpv[jn]; cp_n = cpv[jn];
+            y_next = y;
+            y = dpj - cpj * y;
+            if (j <= top) M[j] = y;
+        }
+        if (s == 1) {
+            const double q = (double)(e[1] - e[0]) / (double)(e[2] - e[1]);
+            M[0] = (1 + q) * y - q * y_next;
+        }
+        if (top == m - 2) {
+            const double q = (double)(e[m - 1] - e[m - 2]) / (double)(e[m - 2] - e[m - 3]);
+            const double mt = dpv[m - 2];
+            const double mb = dpv[m - 3] - cpv[m - 3] * mt;
+            M[m - 1] = (1 + q) * mt - q * mb;
+        }
+    }
+    __syncthreads();
+    {   // evaluation (k_cubic_eval<NAK>): the segment of a sample = the knots at or before it
+        int j = off;                                      // knots in front of the thread's run
+        for (int i = lo; i < hi; ++i) {
+            j += (mask >> (i - lo)) & 1u;
+            const int32_t ej = e[j], en = e[j + 1];
+            const double Kj = K[j], Kn = K[j + 1], bj = M[j], bn = M[j + 1];
+            const double hj = (double)(en - ej);
+            const double t = (double)(i - ej) * sweep_rcp(hj);
+            const double omt = 1 - t;
+            const double h26 = hj * hj * (1.0 / 6);
+            const double c1 = h26 * ((omt * omt * omt - 1) + t) * bj;
+            const double c2 = h26 * (t * t * t - t) * bn;
+            const double v = ((omt * Kj + t * Kn) + c1) + c2;
+            base[i] = v;
+            if (rot) rot[i] = x[i] - v;
+        }
+    }
+    if (want_bcount) {                                    // MEITD.py:362-363, :497-505: the extrema count of the produced baseline
+        __syncthreads();
+        bool nn = false;
+        int total;
+        (void)block_scan(__popc(knot_mask(base, nn)), total);
+        if (tid == 0) out[3] = total;
+    }
+}
+
 }  // namespace itd

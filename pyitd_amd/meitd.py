@@ -19,6 +19,7 @@ One piece of upstream's work is NOT repeated because nothing can observe it: whe
 fails, its loop (:359-366) keeps extracting down to fewer than 6 extrema and then returns its INPUT (:368) — on the golden signals
 that is 209-249 of the ~290 extractions of a MEITD call.
 """
+import threading
 from math import factorial
 
 import numpy
@@ -62,9 +63,9 @@ class _Work:
     """The device arrays of one MEITD run — rows of n float64 in one allocation: four working rows that change roles by
     renaming (no copies), the two lists of kept rotations."""
 
-    def __init__(self, n, device):
-        self.n, self.device = n, device
-        self.eng = _eng(n, device)
+    def __init__(self, n, device, solver="auto"):
+        self.n, self.device, self.solver = n, device, solver
+        self.eng = _eng(n, device, solver)
         self.buf = DeviceBuffer((6 + 2 * _ROWS_KEPT) * n * 8, device)
         self.free_rows = [self.row(i) for i in range(6)]
         self.high0, self.low0 = self.row(6), self.row(6 + _ROWS_KEPT)
@@ -125,17 +126,33 @@ class _Work:
 
 
 _work = {}
+_CACHE_MAX_BYTES = 64 << 20        # device rows kept between calls per device (50 rows x n x 8 B): larger ones are freed when the call returns
+_lock = threading.RLock()          # the module-level API keeps one set of device rows per device: calls are serialised
 
 
-def _work_for(n, device):
+def _work_for(n, device, solver="auto"):
     key = int(device)
     w = _work.get(key)
-    if w is None or w.n != n or w.eng is not _eng(n, device):
+    if w is None or w.n != n or w.solver != solver or w.eng is not _eng(n, device, solver):
         if w is not None:
             w.buf.free()
-        w = _work[key] = _Work(n, device)
+        w = _work[key] = _Work(n, device, solver)
+    w.eng.set_spline_solver({"auto": 0, "serial": 1, "parallel": 2}[solver])
     w.reset()
     return w
+
+
+def release(device=None):
+    """Free the device rows this module keeps between calls (all devices, or one)."""
+    with _lock:
+        for key in [k for k in _work if device is None or k == int(device)]:
+            _work.pop(key).buf.free()
+
+
+def _done(w):
+    """after a call: rows of a long signal do not stay allocated (a 2^24-sample call holds 6.7 GB)"""
+    if isinstance(w, _Work) and (6 + 2 * _ROWS_KEPT) * w.n * 8 > _CACHE_MAX_BYTES:
+        release(w.device)
 
 
 def _proper(wpe, WPEMAX):
@@ -169,28 +186,32 @@ def _determine(wk, src, rot, base, WPEMAX, probed=None):
     return 1 if _proper(wpe, WPEMAX) else 0
 
 
-def retrieve_proper_rotation(x, WPEMAX, device=0):
+def retrieve_proper_rotation(x, WPEMAX, device=0, solver="auto"):
     """MEITD.py:344-368 — the first extraction's rotation if the entropy of the INPUT passes the test, else the input."""
     x = numpy.ascontiguousarray(numpy.asarray(x).astype(dtype=numpy.float64))
-    wk = _work_for(len(x), device)
-    rot = wk.take()
-    wk.upload(x, rot)
-    rot, proper = _retrieve(wk, rot, WPEMAX)
-    out = wk.download(rot)[0] if proper else x
-    wk.give(rot)
+    with _lock:
+        wk = _work_for(len(x), device, solver)
+        rot = wk.take()
+        wk.upload(x, rot)
+        rot, proper = _retrieve(wk, rot, WPEMAX)
+        out = wk.download(rot)[0] if proper else x
+        wk.give(rot)
+        _done(wk)
     return out, proper
 
 
-def determine_if_first_is_proper_rotation(x, WPEMAX, device=0):
+def determine_if_first_is_proper_rotation(x, WPEMAX, device=0, solver="auto"):
     """MEITD.py:371-392 — one extraction; proper if the input's entropy lies in [0.2, WPEMAX)."""
     x = numpy.ascontiguousarray(numpy.asarray(x).astype(dtype=numpy.float64))
-    wk = _work_for(len(x), device)
-    src, rot, base = wk.take(), wk.take(), wk.take()
-    wk.upload(x, src)
-    proper = _determine(wk, src, rot, base, WPEMAX)
-    r, b = wk.download(rot)[0], wk.download(base)[0]
-    for p in (src, rot, base):
-        wk.give(p)
+    with _lock:
+        wk = _work_for(len(x), device, solver)
+        src, rot, base = wk.take(), wk.take(), wk.take()
+        wk.upload(x, src)
+        proper = _determine(wk, src, rot, base, WPEMAX)
+        r, b = wk.download(rot)[0], wk.download(base)[0]
+        for p in (src, rot, base):
+            wk.give(p)
+        _done(wk)
     return r, b, proper
 
 
@@ -263,38 +284,49 @@ def _meitd(wk, data, WPEMAX):
     return n_high, n_low, x
 
 
-def MEITD(data, max_iteration=40, WPEMAX=0.6, device=0):
+def MEITD(data, max_iteration=40, WPEMAX=0.6, device=0, solver="auto"):
     """MEITD.py:395-534 — alternate between peeling a proper rotation off the signal (the "high" list) and off its baseline
-    (the "low" list); dig further down the baselines when neither succeeds.  Returns (high[h, N], low[l, N], residual[N])."""
+    (the "low" list); dig further down the baselines when neither succeeds.  Returns (high[h, N], low[l, N], residual[N]).
+
+    solver: how the spline baselines are solved (pyitd_amd.spline._eng).  "auto" (default) takes the parallel-in-knots form for signals
+    of >= 1024 samples: baselines and entropies then equal scipy's / the reference's to rounding (~1e-14 of the signal's scale), not bit
+    for bit — and the driver's decisions are hard thresholds on them (extrema counts of nearly flat baselines against 5, entropies
+    against 0.2 / WPEMAX): a signal that sits on a threshold may select different components than MEITD.py.  "serial" (FITPACK's own
+    sweep, bit-level against scipy) removes that difference at one GPU thread per extraction.  The module keeps one set of device rows
+    per device between calls (freed above 64 MB; `release()`); calls are serialised by a lock."""
     data = numpy.ascontiguousarray(numpy.asarray(data).astype(dtype=numpy.float64))
-    wk = _work_for(len(data), device)
-    r = _meitd(wk, data, WPEMAX)
-    if r is None:
-        zero = numpy.zeros(len(data))
-        return zero, zero, data
-    n_high, n_low, x = r
-    high = wk.download(wk.high0, n_high) if n_high else numpy.zeros((0, len(data)))
-    low = wk.download(wk.low0, n_low) if n_low else numpy.zeros((0, len(data)))
-    residual = wk.download(x)[0]
-    wk.give(x)
+    with _lock:
+        wk = _work_for(len(data), device, solver)
+        r = _meitd(wk, data, WPEMAX)
+        if r is None:
+            zero = numpy.zeros(len(data))
+            return zero, zero, data
+        n_high, n_low, x = r
+        high = wk.download(wk.high0, n_high) if n_high else numpy.zeros((0, len(data)))
+        low = wk.download(wk.low0, n_low) if n_low else numpy.zeros((0, len(data)))
+        residual = wk.download(x)[0]
+        wk.give(x)
+        _done(wk)
     return high, low, residual
 
 
-def XITD(data, device=0):
-    """MEITD.py:536-549 — MEITD's components and residual, ordered by their entropy (taken on the device rows)."""
+def XITD(data, device=0, solver="auto"):
+    """MEITD.py:536-549 — MEITD's components and residual, ordered by their entropy (taken on the device rows).  solver: see MEITD."""
     data = numpy.ascontiguousarray(numpy.asarray(data).astype(dtype=numpy.float64))
-    wk = _work_for(len(data), device)
-    r = _meitd(wk, data, 0.6)                        # upstream passes its WPEMAX estimate where max_iteration goes (:541)
-    if r is None:
-        zero = numpy.zeros(len(data))
-        rotations = numpy.vstack((numpy.vstack((zero, zero)), data))
-        ent = [weighted_permutation_entropy(rotations[i, :], order=3, normalize=True, device=device) for i in range(3)]
-        return rotations[numpy.argsort(ent), :]
-    n_high, n_low, x = r
-    rows = [wk.kept(wk.high0, k) for k in range(n_high)] + [wk.kept(wk.low0, k) for k in range(n_low)] + [x]
-    ent = [wk.entropy(p) for p in rows]
-    out = numpy.empty((len(rows), wk.n))
-    for k, i in enumerate(numpy.argsort(ent)):
-        out[k] = wk.download(rows[i])[0]
-    wk.give(x)
+    with _lock:
+        wk = _work_for(len(data), device, solver)
+        r = _meitd(wk, data, 0.6)                        # upstream passes its WPEMAX estimate where max_iteration goes (:541)
+        if r is None:
+            zero = numpy.zeros(len(data))
+            rotations = numpy.vstack((numpy.vstack((zero, zero)), data))
+            ent = [weighted_permutation_entropy(rotations[i, :], order=3, normalize=True, device=device) for i in range(3)]
+            return rotations[numpy.argsort(ent), :]
+        n_high, n_low, x = r
+        rows = [wk.kept(wk.high0, k) for k in range(n_high)] + [wk.kept(wk.low0, k) for k in range(n_low)] + [x]
+        ent = [wk.entropy(p) for p in rows]
+        out = numpy.empty((len(rows), wk.n))
+        for k, i in enumerate(numpy.argsort(ent)):
+            out[k] = wk.download(rows[i])[0]
+        wk.give(x)
+        _done(wk)
     return out

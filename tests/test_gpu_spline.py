@@ -302,7 +302,7 @@ def test_meitd_on_other_signals_matches_the_flow_over_the_oracles_operators(P, n
     x = np.sin(2 * np.pi * 3.0 * t) * (1.0 + 0.5 * np.sin(2 * np.pi * 0.4 * t)) + 0.3 * np.sin(2 * np.pi * 41.0 * t + 1.0) + 0.1 * rng.standard_normal(n)
     hi, lo, res = meitd.MEITD(x.copy())
     saved = meitd._work_for
-    meitd._work_for = lambda nn, device=0: meitd_oracle.CpuWork(nn)
+    meitd._work_for = lambda nn, device=0, solver="auto": meitd_oracle.CpuWork(nn)
     try:
         hi2, lo2, res2 = meitd.MEITD(x.copy())
     finally:
@@ -328,7 +328,7 @@ def test_meitd_early_returns(P):
             got = meitd.MEITD(x.copy())
             gx = meitd.XITD(x.copy())
             saved = meitd._work_for
-            meitd._work_for = lambda nn, device=0: meitd_oracle.CpuWork(nn)
+            meitd._work_for = lambda nn, device=0, solver="auto": meitd_oracle.CpuWork(nn)
             saved_wpe = meitd.weighted_permutation_entropy
             meitd.weighted_permutation_entropy = lambda ts, order=3, normalize=False, device=0: meitd_oracle.weighted_permutation_entropy(ts, order, normalize)
             try:
@@ -392,3 +392,45 @@ def test_entropy_of_order_4_long_signal_in_segments(P):
     ref = meitd_oracle.weighted_permutation_entropy(x, order=4, normalize=True)
     got = meitd.weighted_permutation_entropy(x, order=4, normalize=True)
     assert abs(got - ref) < 1e-12 and meitd.weighted_permutation_entropy(x, order=4, normalize=True) == got
+
+
+@pytest.mark.parametrize("n", [1024, 3000, 4097, 8192])
+def test_one_short_signal_in_one_launch_equals_the_launch_sequence(P, n):
+    """A single signal of 1024 .. 8192 samples takes the parallel-in-knots form as ONE launch of one workgroup (itd_nak.hpp:
+    k_nak_small: MEITD's per-call latency); the same signal as a member of a batch of two goes through the launch sequence
+    (knots, compaction, jobs, values, rows, forward, backward, evaluation, count).  Same expressions, same order: baseline,
+    rotation and both knot counts equal bit for bit — noisy, smooth, too few knots for a spline, a NaN in the input."""
+    from pyitd_amd import ITDError
+    from pyitd_amd.spline import _eng
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 100.0
+    cases = {"noisy": np.cumsum(rng.standard_normal(n)) + 3.0 * np.sin(t), "two tones": np.sin(2 * t) + 0.3 * np.sin(31 * t + 1.0),
+             "every sample a knot": ((-1.0) ** np.arange(n)) * (1 + rng.random(n)), "one extremum": -(t - t[n // 2]) ** 2, "monotone": t ** 3}
+    eng = _eng(n, 0)
+    for name, x in cases.items():
+        base2, rot2, k2, bk2 = eng.spline_extract_host(np.stack([x, x[::-1].copy()]), 0, want_rotation=True, want_baseline_knots=True)
+        base1, rot1, k1, bk1 = eng.spline_extract_host(x[None, :], 0, want_rotation=True, want_baseline_knots=True)
+        assert (int(k1[0]), int(bk1[0])) == (int(k2[0]), int(bk2[0])), name
+        assert np.array_equal(base1[0].view(np.uint64), base2[0].view(np.uint64)), name + ": baseline"
+        assert np.array_equal(rot1[0].view(np.uint64), rot2[0].view(np.uint64)), name + ": rotation"
+    x = cases["noisy"].copy()
+    x[n // 3] = np.nan
+    with pytest.raises(ITDError):
+        eng.spline_extract_host(x[None, :], 0)
+
+
+def test_meitd_solver_argument_and_release(P):
+    """MEITD(..., solver=): "serial" runs every extraction through FITPACK's own sweep (bit-level against scipy), "auto" / "parallel"
+    through the parallel-in-knots form — on the golden signal both select the reference's components; release() frees the rows the
+    module keeps between calls."""
+    from pyitd_amd import meitd
+    g = np.load(os.path.join(SPLINE, "meitd_am.npz"))
+    for solver in ("auto", "serial", "parallel"):
+        hi, lo, res = meitd.MEITD(g["x"].copy(), solver=solver)
+        assert hi.shape == g["high"].shape and lo.shape == g["low"].shape, solver
+        _close(res, g["residual"], "residual, solver " + solver, 1e-10)
+    assert meitd._work
+    meitd.release()
+    assert not meitd._work
+    hi, lo, res = meitd.MEITD(g["x"].copy())             # allocates again
+    assert hi.shape == g["high"].shape

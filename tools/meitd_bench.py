@@ -18,7 +18,7 @@ for name in sorted(f for f in os.listdir(G) if f.startswith("meitd_")):
         t0 = time.perf_counter(); xi = meitd.XITD(x.copy()); t_gpu_x = min(t_gpu_x, time.perf_counter() - t0)
     saved = meitd._work_for
     cw = []
-    meitd._work_for = lambda n, device=0: (cw.append(meitd_oracle.CpuWork(n)), cw[-1])[1]
+    meitd._work_for = lambda n, device=0, solver="auto": (cw.append(meitd_oracle.CpuWork(n)), cw[-1])[1]
     try:
         t0 = time.perf_counter(); hi2, lo2, res2 = meitd.MEITD(x.copy()); t_cpu = time.perf_counter() - t0
     finally:
