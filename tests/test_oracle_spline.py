@@ -61,7 +61,7 @@ def test_meitd_driver_logic_matches_reference(name, monkeypatch):
     g = np.load(os.path.join(SPLINE, name + ".npz"))
     works = []
 
-    def work_for(n, device=0):
+    def work_for(n, device=0, solver="auto"):
         works.append(meitd_oracle.CpuWork(n))
         return works[-1]
 
