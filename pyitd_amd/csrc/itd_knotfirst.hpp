@@ -42,11 +42,16 @@ namespace itd {
 constexpr int kKfCap = 128;        // knots of one tile and level the sample pass holds by rank
 
 // ---- geometry of the knot side's launch ----
-constexpr int kKcThreads = 256;                  // threads of a workgroup
+#ifndef ITD_KC_THREADS
+#define ITD_KC_THREADS 512        // eight wavefronts per knot-side workgroup, two candidates per thread (A/B builds: 256 = round 4's four: 70.9
+                                  // against 68.6 us per launch at 2^24 fused from level 2, 98.1 against 95.7 us per decomposition at 2^20)
+#endif
+constexpr int kKcThreads = ITD_KC_THREADS;       // threads of a workgroup
+constexpr int kKcWaves = kKcThreads / 64;
 constexpr int kKcTiles = 64;                     // tiles a workgroup owns at most (KfWs::tpw; one thread per 128-sample group of them)
 constexpr int kKcCap = 1024;                     // candidates a workgroup holds from the second fused level on (more: the signal is left to the level-by-level engine)
 constexpr int kKcCapH = 1720;                    // ... and at the hand-over level, whose candidates' triples stay in registers (KcLay)
-constexpr int kKcEnt = kKcCap / kKcThreads;      // candidates per thread
+constexpr int kKcEnt = (kKcCap + kKcThreads - 1) / kKcThreads;      // candidates per thread
 constexpr int kKcEntH = (kKcCapH + kKcThreads - 1) / kKcThreads;
 constexpr int kKcRound = 2;                      // workgroups whose records a halo search's first round reads (the nearest ones, whatever they hold)
 constexpr int kKcSlab = 3200;                    // table entries (all fused levels) a workgroup may write: ~1.7 x the hand-over level's knots
@@ -238,7 +243,9 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                                                          const int32_t *__restrict__ counts, const TileRec *__restrict__ recs,
                                                          SigState *__restrict__ state)
 {
-    static_assert(TW == 512 && kKcTiles * (TW / 128) == kKcThreads && kKcTiles == 64, "one thread per 128-sample group, one lane per tile");
+    static_assert(TW == 512 && kKcTiles * (TW / 128) <= kKcThreads && kKcTiles == 64 && (kKcThreads == 256 || kKcThreads == 512),
+                  "one thread per 128-sample group (the first 256 threads), one lane per tile");
+    constexpr int HT = kKcTiles * (TW / 128);              // threads that take part in the hand-over's expansion: one per 128-sample group
     // the candidates: position, the level's values at position - 1, position, position + 1,
     // flags, and the number of the range's knots at or before the candidate
     // (c_fl: 1 = a knot of the level, 2 = sticky.  The level's knots by rank, dense index = rank + 1: ranks -1, 0 the two knots in
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     __shared__ __attribute__((aligned(16))) unsigned char s_lds[kKcLds];
     __shared__ unsigned long long t_w[kKcTiles * 8];       // the level's knots as the tiles' flag words
     __shared__ uint32_t s_stage[2][4][16];
-    __shared__ int s_red[8], s_i[8], s_cnt[kKcEntH * 4];
+    __shared__ int s_red[8], s_i[8], s_cnt[kKcEntH * kKcWaves];
     const KcLay<true> LH{s_lds};
     const KcLay<false> LN{s_lds};
     __shared__ double s_ends[4];                           // the level's x[0], x[1], x[n-2], x[n-1] (as far as this workgroup needs them)
@@ -282,9 +289,9 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     int c_in[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int q = tid + r * NT, t = t0 + (q >> 3);
+        const int q = tid + r * HT, t = t0 + (q >> 3);
         w_in[r] = s_in[r] = 0ull; c_in[r] = 0;
-        if (t < t1) {
+        if (tid < HT && t < t1) {
             c_in[r] = counts[(size_t)sig * n_tiles + t];
             w_in[r] = recs[(size_t)sig * n_tiles + t].flags[q & 7];
             s_in[r] = ws.nearw[((size_t)sig * n_tiles + t) * 8 + (q & 7)];
@@ -310,7 +317,9 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     //      fused level's input —, the residual row of a signal that has stopped, the other set of states left ready for the next call
     bool stopped = stop_level >= 0;
     if (!stopped) {
-        int m_last = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        int m_last = 0;
+#pragma unroll
+        for (int k = 0; k < kKcWaves; ++k) m_last += s_red[k];
         if (L0 >= 1 && ((nan_mask >> (L0 - 1)) & 1)) m_last += c_delta;     // the baseline held a NaN: counted under the NaN rules (nan_rules)
         if (m_last < 2) { stopped = true; stop_level = L0; }
         if (w == 0 && tid == 0) st->m[L0] = m_last;
@@ -363,9 +372,11 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     unsigned long long *s_w = reinterpret_cast<unsigned long long *>(LH.k_B());   // (sticky words: until the first level needs k_B)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int q = tid + r * NT;
-        t_w[q] = c_in[r] > 0 ? w_in[r] : 0ull;                               // (an empty tile's record holds no words)
-        s_w[q] = s_in[r];
+        const int q = tid + r * HT;
+        if (tid < HT) {
+            t_w[q] = c_in[r] > 0 ? w_in[r] : 0ull;                           // (an empty tile's record holds no words)
+            s_w[q] = s_in[r];
+        }
     }
     if (tid < 4) s_ends[tid] = end_in;
     if (w == 0 && tid == 0) ks->active = 1;
@@ -382,9 +393,10 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     kc_barrier();
     int c = 0, ck = 0;                                                       // candidates of the range; knots among them
     {
-        const int tt = tid >> 2, g = tid & 3;
-        const unsigned long long Ek = t_w[tt * 8 + 2 * g], Ok = t_w[tt * 8 + 2 * g + 1];
-        const unsigned long long Es = s_w[tt * 8 + 2 * g], Os = s_w[tt * 8 + 2 * g + 1];
+        const int tt = (tid >> 2) & (kKcTiles - 1), g = tid & 3;
+        const bool mine = tid < HT;                                          // (more threads than groups: the others hold no words)
+        const unsigned long long Ek = mine ? t_w[tt * 8 + 2 * g] : 0ull, Ok = mine ? t_w[tt * 8 + 2 * g + 1] : 0ull;
+        const unsigned long long Es = mine ? s_w[tt * 8 + 2 * g] : 0ull, Os = mine ? s_w[tt * 8 + 2 * g + 1] : 0ull;
         unsigned long long E = Ek | Es, O = Ok | Os;
         int tot;
         int o = kc_scan((__popcll(E) + __popcll(O)) | ((__popcll(Ek) + __popcll(Ok)) << 16), s_red, tot);
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const U2 v = {wv[2 * q], wv[2 * q + 1]}; dst[q] = v; }
             }
-        } else {
+        } else if (wave < 2) {
             const int side = wave;                                           // 0: in front (two knots), 1: behind (three)
             const int want = side == 0 ? 2 : 3;
             const int a = lane >> 4, g = lane & 15;
@@ -708,16 +720,16 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             const unsigned long long kb = __ballot(nfl[i] != 0), nb = __ballot((nfl[i] & 1) != 0);
             pk[i] = mbcnt64(kb, 0);
             pn[i] = mbcnt64(nb, 0);
-            if (lane == 0) s_cnt[i * 4 + wave] = __popcll(kb) | (__popcll(nb) << 16);
+            if (lane == 0) s_cnt[i * kKcWaves + wave] = __popcll(kb) | (__popcll(nb) << 16);
         }
         kc_barrier();                                           // (also: every read of the old list and of the knot arrays is done)
         int tot = 0, base[ENT];
 #pragma unroll
         for (int i = 0; i < ENT; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kKcWaves; ++q) {
                 if (q == wave) base[i] = tot;
-                tot += s_cnt[i * 4 + q];
+                tot += s_cnt[i * kKcWaves + q];
             }
         }
         if (li == 1) KC_MARK(46);
