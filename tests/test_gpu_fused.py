@@ -653,3 +653,42 @@ def test_a_captured_fused_call_survives_a_workspace_change(P, torch, oracle):
         assert eng.fuse_repeats == 0
         assert_bits_equal(rows[: int(s["n_rows"][0])].cpu().numpy(), oracle.itd_lean(y_np, m)["rows"], "replay after the change, seed %d" % seed)
     eng.close()
+
+
+def test_a_workload_the_fused_form_cannot_deliver_backs_off_exponentially(P, torch, oracle):
+    """A coarsely quantised signal refuses the fused levels on every attempt.  The automatic mode repeats the refused call level by
+    level and runs the next 16 calls that way, then tries again — and doubles the pause every time the attempt behind a pause refuses
+    (32, 64, ... 1024): over 60 calls that is three wasted attempts (calls 1, 18, 51), not four; every call's rows are the oracle's;
+    itd_get_last_fuse_level says which form a call took; a workload that delivers starts over at 16."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m = 1 << 17, 6
+    x = coarse(sines_noise(n, seed=101))
+    ref = oracle.itd_lean(x, m)
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_min_samples(65536)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    attempts = []
+    for call in range(1, 61):
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+        form = eng.last_fuse_level
+        s = eng.summary(1)
+        if form:
+            attempts.append(call)
+            assert form == 3 and eng.last_fuse_level == 0          # (the summary repeated it level by level)
+        if call in (1, 2, 18, 19, 51, 60):
+            nr = int(s["n_rows"][0])
+            assert nr == ref["rows"].shape[0]
+            assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "call %d" % call)
+    assert attempts == [1, 18, 51] and eng.fuse_repeats == 3
+    y = sines_noise(n, seed=102)                                    # a signal the fused form delivers: the pause starts over
+    yd = torch.from_numpy(y).cuda()
+    torch.cuda.synchronize()
+    eng.set_fuse_mode(FUSE_AUTO)                                    # (clears the pause that is still running)
+    eng.decompose_dev(yd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+    assert eng.last_fuse_level == 3
+    eng.summary(1)
+    assert eng.fuse_repeats == 3 and eng.last_fuse_level == 3
+    eng.close()
