@@ -870,7 +870,8 @@ __device__ __forceinline__ int ne_i(int32_t a, int32_t b) { return a ^ b; }
 // padded to a multiple of 8 so that a tile's workgroup lands on the same XCD as in every other launch (xcd_item)
 __host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 7) & ~7; }
 #ifndef ITD_KF_APPLY_WAVES
-#define ITD_KF_APPLY_WAVES 7      // wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice; 7: 72 VGPRs, no spill; measured 152 us against 157 at 6)
+#define ITD_KF_APPLY_WAVES 8      // wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice; 8: 64 VGPRs, no spill; fused from
+                                  // level 2 at 2^24: 181.9 us at 6, 177.1 at 7, 176.3 at 8 — profiles/r05/ab_sample_pass_occupancy.txt)
 #endif
 #ifndef ITD_KF_FASTGROUP
 #define ITD_KF_FASTGROUP 1        // A/B builds: 0 = every 128-sample group takes the by-rank path
