@@ -223,6 +223,7 @@ def test_kernel_timing_api(P, torch, oracle):
     from pyitd_amd.engine import FUSE_ONLY, TIME_KF_APPLY, TIME_KF_KNOTS
     eng = P.Engine(n, 1, 0)
     eng.set_fuse_mode(FUSE_ONLY)
+    eng.set_fuse_level(3)             # (whatever PYITD_FUSE_LEVEL says: the counts below are level 3's)
     eng.set_timing(steps, stride=stride)
     for _ in range(steps):
         eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
