@@ -14,6 +14,7 @@
 #include <cstring>
 #include <type_traits>
 #include <atomic>
+#include <chrono>
 #include <dlfcn.h>
 #include <memory>
 #include <new>
@@ -150,6 +151,14 @@ __global__ void k_or_nan_flags(const int32_t *__restrict__ totals, int batch, in
     if (b < batch && totals[2 * b + 1]) atomicOr(flag, 1);
 }
 
+__global__ void k_copy_words(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int cnt, int32_t *__restrict__ done_flag, int32_t done_seq)
+{
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
+}
+
 __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +215,11 @@ struct itd_engine {
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
     bool resident_attr[12] = {};
     bool nak_small_attr = false;    // hipFuncSetAttribute done for k_nak_small<true>
+    // a few scalars per call come back to the host in MEITD's operators (counts, six sums): 256 bytes of pinned host memory that the
+    // GPU writes directly (mapped, coherent) — no copy behind the launch, just the stream's synchronisation (a pageable destination
+    // cost ~15 us per call: 110 calls per MEITD run)
+    void *h_small = nullptr, *d_small = nullptr;
+    int32_t small_seq = 0;          // the last word of those 256 bytes: the launch that fills them writes this call's number there last
     int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
     // the fused sparse levels (itd_knotfirst.hpp): workspace (allocated at first use), mode, first fused level
     void *d_kf = nullptr; size_t kf_bytes = 0;
@@ -1045,6 +1059,7 @@ void itd_engine_destroy(itd_engine *e)
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_kf) (void)hipHostFree(e->h_kf);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
+    if (e->h_small) (void)hipHostFree(e->h_small);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (int k = 0; k < 3; ++k) {
@@ -2205,6 +2220,37 @@ int nak_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_
     return ITD_OK;
 }
 
+// the engine's 256 bytes of mapped pinned host memory (h_small / its device address d_small); false: not available (the callers
+// then copy through their own buffers as before)
+bool small_results(itd_engine *e)
+{
+    if (e->h_small) return e->d_small != nullptr;
+    if (hipHostMalloc(&e->h_small, 256, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); e->h_small = nullptr; return false; }
+    if (hipHostGetDevicePointer(&e->d_small, e->h_small, 0) != hipSuccess) { (void)hipGetLastError(); e->d_small = nullptr; return false; }
+    memset(e->h_small, 0, 256);
+    return true;
+}
+
+// Wait for the launch that fills the mapped words: it writes `seq` into their last word behind everything else (system-scope fence),
+// and the host polls that word — a few microseconds behind the kernel's end instead of the ~25 us hipStreamSynchronize takes to come
+// back from an interrupt on a busy host.  Falls back to the synchronisation if the word does not turn up within 2 ms (a long kernel,
+// a fault): the stream's status is what the caller gets then.
+constexpr int kSmallFlag = 63;
+int32_t small_next(itd_engine *e) { e->small_seq = e->small_seq == INT32_MAX ? 1 : e->small_seq + 1; return e->small_seq; }
+int small_wait(itd_engine *e, int32_t seq, hipStream_t st)
+{
+    volatile int32_t *flag = (volatile int32_t *)e->h_small + kSmallFlag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0; *flag != seq; ++spin) {
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            HIP_TRY(e, hipStreamSynchronize(st));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return ITD_OK;
+}
+
 // ONE signal of at most kNakSmallMax samples through the parallel-in-knots form: one launch, one workgroup (itd_nak.hpp: k_nak_small),
 // one 16-byte copy back — knots, NaN flag, validity, and (want_bcount) the knot count of the produced baseline.  Synchronous.
 int nak_small(itd_engine *e, const double *x, int64_t n, int min_extrema, double *base, double *rot, hipStream_t st,
@@ -2214,9 +2260,12 @@ int nak_small(itd_engine *e, const double *x, int64_t n, int min_extrema, double
     const size_t idx_b = (((size_t)L * sizeof(int32_t)) + 255) & ~(size_t)255, out_b = 256;
     int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + 6 * (size_t)L * sizeof(double));
     if (rc) return rc;
-    int32_t *out = (int32_t *)e->d_cub;
+    const bool mapped = small_results(e);
+    int32_t *out = mapped ? (int32_t *)e->d_small : (int32_t *)e->d_cub;
     int32_t *idx = (int32_t *)((char *)e->d_cub + out_b);
     double *arr = (double *)((char *)e->d_cub + out_b + idx_b);
+    const int32_t seq = mapped ? small_next(e) : 0;
+    int32_t *flag = mapped ? (int32_t *)e->d_small + kSmallFlag : nullptr;
     const size_t lds = 4 * (size_t)L * sizeof(double);
     if (lds <= kNakSmallLdsMax) {                          // the sweeps' arrays in LDS (more than 64 KB of dynamic LDS has to be asked for)
         if (!e->nak_small_attr) {
@@ -2224,13 +2273,20 @@ int nak_small(itd_engine *e, const double *x, int64_t n, int min_extrema, double
             e->nak_small_attr = true;
         }
         k_nak_small<true><<<1, kNakSmallThreads, lds, st>>>(x, (int)n, min_extrema, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                             base, rot, baseline_knots_host ? 1 : 0, out);
+                                                             base, rot, baseline_knots_host ? 1 : 0, out, flag, seq);
     } else
         k_nak_small<false><<<1, kNakSmallThreads, 0, st>>>(x, (int)n, min_extrema, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                            base, rot, baseline_knots_host ? 1 : 0, out);
+                                                            base, rot, baseline_knots_host ? 1 : 0, out, flag, seq);
     int32_t h[4] = {0, 0, 0, 0};
-    HIP_TRY(e, hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, st));
-    HIP_TRY(e, hipStreamSynchronize(st));
+    HIP_TRY(e, hipGetLastError());
+    if (mapped) {
+        const int rc2 = small_wait(e, seq, st);
+        if (rc2) return rc2;
+        memcpy(h, e->h_small, sizeof(h));
+    } else {
+        HIP_TRY(e, hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+    }
     if (knots_host) knots_host[0] = h[0];
     if (baseline_knots_host) baseline_knots_host[0] = h[3];
     return h[1] ? ITD_ERR_NONFINITE : ITD_OK;
@@ -2357,8 +2413,18 @@ int itd_count_knots_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t b
     int rc = detect_enqueue(e, x_dev, x_stride, n, batch, mode, -1, st, w, nullptr, 0, false);
     if (rc) return rc;
     std::vector<int32_t> tot(2 * (size_t)batch);
-    HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(e, hipStreamSynchronize(st));
+    const bool mapped = batch <= 16 && small_results(e);       // a few counts: the GPU copies them into the mapped words itself
+    if (mapped) {
+        const int32_t seq = small_next(e);
+        k_copy_words<<<1, 64, 0, st>>>(w.totals, (int32_t *)e->d_small, 2 * batch, (int32_t *)e->d_small + kSmallFlag, seq);
+        HIP_TRY(e, hipGetLastError());
+        rc = small_wait(e, seq, st);
+        if (rc) return rc;
+        memcpy(tot.data(), e->h_small, tot.size() * sizeof(int32_t));
+    } else {
+        HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(e, hipStreamSynchronize(st));
+    }
     bool nan_in = false;
     for (int b = 0; b < batch; ++b) { counts_host[b] = tot[2 * (size_t)b]; nan_in = nan_in || tot[2 * (size_t)b + 1]; }
     return nan_in ? ITD_ERR_NONFINITE : ITD_OK;
@@ -2386,15 +2452,29 @@ int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weig
     double *out_s = reinterpret_cast<double *>(e->d_wpe + out_off);
     long long *out_c = reinterpret_cast<long long *>(out_s + 6);
     int *out_k = reinterpret_cast<int *>(out_c + 6);
+    // (one segment — MEITD's signals —: the sums land in the engine's mapped host words, no copy behind the launch)
+    const bool mapped = nseg == 1 && small_results(e);
+    if (mapped) {
+        part_s = reinterpret_cast<double *>(e->d_small);
+        part_c = reinterpret_cast<long long *>(part_s + 6);
+        part_k = reinterpret_cast<int *>(part_c + 6);
+    }
     // (the knot count of x rides along: a window's middle sample is a knot or not — MEITD.py:346-351, :373-378 ask for both)
-    k_wpe3<<<(unsigned)nseg, kWpeThreads, 0, st>>>(x_dev, nw, seg_len, part_s, part_c, knots_host ? part_k : nullptr);
+    const int32_t seq = mapped ? small_next(e) : 0;
+    k_wpe3<<<(unsigned)nseg, kWpeThreads, 0, st>>>(x_dev, nw, seg_len, part_s, part_c, knots_host ? part_k : nullptr,
+                                                   mapped ? (int32_t *)e->d_small + kSmallFlag : nullptr, seq);
     if (nseg > 1) k_wpe3_combine<<<1, 64, 0, st>>>(part_s, part_c, (int)nseg, out_s, out_c, knots_host ? part_k : nullptr, out_k);
     HIP_TRY(e, hipGetLastError());
     struct { double s[6]; long long c[6]; int k[2]; } res;
     res.k[0] = res.k[1] = 0;
-    if (nseg > 1) HIP_TRY(e, hipMemcpyAsync(&res, out_s, 6 * (sizeof(double) + sizeof(long long)) + (knots_host ? 2 * sizeof(int) : 0), hipMemcpyDeviceToHost, st));
-    else HIP_TRY(e, hipMemcpyAsync(&res, part_s, 6 * (sizeof(double) + sizeof(long long)) + (knots_host ? 2 * sizeof(int) : 0), hipMemcpyDeviceToHost, st));
-    HIP_TRY(e, hipStreamSynchronize(st));
+    const size_t res_b = 6 * (sizeof(double) + sizeof(long long)) + (knots_host ? 2 * sizeof(int) : 0);
+    if (nseg > 1) HIP_TRY(e, hipMemcpyAsync(&res, out_s, res_b, hipMemcpyDeviceToHost, st));
+    else if (!mapped) HIP_TRY(e, hipMemcpyAsync(&res, part_s, res_b, hipMemcpyDeviceToHost, st));
+    if (mapped) {
+        const int rc2 = small_wait(e, seq, st);
+        if (rc2) return rc2;
+        memcpy(&res, e->h_small, res_b);
+    } else HIP_TRY(e, hipStreamSynchronize(st));
     for (int b = 0; b < 6; ++b) { bin_weights_host[b] = res.s[b]; bin_windows_host[b] = (int64_t)res.c[b]; }
     if (knots_host) *knots_host = res.k[0];
     return knots_host && res.k[1] ? ITD_ERR_NONFINITE : ITD_OK;

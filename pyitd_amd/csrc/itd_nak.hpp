@@ -166,7 +166,9 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__
                                                                double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
                                                                double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
                                                                double *__restrict__ base, double *__restrict__ rot, int want_bcount,
-                                                               int32_t *__restrict__ out /* knots, NaN flag, valid, knots of the produced baseline */)
+                                                               int32_t *__restrict__ out /* knots, NaN flag, valid, knots of the produced baseline */,
+                                                               int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
+                                                               /* done_flag (host-mapped): set to done_seq behind the last of `out`'s words — the host polls it */)
 {
     extern __shared__ double s_dyn[];
     double *const subv = LDS ? s_dyn : subg, *const rhsv = LDS ? s_dyn + (n + 2) : rhsg;
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__
     if (!valid) {                                         // fewer knots than the operator needs: the signal is its own baseline
         for (int i = lo; i < hi; ++i) { base[i] = x[i]; if (rot) rot[i] = 0.0; }
         if (want_bcount && tid == 0) out[3] = knots;      // (the baseline IS the signal)
+        if (tid == 0 && done_flag) { __threadfence_system(); *done_flag = done_seq; }
         return;
     }
     for (int k = tid; k < m; k += kNakSmallThreads) K[k] = spline_knot_value(x, n, e, m, k);
@@ -291,6 +294,7 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__
         (void)block_scan(__popc(knot_mask(base, nn)), total);
         if (tid == 0) out[3] = total;
     }
+    if (tid == 0 && done_flag) { __threadfence_system(); *done_flag = done_seq; }
 }
 
 }  // namespace itd

@@ -50,7 +50,9 @@ constexpr int kWpeThreads = 256;
 // part_k (optional): per segment, the number of windows whose MIDDLE sample is a knot of x (ITD.py:59 on x and on -x, raw
 // differences: what the count-only detection counts for samples 1 .. n-2) and whether a sample of the segment's windows is a NaN
 __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__ x, int64_t nw, int64_t seg_len, double *__restrict__ part_s,
-                                                      long long *__restrict__ part_c, int *__restrict__ part_k)
+                                                      long long *__restrict__ part_c, int *__restrict__ part_k,
+                                                      int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
+                                                      /* one segment, results in host-mapped words: set to done_seq behind them (the host polls) */)
 {
     static_assert(kWpeChunk % kWpeThreads == 0 && kWpeChunk < 65536, "three 16-bit counts per word");
     __shared__ double s_x[kWpeChunk + 2], s_l[kWpeChunk];
@@ -131,6 +133,11 @@ __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__
         if (nanf) s_kn[1] = 1;
         __syncthreads();
         if (tid < 2) part_k[(size_t)blockIdx.x * 2 + tid] = s_kn[tid];
+    }
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) { __threadfence_system(); *done_flag = done_seq; }
     }
 }
 

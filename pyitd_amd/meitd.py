@@ -29,7 +29,8 @@ from .spline import _eng
 
 
 def _entropy_from_bins(weights, windows, order=3, normalize=False):
-    """MEITD.py:119-128 from the patterns' weighted counts (in numpy.unique's order; a pattern without windows is absent)."""
+    """MEITD.py:119-128 from the patterns' weighted counts (in numpy.unique's order; a pattern without windows is absent).  The same
+    numpy operations on the same (short) arrays as upstream: the result's bits depend on numpy's summation order and its log2."""
     wc = weights[windows > 0]
     p = numpy.true_divide(wc, wc.sum())
     pe = -numpy.multiply(p, numpy.log2(p)).sum()
