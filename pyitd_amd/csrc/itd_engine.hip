@@ -685,7 +685,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
                 const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
                 void *args[] = {&a_w, &a_xl, &a_xs, &a_n, &a_rec, &a_rows, &a_rs, &a_bases, &a_bs};
-                HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap>), dim3(n_tiles + kf_check_blocks(w.wgs), nb), dim3(kWave), args, 0, cst,
+                const void *apply_fn = bases_c ? reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, true>) : reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, false>);
+                HIP_TRY(e, hipExtLaunchKernel(apply_fn, dim3(n_tiles + kf_check_blocks(w.wgs), nb), dim3(kWave), args, 0, cst,
                                               pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr, pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
             }
         }

@@ -879,7 +879,7 @@ __host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 7) & 
 #ifndef ITD_KF_VERIFY
 #define ITD_KF_VERIFY 15          // timing-only A/B builds: bit k = check Vk is compiled in (the shipped build: all four)
 #endif
-template <int TW, int CAP>
+template <int TW, int CAP, bool BASES>      // BASES: the caller wants the baselines too (get_baselines()): a second row store per level
 __global__ __launch_bounds__(kWave)
 #if ITD_KF_APPLY_WAVES
 __attribute__((amdgpu_waves_per_eu(ITD_KF_APPLY_WAVES, ITD_KF_APPLY_WAVES)))
@@ -980,7 +980,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     const unsigned long long *tf = ws.tflags + ((size_t)sig * ws.nlev) * n_tiles * 8;
     const KfEntry *pool = ws.pool + (size_t)sig * ws.wgs_max * kKcSlab;
     double *rows_s = rows + (int64_t)sig * rows_stride + si;
-    double *bases_s = bases ? bases + (int64_t)sig * bases_stride + si : nullptr;
+    double *bases_s = (BASES && bases) ? bases + (int64_t)sig * bases_stride + si : nullptr;
     unsigned long long wcur = lane < 2 * G2 ? tf[(size_t)t * 8 + lane] : 0ull;       // this level's flag words, lane j holds word j
     bool bad = false;            // wave-uniform findings
     int vbad = 0;                // per-lane findings
@@ -1106,7 +1106,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             else if (last) { re = (xe - be) + be; ro = (xo - bo) + bo; }   // "Out of time!": rotation + baseline, ITD.py:420
             else { re = xe - be; ro = xo - bo; }                     // ITD.py:119
             tile_store2<true>(r_row, p * 8, re, ro);
-            tile_store2<true>(r_bas, p * 8, be, bo);
+            if constexpr (BASES) tile_store2<true>(r_bas, p * 8, be, bo);      // (without: not even a bounds-checked-away store is issued)
             nonfin = nonfin || nonfinite(be) || nonfinite(bo);
             xr[g][0] = be;
             xr[g][1] = bo;
