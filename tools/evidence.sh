@@ -2,7 +2,8 @@
 # One GPU session that collects a round's evidence into gpurun_out/<tag>/ (copied into profiles/<round>/ afterwards):
 #   the -m gpu suite's log; bench.py in the driver's form and with 200 steps; rocprofv3 --kernel-trace --stats of the driver's form;
 #   the PMC traffic passes (tools/traffic.sh); the knot side's phase profile (variants/libprof.so, built with -DITD_PROF=1, if present);
-#   the delivery rates of the fused levels by signal family; two fuzz slices on the fused path.
+#   the delivery rates of the fused levels by signal family; fuzz slices (default mode, batches, everything fused from level 3 / 2);
+#   the suite again in the fused levels' other modes (tools/suite_modes.sh).
 # usage (through gpurun): bash tools/evidence.sh r05
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 tag=${1:-r05}; O=gpurun_out/$tag; mkdir -p $O
@@ -17,8 +18,9 @@ if [ -f variants/libprof.so ]; then PYITD_HIP_LIB=variants/libprof.so timeout -k
 timeout -k 10 900 python tools/kf_rates.py 12 11 > $O/kf_delivery_rates.txt 2>&1 || exit 1; tail -2 $O/kf_delivery_rates.txt
 FUZZ_MIN_N=65536 PYITD_FUSE_MIN=65536 timeout -k 10 600 python tools/fuzz_parity.py 3000 601 > $O/fuzz_3000_long_fused.txt 2>&1 || exit 1; tail -1 $O/fuzz_3000_long_fused.txt
 FUZZ_MIN_N=65536 PYITD_FUSE_MIN=65536 PYITD_FUSE_LEVEL=2 timeout -k 10 600 python tools/fuzz_parity.py 3000 602 > $O/fuzz_3000_long_fused_level2.txt 2>&1 || exit 1; tail -1 $O/fuzz_3000_long_fused_level2.txt
-timeout -k 10 600 python tools/fuzz_parity.py 10000 603 > $O/fuzz_10000_default.txt 2>&1 || exit 1; tail -1 $O/fuzz_10000_default.txt
-timeout -k 10 600 python tools/fuzz_parity.py batch 600 604 > $O/fuzz_600_batches.txt 2>&1 || exit 1; tail -1 $O/fuzz_600_batches.txt
+timeout -k 10 600 python tools/fuzz_parity.py 20000 603 > $O/fuzz_20000_default.txt 2>&1 || exit 1; tail -1 $O/fuzz_20000_default.txt
+timeout -k 10 600 python tools/fuzz_parity.py batch 1500 604 > $O/fuzz_1500_batches.txt 2>&1 || exit 1; tail -1 $O/fuzz_1500_batches.txt
+bash tools/suite_modes.sh $tag || exit 1
 python - <<PY
 import json
 for f in ("bench_default_form", "bench_steps200", "bench_under_rocprof"):
