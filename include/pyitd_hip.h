@@ -223,7 +223,9 @@ int itd_set_fuse_group(itd_engine *e, int32_t chunks);
  *   kind 3          delta added to that entry's knot position;     kind 4   delta added to the run's start index first[level][where];
  *   kind 5          bit (delta & 63) of flag word (slot & 7) of tile `where` at `level` flipped;
  *   kind 6 / 7      the value (delta ulps) / position (delta) of halo knot `slot` (0, 1: the two in front, 2 .. 4: the three behind) as
- *                   knot-side workgroup `where` receives it from its neighbours at `level`.
+ *                   knot-side workgroup `where` receives it from its neighbours at `level`;
+ *   kind 8          delta added to the knot side's count of `level`'s knots (what its stop rules read): the sample pass's check
+ *                   wavefronts count the verified flag words themselves, the verdict compares.
  * `level` is the absolute level (first fused level .. max_iteration + 1). */
 int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta);
 /* Tests only (ABI revision 9): the kernels form the knot spacings' ratio (k1 - k0) / (k2 - k0) of ITD.py:107 with the division's own

@@ -80,6 +80,9 @@ __global__ void k_verdict(SigState *__restrict__ state, int batch, const KfSig *
             if (lend < 0) fail |= kKfFailCapacity;
             // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
             if (!fail && (ks.natural ? ks.m_exact >= 2 : ks.m_exact < 2)) fail |= kKfFailVerify;
+            // the levels' knot counts — what the stop rules were drawn from — as the sample pass's verified flag words have them; a level
+            // that was decomposed had at least 2 (ITD.py:404)
+            for (int j = L0; !fail && j <= lend; ++j) if (ks.m_chk[j] != ks.mlev[j] || (j > L0 && ks.mlev[j] < 2)) fail |= kKfFailVerify;
             if (fail) st.kf_fail = fail;
             else {
                 for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
@@ -678,7 +681,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 #ifdef ITD_DEBUG_GAP
                 k_debug_gap<<<1, 64, 0, cst>>>((long long)(ITD_DEBUG_GAP) * 100);
 #endif
-                if (e->fault_kind >= 0 && e->fault_kind <= 5 && e->fault_level >= L0 && e->fault_level - L0 < w.nlev && e->fault_where >= 0 &&
+                if (e->fault_kind >= 0 && (e->fault_kind <= 5 || e->fault_kind == 8) && e->fault_level >= L0 && e->fault_level - L0 < w.nlev && e->fault_where >= 0 &&
                     e->fault_where < n_tiles)      // (tests only) one field of what the sample pass is about to read, perturbed
                     k_kf_fault<<<1, 64, 0, cst>>>(w, e->fault_kind, e->fault_level - L0, e->fault_where, e->fault_slot & 0xffff, e->fault_delta);
                 const int pair = time_slot(e, ITD_TIME_KF_APPLY);
@@ -1261,6 +1264,9 @@ void kf_verdict(itd_engine *e, int B)
         if (lend < 0) fail |= kKfFailCapacity;      // the steps never reached a stop rule (cannot happen: they run to max_iteration + 1)
         // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
         if (!fail && (ks.natural ? ks.m_exact >= 2 : ks.m_exact < 2)) fail |= kKfFailVerify;
+        // the levels' knot counts — what the stop rules were drawn from — as the sample pass's verified flag words have them; a level
+        // that was decomposed had at least 2 (ITD.py:404)
+        for (int j = L0; !fail && j <= lend; ++j) if (ks.m_chk[j] != ks.mlev[j] || (j > L0 && ks.mlev[j] < 2)) fail |= kKfFailVerify;
         if (fail) { st.kf_fail = fail; continue; }
         for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
         st.m[lend + 1] = ks.m_exact;
@@ -1523,8 +1529,8 @@ int itd_debug_int_ratio_check(int device, int32_t max_den, int64_t *mismatches)
 
 int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta)
 {
-    if (!e || kind > 7 || (kind >= 0 && (level < 2 || level > ITD_MAX_ITERATION + 1 || where < 0 || slot < 0))) return ITD_ERR_INVALID_ARG;
-    if (kind >= 6 && slot > 4) return ITD_ERR_INVALID_ARG;
+    if (!e || kind > 8 || (kind >= 0 && (level < 2 || level > ITD_MAX_ITERATION + 1 || where < 0 || slot < 0))) return ITD_ERR_INVALID_ARG;
+    if ((kind == 6 || kind == 7) && slot > 4) return ITD_ERR_INVALID_ARG;
     e->fault_kind = kind < 0 ? -1 : kind;
     e->fault_level = level; e->fault_where = where; e->fault_slot = slot; e->fault_delta = delta;
     return ITD_OK;

@@ -116,6 +116,8 @@ struct KfSig {
     int32_t m_exact;      // knots of the last pending baseline, counted by the sample pass
     int32_t pad0[3];
     int32_t mlev[kMaxLevels + 2];   // knots of level j's input
+    int32_t m_chk[kMaxLevels + 2];  // the same counted by the sample pass's check wavefronts from the flag words it verifies (the stop rules
+                                    // are drawn from mlev: the verdict requires the two to agree, level by level)
     // ---- the knot side's accumulators: zero between calls (the signal's last workgroup reads and clears them; the workspace starts
     //      zeroed), so no launch has to prepare them ----
     int32_t acc_mlev[kMaxLevels + 2];
@@ -128,7 +130,7 @@ struct KfSig {
     uint32_t seq;         // the generation in the tags of a call's records: bumped by the signal's last workgroup
     uint32_t pad2;
 };
-constexpr size_t kKfSigHead = (8 + kMaxLevels + 2) * sizeof(int32_t);
+constexpr size_t kKfSigHead = (8 + 2 * (kMaxLevels + 2)) * sizeof(int32_t);
 static_assert(offsetof(KfSig, acc_mlev) == kKfSigHead, "KfSig layout");
 
 // what the knot side's launch needs to do k_finalize's work (itd_kernels.hpp) for the hand-over level: the stop test of that level's
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         if (lev == L0) published = lev;
         kc_barrier();
         if (s_i[1]) return false;
-        if (ws.dbg_kind >= 6 && lev == ws.dbg_lev && w == ws.dbg_wg && sig == 0) {   // fault injection (tests): a halo knot as received
+        if ((ws.dbg_kind == 6 || ws.dbg_kind == 7) && lev == ws.dbg_lev && w == ws.dbg_wg && sig == 0) {   // fault injection (tests): a halo knot as received
             if (tid == 0) {
                 const int d = ws.dbg_slot < 2 ? ws.dbg_slot : ck + ws.dbg_slot;     // slots 0, 1: in front; 2 .. 4: behind
                 if (ws.dbg_kind == 6) k_X[d] = __builtin_bit_cast(double, dbits(k_X[d]) + (unsigned long long)(long long)ws.dbg_delta);
@@ -817,6 +819,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             for (int j = 0; j < kMaxLevels + 2; ++j) {
                 ks->mlev[j] = __hip_atomic_load(&ks->acc_mlev[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ks->acc_mlev[j] = 0;
+                ks->m_chk[j] = 0;
             }
             ks->fail = fail;
             ks->m_exact = 0;
@@ -855,6 +858,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
 //       end (first[t+1] == first[t] + kn), so entry 0 / kn+1 of a run is physically the entry its owner tile verifies — the nearest
 //       knot in front of / behind the tile; across two slabs the next slab's copy of the knot in front of it and this slab's copy
 //       of the knot behind it are compared with the owners' entries bit for bit, all four fields (the check wavefronts).
+//   counts  the levels' knot counts (what the knot side's stop rules read) are counted again by the check wavefronts from the verified
+//       flag words (KfSig::m_chk); the verdict (kf_verdict / k_verdict) requires them to agree with the knot side's, level by level.
 // Every field of every entry a tile uses is thereby checked by its owner or equals, through a chain of bitwise equalities, an
 // entry that is; any mismatch refuses the signal (kKfFailVerify).  tests/test_gpu_fused.py injects faults into every one of
 // these (itd_debug_kf_fault) and requires the refusal.
@@ -935,6 +940,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             const int l_last = t1 - 1 - tb;                      // the lane of the range's last tile, if it is in this round
             if (l_last < kWave) cnt = __shfl(f + kt, l_last) - start;
         }
+        if (lane == 0 && cnt > 0) atomicAdd(&ks->m_chk[ws.L0 + li], cnt);      // the level's knots as the verified words have them
         if (start < 0 || cnt < 0 || start + cnt + 2 > pool_n || (t1 < n_tiles && (f_next < 0 || f_next + 2 > pool_n))) vb = 1;
         else if (ITD_KF_VERIFY & 4) {
             const KfEntry *e = pool + start;
@@ -1131,13 +1137,14 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
 // fault injection for the tests (itd_debug_kf_fault): ONE field of the workspace the sample pass is about to read is perturbed,
 // between the knot side's launch and the sample pass.  kind 0 / 1 / 2: X / B / S of entry `slot` (mod the run's length) of tile
 // `tile`'s run at fused level index `li` (delta added to the bit pattern: ulps); 3: its position; 4: first[li][tile]; 5: bit
-// (delta & 63) of flag word `slot` & 7 of the tile flipped.
+// (delta & 63) of flag word `slot` & 7 of the tile flipped; 8: the level's knot count in the signal's head.
 __global__ void k_kf_fault(KfWs ws, int kind, int li, int tile, int slot, int delta)
 {
     if (threadIdx.x || blockIdx.x) return;
     const int n_tiles = ws.n_tiles;
     int32_t *first = ws.first + (size_t)li * n_tiles;
     unsigned long long *tf = ws.tflags + ((size_t)li * n_tiles + tile) * 8;
+    if (kind == 8) { ws.sig[0].mlev[ws.L0 + li] += delta; return; }      // the knot side's count of the level's knots (what the stop rules read)
     if (kind == 4) { first[tile] += delta; return; }
     if (kind == 5) { tf[slot & 7] ^= 1ull << (delta & 63); return; }
     int kn = 0;

@@ -585,6 +585,16 @@ def test_every_injected_fault_is_refused(P, torch, oracle):
                 refused += 1
                 continue
             raise AssertionError("fault not refused: kind %d level %d tile %d (range of %d) slot %d delta %d" % (kind, level, tile, tpw, slot, delta))
+        for k in range(12):                                    # the knot side's count of a level's knots (its stop rules' input)
+            eng.debug_kf_fault(8, L0 + k % (m + 2 - L0), 0, 0, int(rng.choice([1, -1, 2, -40])))
+            injected += 1
+            try:
+                run()
+            except ITDError as err:
+                assert "fused sparse levels" in str(err), str(err)
+                refused += 1
+                continue
+            raise AssertionError("a wrong knot count of level %d was not refused" % (L0 + k % (m + 2 - L0)))
         for k in range(60):                                    # what a workgroup receives from its neighbours
             kind, level = 6 + k % 2, int(rng.integers(L0, m + 2))
             w, slot = int(rng.integers(0, n_tiles // tpw)), int(rng.integers(0, 5))
