@@ -18,7 +18,7 @@ fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child) and rel
 process IS one rank.
 
 Printed JSON (one line, rank 0): the driver contract + "roofline" — the dominant kernel: with the sparse levels fused (the
-default for this workload) k_kf_apply, the one pass over the samples for levels 3 .. 8 (8 B read + 6 x 8 B written per sample);
+default for this workload) k_kf_apply, the one pass over the samples for levels 2 .. 8 (8 B read + 7 x 8 B written per sample);
 with --no-fuse k_extract<double> (24 B per sample and level) — timed with the launch's own hipEvents on the launch stream
 inside the timed region, + the per-kernel fractions + "cpu_baseline" (the C oracle = single-thread port of the reference
 algorithm, timed on this box's host at N = 1) and the other CPU legs SURVEY 8d lists (all host cores over independent signals,

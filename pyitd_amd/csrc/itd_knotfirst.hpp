@@ -27,7 +27,9 @@
 //               stores the rotation row, and RE-DERIVES the next level's knots from the values it has just computed — the exact
 //               predicate on the actual samples.  Any difference from the knot side's flags means the shortcut missed a knot
 //               (a plateau born from rounding somewhere else): the signal's result is discarded (SigState::kf_fail) and the
-//               engine repeats the call level by level.  So whatever this path delivers is, by induction over the levels, bit
+//               engine repeats the call level by level.  It also VERIFIES every table value it maps its samples with (V0 .. V3 in
+//               front of k_kf_apply below: positions and values against its own samples, B and S recomputed, the runs' chain, the
+//               levels' knot counts), so whatever this path delivers is, by induction over the levels and by construction, bit
 //               for bit what the level-by-level engine delivers; what it cannot deliver it reports.
 //
 // Traffic of the fused levels L0 .. L: 8 B read + 8 B per row written per sample, against 24 B per sample and level.
@@ -235,7 +237,7 @@ __device__ unsigned long long *g_kc_prof;   // [workgroups][64]
 #else
 #define KC_MARK(i)
 #endif
-// ---- the knot side: hand-over and every fused level in ONE launch.  grid = wgs * nb workgroups of 256 threads; workgroup id ->
+// ---- the knot side: hand-over and every fused level in ONE launch.  grid = wgs * nb workgroups of kKcThreads (512) threads; workgroup id ->
 //      (signal, range of tpw tiles).  A workgroup waits for its neighbours' records, so it must never keep a neighbour from
 //      starting: a grid that fits the device at once (KfWs::ticketed = 0) takes the id from blockIdx; a larger one hands out
 //      tickets — whoever starts first takes the lowest range, so whatever a resident workgroup waits for has started already
