@@ -11,6 +11,8 @@ export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; rc=$?; tail -2 $O/pytest_gpu.log; [ $rc -ne 0 ] && exit $rc
 timeout -k 10 900 python bench.py > $O/bench_default_form.json 2> $O/bench_default_form.err || exit 1
 timeout -k 10 300 python bench.py --steps 200 --no-extra --no-cpu-baseline > $O/bench_steps200.json 2>/dev/null || exit 1
+# (the same with the first fused level pinned to 3: the sample pass of round 4's shape — six rows — with this round's checks)
+PYITD_FUSE_LEVEL=3 timeout -k 10 300 python bench.py --steps 100 --no-extra --no-cpu-baseline > $O/bench_first_fused_level3.json 2>/dev/null || exit 1
 ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof.err ) || exit 1
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && cut -c1-160 $O/kernel_stats.csv | head -8
 bash tools/traffic.sh $tag > $O/traffic_summary.txt 2>&1; tail -1 $O/traffic_summary.txt | cut -c1-400
@@ -23,7 +25,7 @@ timeout -k 10 600 python tools/fuzz_parity.py batch 1500 604 > $O/fuzz_1500_batc
 bash tools/suite_modes.sh $tag || exit 1
 python - <<PY
 import json
-for f in ("bench_default_form", "bench_steps200", "bench_under_rocprof"):
+for f in ("bench_default_form", "bench_steps200", "bench_first_fused_level3", "bench_under_rocprof"):
     d = json.load(open("$O/%s.json" % f)); r = d["roofline"]
     print(f, d["ms_per_step"], r["frac"], r["avg_launch_us"], r["level0_launch_us"], r["extract_launch_us"], r["knot_side_us"])
 PY
