@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 9
+#define ITD_ABI_VERSION 10
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -423,6 +423,24 @@ int itd_baseline_extract_spline2_f64(itd_engine *e, const double *x_dev, int64_t
                                      int64_t rot_stride, int32_t *knots_host, int32_t *baseline_knots_host, void *stream);
 int itd_subtract_f64(itd_engine *e, const double *a_dev, const double *b_dev, double *out_dev, int64_t count, void *stream);
 int itd_copy(itd_engine *e, void *dst, const void *src, int64_t bytes, int32_t kind, int32_t wait, void *stream);
+/* MEITD's whole selection loop (MEITD.py:395-534 with retrieve_proper_rotation :344-368 and determine_if_first_is_proper_rotation
+ * :371-392) on ONE device-resident signal of 3 .. 8192 samples as one launch of one workgroup (ABI revision 10): the extractions,
+ * extrema counts and entropy tests above run behind one another on the device and the branch is taken there — no host round trip
+ * per operator (the host-driven loop: ~107 of them for a 3000-sample signal).  Only where the engine's solver setting gives the
+ * parallel-in-knots form for such a signal (ITD_SPLINE_PARALLEL, or ITD_SPLINE_AUTO and n >= 1024); otherwise ITD_ERR_INVALID_ARG.
+ * rows_dev: (6 + 2 * 22) rows of n float64 in one allocation — rows 0..5 working rows (the signal in row 5 on entry), rows 6..27
+ * the kept rotations taken off the signal ("high", MEITD.py:447), rows 28..49 those taken off its baselines ("low", :450).
+ * wpemax: MEITD's WPEMAX.  result_host[8]: status, number of high rows, number of low rows, the working row that holds the
+ * residual, entropy probes taken, extractions run, turns of the loop, 0.  status 0: delivered; 1: the signal has fewer than four
+ * extrema (MEITD.py:411-413 returns zeros and the data); 2 (a NaN in a row), 3 (an extraction met fewer than two knots: scipy
+ * raises there), 4 (more than 1024 probes): NOT delivered — run the loop from the host, which reproduces the reference's behaviour
+ * for those.  probe_log_host (log_cap entries of 88 bytes: double w[6]; int32 c[6]; int32 count; int32 0; double entropy): every
+ * entropy probe's six weighted sums, window counts, extrema count and the normalised entropy the device drew from them with its
+ * own log2 — the caller re-draws each with the reference's numpy expression and compares the threshold test
+ * (wpe < WPEMAX and not wpe < 0.2, MEITD.py:364 / :387), the only use an entropy has: selections identical to the reference's by
+ * construction, not by the two log2 agreeing.  Synchronous. */
+int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpemax, int32_t *result_host, void *probe_log_host,
+                        int32_t log_cap, void *stream);
 /* crossways_itd_baseline_extract(data), siftED2D.ipynb cell 1, for `planes` images of rows x cols float64 (the ensemble
  * members of retrieve_statistical_image_component go through in one call): the operator over every row, then over every
  * column of that; over every column, then every row of that; the mean of the two.  Transposes and the mean run on the GPU. */

@@ -17,7 +17,7 @@ HEADERS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) + glob.glob(os.
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -59,6 +59,7 @@ ABI = {
     "itd_baseline_extract_spline2_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_subtract_f64": (_INT, [_P, _P, _P, _P, _I64, _P]),
     "itd_copy": (_INT, [_P, _P, _P, _I64, _I32, _I32, _P]),
+    "itd_meitd_small_f64": (_INT, [_P, _P, _I64, ctypes.c_double, _P, _P, _I32, _P]),
     "itd_crossways_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "itd_crossways_host_f64": (_INT, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "itd_instantaneous_f64": (_INT, [_P, _P, _I64, _P, _P, _P, _P]),

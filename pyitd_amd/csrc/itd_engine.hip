@@ -32,6 +32,7 @@
 #include "itd_spline.hpp"
 #include "itd_nak.hpp"
 #include "itd_wpe.hpp"
+#include "itd_meitd.hpp"
 
 #ifndef ITD_TILE
 #define ITD_TILE 512
@@ -80,9 +81,9 @@ __global__ void k_verdict(SigState *__restrict__ state, int batch, const KfSig *
             if (lend < 0) fail |= kKfFailCapacity;
             // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
             if (!fail && (ks.natural ? ks.m_exact >= 2 : ks.m_exact < 2)) fail |= kKfFailVerify;
-            // the levels' knot counts — what the stop rules were drawn from — as the sample pass's verified flag words have them; a level
-            // that was decomposed had at least 2 (ITD.py:404)
-            for (int j = L0; !fail && j <= lend; ++j) if (ks.m_chk[j] != ks.mlev[j] || (j > L0 && ks.mlev[j] < 2)) fail |= kKfFailVerify;
+            // (the levels' knot counts — what the stop rules were drawn from — the sample pass has compared with its verified flag words'.)
+            // A level that was decomposed had at least 2 knots (ITD.py:404)
+            for (int j = L0; !fail && j <= lend; ++j) if (j > L0 && ks.mlev[j] < 2) fail |= kKfFailVerify;
             if (fail) st.kf_fail = fail;
             else {
                 for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
@@ -218,6 +219,8 @@ struct itd_engine {
     int32_t resident_repeats = 0;   // how often itd_get_summary had to repeat a resident call level by level
     bool resident_attr[12] = {};
     bool nak_small_attr = false;    // hipFuncSetAttribute done for k_nak_small<true>
+    bool meitd_attr[2] = {};        // ... for k_meitd_small<false / true>
+    void *h_meitd_log = nullptr, *d_meitd_log = nullptr;   // k_meitd_small's probe log: mapped pinned host memory (kMeitdLogCap entries)
     // a few scalars per call come back to the host in MEITD's operators (counts, six sums): 256 bytes of pinned host memory that the
     // GPU writes directly (mapped, coherent) — no copy behind the launch, just the stream's synchronisation (a pageable destination
     // cost ~15 us per call: 110 calls per MEITD run)
@@ -1064,6 +1067,7 @@ void itd_engine_destroy(itd_engine *e)
     if (e->h_kf) (void)hipHostFree(e->h_kf);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
     if (e->h_small) (void)hipHostFree(e->h_small);
+    if (e->h_meitd_log) (void)hipHostFree(e->h_meitd_log);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (int k = 0; k < 3; ++k) {
@@ -1264,9 +1268,9 @@ void kf_verdict(itd_engine *e, int B)
         if (lend < 0) fail |= kKfFailCapacity;      // the steps never reached a stop rule (cannot happen: they run to max_iteration + 1)
         // the last pending baseline feeds only the stop test (ITD.py:400-404): its exact count must take the same side of 2
         if (!fail && (ks.natural ? ks.m_exact >= 2 : ks.m_exact < 2)) fail |= kKfFailVerify;
-        // the levels' knot counts — what the stop rules were drawn from — as the sample pass's verified flag words have them; a level
-        // that was decomposed had at least 2 (ITD.py:404)
-        for (int j = L0; !fail && j <= lend; ++j) if (ks.m_chk[j] != ks.mlev[j] || (j > L0 && ks.mlev[j] < 2)) fail |= kKfFailVerify;
+        // (the levels' knot counts — what the stop rules were drawn from — the sample pass has compared with its verified flag words'.)
+        // A level that was decomposed had at least 2 knots (ITD.py:404)
+        for (int j = L0; !fail && j <= lend; ++j) if (j > L0 && ks.mlev[j] < 2) fail |= kKfFailVerify;
         if (fail) { st.kf_fail = fail; continue; }
         for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
         st.m[lend + 1] = ks.m_exact;
@@ -2244,12 +2248,12 @@ bool small_results(itd_engine *e)
 // a fault): the stream's status is what the caller gets then.
 constexpr int kSmallFlag = 63;
 int32_t small_next(itd_engine *e) { e->small_seq = e->small_seq == INT32_MAX ? 1 : e->small_seq + 1; return e->small_seq; }
-int small_wait(itd_engine *e, int32_t seq, hipStream_t st)
+int small_wait(itd_engine *e, int32_t seq, hipStream_t st, int poll_ms = 2)
 {
     volatile int32_t *flag = (volatile int32_t *)e->h_small + kSmallFlag;
     const auto t0 = std::chrono::steady_clock::now();
     for (int spin = 0; *flag != seq; ++spin) {
-        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(poll_ms)) {
             HIP_TRY(e, hipStreamSynchronize(st));
             break;
         }
@@ -2485,6 +2489,54 @@ int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weig
     for (int b = 0; b < 6; ++b) { bin_weights_host[b] = res.s[b]; bin_windows_host[b] = (int64_t)res.c[b]; }
     if (knots_host) *knots_host = res.k[0];
     return knots_host && res.k[1] ? ITD_ERR_NONFINITE : ITD_OK;
+}
+
+// MEITD's whole selection loop on one short device-resident signal as one launch (itd_meitd.hpp: k_meitd_small).  Synchronous.
+int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpemax, int32_t *result_host, void *probe_log_host,
+                        int32_t log_cap, void *stream)
+{
+    if (!e || !rows_dev || !result_host || n < 3 || n > kNakSmallMax || log_cap < 0 || (log_cap > 0 && !probe_log_host)) return ITD_ERR_INVALID_ARG;
+    // (only where the host-driven loop's extractions take the same operator: the parallel-in-knots form of one signal)
+    if (!(e->spline_solver == ITD_SPLINE_PARALLEL || (e->spline_solver == ITD_SPLINE_AUTO && n >= 1024))) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    const int64_t L = n + 2;
+    const size_t idx_b = (((size_t)L * sizeof(int32_t)) + 255) & ~(size_t)255, out_b = 256;
+    int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + 6 * (size_t)L * sizeof(double));
+    if (rc) return rc;
+    if (!small_results(e)) return ITD_ERR_NOMEM;
+    if (!e->h_meitd_log) {
+        if (hipHostMalloc(&e->h_meitd_log, kMeitdLogCap * sizeof(MeitdProbe), hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError(); e->h_meitd_log = nullptr; return ITD_ERR_NOMEM;
+        }
+        HIP_TRY(e, hipHostGetDevicePointer(&e->d_meitd_log, e->h_meitd_log, 0));
+    }
+    int32_t *idx = (int32_t *)((char *)e->d_cub + out_b);
+    double *arr = (double *)((char *)e->d_cub + out_b + idx_b);
+    const int32_t seq = small_next(e);
+    int32_t *flag = (int32_t *)e->d_small + kSmallFlag;
+    const size_t nak_lds = 4 * (size_t)L * sizeof(double);
+    const bool in_lds = nak_lds <= kNakSmallLdsMax;
+    const size_t lds = in_lds && nak_lds > kMeitdWpeLds ? nak_lds : kMeitdWpeLds;   // the two operators take turns in the same bytes
+    if (!e->meitd_attr[in_lds]) {
+        const void *fn = in_lds ? reinterpret_cast<const void *>(&k_meitd_small<true>) : reinterpret_cast<const void *>(&k_meitd_small<false>);
+        HIP_TRY(e, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(in_lds ? kNakSmallLdsMax : kMeitdWpeLds)));
+        e->meitd_attr[in_lds] = true;
+    }
+    if (in_lds)
+        k_meitd_small<true><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
+                                                               (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
+    else
+        k_meitd_small<false><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
+                                                                (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
+    HIP_TRY(e, hipGetLastError());
+    rc = small_wait(e, seq, st, 50);             // (a whole loop: a few milliseconds)
+    if (rc) return rc;
+    if (*((volatile int32_t *)e->h_small + kSmallFlag) != seq) { snprintf(e->err, sizeof(e->err), "k_meitd_small did not finish"); return ITD_ERR_HIP; }
+    memcpy(result_host, e->h_small, sizeof(MeitdOut));
+    const int32_t got = result_host[4] < log_cap ? result_host[4] : log_cap;
+    if (got > 0) memcpy(probe_log_host, e->h_meitd_log, (size_t)(got < kMeitdLogCap ? got : kMeitdLogCap) * sizeof(MeitdProbe));
+    return ITD_OK;
 }
 
 // weighted_permutation_entropy's pass over the samples for any order 2 .. 5: sums_host / windows_host [order^order], indexed by the

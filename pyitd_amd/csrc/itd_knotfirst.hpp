@@ -118,8 +118,6 @@ struct KfSig {
     int32_t m_exact;      // knots of the last pending baseline, counted by the sample pass
     int32_t pad0[3];
     int32_t mlev[kMaxLevels + 2];   // knots of level j's input
-    int32_t m_chk[kMaxLevels + 2];  // the same counted by the sample pass's check wavefronts from the flag words it verifies (the stop rules
-                                    // are drawn from mlev: the verdict requires the two to agree, level by level)
     // ---- the knot side's accumulators: zero between calls (the signal's last workgroup reads and clears them; the workspace starts
     //      zeroed), so no launch has to prepare them ----
     int32_t acc_mlev[kMaxLevels + 2];
@@ -132,7 +130,7 @@ struct KfSig {
     uint32_t seq;         // the generation in the tags of a call's records: bumped by the signal's last workgroup
     uint32_t pad2;
 };
-constexpr size_t kKfSigHead = (8 + 2 * (kMaxLevels + 2)) * sizeof(int32_t);
+constexpr size_t kKfSigHead = (8 + (kMaxLevels + 2)) * sizeof(int32_t);
 static_assert(offsetof(KfSig, acc_mlev) == kKfSigHead, "KfSig layout");
 
 // what the knot side's launch needs to do k_finalize's work (itd_kernels.hpp) for the hand-over level: the stop test of that level's
@@ -821,7 +819,6 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             for (int j = 0; j < kMaxLevels + 2; ++j) {
                 ks->mlev[j] = __hip_atomic_load(&ks->acc_mlev[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ks->acc_mlev[j] = 0;
-                ks->m_chk[j] = 0;
             }
             ks->fail = fail;
             ks->m_exact = 0;
@@ -860,8 +857,8 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
 //       end (first[t+1] == first[t] + kn), so entry 0 / kn+1 of a run is physically the entry its owner tile verifies — the nearest
 //       knot in front of / behind the tile; across two slabs the next slab's copy of the knot in front of it and this slab's copy
 //       of the knot behind it are compared with the owners' entries bit for bit, all four fields (the check wavefronts).
-//   counts  the levels' knot counts (what the knot side's stop rules read) are counted again by the check wavefronts from the verified
-//       flag words (KfSig::m_chk); the verdict (kf_verdict / k_verdict) requires them to agree with the knot side's, level by level.
+//   counts  the levels' knot counts (what the knot side's stop rules read: KfSig::mlev) are counted again from the verified flag words
+//       — one more check wavefront sums what the slabs' chained runs hold, a slab per lane — and have to agree, level by level.
 // Every field of every entry a tile uses is thereby checked by its owner or equals, through a chain of bitwise equalities, an
 // entry that is; any mismatch refuses the signal (kKfFailVerify).  tests/test_gpu_fused.py injects faults into every one of
 // these (itd_debug_kf_fault) and requires the refusal.
@@ -875,7 +872,7 @@ __device__ __forceinline__ int ne_d(double a, double b)
 __device__ __forceinline__ int ne_i(int32_t a, int32_t b) { return a ^ b; }
 // workgroups of the sample pass's grid that verify the tables (V2, V3), in front of the tiles': one per knot-side workgroup,
 // padded to a multiple of 8 so that a tile's workgroup lands on the same XCD as in every other launch (xcd_item)
-__host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 7) & ~7; }
+__host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 1 + 7) & ~7; }     // (+ 1: the wavefront that sums the slabs' counts)
 #ifndef ITD_KF_APPLY_WAVES
 #define ITD_KF_APPLY_WAVES 8      // wavefronts per SIMD the sample pass is compiled for (0 = the compiler's choice; 8: 64 VGPRs, no spill; fused from
                                   // level 2 at 2^24: 181.9 us at 6, 177.1 at 7, 176.3 at 8 — profiles/r05/ab_sample_pass_occupancy.txt)
@@ -884,7 +881,7 @@ __host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 7) & 
 #define ITD_KF_FASTGROUP 1        // A/B builds: 0 = every 128-sample group takes the by-rank path
 #endif
 #ifndef ITD_KF_VERIFY
-#define ITD_KF_VERIFY 15          // timing-only A/B builds: bit k = check Vk is compiled in (the shipped build: all four)
+#define ITD_KF_VERIFY 31          // timing-only A/B builds: bit k = check Vk is compiled in, bit 4 = the levels' knot counts (the shipped build: all)
 #endif
 template <int TW, int CAP, bool BASES>      // BASES: the caller wants the baselines too (get_baselines()): a second row store per level
 __global__ __launch_bounds__(kWave)
@@ -916,6 +913,35 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         //      two slabs   (the first knot at or behind its first sample) this slab's entry cnt + 1: all four fields, bit for bit.
         if (!(ITD_KF_VERIFY & 12)) return;
         const int w = (int)blockIdx.x;
+        if (w == ws.wgs && (ITD_KF_VERIFY & 16)) {
+            // the levels' knot counts: the stop rules and the rows' number are drawn from the knot side's mlev[] — it has to be the
+            // population of the flag words verified here.  A slab per lane: what its chained runs hold (the slab's own wavefront checks
+            // the chain: first[last tile] + that tile's population - first[first tile]), summed over the slabs, level by level.  (Added
+            // up by the slabs' wavefronts with one atomic each the same sum cost the launch 27 us: 3 584 read-modify-writes behind a
+            // memory system full of the tiles' stores — profiles/r05/experiments.)
+            int vb = 0;
+            for (int li = 0; li <= lend - ws.L0; ++li) {
+                const int32_t *firstl = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;
+                const unsigned long long *tfl = ws.tflags + ((size_t)sig * ws.nlev + li) * n_tiles * 8;
+                int tot = 0;
+                for (int wb = 0; wb < ws.wgs; wb += kWave) {
+                    const int a = (wb + lane) * ws.tpw, b = min(n_tiles, a + ws.tpw);
+                    if (wb + lane < ws.wgs && a < b) {
+                        using U2 = unsigned long long __attribute__((ext_vector_type(2)));
+                        const U2 *wp = reinterpret_cast<const U2 *>(tfl + (size_t)(b - 1) * 8);
+                        int kt = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const U2 v = wp[q]; kt += __popcll(v.x) + __popcll(v.y); }
+                        tot += firstl[b - 1] + kt - firstl[a];
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+                vb |= ne_i(tot, ks->mlev[ws.L0 + li]);
+            }
+            if (vb != 0 && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+            return;
+        }
         if (w >= ws.wgs) return;                                 // (the blocks that only pad the count to a multiple of 8)
         const int t0 = w * ws.tpw, t1 = min(n_tiles, t0 + ws.tpw);
         const KfEntry *pool = ws.pool + (size_t)sig * ws.wgs_max * kKcSlab;
@@ -942,7 +968,6 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             const int l_last = t1 - 1 - tb;                      // the lane of the range's last tile, if it is in this round
             if (l_last < kWave) cnt = __shfl(f + kt, l_last) - start;
         }
-        if (lane == 0 && cnt > 0) atomicAdd(&ks->m_chk[ws.L0 + li], cnt);      // the level's knots as the verified words have them
         if (start < 0 || cnt < 0 || start + cnt + 2 > pool_n || (t1 < n_tiles && (f_next < 0 || f_next + 2 > pool_n))) vb = 1;
         else if (ITD_KF_VERIFY & 4) {
             const KfEntry *e = pool + start;

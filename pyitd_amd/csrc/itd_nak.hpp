@@ -161,16 +161,16 @@ __global__ __launch_bounds__(64) void k_nak_backward(CubicArgs A, const double *
 // 3000-sample signal; signals whose worst case does not fit (n > ~4900) keep them in global memory.
 constexpr int kNakSmallMax = 8192, kNakSmallThreads = 1024, kNakSmallPer = kNakSmallMax / kNakSmallThreads;
 constexpr size_t kNakSmallLdsMax = 156 * 1024;
+// The operator's body, for the kNakSmallThreads threads of one workgroup (k_nak_small below; k_meitd_small, itd_meitd.hpp, runs it
+// once per extraction of its loop).  s_dyn: 4 x (n + 2) doubles of LDS when LDS.  Comes back with res = {knots, NaN seen, valid,
+// knots of the produced baseline (want_bcount)} in every thread.  The caller puts a barrier between two uses.
 template <bool LDS>
-__global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__restrict__ x, int n, int min_extrema, int32_t *__restrict__ e,
-                                                               double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
-                                                               double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
-                                                               double *__restrict__ base, double *__restrict__ rot, int want_bcount,
-                                                               int32_t *__restrict__ out /* knots, NaN flag, valid, knots of the produced baseline */,
-                                                               int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
-                                                               /* done_flag (host-mapped): set to done_seq behind the last of `out`'s words — the host polls it */)
+__device__ __forceinline__ void nak_small_body(const double *__restrict__ x, int n, int min_extrema, int32_t *__restrict__ e,
+                                               double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
+                                               double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
+                                               double *__restrict__ base, double *__restrict__ rot, int want_bcount,
+                                               double *__restrict__ s_dyn, int (&res)[4])
 {
-    extern __shared__ double s_dyn[];
     double *const subv = LDS ? s_dyn : subg, *const rhsv = LDS ? s_dyn + (n + 2) : rhsg;
     double *const cpv = LDS ? s_dyn + 2 * (n + 2) : cpg, *const dpv = LDS ? s_dyn + 3 * (n + 2) : dpg;
     __shared__ int s_wave[kNakSmallThreads / 64], s_flag[4];
@@ -218,11 +218,10 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__
     __syncthreads();                                      // (also: s_flag[0] is complete)
     const int m = knots + 2;
     const bool valid = knots >= min_extrema && knots >= 2;
-    if (tid == 0) { out[0] = knots; out[1] = s_flag[0]; out[2] = valid ? 1 : 0; out[3] = 0; }
+    res[0] = knots; res[1] = s_flag[0]; res[2] = valid ? 1 : 0; res[3] = 0;
     if (!valid) {                                         // fewer knots than the operator needs: the signal is its own baseline
         for (int i = lo; i < hi; ++i) { base[i] = x[i]; if (rot) rot[i] = 0.0; }
-        if (want_bcount && tid == 0) out[3] = knots;      // (the baseline IS the signal)
-        if (tid == 0 && done_flag) { __threadfence_system(); *done_flag = done_seq; }
+        if (want_bcount) res[3] = knots;                  // (the baseline IS the signal)
         return;
     }
     for (int k = tid; k < m; k += kNakSmallThreads) K[k] = spline_knot_value(x, n, e, m, k);
@@ -292,9 +291,26 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__
         bool nn = false;
         int total;
         (void)block_scan(__popc(knot_mask(base, nn)), total);
-        if (tid == 0) out[3] = total;
+        res[3] = total;
     }
-    if (tid == 0 && done_flag) { __threadfence_system(); *done_flag = done_seq; }
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__restrict__ x, int n, int min_extrema, int32_t *__restrict__ e,
+                                                               double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
+                                                               double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
+                                                               double *__restrict__ base, double *__restrict__ rot, int want_bcount,
+                                                               int32_t *__restrict__ out /* knots, NaN flag, valid, knots of the produced baseline */,
+                                                               int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
+                                                               /* done_flag (host-mapped): set to done_seq behind the last of `out`'s words — the host polls it */)
+{
+    extern __shared__ double s_dyn[];
+    int res[4];
+    nak_small_body<LDS>(x, n, min_extrema, e, K, dpg, M, cpg, subg, rhsg, base, rot, want_bcount, s_dyn, res);
+    if (threadIdx.x == 0) {
+        out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; out[3] = res[3];
+        if (done_flag) { __threadfence_system(); *done_flag = done_seq; }
+    }
 }
 
 }  // namespace itd

@@ -47,28 +47,25 @@ __device__ __forceinline__ void wpe3_window(double a0, double a1, double a2, uns
 // running sum one by one — the chain of additions is the reference's cumsum, only the windows of other patterns are not in the way.
 constexpr int kWpeChunk = 4096;
 constexpr int kWpeThreads = 256;
-// part_k (optional): per segment, the number of windows whose MIDDLE sample is a knot of x (ITD.py:59 on x and on -x, raw
-// differences: what the count-only detection counts for samples 1 .. n-2) and whether a sample of the segment's windows is a NaN
-__global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__ x, int64_t nw, int64_t seg_len, double *__restrict__ part_s,
-                                                      long long *__restrict__ part_c, int *__restrict__ part_k,
-                                                      int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
-                                                      /* one segment, results in host-mapped words: set to done_seq behind them (the host polls) */)
+// The pass over the windows lo .. hi-1 of x by the NT threads of one workgroup (s_x: kWpeChunk + 2 doubles, s_l: kWpeChunk doubles of
+// LDS).  Threads 0..5 come back with their pattern's sum and window count in (s, c); every thread with its share of kn — the number
+// of windows whose MIDDLE sample is a knot of x (ITD.py:59 on x and on -x, raw differences: what the count-only detection counts for
+// samples 1 .. n-2) — and nanf, whether it saw a NaN.  The order of every pattern's additions does not depend on NT.
+template <int NT>
+__device__ __forceinline__ void wpe3_pass(const double *__restrict__ x, int64_t lo, int64_t hi, double *__restrict__ s_x, double *__restrict__ s_l,
+                                          double &s, long long &c, int &kn, int &nanf)
 {
-    static_assert(kWpeChunk % kWpeThreads == 0 && kWpeChunk < 65536, "three 16-bit counts per word");
-    __shared__ double s_x[kWpeChunk + 2], s_l[kWpeChunk];
-    __shared__ unsigned long long s_wave[2][kWpeThreads / 64];
-    __shared__ int s_kn[2];
-    if (threadIdx.x < 2) s_kn[threadIdx.x] = 0;
-    int kn = 0, nanf = 0;
-    const int64_t lo = (int64_t)blockIdx.x * seg_len, hi = lo + seg_len < nw ? lo + seg_len : nw;
+    static_assert(kWpeChunk % NT == 0 && kWpeChunk < 65536, "three 16-bit counts per word");
+    __shared__ unsigned long long s_wave[2][NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double s = 0.0;                    // (0.0 + w == w: a variance is never -0.0)
-    long long c = 0;
+    s = 0.0;                           // (0.0 + w == w: a variance is never -0.0)
+    c = 0;
+    kn = 0; nanf = 0;
     for (int64_t base = lo; base < hi; base += kWpeChunk) {
         const int m = (int)(hi - base < kWpeChunk ? hi - base : kWpeChunk);
-        for (int k = tid; k < m + 2; k += kWpeThreads) s_x[k] = x[base + k];
+        for (int k = tid; k < m + 2; k += NT) s_x[k] = x[base + k];
         __syncthreads();
-        const int run = (m + kWpeThreads - 1) / kWpeThreads, k0 = tid * run < m ? tid * run : m, k1 = k0 + run < m ? k0 + run : m;
+        const int run = (m + NT - 1) / NT, k0 = tid * run < m ? tid * run : m, k1 = k0 + run < m ? k0 + run : m;
         // patterns 0..2 count in the 16-bit fields of a, 3..5 in those of b
         unsigned long long a = 0ull, b = 0ull;
         for (int k = k0; k < k1; ++k) {
@@ -92,7 +89,7 @@ __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__
         __syncthreads();
         unsigned long long ta = 0ull, tb = 0ull, pa = ia - a, pb = ib - b;      // totals; this thread's places
 #pragma unroll
-        for (int q = 0; q < kWpeThreads / 64; ++q) {
+        for (int q = 0; q < NT / 64; ++q) {
             if (q < wave) { pa += s_wave[0][q]; pb += s_wave[1][q]; }
             ta += s_wave[0][q]; tb += s_wave[1][q];
         }
@@ -124,6 +121,24 @@ __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__
         }
         __syncthreads();
     }
+}
+
+// part_k (optional): per segment, the number of windows whose middle sample is a knot of x and whether a sample of the segment's
+// windows is a NaN
+__global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__ x, int64_t nw, int64_t seg_len, double *__restrict__ part_s,
+                                                      long long *__restrict__ part_c, int *__restrict__ part_k,
+                                                      int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
+                                                      /* one segment, results in host-mapped words: set to done_seq behind them (the host polls) */)
+{
+    __shared__ double s_x[kWpeChunk + 2], s_l[kWpeChunk];
+    __shared__ int s_kn[2];
+    if (threadIdx.x < 2) s_kn[threadIdx.x] = 0;
+    int kn, nanf;
+    const int64_t lo = (int64_t)blockIdx.x * seg_len, hi = lo + seg_len < nw ? lo + seg_len : nw;
+    const int tid = threadIdx.x;
+    double s;
+    long long c;
+    wpe3_pass<kWpeThreads>(x, lo, hi, s_x, s_l, s, c, kn, nanf);
     if (tid < 6) {
         part_s[(size_t)blockIdx.x * 6 + tid] = s;
         part_c[(size_t)blockIdx.x * 6 + tid] = c;

@@ -394,6 +394,16 @@ class Engine:
                                                              _np_ptr(k), _np_ptr(bk), stream))
         return (int(k[0]), int(bk[0])) if want_baseline_knots else int(k[0])
 
+    MEITD_PROBE = np.dtype([("w", np.float64, 6), ("c", np.int32, 6), ("count", np.int32), ("pad", np.int32), ("wpe", np.float64)])
+
+    def meitd_small_dev(self, rows_ptr, n, wpemax, stream=None):
+        """MEITD's selection loop on the device rows at rows_ptr (include/pyitd_hip.h: itd_meitd_small_f64; the signal in row 5):
+        returns (result[8] = status, high rows, low rows, residual's row, probes, extractions, turns, 0; the probes' log)."""
+        res = np.zeros(8, np.int32)
+        log = np.zeros(1024, self.MEITD_PROBE)
+        self._check(self._L.itd_meitd_small_f64(self._h, rows_ptr, n, float(wpemax), _np_ptr(res), _np_ptr(log), len(log), stream))
+        return res, log[:min(int(res[4]), len(log))]
+
     def subtract_dev(self, a_ptr, b_ptr, out_ptr, count, stream=None):
         self._check(self._L.itd_subtract_f64(self._h, a_ptr, b_ptr, out_ptr, count, stream))
 

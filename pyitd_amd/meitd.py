@@ -70,6 +70,9 @@ class _Work:
         self.buf = DeviceBuffer((6 + 2 * _ROWS_KEPT) * n * 8, device)
         self.free_rows = [self.row(i) for i in range(6)]
         self.high0, self.low0 = self.row(6), self.row(6 + _ROWS_KEPT)
+        # the whole loop as one launch: where an extraction of this signal is the one-workgroup parallel-in-knots operator anyway
+        self.one_launch = 3 <= n <= _ONE_LAUNCH_MAX and (solver == "parallel" or (solver == "auto" and n >= 1024))
+        self.last = {}
 
     def row(self, i):
         return self.buf.ptr + i * self.n * 8
@@ -216,8 +219,53 @@ def determine_if_first_is_proper_rotation(x, WPEMAX, device=0, solver="auto"):
     return r, b, proper
 
 
+_ONE_LAUNCH_MAX = 8192      # itd_meitd_small_f64: one workgroup holds the signal's run
+
+
+def _proper_rows(log, WPEMAX):
+    """the threshold test of every logged probe, from entropies re-drawn with the reference's numpy expression (_entropy_from_bins)"""
+    full = (log["c"] > 0).all(axis=1)
+    wpe = numpy.empty(len(log))
+    if full.any():                    # (all six patterns present: the same numpy operations row by row, in one call)
+        w = log["w"][full]
+        p = numpy.true_divide(w, w.sum(axis=1)[:, None])
+        pe = -numpy.multiply(p, numpy.log2(p)).sum(axis=1)
+        pe /= numpy.log2(factorial(3))
+        wpe[full] = pe
+    for i in numpy.flatnonzero(~full):
+        wpe[i] = _entropy_from_bins(log["w"][i], log["c"][i], 3, True)
+    return (wpe < WPEMAX) & ~(wpe < 0.2)
+
+
+def _meitd_one_launch(wk, data, WPEMAX):
+    """The loop as ONE launch (include/pyitd_hip.h: itd_meitd_small_f64; csrc/itd_meitd.hpp).  Returns "host" when the device did not
+    deliver — a NaN, an extraction scipy would refuse, a threshold test that numpy's log2 and the device's draw differently: the
+    host-driven loop below then runs the call and reproduces the reference's behaviour —, else what _meitd returns."""
+    wk.upload(data, wk.row(5))
+    res, log = wk.eng.meitd_small_dev(wk.buf.ptr, wk.n, WPEMAX)
+    status = int(res[0])
+    wk.last = {"one_launch": True, "status": status, "probes": int(res[4]), "extractions": int(res[5]), "turns": int(res[6])}
+    if status >= 2:
+        return "host"
+    if len(log):
+        wd = log["wpe"]
+        if not numpy.array_equal(_proper_rows(log, WPEMAX), (wd < WPEMAX) & ~(wd < 0.2)):
+            wk.last["status"] = -1
+            return "host"
+    if status == 1:
+        return None
+    x = wk.row(int(res[3]))
+    wk.free_rows.remove(x)
+    return int(res[1]), int(res[2]), x
+
+
 def _meitd(wk, data, WPEMAX):
     """MEITD.py:395-534 on device rows.  Returns (n_high, n_low, row of the residual) or None for the early return of :411-413."""
+    if getattr(wk, "one_launch", False):
+        r = _meitd_one_launch(wk, data, WPEMAX)
+        if not isinstance(r, str):
+            return r
+        wk.reset()
     x, rotation, baseline = wk.take(), wk.take(), wk.take()
     wk.upload(data, x)
     n_high = n_low = 0

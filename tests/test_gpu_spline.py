@@ -291,6 +291,92 @@ def test_meitd_keeps_its_arrays_on_the_device(P):
     assert len(lo) + len(hi) == 21
 
 
+def _meitd_both_ways(meitd, x, wpemax=0.6):
+    """MEITD(x) as one launch and as the host-driven loop (the same operators, one launch each): results and operator counts"""
+    got = meitd.MEITD(x.copy(), WPEMAX=wpemax)
+    wk = meitd._work_for(len(x), 0)
+    last = dict(wk.last)
+    calls = {"extract": 0, "probe": 0}
+    orig = {k: getattr(wk, k) for k in calls}
+
+    def counted(k):
+        def f(*a, **kw):
+            calls[k] += 1
+            return orig[k](*a, **kw)
+        return f
+
+    for k in calls:
+        setattr(wk, k, counted(k))
+    wk.one_launch = False
+    try:
+        ref = meitd.MEITD(x.copy(), WPEMAX=wpemax)
+    finally:
+        wk.one_launch = True
+        for k in calls:
+            delattr(wk, k)
+    return got, ref, last, calls
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(SPLINE) if f.startswith("meitd_")))
+def test_meitd_as_one_launch_equals_the_host_driven_loop(P, name):
+    """itd_meitd_small_f64 (csrc/itd_meitd.hpp): the whole loop of MEITD.py:395-534 in one launch — the same extractions, counts and
+    entropy sums as the host-driven loop's launches, the branch taken on the device: the same components bit for bit, the same number
+    of extractions and probes, and every logged threshold test re-drawn with numpy agrees (else the call would have gone to the host)."""
+    from pyitd_amd import meitd
+    x = np.load(os.path.join(SPLINE, name + ".npz"))["x"]
+    got, ref, last, calls = _meitd_both_ways(meitd, x)
+    assert last.get("one_launch") and last["status"] == 0, last
+    assert last["extractions"] == calls["extract"] and last["probes"] == calls["probe"], (last, calls)
+    for a, b, what in zip(got, ref, ("high", "low", "residual")):
+        assert a.shape == b.shape and np.array_equal(a, b), "%s: %s differs from the host-driven loop" % (name, what)
+
+
+@pytest.mark.parametrize("n, seed, wpemax", [(1024, 11, 0.6), (2048, 12, 0.45), (4800, 13, 0.6), (5000, 14, 0.7), (8192, 15, 0.6)])
+def test_meitd_as_one_launch_on_other_signals(P, n, seed, wpemax):
+    """the one-launch loop on other lengths (4800: the last one whose solver arrays fit LDS; 5000, 8192: arrays in global memory) and
+    thresholds"""
+    from pyitd_amd import meitd
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 1000.0
+    x = np.sin(2 * np.pi * 3.0 * t) * (1.0 + 0.5 * np.sin(2 * np.pi * 0.4 * t)) + 0.3 * np.sin(2 * np.pi * 41.0 * t + 1.0) + 0.1 * rng.standard_normal(n)
+    got, ref, last, calls = _meitd_both_ways(meitd, x, wpemax)
+    assert last.get("one_launch") and last["status"] == 0, last
+    assert last["extractions"] == calls["extract"] and last["probes"] == calls["probe"], (last, calls)
+    for a, b, what in zip(got, ref, ("high", "low", "residual")):
+        assert a.shape == b.shape and np.array_equal(a, b), what
+
+
+def test_meitd_one_launch_hands_over_what_it_does_not_model(P):
+    """a NaN in the signal, fewer than four extrema, and a signal below the solver's threshold: the one-launch loop reports / is not
+    taken, and the call behaves like the host-driven loop"""
+    from pyitd_amd import meitd
+    from pyitd_amd._lib import ITDError
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(2000)
+    x[777] = np.nan
+    with pytest.raises(ITDError) as ei:
+        meitd.MEITD(x.copy())
+    assert meitd._work_for(len(x), 0).last["status"] == 2
+    wk = meitd._work_for(len(x), 0)
+    wk.one_launch = False
+    try:
+        with pytest.raises(ITDError) as ej:
+            meitd.MEITD(x.copy())
+    finally:
+        wk.one_launch = True
+    assert ei.value.status == ej.value.status
+    ramp = np.linspace(-1.0, 2.0, 1500)
+    hi, lo, res = meitd.MEITD(ramp.copy())
+    assert meitd._work_for(len(ramp), 0).last["status"] == 1
+    assert not hi.any() and not lo.any() and np.array_equal(res, ramp)
+    short = rng.standard_normal(600)
+    meitd.MEITD(short.copy())
+    assert not meitd._work_for(len(short), 0).one_launch
+    got = meitd.MEITD(short.copy(), solver="parallel")
+    assert meitd._work_for(len(short), 0, "parallel").last.get("one_launch")
+    assert abs((got[0].sum(0) + got[1].sum(0) + got[2]) - short).max() < 1e-9
+
+
 @pytest.mark.parametrize("n, seed", [(500, 1), (2048, 2), (20000, 3), (70000, 4)])
 def test_meitd_on_other_signals_matches_the_flow_over_the_oracles_operators(P, n, seed):
     """MEITD on signals the goldens do not cover (lengths from 500 samples to beyond the entropy's exact-order limit of 65536 windows):

@@ -16,6 +16,16 @@ for name in sorted(f for f in os.listdir(G) if f.startswith("meitd_")):
     for _ in range(5):
         t0 = time.perf_counter(); hi, lo, res = meitd.MEITD(x.copy()); t_gpu = min(t_gpu, time.perf_counter() - t0)
         t0 = time.perf_counter(); xi = meitd.XITD(x.copy()); t_gpu_x = min(t_gpu_x, time.perf_counter() - t0)
+    wk = meitd._work_for(len(x), 0)
+    how = dict(wk.last)
+    t_host = 1e9
+    if wk.one_launch:                           # the same call driven from the host: one launch per operator
+        wk.one_launch = False
+        try:
+            for _ in range(5):
+                t0 = time.perf_counter(); meitd.MEITD(x.copy()); t_host = min(t_host, time.perf_counter() - t0)
+        finally:
+            wk.one_launch = True
     saved = meitd._work_for
     cw = []
     meitd._work_for = lambda n, device=0, solver="auto": (cw.append(meitd_oracle.CpuWork(n)), cw[-1])[1]
@@ -24,6 +34,7 @@ for name in sorted(f for f in os.listdir(G) if f.startswith("meitd_")):
     finally:
         meitd._work_for = saved
     same = hi.shape == hi2.shape and lo.shape == lo2.shape and np.max(np.abs(res - res2)) < 1e-9
-    print("%-24s %d samples: MEITD %.2f ms on the GPU operators (XITD %.2f ms), %.1f ms over the CPU restatement's operators; "
-          "%d + %d components, %d extractions, %d entropy probes, same decisions: %s"
-          % (name[:-4], len(x), t_gpu * 1e3, t_gpu_x * 1e3, t_cpu * 1e3, len(hi), len(lo), cw[-1].calls["extract"], cw[-1].calls["probe"], same))
+    print("%-24s %d samples: MEITD %.2f ms on the GPU (XITD %.2f ms; %s), %.2f ms with one launch per operator, %.1f ms over the CPU "
+          "restatement's operators; %d + %d components, %d extractions, %d entropy probes, same decisions: %s"
+          % (name[:-4], len(x), t_gpu * 1e3, t_gpu_x * 1e3, "the loop as one launch, status %d" % how["status"] if how.get("one_launch") else
+             "one launch per operator", t_host * 1e3, t_cpu * 1e3, len(hi), len(lo), cw[-1].calls["extract"], cw[-1].calls["probe"], same))
