@@ -2502,7 +2502,8 @@ int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpema
     hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
     const int64_t L = n + 2;
     const size_t idx_b = (((size_t)L * sizeof(int32_t)) + 255) & ~(size_t)255, out_b = 256;
-    int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + 6 * (size_t)L * sizeof(double));
+    const size_t arr_b = 6 * (size_t)L * sizeof(double);
+    int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + arr_b + kMeitdLogCap * sizeof(MeitdProbe));
     if (rc) return rc;
     if (!small_results(e)) return ITD_ERR_NOMEM;
     if (!e->h_meitd_log) {
@@ -2513,6 +2514,7 @@ int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpema
     }
     int32_t *idx = (int32_t *)((char *)e->d_cub + out_b);
     double *arr = (double *)((char *)e->d_cub + out_b + idx_b);
+    MeitdProbe *dlog = (MeitdProbe *)((char *)e->d_cub + out_b + idx_b + arr_b);
     const int32_t seq = small_next(e);
     int32_t *flag = (int32_t *)e->d_small + kSmallFlag;
     const size_t nak_lds = 4 * (size_t)L * sizeof(double);
@@ -2525,10 +2527,10 @@ int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpema
     }
     if (in_lds)
         k_meitd_small<true><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                               (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
+                                                               dlog, (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
     else
         k_meitd_small<false><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                                (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
+                                                                dlog, (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
     HIP_TRY(e, hipGetLastError());
     rc = small_wait(e, seq, st, 50);             // (a whole loop: a few milliseconds)
     if (rc) return rc;

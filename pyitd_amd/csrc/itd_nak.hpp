@@ -13,9 +13,14 @@
 //     mu_i M_{i-1} + 2 M_i + lambda_i M_{i+1} = 6 f[x_{i-1}, x_i, x_{i+1}],   mu_i = h_{i-1} / (h_{i-1} + h_i),  i = 1 .. m-2
 // with the not-a-knot ends folded into the first and last row ((2 + r) M_1 + (1 - r) M_2 = d_1, r = h_0 / h_1; mirrored at the
 // other end) — a strictly diagonally dominant tridiagonal system.  Thomas' two recurrences (pivots + forward, then back
-// substitution) contract: every pair of consecutive steps damps a perturbation by at least 1/2, so a thread solves a run of
-// kNakRun consecutive unknowns exactly (to far below rounding) by starting kNakWarm steps early from zero — no inter-thread
-// exchange, every thread independent, two launches.  The result equals FITPACK's to rounding (tests: 1e-10 of the signal's
+// substitution) contract, so a thread solves a run of kNakRun consecutive unknowns exactly (to far below rounding) by starting
+// kNakWarm steps early from zero — no inter-thread exchange, every thread independent, two launches.  How far below: a step passes a
+// perturbation of dp on with the factor mu_j / den_j and one of M (going down) with lambda_j / den_j, den_j >= 3/2; mu_j =
+// 1 / (1 + rho_j) with rho_j = h_j / h_{j-1}, and over k consecutive steps the rho's multiply to h_last / h_first >= 1 / n (the
+// spacings are whole numbers of samples), so prod(1 + rho_j) >= (1 + n^(-1/k))^k.  For k = kNakWarm = 64 and n = 2^31 that is
+// 2^49.8, times (3/2)^64 = 2^37.4 from the pivots: a start error is damped by 2^-87 at least whatever the knots' spacings (the
+// pivots' own recurrence contracts by 1/9 per step) — rounding is 2^-53.  (Rounds 3-4 warmed up over 128 steps on the cruder
+// bound of 1/2 per pair of steps.)  The result equals FITPACK's to rounding (tests: 1e-10 of the signal's
 // scale against the reference-generated vectors; the north star allows 1e-6), not bit for bit: the serial form stays the one
 // the bit-level tests and the image sweeps use (itd_set_spline_solver).
 #pragma once
@@ -29,7 +34,7 @@
 
 namespace itd {
 
-constexpr int kNakRun = 32, kNakWarm = 128;
+constexpr int kNakRun = 16, kNakWarm = 64;
 
 // jobs of the batch from the detected knots: sites e = kidx[b][0 .. knots+1] (first = 0, idx = knots + 1); fewer than
 // max(min_extrema, 2) knots: invalid = the signal is its own baseline (numba_accelerated_itd.py:188-190)
@@ -74,6 +79,18 @@ __device__ __forceinline__ NakRow nak_row(const int32_t *__restrict__ e, const d
     return r;
 }
 
+// One step of the forward elimination: den = diag - sub cp_{j-1}; cp_j = sup / den; dp_j = (rhs - sub dp_{j-1}) / den.  The pivot lies in
+// [1.5, 2 + q] for every row (cp stays in (-1, 1/2]; the not-a-knot rows' q = a ratio of knot spacings > 0): its reciprocal comes from
+// v_rcp_f64 and two Newton steps (~1 ulp, no scaling, no fix-up) and serves both quotients — the two IEEE divisions were ~60 dependent
+// instructions of every step of a chain of kNakWarm + kNakRun of them, the whole time of an extraction of a short signal
+// (51 -> ~15 us for 3000 samples inside MEITD's loop).  The recurrences contract, so the step's rounding does not accumulate.
+__device__ __forceinline__ void nak_step(const NakRow &r, double &cp, double &dp)
+{
+    const double inv = sweep_rcp(r.diag - r.sub * cp);
+    cp = r.sup * inv;
+    dp = (r.rhs - r.sub * dp) * inv;
+}
+
 // the rows of the system, one thread per row, once: every row is met by kNakWarm / kNakRun + 1 = 5 forward runs, and a row costs
 // five divisions.  sub and rhs are stored; sup = 1 - sub and diag = 2 except in the two end rows, which the runs rebuild
 __global__ __launch_bounds__(256) void k_nak_rows(CubicArgs A, double *__restrict__ sub_ws, double *__restrict__ rhs_ws)
@@ -110,9 +127,7 @@ __global__ __launch_bounds__(64) void k_nak_forward(CubicArgs A, double *__restr
         NakRow r;
         if (j == 1 || j == m - 2) r = nak_row(e, S, m, j);       // (the not-a-knot rows: their own diag / sup)
         else { r.sub = subv[j]; r.rhs = rhsv[j]; r.sup = 1 - r.sub; r.diag = 2; }
-        const double den = r.diag - r.sub * cp;
-        cp = r.sup / den;
-        dp = (r.rhs - r.sub * dp) / den;
+        nak_step(r, cp, dp);
         if (j >= s) { cpv[j] = cp; dpv[j] = dp; }
     }
 }
@@ -169,7 +184,7 @@ __device__ __forceinline__ void nak_small_body(const double *__restrict__ x, int
                                                double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
                                                double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
                                                double *__restrict__ base, double *__restrict__ rot, int want_bcount,
-                                               double *__restrict__ s_dyn, int (&res)[4])
+                                               double *__restrict__ s_dyn, int (&res)[4], long long *prof = nullptr)
 {
     double *const subv = LDS ? s_dyn : subg, *const rhsv = LDS ? s_dyn + (n + 2) : rhsg;
     double *const cpv = LDS ? s_dyn + 2 * (n + 2) : cpg, *const dpv = LDS ? s_dyn + 3 * (n + 2) : dpg;
@@ -205,6 +220,8 @@ __device__ __forceinline__ void nak_small_body(const double *__restrict__ x, int
         total = tot;
         return wb + inc - c;
     };
+    long long tp = prof ? (long long)wall_clock64() : 0;
+    auto mark = [&](int k) { if (prof) { const long long t = (long long)wall_clock64(); prof[k] += t - tp; tp = t; } };
     bool has_nan = false;
     const unsigned mask = knot_mask(x, has_nan);
     if (has_nan) s_flag[0] = 1;
@@ -224,39 +241,103 @@ __device__ __forceinline__ void nak_small_body(const double *__restrict__ x, int
         if (want_bcount) res[3] = knots;                  // (the baseline IS the signal)
         return;
     }
+    mark(0);
     for (int k = tid; k < m; k += kNakSmallThreads) K[k] = spline_knot_value(x, n, e, m, k);
     __syncthreads();
+    mark(1);
     for (int j = 1 + tid; j <= m - 2; j += kNakSmallThreads) { const NakRow r = nak_row(e, K, m, j); subv[j] = r.sub; rhsv[j] = r.rhs; }
     __syncthreads();
+    mark(2);
+    // The two sweeps: a thread's run is a chain of kNakWarm + kNakRun dependent steps (one reciprocal's latency each going up, one
+    // multiply-add's going down) — the whole time of the operator for a short signal.  The rows of the next eight steps are therefore
+    // requested before the current eight are chained (with one step's row fetched per step the sweeps waited for LDS every step:
+    // 26 + 15 us per extraction of a 3000-sample signal), and the two not-a-knot rows are taken out of the loop.
     for (int s = 1 + tid * kNakRun; s <= m - 2; s += kNakSmallThreads * kNakRun) {          // k_nak_forward's run
         const int last = min(s + kNakRun - 1, m - 2), j0 = max(1, s - kNakWarm);
+        const int plain_end = last == m - 2 ? last - 1 : last;                               // (>= 1: m >= 4)
         double cp = 0.0, dp = 0.0;
-        double sub_n = subv[j0], rhs_n = rhsv[j0];        // (a step's row is fetched while the step before it divides)
-        for (int j = j0; j <= last; ++j) {
-            NakRow r;
-            r.sub = sub_n; r.rhs = rhs_n; r.sup = 1 - r.sub; r.diag = 2;
-            const int jn = min(j + 1, last);
-            sub_n = subv[jn]; rhs_n = rhsv[jn];
-            if (j == 1 || j == m - 2) r = nak_row(e, K, m, j);
-            const double den = r.diag - r.sub * cp;
-            cp = r.sup / den;
-            dp = (r.rhs - r.sub * dp) / den;
-            if (j >= s) { cpv[j] = cp; dpv[j] = dp; }
+        int j = j0;
+        if (j == 1) {
+            const NakRow r = nak_row(e, K, m, 1);
+            nak_step(r, cp, dp);
+            if (s == 1) { cpv[1] = cp; dpv[1] = dp; }
+            ++j;
+        }
+        // plain rows j .. plain_end: the warm-up (nothing stored) up to s - 1, then the run
+        auto chain = [&](int from, int to, bool store) {
+            int jj0 = from;
+            if (jj0 > to) return;
+            double sb[8], rb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { sb[q] = subv[min(jj0 + q, to)]; rb[q] = rhsv[min(jj0 + q, to)]; }
+            for (; jj0 + 8 <= to + 1; jj0 += 8) {                    // whole blocks: no test inside
+                double sn[8], rn[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { sn[q] = subv[min(jj0 + 8 + q, to)]; rn[q] = rhsv[min(jj0 + 8 + q, to)]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    NakRow r;
+                    r.sub = sb[q]; r.rhs = rb[q]; r.sup = 1 - r.sub; r.diag = 2;
+                    nak_step(r, cp, dp);
+                    if (store) { cpv[jj0 + q] = cp; dpv[jj0 + q] = dp; }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { sb[q] = sn[q]; rb[q] = rn[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                             // the rest of a block
+                if (jj0 + q <= to) {
+                    NakRow r;
+                    r.sub = sb[q]; r.rhs = rb[q]; r.sup = 1 - r.sub; r.diag = 2;
+                    nak_step(r, cp, dp);
+                    if (store) { cpv[jj0 + q] = cp; dpv[jj0 + q] = dp; }
+                }
+            }
+        };
+        chain(j, min(s - 1, plain_end), false);
+        chain(max(j, s), plain_end, true);
+        if (last == m - 2) {
+            const NakRow r = nak_row(e, K, m, m - 2);
+            nak_step(r, cp, dp);
+            cpv[m - 2] = cp; dpv[m - 2] = dp;
         }
     }
     __syncthreads();
+    mark(3);
     for (int s = 1 + tid * kNakRun; s <= m - 2; s += kNakSmallThreads * kNakRun) {          // k_nak_backward's run
         const int top = min(s + kNakRun - 1, m - 2), jt = min(m - 2, top + kNakWarm);
         double y = 0.0, y_next = 0.0;
-        double dp_n = dpv[jt], cp_n = cpv[jt];
-        for (int j = jt; j >= s; --j) {
-            const double dpj = dp_n, cpj = cp_n;
-            const int jn = max(j - 1, s);
-            dp_n = dpv[jn]; cp_n = cpv[jn];
-            y_next = y;
-            y = dpj - cpj * y;
-            if (j <= top) M[j] = y;
-        }
+        // rows jt .. s going down: the warm-up (nothing stored) down to top + 1, then the run
+        auto chain = [&](int from, int to, bool store) {
+            int jj0 = from;
+            if (jj0 < to) return;
+            double db[8], cb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { db[q] = dpv[max(jj0 - q, to)]; cb[q] = cpv[max(jj0 - q, to)]; }
+            for (; jj0 - 8 >= to - 1; jj0 -= 8) {
+                double dn[8], cn[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { dn[q] = dpv[max(jj0 - 8 - q, to)]; cn[q] = cpv[max(jj0 - 8 - q, to)]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    y_next = y;
+                    y = db[q] - cb[q] * y;
+                    if (store) M[jj0 - q] = y;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { db[q] = dn[q]; cb[q] = cn[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (jj0 - q >= to) {
+                    y_next = y;
+                    y = db[q] - cb[q] * y;
+                    if (store) M[jj0 - q] = y;
+                }
+            }
+        };
+        chain(jt, top + 1, false);
+        chain(top, s, true);
         if (s == 1) {
             const double q = (double)(e[1] - e[0]) / (double)(e[2] - e[1]);
             M[0] = (1 + q) * y - q * y_next;
@@ -269,6 +350,7 @@ __device__ __forceinline__ void nak_small_body(const double *__restrict__ x, int
         }
     }
     __syncthreads();
+    mark(4);
     {   // evaluation (k_cubic_eval<NAK>): the segment of a sample = the knots at or before it
         int j = off;                                      // knots in front of the thread's run
         for (int i = lo; i < hi; ++i) {
@@ -286,6 +368,7 @@ __device__ __forceinline__ void nak_small_body(const double *__restrict__ x, int
             if (rot) rot[i] = x[i] - v;
         }
     }
+    mark(5);
     if (want_bcount) {                                    // MEITD.py:362-363, :497-505: the extrema count of the produced baseline
         __syncthreads();
         bool nn = false;

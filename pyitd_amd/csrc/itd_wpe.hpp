@@ -53,7 +53,7 @@ constexpr int kWpeThreads = 256;
 // samples 1 .. n-2) — and nanf, whether it saw a NaN.  The order of every pattern's additions does not depend on NT.
 template <int NT>
 __device__ __forceinline__ void wpe3_pass(const double *__restrict__ x, int64_t lo, int64_t hi, double *__restrict__ s_x, double *__restrict__ s_l,
-                                          double &s, long long &c, int &kn, int &nanf)
+                                          double &s, long long &c, int &kn, int &nanf, long long *prof = nullptr)
 {
     static_assert(kWpeChunk % NT == 0 && kWpeChunk < 65536, "three 16-bit counts per word");
     __shared__ unsigned long long s_wave[2][NT / 64];
@@ -66,17 +66,23 @@ __device__ __forceinline__ void wpe3_pass(const double *__restrict__ x, int64_t 
         for (int k = tid; k < m + 2; k += NT) s_x[k] = x[base + k];
         __syncthreads();
         const int run = (m + NT - 1) / NT, k0 = tid * run < m ? tid * run : m, k1 = k0 + run < m ? k0 + run : m;
+        constexpr int RUN = kWpeChunk / NT;              // (run <= RUN: a thread's windows' patterns and weights stay in registers)
+        unsigned char bins[RUN];
+        double wts[RUN];
         // patterns 0..2 count in the 16-bit fields of a, 3..5 in those of b
         unsigned long long a = 0ull, b = 0ull;
-        for (int k = k0; k < k1; ++k) {
-            unsigned char bin;
-            double wt;
-            const double a0 = s_x[k], a1 = s_x[k + 1], a2 = s_x[k + 2];
-            wpe3_window(a0, a1, a2, bin, wt);
-            if (bin < 3) a += 1ull << (16 * bin); else b += 1ull << (16 * (bin - 3));
-            const double d0 = a1 - a0, d1 = a2 - a1;
-            kn += ((d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0)) ? 1 : 0;
-            nanf |= (a0 != a0 || a1 != a1 || a2 != a2) ? 1 : 0;
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+            const int k = k0 + r;
+            bins[r] = 0; wts[r] = 0.0;
+            if (k < k1) {
+                const double a0 = s_x[k], a1 = s_x[k + 1], a2 = s_x[k + 2];
+                wpe3_window(a0, a1, a2, bins[r], wts[r]);
+                if (bins[r] < 3) a += 1ull << (16 * bins[r]); else b += 1ull << (16 * (bins[r] - 3));
+                const double d0 = a1 - a0, d1 = a2 - a1;
+                kn += ((d1 > 0.0 && d0 <= 0.0) || (d1 < 0.0 && d0 >= 0.0)) ? 1 : 0;
+                nanf |= (a0 != a0 || a1 != a1 || a2 != a2) ? 1 : 0;
+            }
         }
         // exclusive scan over the threads (in thread order = window order)
         unsigned long long ia = a, ib = b;
@@ -96,30 +102,45 @@ __device__ __forceinline__ void wpe3_pass(const double *__restrict__ x, int64_t 
         auto field = [](unsigned long long v, int f) { return (int)((v >> (16 * f)) & 0xffffull); };
         int start[6], total[6];
         for (int q = 0, acc = 0; q < 6; ++q) { total[q] = q < 3 ? field(ta, q) : field(tb, q - 3); start[q] = acc; acc += total[q]; }
-        for (int k = k0; k < k1; ++k) {
-            unsigned char bin;
-            double wt;
-            wpe3_window(s_x[k], s_x[k + 1], s_x[k + 2], bin, wt);
-            int pos;
-            if (bin < 3) { pos = field(pa, bin); pa += 1ull << (16 * bin); } else { pos = field(pb, bin - 3); pb += 1ull << (16 * (bin - 3)); }
-            s_l[start[bin == 0 ? 0 : bin == 1 ? 1 : bin == 2 ? 2 : bin == 3 ? 3 : bin == 4 ? 4 : 5] + pos] = wt;
+#pragma unroll
+        for (int r = 0; r < RUN; ++r) {
+            if (k0 + r < k1) {
+                const int bin = bins[r];
+                int pos;
+                if (bin < 3) { pos = field(pa, bin); pa += 1ull << (16 * bin); } else { pos = field(pb, bin - 3); pb += 1ull << (16 * (bin - 3)); }
+                s_l[start[bin == 0 ? 0 : bin == 1 ? 1 : bin == 2 ? 2 : bin == 3 ? 3 : bin == 4 ? 4 : 5] + pos] = wts[r];
+            }
         }
         __syncthreads();
+        const long long tp0 = prof ? (long long)wall_clock64() : 0;
         if (tid < 6) {
             int k = 0, e = 0;
 #pragma unroll
             for (int q = 0; q < 6; ++q) if (q == tid) { k = start[q]; e = start[q] + total[q]; }
             c += e - k;
-            for (; k + 8 <= e; k += 8) {
-                double w[8];
+            // blocks of 16 weights, the next block requested before this one's chain of additions starts (a chain of up to a few
+            // thousand dependent additions on one lane: it should wait for nothing but itself)
+            if (k + 16 <= e) {
+                double w[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) w[q] = s_l[k + q];
+                for (int q = 0; q < 16; ++q) w[q] = s_l[k + q];
+                for (; k + 32 <= e; k += 16) {
+                    double wn[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s += w[q];
+                    for (int q = 0; q < 16; ++q) wn[q] = s_l[k + 16 + q];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) s += w[q];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) w[q] = wn[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += w[q];
+                k += 16;
             }
             for (; k < e; ++k) s += s_l[k];
         }
         __syncthreads();
+        if (prof) prof[0] += (long long)wall_clock64() - tp0;
     }
 }
 

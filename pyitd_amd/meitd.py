@@ -244,7 +244,9 @@ def _meitd_one_launch(wk, data, WPEMAX):
     wk.upload(data, wk.row(5))
     res, log = wk.eng.meitd_small_dev(wk.buf.ptr, wk.n, WPEMAX)
     status = int(res[0])
-    wk.last = {"one_launch": True, "status": status, "probes": int(res[4]), "extractions": int(res[5]), "turns": int(res[6])}
+    wk.last = {"one_launch": True, "status": status, "probes": int(res[4]), "extractions": int(res[5]), "turns": int(res[6]),
+               "us": {k: int(v) / 100.0 for k, v in zip(("probes", "extractions", "counts", "copies", "probe_sums", "probe_entropy", "", "", "x_knots", "x_values", "x_rows", "x_forward",
+                                                         "x_backward", "x_eval"), res[8:22]) if k}}
     if status >= 2:
         return "host"
     if len(log):

@@ -36,5 +36,5 @@ for name in sorted(f for f in os.listdir(G) if f.startswith("meitd_")):
     same = hi.shape == hi2.shape and lo.shape == lo2.shape and np.max(np.abs(res - res2)) < 1e-9
     print("%-24s %d samples: MEITD %.2f ms on the GPU (XITD %.2f ms; %s), %.2f ms with one launch per operator, %.1f ms over the CPU "
           "restatement's operators; %d + %d components, %d extractions, %d entropy probes, same decisions: %s"
-          % (name[:-4], len(x), t_gpu * 1e3, t_gpu_x * 1e3, "the loop as one launch, status %d" % how["status"] if how.get("one_launch") else
+          % (name[:-4], len(x), t_gpu * 1e3, t_gpu_x * 1e3, "the loop as one launch, status %d, in it %s us" % (how["status"], how["us"]) if how.get("one_launch") else
              "one launch per operator", t_host * 1e3, t_cpu * 1e3, len(hi), len(lo), cw[-1].calls["extract"], cw[-1].calls["probe"], same))
