@@ -176,7 +176,6 @@ __device__ __forceinline__ unsigned long long kc_load(const unsigned long long *
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
 // A workgroup barrier for LDS hand-overs only: __syncthreads() also waits for every global store and atomic the wavefront has in
 // flight (its fence covers global memory: s_waitcnt vmcnt(0)) — here that would put the write-through record stores and the table
 // stores, which no thread of the workgroup ever reads back, on every level's critical path (~1.5 us each).
@@ -532,6 +531,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             };
             int have = 0, dist0 = 1;
             bool edge = false, bad = false, first_round = true, ends_read = false;
+            if (li == 1) KC_MARK(49);
             while (have < want && !edge && !bad) {
                 // the workgroups whose records this round reads, nearest first (all lanes agree)
                 // (lane k of vsel = the k-th workgroup selected, wave-uniform values, read with v_readlane — as four variables chosen
@@ -583,6 +583,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                     if (bad) break;
                     s_stage[side][a][g] = data;
                 }
+                if (li == 1) KC_MARK(50);
                 wave_sync();
                 for (int k = 0; k < nsel && have < want; ++k) {              // (every lane follows the walk; lane 0 writes)
                     const int vv = sel(k);
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                 wave_sync();                                                 // (the staging rows are read before the next round rewrites them)
                 if (reach_edge && have < want) edge = true;
             }
+            if (li == 1) KC_MARK(51);
             if (lane == 0) {
                 if (bad) give_up(kKfFailWait);
                 else if (have < want) {                                      // the signal's end: the virtual knot at sample 0 / n-1 (ITD.py:96,98)
