@@ -34,7 +34,16 @@
 
 namespace itd {
 
-constexpr int kNakRun = 16, kNakWarm = 64;
+#ifndef ITD_NAK_RUN
+#define ITD_NAK_RUN 16
+#endif
+#ifndef ITD_NAK_WARM
+#define ITD_NAK_WARM 64
+#endif
+#ifndef ITD_NAK_DIV
+#define ITD_NAK_DIV 0            // 1 (diagnostic builds): the forward step's two quotients as IEEE divisions
+#endif
+constexpr int kNakRun = ITD_NAK_RUN, kNakWarm = ITD_NAK_WARM;
 
 // jobs of the batch from the detected knots: sites e = kidx[b][0 .. knots+1] (first = 0, idx = knots + 1); fewer than
 // max(min_extrema, 2) knots: invalid = the signal is its own baseline (numba_accelerated_itd.py:188-190)
@@ -86,9 +95,15 @@ __device__ __forceinline__ NakRow nak_row(const int32_t *__restrict__ e, const d
 // (51 -> ~15 us for 3000 samples inside MEITD's loop).  The recurrences contract, so the step's rounding does not accumulate.
 __device__ __forceinline__ void nak_step(const NakRow &r, double &cp, double &dp)
 {
+#if ITD_NAK_DIV
+    const double den = r.diag - r.sub * cp;
+    cp = r.sup / den;
+    dp = (r.rhs - r.sub * dp) / den;
+#else
     const double inv = sweep_rcp(r.diag - r.sub * cp);
     cp = r.sup * inv;
     dp = (r.rhs - r.sub * dp) * inv;
+#endif
 }
 
 // the rows of the system, one thread per row, once: every row is met by kNakWarm / kNakRun + 1 = 5 forward runs, and a row costs
