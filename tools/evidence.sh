@@ -9,13 +9,15 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 tag=${1:-r05}; O=gpurun_out/$tag; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; rc=$?; tail -2 $O/pytest_gpu.log; [ $rc -ne 0 ] && exit $rc
-timeout -k 10 900 python bench.py > $O/bench_default_form.json 2> $O/bench_default_form.err || exit 1
 timeout -k 10 300 python bench.py --steps 200 --no-extra --no-cpu-baseline > $O/bench_steps200.json 2>/dev/null || exit 1
 # (the same with the first fused level pinned to 3: the sample pass of round 4's shape — six rows — with this round's checks)
 PYITD_FUSE_LEVEL=3 timeout -k 10 300 python bench.py --steps 100 --no-extra --no-cpu-baseline > $O/bench_first_fused_level3.json 2>/dev/null || exit 1
 ( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/prof.err ) || exit 1
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv && cut -c1-160 $O/kernel_stats.csv | head -8
 bash tools/traffic.sh $tag > $O/traffic_summary.txt 2>&1; tail -1 $O/traffic_summary.txt | cut -c1-400
+# (the line in the driver's form reads the traffic record of THIS build: traffic_stale false)
+cp gpurun_out/traffic.json profiles/traffic.json
+timeout -k 10 900 python bench.py > $O/bench_default_form.json 2> $O/bench_default_form.err || exit 1
 if [ -f variants/libprof.so ]; then PYITD_HIP_LIB=variants/libprof.so timeout -k 10 200 python tools/knots_prof.py > $O/knots_phase_profile.txt 2>&1 || exit 1; fi
 timeout -k 10 900 python tools/kf_rates.py 12 11 > $O/kf_delivery_rates.txt 2>&1 || exit 1; tail -2 $O/kf_delivery_rates.txt
 FUZZ_MIN_N=65536 PYITD_FUSE_MIN=65536 timeout -k 10 600 python tools/fuzz_parity.py 3000 601 > $O/fuzz_3000_long_fused.txt 2>&1 || exit 1; tail -1 $O/fuzz_3000_long_fused.txt
