@@ -231,8 +231,10 @@ __device__ __forceinline__ void kc_publish(unsigned long long *slot, uint32_t ta
 #if ITD_PROF
 __device__ unsigned long long *g_kc_prof;   // [workgroups][64]
 #define KC_MARK(i) do { if (threadIdx.x == 0 && g_kc_prof) kc_marks[(i)] = (unsigned long long)wall_clock64(); } while (0)
+#define KC_MARK_T(t, i) do { if (threadIdx.x == (t) && g_kc_prof) g_kc_prof[(size_t)blockIdx.x * 64 + (i)] = (unsigned long long)wall_clock64(); } while (0)   /* marks 52 .. 57: other wavefronts' */
 #else
 #define KC_MARK(i)
+#define KC_MARK_T(t, i)
 #endif
 // ---- the knot side: hand-over and every fused level in ONE launch.  grid = wgs * nb workgroups of kKcThreads (512) threads; workgroup id ->
 //      (signal, range of tpw tiles).  A workgroup waits for its neighbours' records, so it must never keep a neighbour from
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const U2 v = {wv[2 * q], wv[2 * q + 1]}; dst[q] = v; }
             }
+            if (li == 1) KC_MARK_T(192, 53);
         } else if (wave < 2) {
             const int side = wave;                                           // 0: in front (two knots), 1: behind (three)
             const int want = side == 0 ? 2 : 3;
@@ -611,6 +614,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
                 if (reach_edge && have < want) edge = true;
             }
             if (li == 1) KC_MARK(51);
+            if (li == 1) KC_MARK_T(64, 52);
             if (lane == 0) {
                 if (bad) give_up(kKfFailWait);
                 else if (have < want) {                                      // the signal's end: the virtual knot at sample 0 / n-1 (ITD.py:96,98)
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         kc_marks[61] = (unsigned long long)(sig * W + w);
         kc_marks[62] = (unsigned long long)blockIdx.x;
         unsigned long long *o = g_kc_prof + (size_t)blockIdx.x * 64;
-        for (int i = 0; i < 64; ++i) o[i] = kc_marks[i];
+        for (int i = 0; i < 64; ++i) if (i < 52 || i > 57) o[i] = kc_marks[i];
     }
 #endif
 }

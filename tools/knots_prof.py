@@ -41,7 +41,7 @@ for li in range(M + 2 - L0):
     names += [(4 + 4 * li, "L%d: knots by rank, words" % (L0 + li)), (5 + 4 * li, "L%d: halo arrived" % (L0 + li)),
               (6 + 4 * li, "L%d: B, S, table" % (L0 + li)), (7 + 4 * li, "L%d: map + compaction" % (L0 + li))]
 names += [(60, "end")]
-fine = [(4 + 4, "second fused level: knots by rank, words"), (49, "  halo: search set up (wavefront 0)"), (50, "  halo: granules arrived"), (51, "  halo: walked"), (5 + 4, "  halo: barrier"),
+fine = [(4 + 4, "second fused level: knots by rank, words"), (49, "  halo: search set up (wavefront 0)"), (50, "  halo: granules arrived"), (51, "  halo: walked"), (52, "    (wavefront 1: its side walked)"), (53, "    (wavefront 3: the tiles' words and run starts left)"), (5 + 4, "  halo: barrier"),
         (6 + 4, "second fused level: B, S, table"), (44, "  maps done"), (45, "  end samples (thread 0)"), (46, "  scan"), (47, "  record's fixed part (thread 0)"), (48, "  compaction writes"), (7 + 4, "  barrier")]
 prev = b[:, 0]
 print("%-44s %9s %9s %9s   %s" % ("mark", "median at", "max at", "d median", "(us since the first workgroup's start)"))
@@ -55,5 +55,8 @@ for k, nm in names:
 if (b[:, 44] > 0).any():
     prev = b[:, fine[0][0]]
     for k, nm in fine[1:]:
+        if k in (52, 53):       # other wavefronts' marks: since the level's start, not part of wavefront 0's chain
+            print("%-44s %9.2f %9s %9s   (%.2f us behind the level's start)" % (nm, np.median(us(b[:, k])), "", "", np.median(b[:, k] - b[:, fine[0][0]]) / 100.0))
+            continue
         print("%-44s %9.2f %9s %9.2f" % (nm, np.median(us(b[:, k])), "", np.median(b[:, k] - prev) / 100.0))
         prev = b[:, k]
