@@ -155,12 +155,10 @@ __global__ void k_or_nan_flags(const int32_t *__restrict__ totals, int batch, in
     if (b < batch && totals[2 * b + 1]) atomicOr(flag, 1);
 }
 
-__global__ void k_copy_words(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int cnt, int32_t *__restrict__ done_flag, int32_t done_seq)
+// up to 32 counts for a polling host: self-validating words (itd_kernels.hpp: small_put)
+__global__ void k_copy_words(const int32_t *__restrict__ src, unsigned long long *__restrict__ words, int cnt, int32_t seq)
 {
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = src[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) small_put(words, i, (uint32_t)src[i], (uint32_t)seq);
 }
 
 __global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, int64_t cnt)
@@ -220,12 +218,11 @@ struct itd_engine {
     bool resident_attr[12] = {};
     bool nak_small_attr = false;    // hipFuncSetAttribute done for k_nak_small<true>
     bool meitd_attr[2] = {};        // ... for k_meitd_small<false / true>
-    void *h_meitd_log = nullptr, *d_meitd_log = nullptr;   // k_meitd_small's probe log: mapped pinned host memory (kMeitdLogCap entries)
     // a few scalars per call come back to the host in MEITD's operators (counts, six sums): 256 bytes of pinned host memory that the
     // GPU writes directly (mapped, coherent) — no copy behind the launch, just the stream's synchronisation (a pageable destination
     // cost ~15 us per call: 110 calls per MEITD run)
     void *h_small = nullptr, *d_small = nullptr;
-    int32_t small_seq = 0;          // the last word of those 256 bytes: the launch that fills them writes this call's number there last
+    int32_t small_seq = 0;          // the number of the call whose scalars are awaited: every word of a result carries it in its high half (small_put)
     int32_t resident_window = 0;    // segments per pass over a level's ranks (itd_set_resident_window; 0 = automatic)   // hipFuncSetAttribute done per kernel instance
     // the fused sparse levels (itd_knotfirst.hpp): workspace (allocated at first use), mode, first fused level
     void *d_kf = nullptr; size_t kf_bytes = 0;
@@ -1067,7 +1064,6 @@ void itd_engine_destroy(itd_engine *e)
     if (e->h_kf) (void)hipHostFree(e->h_kf);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
     if (e->h_small) (void)hipHostFree(e->h_small);
-    if (e->h_meitd_log) (void)hipHostFree(e->h_meitd_log);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (int k = 0; k < 3; ++k) {
@@ -2233,34 +2229,41 @@ int nak_enqueue(itd_engine *e, const double *x, int64_t n, int batch, int64_t x_
 
 // the engine's 256 bytes of mapped pinned host memory (h_small / its device address d_small); false: not available (the callers
 // then copy through their own buffers as before)
+constexpr int kSmallWords = 32;           // 8-byte words of mapped host memory an operator's scalars come back in
 bool small_results(itd_engine *e)
 {
     if (e->h_small) return e->d_small != nullptr;
-    if (hipHostMalloc(&e->h_small, 256, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); e->h_small = nullptr; return false; }
+    if (hipHostMalloc(&e->h_small, kSmallWords * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); e->h_small = nullptr; return false; }
     if (hipHostGetDevicePointer(&e->d_small, e->h_small, 0) != hipSuccess) { (void)hipGetLastError(); e->d_small = nullptr; return false; }
-    memset(e->h_small, 0, 256);
+    memset(e->h_small, 0, kSmallWords * 8);
     return true;
 }
 
-// Wait for the launch that fills the mapped words: it writes `seq` into their last word behind everything else (system-scope fence),
-// and the host polls that word — a few microseconds behind the kernel's end instead of the ~25 us hipStreamSynchronize takes to come
-// back from an interrupt on a busy host.  Falls back to the synchronisation if the word does not turn up within 2 ms (a long kernel,
-// a fault): the stream's status is what the caller gets then.
-constexpr int kSmallFlag = 63;
+// Wait for the launch that fills the first `nwords` mapped words: every word carries the call's number in its high half (small_put) —
+// whatever order the stores reach the host in, a result is taken only when all of its words are this call's.  The host polls: a few
+// microseconds behind the kernel's end instead of the ~25 us hipStreamSynchronize takes to come back from an interrupt on a busy host.
+// Falls back to the synchronisation if the words do not turn up within poll_ms (a long kernel, a fault).
 int32_t small_next(itd_engine *e) { e->small_seq = e->small_seq == INT32_MAX ? 1 : e->small_seq + 1; return e->small_seq; }
-int small_wait(itd_engine *e, int32_t seq, hipStream_t st, int poll_ms = 2)
+int small_wait(itd_engine *e, int32_t seq, int nwords, hipStream_t st, int poll_ms = 2)
 {
-    volatile int32_t *flag = (volatile int32_t *)e->h_small + kSmallFlag;
+    volatile unsigned long long *w = (volatile unsigned long long *)e->h_small;
+    auto all_here = [&]() {
+        for (int i = 0; i < nwords; ++i) if ((uint32_t)(w[i] >> 32) != (uint32_t)seq) return false;
+        return true;
+    };
     const auto t0 = std::chrono::steady_clock::now();
-    for (int spin = 0; *flag != seq; ++spin) {
-        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(poll_ms)) {
+    bool synced = false;
+    for (int spin = 0; !all_here(); ++spin) {
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(synced ? 2000 : poll_ms)) {
+            if (synced) { snprintf(e->err, sizeof(e->err), "the launch's result words did not arrive"); return ITD_ERR_HIP; }
             HIP_TRY(e, hipStreamSynchronize(st));
-            break;
+            synced = true;
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return ITD_OK;
 }
+inline uint32_t small_get(const itd_engine *e, int i) { return (uint32_t)((const volatile unsigned long long *)e->h_small)[i]; }
 
 // ONE signal of at most kNakSmallMax samples through the parallel-in-knots form: one launch, one workgroup (itd_nak.hpp: k_nak_small),
 // one 16-byte copy back — knots, NaN flag, validity, and (want_bcount) the knot count of the produced baseline.  Synchronous.
@@ -2272,11 +2275,11 @@ int nak_small(itd_engine *e, const double *x, int64_t n, int min_extrema, double
     int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + 6 * (size_t)L * sizeof(double));
     if (rc) return rc;
     const bool mapped = small_results(e);
-    int32_t *out = mapped ? (int32_t *)e->d_small : (int32_t *)e->d_cub;
+    int32_t *out = (int32_t *)e->d_cub;
     int32_t *idx = (int32_t *)((char *)e->d_cub + out_b);
     double *arr = (double *)((char *)e->d_cub + out_b + idx_b);
     const int32_t seq = mapped ? small_next(e) : 0;
-    int32_t *flag = mapped ? (int32_t *)e->d_small + kSmallFlag : nullptr;
+    unsigned long long *words = mapped ? (unsigned long long *)e->d_small : nullptr;
     const size_t lds = 4 * (size_t)L * sizeof(double);
     if (lds <= kNakSmallLdsMax) {                          // the sweeps' arrays in LDS (more than 64 KB of dynamic LDS has to be asked for)
         if (!e->nak_small_attr) {
@@ -2284,16 +2287,16 @@ int nak_small(itd_engine *e, const double *x, int64_t n, int min_extrema, double
             e->nak_small_attr = true;
         }
         k_nak_small<true><<<1, kNakSmallThreads, lds, st>>>(x, (int)n, min_extrema, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                             base, rot, baseline_knots_host ? 1 : 0, out, flag, seq);
+                                                             base, rot, baseline_knots_host ? 1 : 0, out, words, seq);
     } else
         k_nak_small<false><<<1, kNakSmallThreads, 0, st>>>(x, (int)n, min_extrema, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                            base, rot, baseline_knots_host ? 1 : 0, out, flag, seq);
+                                                            base, rot, baseline_knots_host ? 1 : 0, out, words, seq);
     int32_t h[4] = {0, 0, 0, 0};
     HIP_TRY(e, hipGetLastError());
     if (mapped) {
-        const int rc2 = small_wait(e, seq, st);
+        const int rc2 = small_wait(e, seq, 4, st);
         if (rc2) return rc2;
-        memcpy(h, e->h_small, sizeof(h));
+        for (int q = 0; q < 4; ++q) h[q] = (int32_t)small_get(e, q);
     } else {
         HIP_TRY(e, hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(e, hipStreamSynchronize(st));
@@ -2424,14 +2427,14 @@ int itd_count_knots_f64(itd_engine *e, const double *x_dev, int64_t n, int32_t b
     int rc = detect_enqueue(e, x_dev, x_stride, n, batch, mode, -1, st, w, nullptr, 0, false);
     if (rc) return rc;
     std::vector<int32_t> tot(2 * (size_t)batch);
-    const bool mapped = batch <= 16 && small_results(e);       // a few counts: the GPU copies them into the mapped words itself
+    const bool mapped = 2 * batch <= kSmallWords && small_results(e);       // a few counts: the GPU copies them into the mapped words itself
     if (mapped) {
         const int32_t seq = small_next(e);
-        k_copy_words<<<1, 64, 0, st>>>(w.totals, (int32_t *)e->d_small, 2 * batch, (int32_t *)e->d_small + kSmallFlag, seq);
+        k_copy_words<<<1, 64, 0, st>>>(w.totals, (unsigned long long *)e->d_small, 2 * batch, seq);
         HIP_TRY(e, hipGetLastError());
-        rc = small_wait(e, seq, st);
+        rc = small_wait(e, seq, 2 * batch, st);
         if (rc) return rc;
-        memcpy(tot.data(), e->h_small, tot.size() * sizeof(int32_t));
+        for (int i = 0; i < 2 * batch; ++i) tot[(size_t)i] = (int32_t)small_get(e, i);
     } else {
         HIP_TRY(e, hipMemcpyAsync(tot.data(), w.totals, tot.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(e, hipStreamSynchronize(st));
@@ -2465,15 +2468,10 @@ int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weig
     int *out_k = reinterpret_cast<int *>(out_c + 6);
     // (one segment — MEITD's signals —: the sums land in the engine's mapped host words, no copy behind the launch)
     const bool mapped = nseg == 1 && small_results(e);
-    if (mapped) {
-        part_s = reinterpret_cast<double *>(e->d_small);
-        part_c = reinterpret_cast<long long *>(part_s + 6);
-        part_k = reinterpret_cast<int *>(part_c + 6);
-    }
     // (the knot count of x rides along: a window's middle sample is a knot or not — MEITD.py:346-351, :373-378 ask for both)
     const int32_t seq = mapped ? small_next(e) : 0;
     k_wpe3<<<(unsigned)nseg, kWpeThreads, 0, st>>>(x_dev, nw, seg_len, part_s, part_c, knots_host ? part_k : nullptr,
-                                                   mapped ? (int32_t *)e->d_small + kSmallFlag : nullptr, seq);
+                                                   mapped ? (unsigned long long *)e->d_small : nullptr, seq);
     if (nseg > 1) k_wpe3_combine<<<1, 64, 0, st>>>(part_s, part_c, (int)nseg, out_s, out_c, knots_host ? part_k : nullptr, out_k);
     HIP_TRY(e, hipGetLastError());
     struct { double s[6]; long long c[6]; int k[2]; } res;
@@ -2482,9 +2480,14 @@ int itd_wpe3_f64(itd_engine *e, const double *x_dev, int64_t n, double *bin_weig
     if (nseg > 1) HIP_TRY(e, hipMemcpyAsync(&res, out_s, res_b, hipMemcpyDeviceToHost, st));
     else if (!mapped) HIP_TRY(e, hipMemcpyAsync(&res, part_s, res_b, hipMemcpyDeviceToHost, st));
     if (mapped) {
-        const int rc2 = small_wait(e, seq, st);
+        const int rc2 = small_wait(e, seq, 20, st);
         if (rc2) return rc2;
-        memcpy(&res, e->h_small, res_b);
+        for (int b = 0; b < 6; ++b) {
+            const unsigned long long bits = (unsigned long long)small_get(e, 2 * b) | ((unsigned long long)small_get(e, 2 * b + 1) << 32);
+            memcpy(&res.s[b], &bits, sizeof(double));
+            res.c[b] = (long long)small_get(e, 12 + b);
+        }
+        res.k[0] = (int)small_get(e, 18); res.k[1] = (int)small_get(e, 19);
     } else HIP_TRY(e, hipStreamSynchronize(st));
     for (int b = 0; b < 6; ++b) { bin_weights_host[b] = res.s[b]; bin_windows_host[b] = (int64_t)res.c[b]; }
     if (knots_host) *knots_host = res.k[0];
@@ -2505,18 +2508,10 @@ int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpema
     const size_t arr_b = 6 * (size_t)L * sizeof(double);
     int rc = grow(e, &e->d_cub, &e->cub_bytes, out_b + idx_b + arr_b + kMeitdLogCap * sizeof(MeitdProbe));
     if (rc) return rc;
-    if (!small_results(e)) return ITD_ERR_NOMEM;
-    if (!e->h_meitd_log) {
-        if (hipHostMalloc(&e->h_meitd_log, kMeitdLogCap * sizeof(MeitdProbe), hipHostMallocMapped) != hipSuccess) {
-            (void)hipGetLastError(); e->h_meitd_log = nullptr; return ITD_ERR_NOMEM;
-        }
-        HIP_TRY(e, hipHostGetDevicePointer(&e->d_meitd_log, e->h_meitd_log, 0));
-    }
     int32_t *idx = (int32_t *)((char *)e->d_cub + out_b);
     double *arr = (double *)((char *)e->d_cub + out_b + idx_b);
     MeitdProbe *dlog = (MeitdProbe *)((char *)e->d_cub + out_b + idx_b + arr_b);
-    const int32_t seq = small_next(e);
-    int32_t *flag = (int32_t *)e->d_small + kSmallFlag;
+    MeitdOut *dout = (MeitdOut *)e->d_cub;                 // (the first 256 bytes of the workspace)
     const size_t nak_lds = 4 * (size_t)L * sizeof(double);
     const bool in_lds = nak_lds <= kNakSmallLdsMax;
     const size_t lds = in_lds && nak_lds > kMeitdWpeLds ? nak_lds : kMeitdWpeLds;   // the two operators take turns in the same bytes
@@ -2526,18 +2521,17 @@ int itd_meitd_small_f64(itd_engine *e, double *rows_dev, int64_t n, double wpema
         e->meitd_attr[in_lds] = true;
     }
     if (in_lds)
-        k_meitd_small<true><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                               dlog, (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
+        k_meitd_small<true><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L, dlog, dout);
     else
-        k_meitd_small<false><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L,
-                                                                dlog, (MeitdProbe *)e->d_meitd_log, (MeitdOut *)e->d_small, flag, seq);
+        k_meitd_small<false><<<1, kNakSmallThreads, lds, st>>>(rows_dev, (int)n, wpemax, idx, arr, arr + L, arr + 2 * L, arr + 3 * L, arr + 4 * L, arr + 5 * L, dlog, dout);
     HIP_TRY(e, hipGetLastError());
-    rc = small_wait(e, seq, st, 50);             // (a whole loop: a few milliseconds)
-    if (rc) return rc;
-    if (*((volatile int32_t *)e->h_small + kSmallFlag) != seq) { snprintf(e->err, sizeof(e->err), "k_meitd_small did not finish"); return ITD_ERR_HIP; }
-    memcpy(result_host, e->h_small, sizeof(MeitdOut));
+    // (a whole loop: milliseconds — the header and the log are plain copies behind it)
+    MeitdOut ho;
+    HIP_TRY(e, hipMemcpyAsync(&ho, dout, sizeof(ho), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    memcpy(result_host, &ho, sizeof(MeitdOut));
     const int32_t got = result_host[4] < log_cap ? result_host[4] : log_cap;
-    if (got > 0) memcpy(probe_log_host, e->h_meitd_log, (size_t)(got < kMeitdLogCap ? got : kMeitdLogCap) * sizeof(MeitdProbe));
+    if (got > 0) HIP_TRY(e, hipMemcpy(probe_log_host, dlog, (size_t)(got < kMeitdLogCap ? got : kMeitdLogCap) * sizeof(MeitdProbe), hipMemcpyDeviceToHost));
     return ITD_OK;
 }
 

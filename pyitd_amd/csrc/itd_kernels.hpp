@@ -638,6 +638,23 @@ __device__ int far_nonempty(const int32_t *__restrict__ cnts, const int32_t *__r
     return -1;
 }
 
+// ---- scalars for a polling host: one 32-bit value and its call's number in ONE 8-byte store to host-mapped memory -------------------
+// A few operators hand a handful of scalars back to a host that polls for them (itd_engine.hip: small_wait) instead of synchronising
+// the stream.  Data words followed by a fence and a flag word are NOT enough on this path: stores of one wavefront to host memory can
+// arrive out of order (a 5000-call fuzz of MEITD's host-driven loop saw the flag in front of the data about once per 100 000
+// launches — a stale NaN flag or knot count, i.e. a wrong branch).  So every word validates itself: value in the low half, the call's
+// number in the high half, written whole or not at all; the host takes a result only when all of its words carry the number it waits for.
+__device__ __forceinline__ void small_put(unsigned long long *words, int i, uint32_t value, uint32_t tag)
+{
+    __hip_atomic_store(words + i, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void small_put_f64(unsigned long long *words, int i, double v, uint32_t tag)     // two words: low, high
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    small_put(words, i, (uint32_t)b, tag);
+    small_put(words, i + 1, (uint32_t)(b >> 32), tag);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_extract (further down, after the helpers it shares with k_scan0): one extraction on one tile, one wavefront, the tile
 // held in REGISTERS; grid = (ceil(n_tiles / KT), batch), 64 threads, KT = kTilesPerWave consecutive tiles per wavefront.

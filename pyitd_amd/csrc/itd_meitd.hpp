@@ -11,7 +11,7 @@
 //
 // What keeps the selections the reference's: counts are integers; the extraction is the launch form's, bit for bit; the entropy's
 // six sums are the launch form's, bit for bit; only the six logarithms differ in who takes them (the device's log2 here, numpy's
-// there).  Every probe's sums, counts and entropy are therefore LOGGED (MeitdProbe, host-mapped), and the caller re-draws each
+// there).  Every probe's sums, counts and entropy are therefore LOGGED (MeitdProbe), and the caller re-draws each
 // entropy with numpy and compares the threshold test — the only thing an entropy is ever used for (`_proper`, MEITD.py:364 / :387);
 // one differing test and the call is repeated by the host-driven loop.  The same fallback serves everything this kernel does not
 // model: a NaN in any row, an extraction with fewer than two knots (scipy raises there), a full log.
@@ -174,9 +174,8 @@ template <bool LDS>
 __global__ __launch_bounds__(kNakSmallThreads) void k_meitd_small(double *__restrict__ rows, int n, double wpemax, int32_t *__restrict__ e,
                                                                  double *__restrict__ K, double *__restrict__ dpg, double *__restrict__ M,
                                                                  double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
-                                                                 MeitdProbe *__restrict__ log /* device memory */,
-                                                                 MeitdProbe *__restrict__ log_out /* host-mapped: filled at the end */,
-                                                                 MeitdOut *__restrict__ out, int32_t *__restrict__ done_flag, int32_t done_seq)
+                                                                 MeitdProbe *__restrict__ log, MeitdOut *__restrict__ out /* both device memory: the host copies them
+                                                                                                                          behind the launch (milliseconds long) */)
 {
     extern __shared__ double s_dyn[];
     __shared__ MeitdCtx c;
@@ -294,19 +293,10 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_meitd_small(double *__rest
         ++digs;
     }
     __syncthreads();
-    {   // the probes' log goes to the host in one piece (a probe that wrote its entry there itself waited for the bus at its barrier)
-        const int words = min(c.probes, kMeitdLogCap) * (int)(sizeof(MeitdProbe) / sizeof(double));
-        const double *src = reinterpret_cast<const double *>(log);
-        double *dst = reinterpret_cast<double *>(log_out);
-        for (int i = threadIdx.x; i < words; i += kNakSmallThreads) dst[i] = src[i];
-        __threadfence_system();
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
         out->status = status; out->n_high = n_high; out->n_low = n_low; out->x_row = x;
         out->probes = c.probes; out->extractions = c.extractions; out->steps = steps; out->pad = 0;
         for (int q = 0; q < 16; ++q) out->ticks[q] = (int32_t)c.t_op[q];
-        if (done_flag) { __threadfence_system(); *done_flag = done_seq; }
     }
 }
 

@@ -399,15 +399,15 @@ __global__ __launch_bounds__(kNakSmallThreads) void k_nak_small(const double *__
                                                                double *__restrict__ cpg, double *__restrict__ subg, double *__restrict__ rhsg,
                                                                double *__restrict__ base, double *__restrict__ rot, int want_bcount,
                                                                int32_t *__restrict__ out /* knots, NaN flag, valid, knots of the produced baseline */,
-                                                               int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
-                                                               /* done_flag (host-mapped): set to done_seq behind the last of `out`'s words — the host polls it */)
+                                                               unsigned long long *__restrict__ done_words = nullptr, int32_t done_seq = 0
+                                                               /* done_words (host-mapped): the same four values as self-validating words (small_put) — the host polls them */)
 {
     extern __shared__ double s_dyn[];
     int res[4];
     nak_small_body<LDS>(x, n, min_extrema, e, K, dpg, M, cpg, subg, rhsg, base, rot, want_bcount, s_dyn, res);
     if (threadIdx.x == 0) {
-        out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; out[3] = res[3];
-        if (done_flag) { __threadfence_system(); *done_flag = done_seq; }
+        if (done_words) { for (int q = 0; q < 4; ++q) small_put(done_words, q, (uint32_t)res[q], (uint32_t)done_seq); }
+        else { out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; out[3] = res[3]; }
     }
 }
 

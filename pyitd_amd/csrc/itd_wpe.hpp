@@ -148,8 +148,9 @@ __device__ __forceinline__ void wpe3_pass(const double *__restrict__ x, int64_t 
 // windows is a NaN
 __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__ x, int64_t nw, int64_t seg_len, double *__restrict__ part_s,
                                                       long long *__restrict__ part_c, int *__restrict__ part_k,
-                                                      int32_t *__restrict__ done_flag = nullptr, int32_t done_seq = 0
-                                                      /* one segment, results in host-mapped words: set to done_seq behind them (the host polls) */)
+                                                      unsigned long long *__restrict__ done_words = nullptr, int32_t done_seq = 0
+                                                      /* one segment, a polling host: the results as self-validating words (small_put) — words 0..11 the six
+                                                         sums (low, high), 12..17 the six window counts, 18 the knots, 19 the NaN flag */)
 {
     __shared__ double s_x[kWpeChunk + 2], s_l[kWpeChunk];
     __shared__ int s_kn[2];
@@ -161,19 +162,17 @@ __global__ __launch_bounds__(kWpeThreads) void k_wpe3(const double *__restrict__
     long long c;
     wpe3_pass<kWpeThreads>(x, lo, hi, s_x, s_l, s, c, kn, nanf);
     if (tid < 6) {
-        part_s[(size_t)blockIdx.x * 6 + tid] = s;
-        part_c[(size_t)blockIdx.x * 6 + tid] = c;
+        if (done_words) { small_put_f64(done_words, 2 * tid, s, (uint32_t)done_seq); small_put(done_words, 12 + tid, (uint32_t)c, (uint32_t)done_seq); }
+        else { part_s[(size_t)blockIdx.x * 6 + tid] = s; part_c[(size_t)blockIdx.x * 6 + tid] = c; }
     }
-    if (part_k) {
+    if (part_k || done_words) {
         if (kn) atomicAdd(&s_kn[0], kn);
         if (nanf) s_kn[1] = 1;
         __syncthreads();
-        if (tid < 2) part_k[(size_t)blockIdx.x * 2 + tid] = s_kn[tid];
-    }
-    if (done_flag) {
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) { __threadfence_system(); *done_flag = done_seq; }
+        if (tid < 2) {
+            if (done_words) small_put(done_words, 18 + tid, (uint32_t)s_kn[tid], (uint32_t)done_seq);
+            else part_k[(size_t)blockIdx.x * 2 + tid] = s_kn[tid];
+        }
     }
 }
 

@@ -346,6 +346,19 @@ def test_meitd_as_one_launch_on_other_signals(P, n, seed, wpemax):
         assert a.shape == b.shape and np.array_equal(a, b), what
 
 
+def test_meitd_fuzz_slice(P):
+    """200 fixed-seed cases of tools/meitd_fuzz.py: MEITD as one launch against the host-driven loop (one launch per operator, every
+    scalar polled from the mapped result words) — the same components bit for bit, the same operator counts, the same errors.  (The
+    open-ended runs of the tool are what caught the result words arriving out of order behind a flag word: DESIGN.md section 9.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("meitd_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "meitd_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    bad, handed, early = mod.run(200, 5, log=lines.append)
+    assert bad == 0, "\n".join(lines)
+
+
 def test_meitd_one_launch_hands_over_what_it_does_not_model(P):
     """a NaN in the signal, fewer than four extrema, and a signal below the solver's threshold: the one-launch loop reports / is not
     taken, and the call behaves like the host-driven loop"""
