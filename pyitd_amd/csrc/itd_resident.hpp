@@ -31,9 +31,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef ITD_RES_INT_RATIO
-#define ITD_RES_INT_RATIO 1
-#endif
 // timing-only ablations of k_resident (results are wrong by construction): 1 no knot values / slopes, 2 no prefix over the
 // words, 4 no state resets, 8 no row / baseline stores, 16 no knot list, 32 no by-rank reads in the map, 64 never stop naturally
 // (every build that is compared with another needs it: the level count must not depend on the values), 128 no scan loads
@@ -343,11 +340,7 @@ __global__ __launch_bounds__(TH, SPT == 4 ? ITD_RES_MINW : 4) void k_resident(co
                         const int e0 = ek[sl - 1], e1 = ek[sl], e2 = ek[sl + 1];
                         const double xm1 = Xk[sl - 1];
                         xp1 = Xk[sl + 1];
-#if ITD_RES_INT_RATIO
-                        const double frac = int_ratio(e1 - e0, e2 - e0);      // (the correctly rounded quotient of two small positive integers: itd_kernels.hpp)
-#else
-                        const double frac = (double)(e1 - e0) / (double)(e2 - e0);
-#endif
+                        const double frac = (double)(e1 - e0) / (double)(e2 - e0);      // (int_ratio here: no difference, profiles/r05/experiments)
                         const double t = frac * (xp1 - xm1);
                         const double u = xm1 + t;
                         v = 0.5 * u + 0.5 * x0;
