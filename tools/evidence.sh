@@ -27,7 +27,7 @@ timeout -k 10 600 python tools/fuzz_parity.py batch 1500 604 > $O/fuzz_1500_batc
 # MEITD: the loop as one launch against one launch per operator (wall time, operators one by one, 1000 random signals), the spline solver
 timeout -k 10 300 python tools/meitd_bench.py > $O/meitd_wall_time.txt 2>&1 || exit 1; cut -c1-100 $O/meitd_wall_time.txt
 timeout -k 10 300 python tools/meitd_ops.py > $O/meitd_ops.txt 2>&1 || exit 1
-timeout -k 10 600 python tools/meitd_fuzz.py 1000 7 > $O/meitd_fuzz_1000.txt 2>&1 || exit 1; tail -1 $O/meitd_fuzz_1000.txt
+timeout -k 10 600 python tools/meitd_fuzz.py 5000 7 > $O/meitd_fuzz_5000.txt 2>&1 || exit 1; tail -1 $O/meitd_fuzz_5000.txt
 timeout -k 10 300 python tools/spline_long_bench.py > $O/spline_long_signal.txt 2>&1 || exit 1; tail -1 $O/spline_long_signal.txt
 bash tools/suite_modes.sh $tag || exit 1
 python - <<PY
