@@ -58,6 +58,8 @@ typedef enum itd_status {
 #define ITD_DETECT_ZERO_CROSS 4 /* find_extrema's test, itd_fourier_decomposition.py:23-27: sign change x[i] -> x[i+1] */
 
 typedef struct itd_engine itd_engine; /* opaque; not thread-safe: one engine per host thread/stream */
+/* (Debugging: with PYITD_POISON=1 in the environment every workspace the library allocates is filled with 0xFF bytes before its
+ *  first use — reading memory nobody wrote gives NaNs / -1 on every run instead of whatever the allocation happened to hold.) */
 
 int itd_abi_version(void);
 const char *itd_status_string(int status);

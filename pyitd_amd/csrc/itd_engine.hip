@@ -306,6 +306,19 @@ struct itd_engine {
 
 namespace {
 
+// PYITD_POISON=1 (a debugging switch of the environment, read once): every workspace the library allocates is filled with 0xFF bytes
+// (NaNs / -1) before its first use, so that a kernel that reads memory nobody wrote fails on every run instead of once in ten
+// thousand — what tools/stream_fuzz.py and the suite are run under in the evidence session.  Off: allocations cost what they cost.
+inline bool poison_on()
+{
+    static const bool on = [] { const char *v = getenv("PYITD_POISON"); return v && *v && *v != '0'; }();
+    return on;
+}
+inline void poison(void *p, size_t bytes)
+{
+    if (p && bytes && poison_on()) { (void)hipMemset(p, 0xFF, bytes); (void)hipDeviceSynchronize(); }   // (a fill on the null stream is not ordered with the engines' non-blocking streams)
+}
+
 int fail_hip(itd_engine *e, hipError_t rc, const char *what)
 {
     if (e) snprintf(e->err, sizeof(e->err), "%s: %s (%d)", what, hipGetErrorString(rc), (int)rc);
@@ -429,6 +442,7 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
     const size_t total = b_sig + b_pool + b_first + b_tf + b_tie + b_rec;
     const hipError_t rc = hipMalloc(&e->d_kf, total);
     if (rc != hipSuccess) { e->d_kf = nullptr; fail_hip(e, rc, "hipMalloc(fused levels' workspace)"); return rc == hipErrorOutOfMemory ? ITD_ERR_NOMEM : ITD_ERR_HIP; }
+    poison(e->d_kf, total);
     e->kf_bytes = total;
     e->ws_bytes += (int64_t)total;
     char *p = (char *)e->d_kf;
@@ -440,7 +454,8 @@ int ensure_kf_ws(itd_engine *e, int tpw, bool may_allocate)
     w.nearw = (unsigned long long *)p; p += b_tie;
     w.rec = (unsigned long long *)p;
     // the signals' generation counters start at 0 and no record carries a tag yet
-    if (hipMemset(w.sig, 0, b_sig) != hipSuccess || hipMemset(w.rec, 0, b_rec) != hipSuccess) return ITD_ERR_HIP;
+    // (hipMemset runs on the null stream; the launches that use the workspace on non-blocking streams: the fills have to be over first)
+    if (hipMemset(w.sig, 0, b_sig) != hipSuccess || hipMemset(w.rec, 0, b_rec) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ITD_ERR_HIP;
     w.wgs_max = (int32_t)wgs; w.rec_levels = kKfLevels;
     {   // how many knot-side workgroups are resident at once: a grid within that takes its ids from blockIdx (itd_knotfirst.hpp)
         int per_cu = 0, cus = 0;
@@ -901,6 +916,7 @@ int grow(itd_engine *e, Tp **p, size_t *have, size_t want)
     *have = 0;
     hipError_t rc = hipMalloc((void **)p, want);
     if (rc != hipSuccess) { fail_hip(e, rc, "hipMalloc(io)"); return ITD_ERR_NOMEM; }
+    poison(*p, want);
     *have = want;
     return ITD_OK;
 }
@@ -1017,7 +1033,7 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->tiles_half = (int64_t)B * e->max_tiles;
     e->gsum_third = (int64_t)B * max_groups * kGsumPitch;
     hipError_t rc = hipSuccess;
-    auto alloc = [&](void **p, size_t bytes) { if (rc == hipSuccess) { rc = hipMalloc(p, bytes); if (rc == hipSuccess) e->ws_bytes += (int64_t)bytes; } };
+    auto alloc = [&](void **p, size_t bytes) { if (rc == hipSuccess) { rc = hipMalloc(p, bytes); if (rc == hipSuccess) { e->ws_bytes += (int64_t)bytes; poison(*p, bytes); } } };
     alloc((void **)&e->d_lists, (size_t)e->max_tiles * T * sizeof(int32_t));   // API helpers only (one signal)
     alloc((void **)&e->d_counts, 2 * (size_t)e->tiles_half * sizeof(int32_t));
     alloc((void **)&e->d_recs, 2 * (size_t)e->tiles_half * sizeof(TileRec));
@@ -1519,7 +1535,7 @@ int itd_debug_int_ratio_check(int device, int32_t max_den, int64_t *mismatches)
     if (!mismatches || max_den < 1) return ITD_ERR_INVALID_ARG;
     DevGuard g(device);
     unsigned long long *d = nullptr, h = 0;
-    if (hipMalloc(&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess) { (void)hipFree(d); return ITD_ERR_HIP; }
+    if (hipMalloc(&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(d); return ITD_ERR_HIP; }
     k_int_ratio_check<<<1024, 256>>>(max_den, d);
     const bool ok = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipFree(d);

@@ -29,6 +29,10 @@ timeout -k 10 300 python tools/meitd_bench.py > $O/meitd_wall_time.txt 2>&1 || e
 timeout -k 10 300 python tools/meitd_ops.py > $O/meitd_ops.txt 2>&1 || exit 1
 timeout -k 10 600 python tools/meitd_fuzz.py 5000 7 > $O/meitd_fuzz_5000.txt 2>&1 || exit 1; tail -1 $O/meitd_fuzz_5000.txt
 timeout -k 10 300 python tools/spline_long_bench.py > $O/spline_long_signal.txt 2>&1 || exit 1; tail -1 $O/spline_long_signal.txt
+# the block-wise operators against the recipe's CPU statement, plain and with poisoned workspaces; the parity fuzz with poisoned workspaces
+timeout -k 10 600 python tools/stream_fuzz.py 5000 9 > $O/stream_fuzz_5000.txt 2>&1 || exit 1; tail -1 $O/stream_fuzz_5000.txt
+PYITD_POISON=1 timeout -k 10 600 python tools/stream_fuzz.py 2000 10 > $O/stream_fuzz_2000_poisoned.txt 2>&1 || exit 1; tail -1 $O/stream_fuzz_2000_poisoned.txt
+PYITD_POISON=1 timeout -k 10 600 python tools/fuzz_parity.py 5000 605 > $O/fuzz_5000_default_poisoned.txt 2>&1 || exit 1; tail -1 $O/fuzz_5000_default_poisoned.txt
 bash tools/suite_modes.sh $tag || exit 1
 python - <<PY
 import json

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The -m gpu suite with the fused sparse levels in their other modes (every Engine reads these variables at creation: pyitd_amd/engine.py):
-# off; fusing every signal of >= 65536 samples; that with 16-tile knot-side workgroups; that with the first fused level pinned to 2.
+# off; fusing every signal of >= 65536 samples; that with 16-tile knot-side workgroups; that with the first fused level pinned to 2;
+# and with every workspace the library allocates filled with 0xFF bytes first (PYITD_POISON=1: a kernel that reads what nobody wrote fails).
 # usage (through gpurun): bash tools/suite_modes.sh r05
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 tag=${1:-r05}; O=gpurun_out/$tag; mkdir -p $O
@@ -11,4 +12,6 @@ run fuse_off PYITD_FUSE_MODE=1
 run fuse_min_65536 PYITD_FUSE_MIN=65536
 run fuse_min_65536_range16 PYITD_FUSE_MIN=65536 PYITD_FUSE_RANGE=16
 run fuse_min_65536_level2 PYITD_FUSE_MIN=65536 PYITD_FUSE_LEVEL=2
+run poisoned_workspaces PYITD_POISON=1
+run poisoned_workspaces_fuse_min_65536 PYITD_POISON=1 PYITD_FUSE_MIN=65536
 exit $rc_all
