@@ -33,6 +33,8 @@ timeout -k 10 300 python tools/spline_long_bench.py > $O/spline_long_signal.txt 
 timeout -k 10 600 python tools/stream_fuzz.py 5000 9 > $O/stream_fuzz_5000.txt 2>&1 || exit 1; tail -1 $O/stream_fuzz_5000.txt
 PYITD_POISON=1 timeout -k 10 600 python tools/stream_fuzz.py 2000 10 > $O/stream_fuzz_2000_poisoned.txt 2>&1 || exit 1; tail -1 $O/stream_fuzz_2000_poisoned.txt
 PYITD_POISON=1 timeout -k 10 600 python tools/fuzz_parity.py 5000 605 > $O/fuzz_5000_default_poisoned.txt 2>&1 || exit 1; tail -1 $O/fuzz_5000_default_poisoned.txt
+timeout -k 10 600 python tools/ops_fuzz.py 30000 2 2>/dev/null > $O/ops_fuzz_30000.txt || exit 1; tail -1 $O/ops_fuzz_30000.txt
+PYITD_POISON=1 timeout -k 10 600 python tools/ops_fuzz.py 5000 3 2>/dev/null > $O/ops_fuzz_5000_poisoned.txt || exit 1; tail -1 $O/ops_fuzz_5000_poisoned.txt
 bash tools/suite_modes.sh $tag || exit 1
 python - <<PY
 import json
