@@ -432,9 +432,11 @@ int itd_copy(itd_engine *e, void *dst, const void *src, int64_t bytes, int32_t k
  * parallel-in-knots form for such a signal (ITD_SPLINE_PARALLEL, or ITD_SPLINE_AUTO and n >= 1024); otherwise ITD_ERR_INVALID_ARG.
  * rows_dev: (6 + 2 * 22) rows of n float64 in one allocation — rows 0..5 working rows (the signal in row 5 on entry), rows 6..27
  * the kept rotations taken off the signal ("high", MEITD.py:447), rows 28..49 those taken off its baselines ("low", :450).
- * wpemax: MEITD's WPEMAX.  result_host[16]: status, number of high rows, number of low rows, the working row that holds the
- * residual, entropy probes taken, extractions run, turns of the loop, 0, then (a diagnostic) the launch's time in units of 10 ns
- * spent in the probes, the extractions, the extrema counts and the row copies / subtractions, and four zeros.  status 0: delivered; 1: the signal has fewer than four
+ * wpemax: MEITD's WPEMAX.  result_host[24]: status, number of high rows, number of low rows, the working row that holds the
+ * residual, entropy probes taken, extractions run, turns of the loop, 0, then sixteen diagnostic words — the launch's time in
+ * units of 10 ns spent in the probes, the extractions, the extrema counts, the row copies / subtractions, the probes' ordered sums,
+ * their entropies, two zeros, the extractions' phases (knots, knot values, rows, forward sweep, backward sweep, evaluation), two
+ * zeros.  status 0: delivered; 1: the signal has fewer than four
  * extrema (MEITD.py:411-413 returns zeros and the data); 2 (a NaN in a row), 3 (an extraction met fewer than two knots: scipy
  * raises there), 4 (more than 1024 probes): NOT delivered — run the loop from the host, which reproduces the reference's behaviour
  * for those.  probe_log_host (log_cap entries of 88 bytes: double w[6]; int32 c[6]; int32 count; int32 0; double entropy): every

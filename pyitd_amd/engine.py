@@ -398,7 +398,7 @@ class Engine:
 
     def meitd_small_dev(self, rows_ptr, n, wpemax, stream=None):
         """MEITD's selection loop on the device rows at rows_ptr (include/pyitd_hip.h: itd_meitd_small_f64; the signal in row 5):
-        returns (result[16] = status, high rows, low rows, residual's row, probes, extractions, turns, 0, then the launch's time per
+        returns (result[24] = status, high rows, low rows, residual's row, probes, extractions, turns, 0, then the launch's time per
         operator kind in 10 ns units: probes, extractions, counts, copies; the probes' log)."""
         res = np.zeros(24, np.int32)
         log = np.zeros(1024, self.MEITD_PROBE)
