@@ -38,6 +38,7 @@ PYITD_POISON=1 timeout -k 10 600 python tools/ops_fuzz.py 5000 3 2>/dev/null > $
 timeout -k 10 600 python tools/tfe_fuzz.py 3000 1 > $O/tfe_fuzz_3000.txt 2>&1 || exit 1; tail -1 $O/tfe_fuzz_3000.txt
 timeout -k 10 600 python tools/spline_fuzz.py 3000 2 > $O/spline_fuzz_3000.txt 2>&1 || exit 1; tail -1 $O/spline_fuzz_3000.txt
 timeout -k 10 600 python tools/batch_ops_fuzz.py 5000 2 > $O/batch_ops_fuzz_5000.txt 2>&1 || exit 1; tail -1 $O/batch_ops_fuzz_5000.txt
+timeout -k 10 600 python tools/repair_fuzz.py 500 2 2>/dev/null > $O/repair_fuzz_500.txt || exit 1; tail -1 $O/repair_fuzz_500.txt
 bash tools/suite_modes.sh $tag || exit 1
 python - <<PY
 import json
