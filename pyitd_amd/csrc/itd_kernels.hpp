@@ -1074,7 +1074,10 @@ __device__ __forceinline__ int launch_item(int b, int n_items, int level)
 // path for full, ragged and unaligned tiles, and every access is unconditional — so the compiler can count them and wait for
 // exactly the load it needs (vmcnt) instead of for all of them.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBufNT = 2;   // aux bits of the raw buffer builtins on gfx94x/gfx950: 2 = nt
+#ifndef ITD_BUF_AUX
+#define ITD_BUF_AUX 2            // A/B builds: the aux bits of the streaming accesses (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
+constexpr int kBufNT = ITD_BUF_AUX;   // aux bits of the raw buffer builtins on gfx94x/gfx950: 2 = nt
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void *base, int64_t bytes_left)
 {
     const int64_t lim = bytes_left < 0 ? 0 : (bytes_left > 0x7fffffffll ? 0x7fffffffll : bytes_left);
