@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ITD_ABI_VERSION 10
+#define ITD_ABI_VERSION 11
 
 /* rotations/baselines hold at most 22 rows in the reference (ITD.py:384-385): max_iteration <= 20 */
 #define ITD_MAX_ROWS 22
@@ -230,6 +230,10 @@ int itd_set_fuse_group(itd_engine *e, int32_t chunks);
  *                   wavefronts count the verified flag words themselves, the verdict compares.
  * `level` is the absolute level (first fused level .. max_iteration + 1). */
 int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where, int32_t slot, int32_t delta);
+/* Tests only (ABI revision 11): the armed fault lands in signal `signal` of the batch instead of signal 0 (kinds 6 / 7: in that signal's
+ * knot-side workgroup `where`) — the fused levels of a batch run many signals per launch, and what is verified for signal 0 has to hold
+ * for every other one. */
+int itd_debug_kf_fault_signal(itd_engine *e, int32_t signal);
 /* Tests only (ABI revision 9): the kernels form the knot spacings' ratio (k1 - k0) / (k2 - k0) of ITD.py:107 with the division's own
  * instruction sequence minus its range scaling and special-case fix-up, which do nothing for exact small integers (itd_kernels.hpp:
  * int_ratio).  This runs that sequence against the compiler's full float64 division on the device for EVERY pair 0 <= a <= b <= max_den
@@ -270,6 +274,16 @@ int itd_set_batch_chunk(itd_engine *e, int32_t signals_per_chunk);
  * from / joined to the caller's stream by events), so that one chunk's launch boundaries and tails overlap another's work.
  * 1 .. 4; default 2 (with automatic chunks of about 1.2e7 samples: 32.5 ms against 35.9 ms over one stream for 1024 x 2^20). */
 int itd_set_batch_streams(itd_engine *e, int32_t streams);
+/* ABI revision 11.  on = 1: a batch whose chunks run the fused sparse levels (itd_set_fuse_mode) is PIPELINED (needs
+ * itd_set_batch_streams >= 2): the caller's stream runs every chunk's level launches and its knot side in order, ONE stream of the
+ * engine the chunks' passes over the samples, chunk k's beside chunk k + 1's knot side (latency-bound: ~50 us per chunk with HBM idle).
+ * A 65 KB workgroup finds no room on a device that one-wavefront workgroups have filled, so each sample pass waits behind a gate (one
+ * wavefront that returns when every workgroup of the next knot side has started) instead of behind an event.  on = 0 (default): the
+ * chunks rotate over the streams, each chunk's launches in order on its stream.  Measured on 512 x 2^20 samples, 8 levels: 12.8-13.0 ms
+ * pipelined against 11.9-12.3 ms rotating — a resident knot side costs the memory-bound launches a quarter of the wave slots, more than
+ * hiding it returns (profiles/r06/experiments/README.md); kept for devices / shapes where that balance differs.  Results do not depend
+ * on it; a call that is being captured into a hipGraph always takes the rotating form. */
+int itd_set_batch_pipeline(itd_engine *e, int32_t on);
 
 /* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
  * launch); to inspect them run itd_detect_* on the input or on a stored baseline row.  The single-level operators

@@ -17,7 +17,7 @@ HEADERS = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) + glob.glob(os.
 
 MAX_ROWS = 22
 MAX_ITERATION = 20
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # name -> (restype, argtypes); mirrors include/pyitd_hip.h one to one
 _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
@@ -80,6 +80,7 @@ ABI = {
     "itd_set_nan_input_mode": (_INT, [_P, _I32]),
     "itd_set_batch_chunk": (_INT, [_P, _I32]),
     "itd_set_batch_streams": (_INT, [_P, _I32]),
+    "itd_set_batch_pipeline": (_INT, [_P, _I32]),
     "itd_set_level0_mode": (_INT, [_P, _I32]),
     "itd_set_host_keep_baselines": (_INT, [_P, _I32]),
     "itd_get_last_baselines_host": (_INT, [_P, _P, _I64, _I32]),
@@ -95,6 +96,7 @@ ABI = {
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),
     "itd_set_fuse_group": (_INT, [_P, _I32]),
     "itd_debug_kf_fault": (_INT, [_P, _I32, _I32, _I32, _I32, _I32]),
+    "itd_debug_kf_fault_signal": (_INT, [_P, _I32]),
     "itd_debug_int_ratio_check": (_INT, [_INT, _I32, ctypes.POINTER(_I64)]),
     "itd_get_fuse_repeats": (_INT, [_P]),
     "itd_get_last_fuse_level": (_INT, [_P]),

@@ -211,6 +211,14 @@ struct itd_engine {
     int32_t batch_streams = 2;     // chunks of a batch rotate over this many streams (itd_set_batch_streams): 1 .. kMaxBatchStreams
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // the others besides the caller's, created on demand
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // the batch pipeline (itd_set_batch_pipeline; enqueue_decompose): the fused levels' knot side of chunk k + 1 on aux_stream[0] beside the
+    // memory-bound launches of the caller's stream
+    int32_t batch_pipeline = 0;                    // off by default: measured 12.8-13.0 ms against the rotating chunks' 11.9-12.3 on 512 x 2^20 (profiles/r06/experiments)
+    std::vector<hipEvent_t> ev_pipe;               // two per chunk: the chunk's level launches are done (caller's stream) / its knot side is (aux_stream[0])
+    unsigned long long *d_kf_started = nullptr;    // KfWs::started: knot-side workgroups that have started, over the engine's life
+    unsigned long long kf_started_target = 0;      // ... as many as have been launched
+    long long pipe_gate_timeout = 5000000;         // ticks of the 100 MHz clock the pipeline's waits last at most (50 ms: longer than a knot side
+                                                   // whose own halo waits are given up, ITD_KC_TIMEOUT)
 
     int32_t resident_mode = ITD_RESIDENT_AUTO;   // short signals as one workgroup each, one launch (itd_set_resident_mode)
     int32_t resident_off_left = 0;  // automatic mode: decompositions still to run level by level after a resident call met a non-finite value
@@ -255,6 +263,7 @@ struct itd_engine {
     int last_kf_form = 0;          // ... as enqueued (itd_get_last_fuse_level): stays when a summary has drawn the verdict (last_kf = false then)
     // fault injection into the fused levels' workspace (itd_debug_kf_fault; tests only): kind < 0 = none
     int32_t fault_kind = -1, fault_level = 0, fault_where = 0, fault_slot = 0, fault_delta = 0;
+    int32_t fault_sig = 0;         // the signal of the batch the fault lands in (itd_debug_kf_fault_signal)
     int32_t spline_solver = ITD_SPLINE_AUTO;   // FITPACK flavour: serial bit-level sweep or the parallel moment form (itd_set_spline_solver)
     int32_t l0_mode = ITD_LEVEL0_AUTO;   // how level 0 finds its knots (itd_set_level0_mode)
     int32_t l0_records_left = 0;   // automatic mode: decompositions still to run record-driven after a fused launch fell short
@@ -552,7 +561,28 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     // chunks that share one knot side of the fused levels (grid.y of its launches: at most 65535 signals)
     const int group = (kf && n_chunks > 1) ? std::max(1, std::min<int>(e->fuse_group, kMaxGridY / chunk)) : 1;
     const int n_seqs = (n_chunks + group - 1) / group;
-    const int S = (e->chunk == 0 && (int64_t)chunk * n > ((int64_t)3 << 22)) ? 1 : std::min<int>(e->batch_streams, n_seqs);
+    // The batch pipeline (itd_set_batch_pipeline): with fused levels the chunks do not rotate over the streams — the caller's stream runs
+    // every chunk's level launches and knot side in order, aux_stream[0] the sample passes, each beside the NEXT chunk's knot side
+    // (below).  Not while capturing: a graph replays by its dependencies, a gate would poll in vain.
+    const bool pipelined = kf && !capturing && e->batch_pipeline && e->batch_streams > 1 && n_chunks > 1 && group == 1;
+    const int S = pipelined ? 1 : ((e->chunk == 0 && (int64_t)chunk * n > ((int64_t)3 << 22)) ? 1 : std::min<int>(e->batch_streams, n_seqs));
+    if (pipelined) {
+        if (!e->aux_stream[0]) {
+            HIP_TRY(e, hipStreamCreateWithFlags(&e->aux_stream[0], hipStreamNonBlocking));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
+        }
+        if (!e->d_kf_started) {
+            HIP_TRY(e, hipMalloc(&e->d_kf_started, 16));
+            HIP_TRY(e, hipMemset(e->d_kf_started, 0, 16));
+            HIP_TRY(e, hipDeviceSynchronize());          // (a fill on the null stream is not ordered with the engine's non-blocking streams)
+            e->kf_started_target = 0;
+        }
+        while (e->ev_pipe.size() < 1) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->ev_pipe.push_back(ev);
+        }
+    }
     if (S > 1) {
         if (!e->ev_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         HIP_TRY(e, hipEventRecord(e->ev_fork, st));
@@ -670,6 +700,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             //  its share of the device only)
             w.ticketed = ((int64_t)w.wgs * nb * S > e->kf_resident_wgs || e->kf_force_tickets) ? 1 : 0;
             w.dbg_kind = e->fault_kind; w.dbg_lev = e->fault_level; w.dbg_wg = e->fault_where; w.dbg_slot = e->fault_slot; w.dbg_delta = e->fault_delta;
+            w.dbg_sig = e->fault_sig - b0;               // (relative to this launch's first signal; outside it: no workgroup matches)
+            w.started = pipelined ? e->d_kf_started : nullptr;
             const size_t B0 = (size_t)b0;
             w.sig += B0; w.pool += B0 * (size_t)w.wgs_max * kKcSlab; w.rec += B0 * (size_t)w.rec_levels * w.wgs_max * kKcRecGran;
             w.first += B0 * (size_t)w.nlev * n_tiles; w.tflags += B0 * (size_t)w.nlev * n_tiles * 8; w.nearw += B0 * (size_t)n_tiles * 8;
@@ -691,14 +723,15 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 void *args[] = {&a_w, &a_f, &a_xl, &a_ls, &a_n, &a_m, &a_c, &a_r, &a_st};
                 HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_kf_knots<T>), dim3((unsigned)w.wgs * (unsigned)nb), dim3(kKcThreads), args, 0, kst,
                                               p_kn >= 0 ? e->ev[2 * (size_t)p_kn] : nullptr, p_kn >= 0 ? e->ev[2 * (size_t)p_kn + 1] : nullptr, 0));
+                if (w.started) e->kf_started_target += (unsigned long long)w.wgs * (unsigned long long)nb;
             }
             if (phase & 4) {
 #ifdef ITD_DEBUG_GAP
                 k_debug_gap<<<1, 64, 0, cst>>>((long long)(ITD_DEBUG_GAP) * 100);
 #endif
                 if (e->fault_kind >= 0 && (e->fault_kind <= 5 || e->fault_kind == 8) && e->fault_level >= L0 && e->fault_level - L0 < w.nlev && e->fault_where >= 0 &&
-                    e->fault_where < n_tiles)      // (tests only) one field of what the sample pass is about to read, perturbed
-                    k_kf_fault<<<1, 64, 0, cst>>>(w, e->fault_kind, e->fault_level - L0, e->fault_where, e->fault_slot & 0xffff, e->fault_delta);
+                    e->fault_where < n_tiles && e->fault_sig >= b0 && e->fault_sig < b0 + nb)      // (tests only) one field of what the sample pass is about to read, perturbed
+                    k_kf_fault<<<1, 64, 0, cst>>>(w, e->fault_sig - b0, e->fault_kind, e->fault_level - L0, e->fault_where, e->fault_slot & 0xffff, e->fault_delta);
                 const int pair = time_slot(e, ITD_TIME_KF_APPLY);
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
                 const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
@@ -710,8 +743,40 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         }
         return ITD_OK;
     };
+    if (pipelined) {
+        // caller's stream X:   A_0 K_0 | A_1 K_1 | A_2 K_2 | ...                      A_k: chunk k's level launches, K_k: its knot side
+        // aux_stream[0]   Y:        g_1 P_0 | g_2 P_1 | ...  | P_last                P_k: its sample pass, g_k: a gate (k_kf_gate)
+        // A knot side needs room when it STARTS: 65 KB of LDS and eight wave slots per workgroup, which a device full of one-wavefront
+        // workgroups never has (profiles/r04/experiments/README.md) — but once its workgroups are resident it needs no bandwidth and
+        // runs hidden beside a memory-bound launch.  So K_k follows A_k in stream order (started ~2 us after A_k's last wavefront has
+        // gone), and the OTHER stream's next sample pass waits behind a gate — one wavefront that returns when every workgroup of
+        // K_k has started (KfWs::started) — instead of filling the device the moment A_k drains.  P_{k-1} then runs beside K_k, its
+        // tail beside A_{k+1}.  The gate also orders P_{k-1} behind K_{k-1}, which ended before A_k began.  No event crosses the
+        // queues on the way (an event costs ~13 us of idle device, measured), except at the call's two ends.
+        const hipStream_t q = e->aux_stream[0];
+        if (!e->ev_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+        HIP_TRY(e, hipStreamWaitEvent(q, e->ev_fork, 0));
+        for (int k = 0; k < n_chunks; ++k) {
+            const int b0 = k * chunk, nb = std::min(chunk, batch - b0);
+            int rc = run_chunk(b0, nb, st, 3);
+            if (rc) return rc;
+            if (k >= 1) {
+                k_kf_gate<<<1, kWave, 0, q>>>(e->d_kf_started, e->kf_started_target, e->pipe_gate_timeout);
+                rc = run_chunk(b0 - chunk, chunk, q, 4);
+                if (rc) return rc;
+            }
+        }
+        HIP_TRY(e, hipEventRecord(e->ev_pipe[0], st));
+        HIP_TRY(e, hipStreamWaitEvent(q, e->ev_pipe[0], 0));
+        const int bl = (n_chunks - 1) * chunk;
+        const int rc = run_chunk(bl, batch - bl, q, 4);
+        if (rc) return rc;
+        HIP_TRY(e, hipEventRecord(e->ev_join[0], q));
+        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[0], 0));
+    }
     int seq_no = 0;
-    for (int s0 = 0; s0 < batch; s0 += chunk * group, ++seq_no) {
+    for (int s0 = pipelined ? batch : 0; s0 < batch; s0 += chunk * group, ++seq_no) {
         const int lane_s = seq_no % S;
         const hipStream_t cst = lane_s == 0 ? st : e->aux_stream[lane_s - 1];   // this launch sequence's stream
         const int s1 = std::min(batch, s0 + chunk * group);
@@ -1027,6 +1092,8 @@ int itd_engine_create(itd_engine **out, int device_id, int64_t max_n, int32_t ma
     e->max_n = max_n;
     e->max_batch = max_batch;
     e->max_tiles = tiles_of(max_n);
+    // (sweeps only, tools/pipeline_sweep.py: the batch pipeline's two constants)
+    if (const char *v = getenv("PYITD_PIPE_GATE_US")) e->pipe_gate_timeout = 100ll * atoll(v);
     DevGuard g(device_id);
     const size_t B = (size_t)max_batch;
     const int max_groups = groups_of((int)e->max_tiles);
@@ -1087,6 +1154,8 @@ void itd_engine_destroy(itd_engine *e)
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (auto ev : e->ev_pipe) if (ev) (void)hipEventDestroy(ev);
+    (void)hipFree(e->d_kf_started);
     delete e;
 }
 
@@ -1552,6 +1621,13 @@ int itd_debug_kf_fault(itd_engine *e, int32_t kind, int32_t level, int32_t where
     return ITD_OK;
 }
 
+int itd_debug_kf_fault_signal(itd_engine *e, int32_t signal)
+{
+    if (!e || signal < 0) return ITD_ERR_INVALID_ARG;
+    e->fault_sig = signal;
+    return ITD_OK;
+}
+
 int itd_get_fuse_repeats(const itd_engine *e) { return e ? e->fuse_repeats : -1; }
 int itd_get_last_fuse_level(const itd_engine *e) { return !e ? -1 : (e->ran && e->last_kf_form ? e->last_kf_form : 0); }
 int64_t itd_get_fuse_signal_repairs(const itd_engine *e) { return e ? e->fuse_signal_repairs : -1; }
@@ -1582,6 +1658,13 @@ int itd_set_batch_streams(itd_engine *e, int32_t streams)
 {
     if (!e || streams < 1 || streams > 4) return ITD_ERR_INVALID_ARG;
     e->batch_streams = streams;
+    return ITD_OK;
+}
+
+int itd_set_batch_pipeline(itd_engine *e, int32_t on)
+{
+    if (!e || on < 0 || on > 1) return ITD_ERR_INVALID_ARG;
+    e->batch_pipeline = on;
     return ITD_OK;
 }
 

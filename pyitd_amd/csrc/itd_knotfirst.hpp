@@ -158,6 +158,10 @@ struct KfWs {
     // fault injection (itd_debug_kf_fault, tests only): kind 6 / 7 = a halo knot's value / position as this launch's workgroup `wg`
     // receives it at level `lev` is perturbed (kinds 0 .. 5 are applied to the workspace by k_kf_fault between the two launches)
     int32_t dbg_kind, dbg_lev, dbg_wg, dbg_slot, dbg_delta;
+    int32_t dbg_sig;              // ... of signal dbg_sig of the launch
+    // the batch pipeline (itd_engine.hip, enqueue_decompose): every knot-side workgroup counts itself here when it starts — a counter that
+    // only ever grows; k_kf_gate on the memory-bound launches' stream returns when all of a launch's workgroups are resident.  NULL: not counted
+    unsigned long long *started;
 };
 
 __device__ __forceinline__ bool kf_pred(double yl, double yc, double yr)
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     for (int i = 0; i < 64; ++i) kc_marks[i] = 0;
 #endif
     KC_MARK(0);
+    if (ws.started && tid == 0) atomicAdd(ws.started, 1ull);      // (in front of every return: the gate counts workgroups, whatever they go on to do)
     int id = blockIdx.x;
     if (ws.ticketed) {
         if (tid == 0) s_i[0] = atomicAdd(&ws.sig[0].ticket, 1);
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
         if (lev == L0) published = lev;
         kc_barrier();
         if (s_i[1]) return false;
-        if ((ws.dbg_kind == 6 || ws.dbg_kind == 7) && lev == ws.dbg_lev && w == ws.dbg_wg && sig == 0) {   // fault injection (tests): a halo knot as received
+        if ((ws.dbg_kind == 6 || ws.dbg_kind == 7) && lev == ws.dbg_lev && w == ws.dbg_wg && sig == ws.dbg_sig) {   // fault injection (tests): a halo knot as received
             if (tid == 0) {
                 const int d = ws.dbg_slot < 2 ? ws.dbg_slot : ck + ws.dbg_slot;     // slots 0, 1: in front; 2 .. 4: behind
                 if (ws.dbg_kind == 6) k_X[d] = __builtin_bit_cast(double, dbits(k_X[d]) + (unsigned long long)(long long)ws.dbg_delta);
@@ -876,6 +881,97 @@ __device__ __forceinline__ int ne_d(double a, double b)
     return (int)((unsigned)x | (unsigned)(x >> 32));
 }
 __device__ __forceinline__ int ne_i(int32_t a, int32_t b) { return a ^ b; }
+#ifndef ITD_KF_VERIFY
+#define ITD_KF_VERIFY 31          // timing-only A/B builds: bit k = check Vk is compiled in, bit 4 = the levels' knot counts (the shipped build: all)
+#endif
+// ---- V2, V3 and the counts: what can be verified on the tables themselves.  One wavefront per knot-side workgroup (slab) and level.
+//      Entries 1 .. cnt of the slab's table are the range's knots, 0 and cnt + 1 the copies of the knots around the range.
+//      V3 inside   first[t + 1] == first[t] + (population of tile t's flag words) for the range's tiles: the runs chain;
+//      V2          B of entries 1 .. cnt from the positions and values of entries r-1, r, r+1 (ITD.py:107-110), S of entries
+//                  0 .. cnt from B and X of entries r, r+1 (ITD.py:115-116), bit for bit;
+//      V3 across   the next slab's entry 0 (its copy of the knot in front of it) equals this slab's entry cnt, its entry 1
+//      two slabs   (the first knot at or behind its first sample) this slab's entry cnt + 1: all four fields, bit for bit.
+//      Returns != 0 in some lane if anything differs.
+__device__ __forceinline__ int kf_check_slab(const KfWs &ws, int sig, int w, int li, int lane)
+{
+    const int n_tiles = ws.n_tiles;
+    const int t0 = w * ws.tpw, t1 = min(n_tiles, t0 + ws.tpw);
+    const KfEntry *pool = ws.pool + (size_t)sig * ws.wgs_max * kKcSlab;
+    const int pool_n = ws.wgs_max * kKcSlab;
+    int vb = 0;
+    const int32_t *firstl = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;
+    const unsigned long long *tfl = ws.tflags + ((size_t)sig * ws.nlev + li) * n_tiles * 8;
+    const int start = firstl[t0];
+    const int f_next = t1 < n_tiles ? firstl[t1] : -1;
+    int cnt = 0;
+    for (int tb = t0; tb < t1; tb += kWave) {                // a tile per lane: the chain of the runs; the range's knot count
+        const int tt = tb + lane;
+        int f = 0, fn = 0, kt = 0;
+        if (tt < t1) {
+            using U2 = unsigned long long __attribute__((ext_vector_type(2)));
+            const U2 *wp = reinterpret_cast<const U2 *>(tfl + (size_t)tt * 8);
+            f = firstl[tt];
+            fn = tt + 1 < t1 ? firstl[tt + 1] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const U2 v = wp[q]; kt += __popcll(v.x) + __popcll(v.y); }
+            if ((ITD_KF_VERIFY & 8) && tt + 1 < t1) vb |= ne_i(fn, f + kt);
+        }
+        const int l_last = t1 - 1 - tb;                      // the lane of the range's last tile, if it is in this round
+        if (l_last < kWave) cnt = __shfl(f + kt, l_last) - start;
+    }
+    if (start < 0 || cnt < 0 || start + cnt + 2 > pool_n || (t1 < n_tiles && (f_next < 0 || f_next + 2 > pool_n))) vb = 1;
+    else if (ITD_KF_VERIFY & 4) {
+        const KfEntry *e = pool + start;
+        auto check = [&](const KfEntry &em, const KfEntry &e0, const KfEntry &e1, bool with_b) {
+            const double Sv = (e1.B - e0.B) / (e1.X - e0.X);                         // ITD.py:115-116
+            int bad_ = ne_d(Sv, e0.S);
+            const double frac = (double)(e0.pos - em.pos) / (double)(e1.pos - em.pos);
+            const double tt = frac * (e1.X - em.X);
+            const double u = em.X + tt;
+            const double Bv = 0.5 * u + 0.5 * e0.X;                                  // ITD.py:107-110
+            if (with_b) bad_ |= ne_d(Bv, e0.B);
+            return bad_;
+        };
+        for (int r = lane; r <= cnt; r += ITD_KF_CHECK_STEP * kWave) {       // two entries per lane and round: their loads fly together
+            const int r2 = r + kWave, q2 = min(r2, cnt);     // (beyond the slab's entries: the last one again, not counted)
+            const KfEntry a0 = e[r], a1 = e[r + 1], am = e[max(r - 1, 0)];
+            const KfEntry b0 = e[q2], b1 = e[q2 + 1], bm = e[q2 - 1 < 0 ? 0 : q2 - 1];
+            vb |= check(am, a0, a1, r >= 1);
+            if (ITD_KF_CHECK_STEP == 2 && r2 <= cnt) vb |= check(bm, b0, b1, true);
+        }
+        if (t1 < n_tiles && lane < 2) {
+            const KfEntry a = pool[f_next + lane], o = e[cnt + lane];
+            vb |= ne_i(a.pos, o.pos) | ne_d(a.X, o.X) | ne_d(a.B, o.B) | ne_d(a.S, o.S);
+        }
+    }
+    return vb;
+}
+// the levels' knot counts: the stop rules and the rows' number are drawn from the knot side's mlev[] — it has to be the population of
+// the flag words the sample pass verifies.  A slab per lane: what its chained runs hold (the slab's own check verifies the chain:
+// first[last tile] + that tile's population - first[first tile]), summed over the slabs.  (Added up by the slabs' wavefronts with one
+// atomic each the same sum cost the launch 27 us: 3 584 read-modify-writes behind a memory system full of the tiles' stores —
+// profiles/r05/experiments.)  Wave-uniform result: != 0 if level index li's count differs.
+__device__ __forceinline__ int kf_check_counts(const KfWs &ws, int sig, const KfSig *ks, int li, int lane)
+{
+    const int n_tiles = ws.n_tiles;
+    const int32_t *firstl = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;
+    const unsigned long long *tfl = ws.tflags + ((size_t)sig * ws.nlev + li) * n_tiles * 8;
+    int tot = 0;
+    for (int wb = 0; wb < ws.wgs; wb += kWave) {
+        const int a = (wb + lane) * ws.tpw, b = min(n_tiles, a + ws.tpw);
+        if (wb + lane < ws.wgs && a < b) {
+            using U2 = unsigned long long __attribute__((ext_vector_type(2)));
+            const U2 *wp = reinterpret_cast<const U2 *>(tfl + (size_t)(b - 1) * 8);
+            int kt = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const U2 v = wp[q]; kt += __popcll(v.x) + __popcll(v.y); }
+            tot += firstl[b - 1] + kt - firstl[a];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    return ne_i(tot, ks->mlev[ws.L0 + li]);
+}
 // workgroups of the sample pass's grid that verify the tables (V2, V3), in front of the tiles': one per knot-side workgroup,
 // padded to a multiple of 8 so that a tile's workgroup lands on the same XCD as in every other launch (xcd_item)
 __host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 1 + 7) & ~7; }     // (+ 1: the wavefront that sums the slabs' counts)
@@ -885,9 +981,6 @@ __host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 1 + 7
 #endif
 #ifndef ITD_KF_FASTGROUP
 #define ITD_KF_FASTGROUP 1        // A/B builds: 0 = every 128-sample group takes the by-rank path
-#endif
-#ifndef ITD_KF_VERIFY
-#define ITD_KF_VERIFY 31          // timing-only A/B builds: bit k = check Vk is compiled in, bit 4 = the levels' knot counts (the shipped build: all)
 #endif
 template <int TW, int CAP, bool BASES>      // BASES: the caller wants the baselines too (get_baselines()): a second row store per level
 __global__ __launch_bounds__(kWave)
@@ -901,109 +994,40 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     constexpr int G2 = TW / 128;
     __shared__ double s_X[CAP + 2], s_B[CAP + 2], s_S[CAP + 2];
     __shared__ int32_t s_P[CAP + 2];
-    const int sig = blockIdx.y, lane = lane_id();
-    KfSig *ks = ws.sig + sig;
+    // The grid is (n_tiles + n_chk, signals); workgroups are dispatched in the order of their linear id (x fastest).  The FIRST n_chk x signals
+    // of them are the check wavefronts of ALL the launch's signals (their dependent loads, ~40 round trips, take 40-70 us: in front of
+    // every signal's own tiles the last signals' check wavefronts outlived the launch's tiles — a batch chunk's sample pass took 103 us
+    // against 88 for the same samples as one signal), the rest the tiles, signal after signal.
+    const int lane = lane_id();
     const int n_tiles = ws.n_tiles;
+    const int n_chk = kf_check_blocks(ws.wgs);
+    const int lin = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, n_chk_all = n_chk * (int)gridDim.y;
+    const bool is_chk = lin < n_chk_all;
+    const int sig = is_chk ? lin / n_chk : (lin - n_chk_all) / n_tiles;
+    const int item = is_chk ? lin - sig * n_chk : (lin - n_chk_all) - sig * n_tiles;
+    KfSig *ks = ws.sig + sig;
     if (!ks->active || ks->fail) return;
     const int lend = ks->lend, natural = ks->natural;
     if (lend < 0) return;
-    const int n_chk = kf_check_blocks(ws.wgs);   // (the grid's FIRST workgroups: they overlap the tiles' instead of trailing them)
-    if ((int)blockIdx.x < n_chk) {
-        // ---- one wavefront per knot-side workgroup, level after level: what can be verified on the tables themselves, a knot (or a tile) per
-        //      lane instead of a handful of lanes in every tile's wavefront.  Entries 1 .. cnt of the slab's table are the range's
-        //      knots, 0 and cnt + 1 the copies of the knots around the range.
-        //      V3 inside   first[t + 1] == first[t] + (population of tile t's flag words) for the range's tiles: the runs chain;
-        //      V2          B of entries 1 .. cnt from the positions and values of entries r-1, r, r+1 (ITD.py:107-110), S of entries
-        //                  0 .. cnt from B and X of entries r, r+1 (ITD.py:115-116), bit for bit;
-        //      V3 across   the next slab's entry 0 (its copy of the knot in front of it) equals this slab's entry cnt, its entry 1
-        //      two slabs   (the first knot at or behind its first sample) this slab's entry cnt + 1: all four fields, bit for bit.
+    if (is_chk) {
+        // ---- one wavefront per knot-side workgroup, level after level: what can be verified on the tables themselves (kf_check_slab,
+        //      kf_check_counts above), a knot (or a tile) per lane instead of a handful of lanes in every tile's wavefront
         if (!(ITD_KF_VERIFY & 12)) return;
-        const int w = (int)blockIdx.x;
+        const int w = item;
+        int vb = 0;
         if (w == ws.wgs && (ITD_KF_VERIFY & 16)) {
-            // the levels' knot counts: the stop rules and the rows' number are drawn from the knot side's mlev[] — it has to be the
-            // population of the flag words verified here.  A slab per lane: what its chained runs hold (the slab's own wavefront checks
-            // the chain: first[last tile] + that tile's population - first[first tile]), summed over the slabs, level by level.  (Added
-            // up by the slabs' wavefronts with one atomic each the same sum cost the launch 27 us: 3 584 read-modify-writes behind a
-            // memory system full of the tiles' stores — profiles/r05/experiments.)
-            int vb = 0;
-            for (int li = 0; li <= lend - ws.L0; ++li) {
-                const int32_t *firstl = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;
-                const unsigned long long *tfl = ws.tflags + ((size_t)sig * ws.nlev + li) * n_tiles * 8;
-                int tot = 0;
-                for (int wb = 0; wb < ws.wgs; wb += kWave) {
-                    const int a = (wb + lane) * ws.tpw, b = min(n_tiles, a + ws.tpw);
-                    if (wb + lane < ws.wgs && a < b) {
-                        using U2 = unsigned long long __attribute__((ext_vector_type(2)));
-                        const U2 *wp = reinterpret_cast<const U2 *>(tfl + (size_t)(b - 1) * 8);
-                        int kt = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { const U2 v = wp[q]; kt += __popcll(v.x) + __popcll(v.y); }
-                        tot += firstl[b - 1] + kt - firstl[a];
-                    }
-                }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-                vb |= ne_i(tot, ks->mlev[ws.L0 + li]);
-            }
+            for (int li = 0; li <= lend - ws.L0; ++li) vb |= kf_check_counts(ws, sig, ks, li, lane);
             if (vb != 0 && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
             return;
         }
         if (w >= ws.wgs) return;                                 // (the blocks that only pad the count to a multiple of 8)
-        const int t0 = w * ws.tpw, t1 = min(n_tiles, t0 + ws.tpw);
-        const KfEntry *pool = ws.pool + (size_t)sig * ws.wgs_max * kKcSlab;
-        const int pool_n = ws.wgs_max * kKcSlab;
-        int vb = 0;
-        for (int li = 0; li <= lend - ws.L0; ++li) {             // (one workgroup per slab, all its levels: every workgroup of this grid
-        const int32_t *firstl = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;          // costs dispatch time — 3072 of them, one
-        const unsigned long long *tfl = ws.tflags + ((size_t)sig * ws.nlev + li) * n_tiles * 8;   // per level and slab, cost 6 us)
-        const int start = firstl[t0];
-        const int f_next = t1 < n_tiles ? firstl[t1] : -1;
-        int cnt = 0;
-        for (int tb = t0; tb < t1; tb += kWave) {                // a tile per lane: the chain of the runs; the range's knot count
-            const int tt = tb + lane;
-            int f = 0, fn = 0, kt = 0;
-            if (tt < t1) {
-                using U2 = unsigned long long __attribute__((ext_vector_type(2)));
-                const U2 *wp = reinterpret_cast<const U2 *>(tfl + (size_t)tt * 8);
-                f = firstl[tt];
-                fn = tt + 1 < t1 ? firstl[tt + 1] : 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const U2 v = wp[q]; kt += __popcll(v.x) + __popcll(v.y); }
-                if ((ITD_KF_VERIFY & 8) && tt + 1 < t1) vb |= ne_i(fn, f + kt);
-            }
-            const int l_last = t1 - 1 - tb;                      // the lane of the range's last tile, if it is in this round
-            if (l_last < kWave) cnt = __shfl(f + kt, l_last) - start;
-        }
-        if (start < 0 || cnt < 0 || start + cnt + 2 > pool_n || (t1 < n_tiles && (f_next < 0 || f_next + 2 > pool_n))) vb = 1;
-        else if (ITD_KF_VERIFY & 4) {
-            const KfEntry *e = pool + start;
-            auto check = [&](const KfEntry &em, const KfEntry &e0, const KfEntry &e1, bool with_b) {
-                const double Sv = (e1.B - e0.B) / (e1.X - e0.X);                         // ITD.py:115-116
-                int bad_ = ne_d(Sv, e0.S);
-                const double frac = (double)(e0.pos - em.pos) / (double)(e1.pos - em.pos);
-                const double tt = frac * (e1.X - em.X);
-                const double u = em.X + tt;
-                const double Bv = 0.5 * u + 0.5 * e0.X;                                  // ITD.py:107-110
-                if (with_b) bad_ |= ne_d(Bv, e0.B);
-                return bad_;
-            };
-            for (int r = lane; r <= cnt; r += ITD_KF_CHECK_STEP * kWave) {       // two entries per lane and round: their loads fly together
-                const int r2 = r + kWave, q2 = min(r2, cnt);     // (beyond the slab's entries: the last one again, not counted)
-                const KfEntry a0 = e[r], a1 = e[r + 1], am = e[max(r - 1, 0)];
-                const KfEntry b0 = e[q2], b1 = e[q2 + 1], bm = e[q2 - 1 < 0 ? 0 : q2 - 1];
-                vb |= check(am, a0, a1, r >= 1);
-                if (ITD_KF_CHECK_STEP == 2 && r2 <= cnt) vb |= check(bm, b0, b1, true);
-            }
-            if (t1 < n_tiles && lane < 2) {
-                const KfEntry a = pool[f_next + lane], o = e[cnt + lane];
-                vb |= ne_i(a.pos, o.pos) | ne_d(a.X, o.X) | ne_d(a.B, o.B) | ne_d(a.S, o.S);
-            }
-        }
-        }
+        // (one workgroup per slab, all its levels: every workgroup of this grid costs dispatch time — 3072 of them, one per level and
+        //  slab, cost 6 us)
+        for (int li = 0; li <= lend - ws.L0; ++li) vb |= kf_check_slab(ws, sig, w, li, lane);
         if (__any(vb != 0) && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
         return;
     }
-    const int t = xcd_item((int)blockIdx.x - n_chk, n_tiles);
+    const int t = xcd_item(item, n_tiles);
     const int ni = (int)n, si = t * TW, rem = ni - si;
     const double *xs = xl + (int64_t)sig * xl_stride;
     const __amdgpu_buffer_rsrc_t rx = tile_rsrc32(xs + si, rem, 8);
@@ -1167,22 +1191,34 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     if ((bad || __any(vbad != 0)) && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
 }
 
+// The gate of the batch pipeline: ONE wavefront on the stream of the memory-bound launches.  The knot side of the next chunk has just become
+// ready on the engine's second stream (an event behind the launch that wrote its input); this launch returns when every workgroup of
+// it has started (KfWs::started has reached `target`), so that the launch behind the gate — tens of thousands of one-wavefront
+// workgroups — cannot take the LDS and the wave slots the knot side's 65 KB workgroups need: side by side from then on, the
+// latency-bound launch hides behind the memory-bound ones (tools/anyorder_probe.hip: no gate 229 us, gate 192, the parts 62 + 2 x 87).
+// Gives up after `timeout` ticks of the 100 MHz clock (the launches then share the device as they can; results do not depend on it).
+__global__ __launch_bounds__(kWave) void k_kf_gate(const unsigned long long *started, unsigned long long target, long long timeout)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < timeout) __builtin_amdgcn_s_sleep(4);
+}
+
 // fault injection for the tests (itd_debug_kf_fault): ONE field of the workspace the sample pass is about to read is perturbed,
 // between the knot side's launch and the sample pass.  kind 0 / 1 / 2: X / B / S of entry `slot` (mod the run's length) of tile
 // `tile`'s run at fused level index `li` (delta added to the bit pattern: ulps); 3: its position; 4: first[li][tile]; 5: bit
 // (delta & 63) of flag word `slot` & 7 of the tile flipped; 8: the level's knot count in the signal's head.
-__global__ void k_kf_fault(KfWs ws, int kind, int li, int tile, int slot, int delta)
+__global__ void k_kf_fault(KfWs ws, int sig, int kind, int li, int tile, int slot, int delta)
 {
     if (threadIdx.x || blockIdx.x) return;
     const int n_tiles = ws.n_tiles;
-    int32_t *first = ws.first + (size_t)li * n_tiles;
-    unsigned long long *tf = ws.tflags + ((size_t)li * n_tiles + tile) * 8;
-    if (kind == 8) { ws.sig[0].mlev[ws.L0 + li] += delta; return; }      // the knot side's count of the level's knots (what the stop rules read)
+    int32_t *first = ws.first + ((size_t)sig * ws.nlev + li) * n_tiles;                 // (signal `sig` of the launch)
+    unsigned long long *tf = ws.tflags + (((size_t)sig * ws.nlev + li) * n_tiles + tile) * 8;
+    if (kind == 8) { ws.sig[sig].mlev[ws.L0 + li] += delta; return; }    // the knot side's count of the level's knots (what the stop rules read)
     if (kind == 4) { first[tile] += delta; return; }
     if (kind == 5) { tf[slot & 7] ^= 1ull << (delta & 63); return; }
     int kn = 0;
     for (int q = 0; q < 8; ++q) kn += __popcll(tf[q]);
-    KfEntry *en = ws.pool + first[tile] + slot % (kn + 2);
+    KfEntry *en = ws.pool + (size_t)sig * ws.wgs_max * kKcSlab + first[tile] + slot % (kn + 2);
     if (kind == 0) en->X = __builtin_bit_cast(double, dbits(en->X) + (unsigned long long)(long long)delta);
     if (kind == 1) en->B = __builtin_bit_cast(double, dbits(en->B) + (unsigned long long)(long long)delta);
     if (kind == 2) en->S = __builtin_bit_cast(double, dbits(en->S) + (unsigned long long)(long long)delta);

@@ -56,6 +56,9 @@ class Engine:
         mode = os.environ.get("PYITD_FUSE_MIN")         # samples per launch sequence from which FUSE_AUTO fuses (tests: 65536)
         if mode:
             self.set_fuse_min_samples(int(mode))
+        mode = os.environ.get("PYITD_BATCH_PIPELINE")   # fused batches: 1 = pipelined instead of rotating chunks (A/B runs)
+        if mode:
+            self.set_batch_pipeline(int(mode))
         mode = os.environ.get("PYITD_RESIDENT_MODE")    # and for the one-workgroup form of short signals (RESIDENT_*)
         if mode:
             self.set_resident_mode(int(mode))
@@ -157,6 +160,10 @@ class Engine:
         itd_debug_kf_fault); kind < 0 disarms."""
         self._check(self._L.itd_debug_kf_fault(self._h, int(kind), int(level), int(where), int(slot), int(delta)))
 
+    def debug_kf_fault_signal(self, signal):
+        """Tests only: the armed fault lands in signal `signal` of the batch (default 0)."""
+        self._check(self._L.itd_debug_kf_fault_signal(self._h, int(signal)))
+
     def set_fuse_level(self, first_fused_level):
         """The first fused level, 2 .. max_iteration, or 0 (default) = automatic: 2 where a launch sequence covers >= 2^22 samples, else 3."""
         self._check(self._L.itd_set_fuse_level(self._h, int(first_fused_level)))
@@ -207,6 +214,11 @@ class Engine:
     def set_batch_streams(self, streams):
         """1 or 2: the chunks of a batched decomposition alternate over that many streams."""
         self._check(self._L.itd_set_batch_streams(self._h, int(streams)))
+
+    def set_batch_pipeline(self, on):
+        """Fused batches: 1 = chunk k's pass over the samples runs on the engine's second stream beside chunk k + 1's knot side (behind a
+        gate: include/pyitd_hip.h); 0 (default, measured faster on MI355X) = the chunks rotate over the streams."""
+        self._check(self._L.itd_set_batch_pipeline(self._h, int(on)))
 
     def kernel_timing(self, which=TIME_EXTRACT):
         """(total ms, launches) of the recorded launches of class `which` (TIME_*)."""

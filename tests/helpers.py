@@ -79,6 +79,37 @@ def fuzz_signal(rng, kind, n):
     return rng.standard_normal(n) * np.exp(rng.uniform(-300, 300))   # extreme magnitudes
 
 
+def kf_rates_draws(seed=11, cases=12, families=11):
+    """The random draws of tools/kf_rates.py, in its order: (draw index, family, max_iteration, signal) — families 0 .. 7 are fuzz_signal's,
+    8 the bench signal (sines + noise), 9 / 10 the same as 16- / 12-bit PCM; 70 000 .. 400 000 samples, half of them float32; a draw with
+    a non-finite sample is counted and skipped.  The sweep's seed and the index name a case for good (tests keep indices, not arrays)."""
+    rng = np.random.default_rng(seed)
+    idx = 0
+    for kind in range(families):
+        for m in (3, 7, 11):
+            for _ in range(cases):
+                n = int(rng.integers(70000, 400000))
+                if kind >= 8:
+                    x = sines_noise(n, seed=int(rng.integers(0, 1 << 30)))
+                    if kind >= 9:        # int16 / 12-bit PCM as float32 (the reference's own domain: PyITD.ipynb cell 2)
+                        sc = 32768.0 if kind == 9 else 2048.0
+                        x = (np.round(x.astype(np.float64) / np.abs(x).max() * (sc - 1)) / sc).astype(np.float32)
+                else:
+                    x = fuzz_signal(rng, kind, n)
+                idx += 1
+                if not np.all(np.isfinite(x)):
+                    continue
+                if kind not in (7,) and rng.random() < 0.5:
+                    x = x.astype(np.float32)
+                yield idx - 1, kind, m, x
+
+
+# Draws of kf_rates_draws(seed=11) on which round 4's first knot-side launch delivered WRONG rows (a halo search re-read an end workgroup
+# it had already passed and doubled a knot) with every verification of that time green: the delivery-rate sweep found them
+# (profiles/r04); tests/test_gpu_fused.py holds them "delivered or refused, never wrong" at every range size.
+ROUND4_WRONG_ROWS = (25, 26, 35, 54, 57, 62, 64, 67, 162, 169, 279)
+
+
 def canon_u64(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     return np.where(np.isnan(a), np.uint64(0x7FF8000000000000), a.view(np.uint64))

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.itd_abi_version() == 10
+    assert lib.itd_abi_version() == 11
     assert lib.itd_status_string(0) == b"ok"
     assert b"argument" in lib.itd_status_string(1)
 

@@ -4,7 +4,7 @@ deliver — smooth, quantised, NaN-producing input — they report, after which 
 import numpy as np
 import pytest
 
-from helpers import assert_bits_equal, chirp, coarse, fuzz_signal, load_golden, sines_noise
+from helpers import ROUND4_WRONG_ROWS, assert_bits_equal, chirp, coarse, fuzz_signal, kf_rates_draws, load_golden, sines_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ def _run(P, torch, x, m, mode, L0=3, bases=True):
     eng = P.Engine(n, 1, 0)
     eng.set_fuse_mode(mode)
     eng.set_fuse_level(L0)
-    eng.set_fuse_min_samples(65536)          # (the automatic mode fuses from 6 * 2^20 samples per launch sequence by default)
+    eng.set_fuse_min_samples(65536)          # (the automatic mode fuses from 2 * 2^20 samples per launch sequence by default)
     xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
     bs = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda") if bases else None
@@ -621,6 +621,225 @@ def test_every_injected_fault_is_refused(P, torch, oracle):
         eng.close()
     assert injected == refused >= 1000
     assert halo_refused + halo_exact == 180 and halo_refused >= 100
+
+
+def test_injected_faults_at_the_shipped_hand_over_level(P, torch, oracle):
+    """The same proof for the configuration the headline runs: one signal of 2^22 samples, the first fused level chosen by the engine
+    (level 2: the hand-over layout — 1720 candidates, the triples in registers —, 64-tile ranges), and 32-tile ranges beside it.  Single
+    faults in every field the sample pass reads, at levels 2 .. 8, in range-first, range-last and interior tiles: all refused; the knot
+    side's level counts: refused; faults in the halo a workgroup receives — at the hand-over level above all — refused or swallowed by
+    rounding, never a different result."""
+    from pyitd_amd import ITDError
+    from pyitd_amd.engine import FUSE_ONLY
+    n, m = 1 << 22, 7
+    x = sines_noise(n, seed=123)
+    ref = oracle.itd_lean(x, m)
+    assert ref["rows"].shape[0] == m + 2 and ref["stop"] == "timeout"
+    xd = torch.from_numpy(x).cuda()
+    ref_d = torch.from_numpy(ref["rows"]).cuda().view(torch.int64)
+    rows = torch.zeros((m + 2, n), dtype=torch.float64, device="cuda")
+    n_tiles = n // 512
+    rng = np.random.default_rng(606)
+    injected = refused = halo_refused = halo_exact = 0
+    for tpw, faults in ((0, 1000), (32, 240)):
+        eng = P.Engine(n, 1, 0)
+        eng.set_fuse_range(tpw)                                # 0 = automatic: 64 tiles
+        eng.set_fuse_mode(FUSE_ONLY)
+        tpw = tpw or 64
+
+        def run():
+            rows.zero_()
+            torch.cuda.synchronize()
+            eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+            return eng.summary(1)
+
+        run()
+        assert eng.last_fuse_level == 2, "the automatic first fused level of a 2^22-sample call"
+        assert torch.equal(rows.view(torch.int64), ref_d), "no fault"
+        L0 = 2
+        for k in range(faults):
+            kind = int(rng.integers(0, 6))
+            level = L0 if k % 4 == 0 else int(rng.integers(L0, m + 2))      # a quarter of them at the hand-over level
+            where = k % 3
+            w = int(rng.integers(0, n_tiles // tpw))
+            tile = w * tpw + (0 if where == 0 else tpw - 1 if where == 1 else int(rng.integers(1, tpw - 1)))
+            slot = int(rng.integers(0, 64))
+            delta = int(rng.choice([1, -1, 2, -3, 1 << 20, -(1 << 30)])) if kind <= 2 else int(rng.choice([1, -1])) if kind <= 4 else int(rng.integers(0, 64))
+            eng.debug_kf_fault(kind, level, tile, slot, delta)
+            injected += 1
+            try:
+                run()
+            except ITDError as err:
+                assert "fused sparse levels" in str(err) and "fail bits" in str(err), str(err)
+                refused += 1
+                continue
+            raise AssertionError("fault not refused: kind %d level %d tile %d (range of %d) slot %d delta %d" % (kind, level, tile, tpw, slot, delta))
+        for k in range(14):
+            eng.debug_kf_fault(8, L0 + k % (m + 2 - L0), 0, 0, int(rng.choice([1, -1, 2, -40])))
+            injected += 1
+            try:
+                run()
+            except ITDError:
+                refused += 1
+                continue
+            raise AssertionError("a wrong knot count of level %d was not refused" % (L0 + k % (m + 2 - L0)))
+        for k in range(120):                                   # the halo as received: two of three at the hand-over level
+            kind, level = 6 + k % 2, (L0 if k % 3 else int(rng.integers(L0, m + 2)))
+            w, slot = int(rng.integers(0, n_tiles // tpw)), int(rng.integers(0, 5))
+            eng.debug_kf_fault(kind, level, w, slot, int(rng.choice([1, -1, 1 << 25])) if kind == 6 else int(rng.choice([1, -1])))
+            try:
+                run()
+            except ITDError as err:
+                assert "fused sparse levels" in str(err), str(err)
+                halo_refused += 1
+                continue
+            assert torch.equal(rows.view(torch.int64), ref_d), "halo fault delivered: kind %d level %d workgroup %d slot %d" % (kind, level, w, slot)
+            halo_exact += 1
+        eng.debug_kf_fault(-1)
+        run()
+        assert torch.equal(rows.view(torch.int64), ref_d), "disarmed"
+        eng.close()
+    assert injected == refused >= 1200
+    assert halo_refused + halo_exact == 240 and halo_refused >= 120
+
+
+def test_injected_faults_in_a_later_signal_of_a_batch(P, torch, oracle):
+    """... and for batches, which run many signals per launch: eight signals of 2^19 samples (one launch sequence of 2^22: first fused
+    level 2), the fault in signal b > 0 (itd_debug_kf_fault_signal).  The automatic mode: the faulted signal — and only it — is refused
+    and run again on its own (itd_get_fuse_signal_repairs counts it), the whole batch equals the oracle afterwards; > 1000 faults."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m, B = 1 << 19, 7, 8
+    x = np.stack([sines_noise(n, seed=900 + b, fscale=1 + b / 40.0) for b in range(B)])
+    refs = [oracle.itd_lean(x[b], m) for b in range(B)]
+    assert all(r["rows"].shape[0] == m + 2 for r in refs)
+    ref_d = torch.from_numpy(np.stack([r["rows"] for r in refs])).cuda().view(torch.int64)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.zeros((B, m + 2, n), dtype=torch.float64, device="cuda")
+    n_tiles, tpw, L0 = n // 512, 64, 2
+    eng = P.Engine(n, B, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+
+    def run():
+        rows.zero_()
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
+        s = eng.summary(B)
+        assert eng.last_fuse_level == L0
+        return s
+
+    run()
+    assert (eng.fuse_repeats, eng.fuse_signal_repairs) == (0, 0)
+    assert torch.equal(rows.view(torch.int64), ref_d), "no fault"
+    rng = np.random.default_rng(707)
+    refused = halo_refused = halo_exact = 0
+    for k in range(1000):
+        kind = int(rng.integers(0, 6)) if k % 25 else 8
+        b = 1 + k % (B - 1)
+        level = L0 if k % 4 == 0 else int(rng.integers(L0, m + 2))
+        where = k % 3
+        w = int(rng.integers(0, n_tiles // tpw))
+        tile = w * tpw + (0 if where == 0 else tpw - 1 if where == 1 else int(rng.integers(1, tpw - 1)))
+        slot = int(rng.integers(0, 64))
+        delta = int(rng.choice([1, -1, 2, -3, 1 << 20, -(1 << 30)])) if kind <= 2 else int(rng.choice([1, -1])) if kind in (3, 4, 8) else int(rng.integers(0, 64))
+        eng.debug_kf_fault(kind, level, 0 if kind == 8 else tile, slot, delta)
+        eng.debug_kf_fault_signal(b)
+        before = eng.fuse_signal_repairs
+        run()
+        assert eng.fuse_repeats == 0
+        assert eng.fuse_signal_repairs == before + 1, "fault in signal %d not refused: kind %d level %d tile %d slot %d delta %d" % (b, kind, level, tile, slot, delta)
+        assert torch.equal(rows.view(torch.int64), ref_d), "after the repair of signal %d (kind %d level %d)" % (b, kind, level)
+        refused += 1
+    for k in range(120):
+        kind, level = 6 + k % 2, (L0 if k % 3 else int(rng.integers(L0, m + 2)))
+        b, w, slot = 1 + k % (B - 1), int(rng.integers(0, n_tiles // tpw)), int(rng.integers(0, 5))
+        eng.debug_kf_fault(kind, level, w, slot, int(rng.choice([1, -1, 1 << 25])) if kind == 6 else int(rng.choice([1, -1])))
+        eng.debug_kf_fault_signal(b)
+        before = eng.fuse_signal_repairs
+        run()
+        assert eng.fuse_signal_repairs - before in (0, 1)
+        halo_refused += eng.fuse_signal_repairs - before
+        halo_exact += 1 - (eng.fuse_signal_repairs - before)
+        assert torch.equal(rows.view(torch.int64), ref_d), "halo fault in signal %d: kind %d level %d workgroup %d slot %d" % (b, kind, level, w, slot)
+    eng.debug_kf_fault(-1)
+    eng.debug_kf_fault_signal(0)
+    before = eng.fuse_signal_repairs
+    run()
+    assert eng.fuse_signal_repairs == before and torch.equal(rows.view(torch.int64), ref_d), "disarmed"
+    eng.close()
+    assert refused == 1000 and halo_refused >= 60 and halo_refused + halo_exact == 120
+
+
+_R4_CASES = {}
+
+
+@pytest.mark.parametrize("tiles", [16, 32, 64])
+def test_the_inputs_of_round_four_s_wrong_rows(P, torch, oracle, tiles):
+    """The eleven draws of the delivery-rate sweep (tools/kf_rates.py, seed 11) on which round 4's first knot-side launch delivered
+    wrong rows behind green verifications (helpers.ROUND4_WRONG_ROWS: regenerated from the sweep's seed, not stored): 8 and 12 levels,
+    every range size — delivered bit for bit or refused, never anything else."""
+    from pyitd_amd import ITDError
+    from pyitd_amd.engine import FUSE_ONLY
+    if not _R4_CASES:
+        for idx, kind, m_, x in kf_rates_draws(11):
+            if idx in ROUND4_WRONG_ROWS:
+                _R4_CASES[idx] = x
+            if idx >= max(ROUND4_WRONG_ROWS):
+                break
+    assert sorted(_R4_CASES) == sorted(ROUND4_WRONG_ROWS)
+    delivered = 0
+    for idx, x in sorted(_R4_CASES.items()):
+        n = len(x)
+        xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        for m in (7, 11):
+            ref = oracle.itd_lean(x, m)
+            eng = P.Engine(n, 1, 0)
+            eng.set_fuse_mode(FUSE_ONLY)
+            eng.set_fuse_range(tiles)
+            rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            try:
+                eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), None, None)
+                s = eng.summary(1)
+            except ITDError:
+                continue
+            finally:
+                eng.close()
+            nr = int(s["n_rows"][0])
+            assert nr == ref["rows"].shape[0], "draw %d, %d levels, %d-tile ranges" % (idx, m + 1, tiles)
+            assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "draw %d, %d levels, %d-tile ranges" % (idx, m + 1, tiles))
+            delivered += 1
+    assert delivered >= 8
+
+
+def test_batch_pipeline_equals_the_rotating_chunks(P, torch, oracle):
+    """itd_set_batch_pipeline(1): the chunks' knot sides in stream order behind their level launches, the sample passes on the engine's
+    second stream behind a gate (itd_engine.hip) — the same rows, bit for bit, as the rotating chunks and the oracle; a refusing member
+    is run again on its own in either form."""
+    from pyitd_amd.engine import FUSE_AUTO
+    n, m, B = 1 << 17, 7, 24
+    x = np.stack([sines_noise(n, seed=300 + b, fscale=1 + b / 64.0) for b in range(B)])
+    x[13] = coarse(x[13])
+    refs = [oracle.itd_lean(x[b], m) for b in range(B)]
+    xd = torch.from_numpy(x).cuda()
+    got = []
+    for pipe in (0, 1):
+        eng = P.Engine(n, B, 0)
+        eng.set_fuse_mode(FUSE_AUTO)
+        eng.set_fuse_min_samples(65536)
+        eng.set_batch_chunk(5)                       # five chunks, the last one short
+        eng.set_batch_pipeline(pipe)
+        rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):                           # (twice: the engine's state sets and the gate's counter go on from call to call)
+            eng.decompose_dev(xd.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
+            s = eng.summary(B)
+        assert eng.last_fuse_level >= 2 and eng.fuse_repeats == 0 and eng.fuse_signal_repairs == 2
+        for b in range(B):
+            nr = refs[b]["rows"].shape[0]
+            assert int(s["n_rows"][b]) == nr
+            assert_bits_equal(rows[b, :nr].cpu().numpy(), refs[b]["rows"], "pipeline %d, signal %d" % (pipe, b))
+        got.append(rows)
+        eng.close()
 
 
 def test_a_captured_fused_call_survives_a_workspace_change(P, torch, oracle):

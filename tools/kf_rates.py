@@ -11,10 +11,9 @@ import pyitd_amd
 from pyitd_amd.engine import FUSE_ONLY
 from pyitd_amd import ITDError
 from oracle import cpu_oracle
-from helpers import sines_noise, fuzz_signal, canon_u64
+from helpers import canon_u64, kf_rates_draws
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 NAMES = ["white noise", "random walk", "quantised (plateaus)", "smooth + few knots", "sine + noise at a random level",
          "constant stretches with bursts", "alternating, random amplitudes", "extreme magnitudes", "sines + noise (the bench signal)",
          "the bench signal as 16-bit PCM", "the bench signal as 12-bit PCM"]
@@ -60,25 +59,16 @@ n_wrong = 0
 
 print("%-36s %-6s %s" % ("family", "levels", "outcomes over %d draws (n in 70 000 .. 400 000, float32 / float64)" % cases))
 wrong = 0
-for kind in range(11):
-    for m in (3, 7, 11):
-        tally = {}
-        for c in range(cases):
-            n = int(rng.integers(70000, 400000))
-            if kind >= 8:
-                x = sines_noise(n, seed=int(rng.integers(0, 1 << 30)))
-                if kind >= 9:        # int16 / 12-bit PCM as float32 (the reference's own domain: PyITD.ipynb cell 2)
-                    sc = 32768.0 if kind == 9 else 2048.0
-                    x = (np.round(x.astype(np.float64) / np.abs(x).max() * (sc - 1)) / sc).astype(np.float32)
-            else:
-                x = fuzz_signal(rng, kind, n)
-            if not np.all(np.isfinite(x)):
-                continue
-            if kind not in (7,) and rng.random() < 0.5:
-                x = x.astype(np.float32)
-            r = one(x, m)
-            tally[r] = tally.get(r, 0) + 1
-            wrong += r == "WRONG"
-        print("%-36s %-6d %s" % (NAMES[kind], m + 1, ", ".join("%s: %d" % kv for kv in sorted(tally.items()))), flush=True)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+tallies = {}
+for idx, kind, m, x in kf_rates_draws(seed, cases):      # (tests/helpers.py: the sweep's seed and a draw's index name a case for good)
+    r = one(x, m)
+    if r.startswith("WRONG"):
+        print("   draw %d of kf_rates_draws(seed=%d, cases=%d)" % (idx, seed, cases), flush=True)
+    t = tallies.setdefault((kind, m), {})
+    t[r] = t.get(r, 0) + 1
+    wrong += r == "WRONG"
+for (kind, m), tally in sorted(tallies.items()):
+    print("%-36s %-6d %s" % (NAMES[kind], m + 1, ", ".join("%s: %d" % kv for kv in sorted(tally.items()))), flush=True)
 print("WRONG results: %d" % wrong)
 sys.exit(1 if wrong else 0)
