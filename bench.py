@@ -911,6 +911,15 @@ def audio_leg(torch, dev, path, log2n=22, max_iteration=9):
         knots_ok = knots_ok and np.array_equal(got, ref["knots"][j])
         level_in = bases[j].cpu().numpy()
     rows_ok = bool(np.array_equal(rows[:nr].cpu().numpy().view(np.uint64), ref["rows"].view(np.uint64)))
+    # the bytes the timed form itself moves per sample (rows only, no baselines buffer): level launches 20 / 24 B (the last one writes one
+    # row: 16), the fused levels 8 B in + 8 B per row, a capped call also the baseline it hands on (8 B) and the scan of it (8 B)
+    L0f, capf = eng.last_fuse_level, eng.last_fuse_cap
+    if not L0f:
+        own_bytes = 20.0 + 24.0 * (nr - 2) + 16.0
+    elif not capf:
+        own_bytes = 20.0 + 24.0 * (L0f - 1) + 8.0 + 8.0 * (nr - L0f)
+    else:
+        own_bytes = 20.0 + 24.0 * (L0f - 1) + 8.0 + 8.0 * (capf - L0f) + 8.0 + 8.0 + 24.0 * max(nr - 1 - capf, 0) + 16.0
     out = {"input": label, "sample_rate": int(sr), "samples_in_file": int(a.shape[0]),
            "exact_ties_of_neighbouring_samples": int(np.count_nonzero(x_host[1:] == x_host[:-1])),
            "workload": "clip tiled to 2^%d float32 samples (numpy.resize), %d levels (max_iteration=%d)" % (log2n, max_iteration + 1, max_iteration),
@@ -919,6 +928,10 @@ def audio_leg(torch, dev, path, log2n=22, max_iteration=9):
            "timing": "10 calls back to back + one summary (a refused fused call is repeated there), wall clock",
            "fuse_repeats_in_warm_up": rep_warm, "fuse_repeats_in_timed_calls": eng.fuse_repeats - rep_warm,
            "first_fused_level_of_timed_calls": eng.last_fuse_level,
+           # capped fused levels (itd_set_fuse_cap, automatic): the engine learned from the first refusal at which level this input's fused form
+           # fails and keeps the levels in front of it fused; 0 = no cap
+           "fused_levels_capped_at": eng.last_fuse_cap,
+           "own_bytes_per_sample": own_bytes, "own_bytes_frac_of_peak": round(own_bytes * n / dt / 1e9 / HBM_PEAK_GBPS, 4),
            # the reference flow's bytes over the measured time (an equivalent rate: 20 + 24 (L - 1) + 16 B/sample, the last level writes one row)
            "hbm_reference_flow_equivalent_GBps": round((20.0 + 24.0 * (nr - 2) + 16.0) * n / dt / 1e9, 1),
            "knot_indices_bit_exact_every_level": bool(knots_ok), "rows_bit_exact": rows_ok}

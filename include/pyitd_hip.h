@@ -214,6 +214,17 @@ int itd_set_fuse_level(itd_engine *e, int32_t first_fused_level);
  * ranges hold denser lists and cost more workgroups. */
 int itd_set_fuse_range(itd_engine *e, int32_t tiles);
 int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
+/* ABI revision 11: capped fused levels.  A workload whose fused form is refused at the same level every time — exactly periodic input
+ * whose baseline collapses to a handful of knots at some level (BASELINE configs[4]'s substitute clip: 1049 knots, then 3, at level 8):
+ * every sample a near tie there — keeps the fused form for the levels in front of that one: levels first_fused .. cap - 1 run fused
+ * (the sample pass also stores the baseline behind level cap - 1), levels cap .. max_iteration + 1 one launch each from a scan of that
+ * baseline.  first_level_not_fused = 0 (default): automatic — a whole-call refusal records the lowest level at which anything failed
+ * (verification, non-finite knot data) and the engine's next calls are capped there instead of running level by level (every 256th
+ * call tries all levels again); -1: never; 4 .. max_iteration + 1: always this cap (tests).  A cap leaves at least two fused levels or
+ * is ignored.  Results are bit-identical either way. */
+int itd_set_fuse_cap(itd_engine *e, int32_t first_level_not_fused);
+/* the cap of the last decomposition as it was enqueued (0: none — every level from the first fused one on ran fused, or no fused levels) */
+int itd_get_last_fuse_cap(const itd_engine *e);
 /* batches: how many consecutive chunks (itd_set_batch_chunk) share ONE knot-side launch of the fused levels (default 1; sharing it
  * paid while the knot side was a dozen launches) */
 int itd_set_fuse_group(itd_engine *e, int32_t chunks);

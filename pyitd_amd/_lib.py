@@ -95,6 +95,8 @@ ABI = {
     "itd_set_fuse_level": (_INT, [_P, _I32]),
     "itd_set_fuse_min_samples": (_INT, [_P, _I64]),
     "itd_set_fuse_group": (_INT, [_P, _I32]),
+    "itd_set_fuse_cap": (_INT, [_P, _I32]),
+    "itd_get_last_fuse_cap": (_INT, [_P]),
     "itd_debug_kf_fault": (_INT, [_P, _I32, _I32, _I32, _I32, _I32]),
     "itd_debug_kf_fault_signal": (_INT, [_P, _I32]),
     "itd_debug_int_ratio_check": (_INT, [_INT, _I32, ctypes.POINTER(_I64)]),

@@ -85,7 +85,9 @@ __global__ void k_verdict(SigState *__restrict__ state, int batch, const KfSig *
             // A level that was decomposed had at least 2 knots (ITD.py:404)
             for (int j = L0; !fail && j <= lend; ++j) if (j > L0 && ks.mlev[j] < 2) fail |= kKfFailVerify;
             if (fail) st.kf_fail = fail;
-            else {
+            else if (ks.cont) {         // capped fused levels that did not stop: the level launches behind them wrote the rest of the state
+                for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
+            } else {
                 for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
                 st.m[lend + 1] = ks.m_exact;
                 st.fin_stopped = ks.natural;
@@ -241,6 +243,11 @@ struct itd_engine {
                                                      // follows a back-off directly (a workload the fused form cannot deliver — periodic, collapsing input —
                                                      // pays one wasted attempt in 17, then 33, ... 1025 calls), back to 16 after a delivered call
     bool fuse_probe = false;                         // the call being summarised was the first fused attempt after a back-off
+    // capped fused levels: a workload whose fused form fails at the same level every time keeps the fused form for the levels in front of it
+    int32_t fuse_cap = 0;                            // itd_set_fuse_cap: the first level NOT fused (0 = whatever the engine has learned)
+    int32_t fuse_cap_auto = 0;                       // learned from a refusal's KfSig::fail_lev (0 = none)
+    int32_t fuse_cap_calls = 0;                      // delivered calls under the learned cap: every 256th call tries all levels again
+    int last_kf_cap = 0, last_kf_cap_form = 0;       // the cap of the last call (as enqueued: itd_get_last_fuse_cap; 0 = all levels fused)
     bool kf_force_tickets = false;                   // a halo wait was given up on this engine (kKfFailWait): workgroup ids are tickets from then on
     bool fuse_level2_off = false;                    // automatic first fused level: a level-2 list has outgrown its workgroup, level 3 from then on
     bool fuse_no_memory = false;                     // the fused levels' workspace could not be allocated: level by level from then on
@@ -497,9 +504,9 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     kf = kf && fuse0 && L0 >= 2 && L0 <= M && n < ((int64_t)1 << 31) - 65536;
     // a call that is being captured into a graph must be complete in itself (the graph may be replayed any number of times) and
     // cannot allocate: a captured call on an engine whose fused workspace does not exist yet runs level by level
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    const bool capturing = cap != hipStreamCaptureStatusNone;
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
     const int kf_tpw = kf_tiles_per_wg(e, L0);
     if (kf && capturing && ensure_kf_ws(e, kf_tpw, false) != ITD_OK) kf = false;
     if (kf) {
@@ -512,6 +519,14 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             kf = false;
         } else if (rc) return rc;
     }
+    // capped fused levels: levels L0 .. cap - 1 fused, cap .. M + 1 one launch each behind a scan of the baseline the sample pass leaves
+    int cap = 0;
+    if (kf) {
+        cap = e->fuse_cap ? e->fuse_cap : e->fuse_cap_auto;                          // (fuse_cap -1 = never: falls out below)
+        if (cap > 0 && !e->fuse_cap && (e->fuse_cap_calls & 255) == 255) cap = 0;  // (a learned cap is probed now and then: workloads change)
+        if (cap < L0 + 2 || cap > M + 1) cap = 0;                                    // (fewer than two fused levels are not worth a knot side; beyond the call's levels: no cap)
+    }
+    const int Mk = cap ? cap - 2 : M;               // the knot side's "max_iteration": its levels are L0 .. Mk + 1
     const int n_tiles = (int)tiles_of(n);
     const int n_groups = groups_of(n_tiles);
     const int64_t R = (int64_t)M + 2;
@@ -611,24 +626,11 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
         double *bases_c = bases_user ? bases_user + (int64_t)b0 * rows_stride : nullptr;
         double *pp_c = e->d_pp + (int64_t)b0 * 3 * e->pp_pitch;
         double *xm_c = pp_c + 2 * e->pp_pitch;   // NaN-input repeat: the mutated signal, one per signal at the slots' stride
-        if (phase & 1) {
-        if (nan_input) {
-            k_nan_level0<Tin, T><<<dim3(n_tiles, nb), blk, 0, cst>>>(xc, x_stride, n, n_tiles, xm_c, 3 * e->pp_pitch, cnt(0), rec(0),
-                                                                    gs(0), state);
-        } else if (!fuse0) {
-            const int pair = time_slot(e, ITD_TIME_SCAN0);
-            const Tin *a_x = xc; int64_t a_xs = x_stride, a_n = n; int a_nt = n_tiles;
-            int32_t *a_c = cnt(0), *a_g = gs(0); TileRec *a_r = rec(0); SigState *a_st = state;
-            void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_c, &a_r, &a_g, &a_st};
-            HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_scan0<Tin, T, kScanTilesPerWave>),
-                                          dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, nb), blk, args, 0, cst,
-                                          pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,
-                                          pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
-        }
-
         const int j_last = kf ? L0 - 1 : M + 1;
         unsigned long long *near_c = kf ? e->kf.nearw + (size_t)b0 * n_tiles * 8 : nullptr;
-        for (int j = 0; j <= j_last; ++j) {
+        // the level launches ja .. jb of this chunk (one k_extract each)
+        auto run_levels = [&](const int ja, const int jb) -> int {
+        for (int j = ja; j <= jb; ++j) {
             // extraction j+1: input = level-j signal, rotation -> rows[j], baseline -> bases[j]
             double *base_out;
             int64_t base_stride;
@@ -644,7 +646,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 if (j >= 1) { base_in = pp_c + (int64_t)((j - 1) % 3) * e->pp_pitch; base_in_stride = 3 * e->pp_pitch; }
             }
             double *rot_out = rows_c + (int64_t)j * (n + ITD_ROW_PAD);
-            const bool final_level = !kf && (j == M + 1);
+            const bool final_level = j == M + 1;        // (with fused levels: only behind capped ones)
             const int pair = time_slot(e, final_level ? ITD_TIME_EXTRACT_FINAL : (j == 0 ? ITD_TIME_EXTRACT_L0 : ITD_TIME_EXTRACT));
             // launched through hipExtLaunchKernel: when this step is instrumented the two events take the dispatch's own
             // begin / end timestamps (no marker packets in the stream: nothing is added to the timed region)
@@ -676,25 +678,49 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
 #undef ITD_LAUNCH_EXTRACT
 #undef ITD_LAUNCH_EXTRACT_KT
         }
-        // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch).  With fused sparse levels
-        // the knot side's launch does this for its first level (k_kf_knots: KfFin) — one launch less
-        if (!kf) {
+        return ITD_OK;
+        };
+        // stop test on the last pending baseline (ITD.py:400-404 takes priority over the timeout branch) and the residual row
+        auto run_finalize = [&]() {
             // blocks per signal: a thread of the row fix-up moves 8 samples (four 16-byte accesses) before the grid is widened
             const int fb = (int)std::min<int64_t>(std::max<int64_t>((n + 8 * kFinalizeThreads - 1) / (8 * kFinalizeThreads), 1), 1024);
             int32_t *og = other_gsum + (int64_t)b0 * n_groups * kGsumPitch;
-            const int jf = j_last + 1;      // the level whose input is pending: max_iteration + 2
+            const int jf = M + 2;      // the level whose input is pending
             if (bases_c)
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, bases_c, rows_stride, n, 0,
                                                                        gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
             else
                 k_finalize<<<dim3(fb, nb), kFinalizeThreads, 0, cst>>>(rows_c, rows_stride, n, pp_c, 3 * e->pp_pitch,
                                                                        e->pp_pitch, 3, gs(jf), n_tiles, jf, state, other_state + b0, og, e->gsum_third);
+        };
+        if (phase & 1) {
+        if (nan_input) {
+            k_nan_level0<Tin, T><<<dim3(n_tiles, nb), blk, 0, cst>>>(xc, x_stride, n, n_tiles, xm_c, 3 * e->pp_pitch, cnt(0), rec(0),
+                                                                    gs(0), state);
+        } else if (!fuse0) {
+            const int pair = time_slot(e, ITD_TIME_SCAN0);
+            const Tin *a_x = xc; int64_t a_xs = x_stride, a_n = n; int a_nt = n_tiles;
+            int32_t *a_c = cnt(0), *a_g = gs(0); TileRec *a_r = rec(0); SigState *a_st = state; int a_lv = 0;
+            void *args[] = {&a_x, &a_xs, &a_n, &a_nt, &a_c, &a_r, &a_g, &a_st, &a_lv};
+            HIP_TRY(e, hipExtLaunchKernel(reinterpret_cast<const void *>(&k_scan0<Tin, T, kScanTilesPerWave>),
+                                          dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, nb), blk, args, 0, cst,
+                                          pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr,
+                                          pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
         }
+
+        {
+            const int rc = run_levels(0, j_last);
+            if (rc) return rc;
+        }
+        // With fused sparse levels the knot side's launch does k_finalize's work for its first level (k_kf_knots: KfFin) — one launch less
+        if (!kf) run_finalize();
         }
         if (kf && (phase & 6)) {
             // ---- levels L0 .. M + 1 fused: hand-over, the knot-side steps, ONE pass over the samples, the verdict ----
             KfWs w = e->kf;
-            w.n_tiles = n_tiles; w.L0 = L0; w.nlev = M + 3 - L0;
+            w.n_tiles = n_tiles; w.L0 = L0; w.nlev = Mk + 3 - L0;
+            w.cap = cap;
+            w.xnext = cap ? pp_c + (int64_t)((cap - 1) % 3) * e->pp_pitch : nullptr; w.xnext_stride = 3 * e->pp_pitch;
             w.tpw = kf_tpw; w.wgs = (n_tiles + kf_tpw - 1) / kf_tpw; w.nb = nb;
             // (ids from blockIdx only where the whole grid is resident at once — with S streams in flight each launch may count on
             //  its share of the device only)
@@ -712,7 +738,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             if (phase & 2) {
                 // ONE launch: hand-over and every fused level (timed from its dispatch's own begin / end timestamps)
                 const int p_kn = time_slot(e, ITD_TIME_KF_KNOTS);
-                KfWs a_w = w; int64_t a_ls = xl_stride, a_n = n; const double *a_xl = xl; int a_m = M;
+                KfWs a_w = w; int64_t a_ls = xl_stride, a_n = n; const double *a_xl = xl; int a_m = Mk;
                 const int32_t *a_c = cnt(L0); const TileRec *a_r = rec(L0); SigState *a_st = state;
                 KfFin a_f;      // k_finalize's work for the first fused level (the stop test of its input, the other state set)
                 a_f.rows = rows_c; a_f.rows_stride = rows_stride;
@@ -736,9 +762,24 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
                 KfWs a_w = w; const double *a_xl = xl; int64_t a_xs = xl_stride, a_n = n, a_rs = rows_stride, a_bs = rows_stride;
                 const TileRec *a_rec = rec(L0); double *a_rows = rows_c, *a_bases = bases_c;
                 void *args[] = {&a_w, &a_xl, &a_xs, &a_n, &a_rec, &a_rows, &a_rs, &a_bases, &a_bs};
-                const void *apply_fn = bases_c ? reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, true>) : reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, false>);
+                const void *apply_fn = cap ? (bases_c ? reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, true, true>) : reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, false, true>))
+                                           : (bases_c ? reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, true, false>) : reinterpret_cast<const void *>(&k_kf_apply<T, kKfCap, false, false>));
                 HIP_TRY(e, hipExtLaunchKernel(apply_fn, dim3(n_tiles + kf_check_blocks(w.wgs), nb), dim3(kWave), args, 0, cst,
                                               pair >= 0 ? e->ev[2 * (size_t)pair] : nullptr, pair >= 0 ? e->ev[2 * (size_t)pair + 1] : nullptr, 0));
+                if (cap) {
+                    // ---- capped: levels cap .. M + 1 one launch each, from a scan of the baseline the sample pass has stored (the
+                    //      input of level cap: its knots' records, counts and group sums, the level's end samples).  A signal that
+                    //      stopped inside the fused levels carries SigState::skip: these launches return at once for it.  Should the
+                    //      fused levels refuse, the whole call is repeated anyway: what runs here then is discarded.
+                    const int64_t ge = (int64_t)nb * n_groups * kGsumPitch;
+                    k_clear_gsum<<<(int)std::min<int64_t>((ge + 255) / 256, 1024), 256, 0, cst>>>(gs(cap), gs(cap + 1), ge);
+                    const double *a_x = bases_c ? bases_c + (int64_t)(cap - 1) * n : pp_c + (int64_t)((cap - 1) % 3) * e->pp_pitch;
+                    k_scan0<double, T, kScanTilesPerWave><<<dim3((n_tiles + kScanTilesPerWave - 1) / kScanTilesPerWave, nb), blk, 0, cst>>>(
+                        a_x, bases_c ? rows_stride : 3 * e->pp_pitch, n, n_tiles, cnt(cap), rec(cap), gs(cap), state, cap);
+                    const int rc = run_levels(cap, M + 1);
+                    if (rc) return rc;
+                    run_finalize();
+                }
             }
         }
         return ITD_OK;
@@ -818,7 +859,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_nan_input = nan_input;
     e->last_kf = kf;
     e->last_kf_level = L0;
-    if (!repair_need) e->last_kf_form = kf ? L0 : 0;
+    e->last_kf_cap = kf ? cap : 0;
+    if (!repair_need) { e->last_kf_form = kf ? L0 : 0; e->last_kf_cap_form = kf ? cap : 0; }
     return ITD_OK;
 }
 
@@ -1354,6 +1396,7 @@ void kf_verdict(itd_engine *e, int B)
         for (int j = L0; !fail && j <= lend; ++j) if (j > L0 && ks.mlev[j] < 2) fail |= kKfFailVerify;
         if (fail) { st.kf_fail = fail; continue; }
         for (int j = L0 + 1; j <= lend; ++j) st.m[j] = ks.mlev[j];
+        if (ks.cont) continue;          // capped fused levels that did not stop: the level launches behind them wrote the rest of the state
         st.m[lend + 1] = ks.m_exact;
         st.fin_stopped = ks.natural;
         st.fin_stop_level = ks.natural ? lend + 1 : -1;
@@ -1432,7 +1475,13 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         // repeated level by level and the engine's next decompositions start that way.
         int nfail = 0;
         for (int b = 0; b < B; ++b) nfail += e->h_state[b].kf_fail != 0;
-        if (!nfail) { e->fuse_off_span = 16; e->fuse_probe = false; }      // delivered: the back-off starts over
+        if (!nfail) {      // delivered: the back-off starts over
+            e->fuse_off_span = 16; e->fuse_probe = false;
+            if (!e->fuse_cap && e->fuse_cap_auto) {
+                if (e->last_kf_cap) ++e->fuse_cap_calls;
+                else if (e->last_m + 1 >= e->fuse_cap_auto) { e->fuse_cap_auto = 0; e->fuse_cap_calls = 0; }   // the probe without the cap was delivered: the workload has changed
+            }
+        }
         if (nfail) {
             if (e->fuse_mode == ITD_FUSE_ONLY) {
                 int code = 0;
@@ -1450,7 +1499,20 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                 if (rc) return rc;
             } else {
                 ++e->fuse_repeats;
-                if (!can_shrink) kf_levels_off(e);
+                // Where did it fail?  A workload whose fused form fails at the same level every time (periodic input whose baseline collapses
+                // there: BASELINE configs[4]'s substitute clip at level 8) keeps the fused form for the levels in front of it: the engine's
+                // next calls cap their fused levels at the lowest level anything failed at (KfSig::fail_lev) and run the rest level by level
+                bool capped_next = false;
+                if (!e->fuse_cap && !(bits & (kKfFailCapacity | kKfFailWait))) {
+                    int fl = 99;
+                    for (int b = 0; b < B; ++b)
+                        if (e->h_state[b].kf_fail) fl = std::min<int>(fl, reinterpret_cast<const KfSig *>(e->h_kf + (size_t)b * kKfSigHead)->fail_lev);
+                    const int L0 = e->last_kf_level;
+                    if (fl >= L0 + 2 && fl <= e->last_m + 1 && (e->last_kf_cap == 0 || fl < e->last_kf_cap)) {
+                        e->fuse_cap_auto = fl; e->fuse_cap_calls = 0; capped_next = true;
+                    } else e->fuse_cap_auto = 0;
+                }
+                if (!can_shrink && !capped_next) kf_levels_off(e);
                 const int rc = repeat(want_fused(e), false);
                 if (rc) return rc;
             }
@@ -1627,6 +1689,16 @@ int itd_debug_kf_fault_signal(itd_engine *e, int32_t signal)
     e->fault_sig = signal;
     return ITD_OK;
 }
+
+int itd_set_fuse_cap(itd_engine *e, int32_t first_level_not_fused)
+{
+    if (!e || first_level_not_fused < -1 || first_level_not_fused > ITD_MAX_ITERATION + 1 || (first_level_not_fused > 0 && first_level_not_fused < 4)) return ITD_ERR_INVALID_ARG;
+    e->fuse_cap = first_level_not_fused;
+    e->fuse_cap_auto = 0;
+    e->fuse_cap_calls = 0;
+    return ITD_OK;
+}
+int itd_get_last_fuse_cap(const itd_engine *e) { return !e ? -1 : (e->ran && e->last_kf_form ? e->last_kf_cap_form : 0); }
 
 int itd_get_fuse_repeats(const itd_engine *e) { return e ? e->fuse_repeats : -1; }
 int itd_get_last_fuse_level(const itd_engine *e) { return !e ? -1 : (e->ran && e->last_kf_form ? e->last_kf_form : 0); }

@@ -1129,13 +1129,17 @@ __device__ __forceinline__ void tile_store2(__amdgpu_buffer_rsrc_t r, int voff, 
 template <typename Tin, int TW, int KT>
 __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, int64_t x_stride, int64_t n, int n_tiles,
                                                  int32_t *__restrict__ counts, TileRec *__restrict__ recs,
-                                                 int32_t *__restrict__ gsum_out, SigState *__restrict__ state)
+                                                 int32_t *__restrict__ gsum_out, SigState *__restrict__ state, int level)
 {
+    // level > 0: the scan of a stored baseline as the input of level `level` (the fused sparse levels capped below the call's last level:
+    // the level launches go on from what the sample pass left — itd_engine.hip); the end samples go to that level's slot, and a NaN is
+    // not the caller's (the fused levels refuse non-finite data: the call is repeated)
     constexpr int G2 = TW / 128;
     __shared__ __attribute__((aligned(16))) int32_t s_rec[sizeof(TileRec) / 4];
     __shared__ int32_t s_pos[8];
     const int lane = lane_id();
     const int t0 = xcd_item(blockIdx.x, gridDim.x) * KT, sig = blockIdx.y;
+    const int es = level & 1;
     const Tin *x = xin + (int64_t)sig * x_stride;
     SigState *st = state + sig;
     if (st->skip > 0) return;       // (the device-side repair: this signal's first result stands)
@@ -1183,17 +1187,24 @@ __global__ __launch_bounds__(kWave) void k_scan0(const Tin *__restrict__ xin, in
 #pragma unroll
             for (int g = 0; g < G2; ++g) {
                 const int p = 128 * g + 2 * lane;
-                if (s == 0 && p == 0) { st->ends[0][0] = xr[g][0]; st->ends[0][1] = xr[g][1]; }
-                if (p == nrem - 2) { st->ends[0][2] = xr[g][0]; st->ends[0][3] = xr[g][1]; }
-                if (p + 1 == nrem - 2) st->ends[0][2] = xr[g][1];
-                if (p == nrem - 1) st->ends[0][3] = xr[g][0];
+                if (s == 0 && p == 0) { st->ends[es][0] = xr[g][0]; st->ends[es][1] = xr[g][1]; }
+                if (p == nrem - 2) { st->ends[es][2] = xr[g][0]; st->ends[es][3] = xr[g][1]; }
+                if (p + 1 == nrem - 2) st->ends[es][2] = xr[g][1];
+                if (p == nrem - 1) st->ends[es][3] = xr[g][0];
             }
         }
         scan_publish<TW>(xr, xlo, xhi, s, nrem, (size_t)sig * n_tiles + t,
                          ((size_t)sig * groups_of(n_tiles) + t / kTilesPerGroup) * kGsumPitch, counts, recs, gsum_out, s_rec, s_pos);
         wave_sync();   // the next tile reuses the record staging
     }
-    if (__any(nan_in) && lane == 0) st->in_nan = 1;
+    if (level == 0 && __any(nan_in) && lane == 0) st->in_nan = 1;
+}
+
+// the group sums of `levels` consecutive rotating buffers cleared for the signals of a launch sequence (in front of a k_scan0 that starts
+// the level launches in the middle of a decomposition: the buffers hold earlier levels' sums)
+__global__ void k_clear_gsum(int32_t *a, int32_t *b, int64_t elems)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (int64_t)gridDim.x * blockDim.x) { a[i] = 0; b[i] = 0; }
 }
 
 

@@ -96,6 +96,9 @@ constexpr uint32_t kKcPoison = 0xffffffffu;      // a record of a workgroup that
 #ifndef ITD_KF_CHECK_STEP
 #define ITD_KF_CHECK_STEP 2       // A/B builds: 1 = one table entry per lane and round in the check wavefronts
 #endif
+#ifndef ITD_KC_PRIO
+#define ITD_KC_PRIO 0
+#endif
 #ifndef ITD_KC_TIMEOUT
 #define ITD_KC_TIMEOUT 4000000ll                 // ticks of the 100 MHz wall clock a halo search waits at most (40 ms)
 #endif
@@ -116,7 +119,11 @@ struct KfSig {
     int32_t lend;         // the last fused level: rows 0 .. lend are the result (-1: the signal is not active)
     int32_t natural;      // at lend: 1 = natural stop (row lend = the level's input), 0 = "Out of time!" (rotation + baseline)
     int32_t m_exact;      // knots of the last pending baseline, counted by the sample pass
-    int32_t pad0[3];
+    int32_t fail_lev;     // the lowest level at which anything failed (99: nowhere): verification of that level's knots or tables by the sample
+                          // pass, non-finite knot data — what the engine's next calls cap their fused levels at (KfWs::cap)
+    int32_t cont;         // 1: the fused levels were capped (KfWs::cap) and did not stop: rows 0 .. lend are rotations, the baseline behind
+                          // level lend is in memory and the level launches go on from there
+    int32_t pad0[1];
     int32_t mlev[kMaxLevels + 2];   // knots of level j's input
     // ---- the knot side's accumulators: zero between calls (the signal's last workgroup reads and clears them; the workspace starts
     //      zeroed), so no launch has to prepare them ----
@@ -162,6 +169,12 @@ struct KfWs {
     // the batch pipeline (itd_engine.hip, enqueue_decompose): every knot-side workgroup counts itself here when it starts — a counter that
     // only ever grows; k_kf_gate on the memory-bound launches' stream returns when all of a launch's workgroups are resident.  NULL: not counted
     unsigned long long *started;
+    // Capped fused levels (partial fusion): cap != 0 = the fused levels end at level cap - 1 although the call asks for more — a workload
+    // whose fused form fails at level cap every time (periodic input whose baseline collapses there) keeps the fused form for the levels
+    // in front of it.  The sample pass then stores the baseline behind level cap - 1 (the input of level cap) at xnext and the engine
+    // goes on level by level from a scan of it (k_scan0).
+    int32_t cap;
+    double *xnext; int64_t xnext_stride;
 };
 
 __device__ __forceinline__ bool kf_pred(double yl, double yc, double yr)
@@ -271,6 +284,9 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
     for (int i = 0; i < 64; ++i) kc_marks[i] = 0;
 #endif
     KC_MARK(0);
+#if ITD_KC_PRIO
+    __builtin_amdgcn_s_setprio(ITD_KC_PRIO);       // A/B builds: the knot side's wavefronts issue in front of a co-resident launch's (batches)
+#endif
     if (ws.started && tid == 0) atomicAdd(ws.started, 1ull);      // (in front of every return: the gate counts workgroups, whatever they go on to do)
     int id = blockIdx.x;
     if (ws.ticketed) {
@@ -360,6 +376,9 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             ks->active = 0;
             ks->lend = -1;
             ks->fail = stopped ? 0 : kKfFailNonFinite;                        // NaN rules / an unfinished level 0: not this path's
+            ks->fail_lev = 99;
+            ks->cont = 0;
+            if (ws.cap && stopped) st->skip = 1;                              // (capped: the level launches behind the sample pass have nothing to do)
         }
         launch_done();
         return;
@@ -835,6 +854,11 @@ __global__ __launch_bounds__(kKcThreads) void k_kf_knots(KfWs ws, KfFin fin, con
             ks->m_exact = 0;
             ks->natural = natural;
             ks->lend = lend;
+            ks->fail_lev = nf ? 64 - nf : 99;
+            // capped fused levels: a signal that stops inside them is finished here (the level launches behind the sample pass return at
+            // once: SigState::skip); one that does not goes on from the baseline the sample pass leaves
+            ks->cont = (ws.cap && !natural) ? 1 : 0;
+            if (ws.cap && natural) st->skip = 1;
             ks->acc_fail = 0;
             ks->nf = 0;
             ks->done = 0;
@@ -982,7 +1006,8 @@ __host__ __device__ constexpr int kf_check_blocks(int wgs) { return (wgs + 1 + 7
 #ifndef ITD_KF_FASTGROUP
 #define ITD_KF_FASTGROUP 1        // A/B builds: 0 = every 128-sample group takes the by-rank path
 #endif
-template <int TW, int CAP, bool BASES>      // BASES: the caller wants the baselines too (get_baselines()): a second row store per level
+template <int TW, int CAP, bool BASES, bool PART>      // BASES: the caller wants the baselines too (get_baselines()): a second row store per level
+                                                       // PART: capped fused levels (KfWs::cap): the last fused level's baseline is stored for the level launches behind
 __global__ __launch_bounds__(kWave)
 #if ITD_KF_APPLY_WAVES
 __attribute__((amdgpu_waves_per_eu(ITD_KF_APPLY_WAVES, ITD_KF_APPLY_WAVES)))
@@ -1009,22 +1034,24 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     if (!ks->active || ks->fail) return;
     const int lend = ks->lend, natural = ks->natural;
     if (lend < 0) return;
+    const bool cont = PART && ks->cont != 0;      // the level launches go on behind level lend: its row is a rotation like any other
     if (is_chk) {
         // ---- one wavefront per knot-side workgroup, level after level: what can be verified on the tables themselves (kf_check_slab,
         //      kf_check_counts above), a knot (or a tile) per lane instead of a handful of lanes in every tile's wavefront
         if (!(ITD_KF_VERIFY & 12)) return;
         const int w = item;
         int vb = 0;
+        int fl = 99;                                             // the first level at which something differs
         if (w == ws.wgs && (ITD_KF_VERIFY & 16)) {
-            for (int li = 0; li <= lend - ws.L0; ++li) vb |= kf_check_counts(ws, sig, ks, li, lane);
-            if (vb != 0 && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+            for (int li = 0; li <= lend - ws.L0; ++li) { vb |= kf_check_counts(ws, sig, ks, li, lane); if (vb != 0 && fl == 99) fl = ws.L0 + li; }
+            if (vb != 0 && lane == 0) { atomicOr(&ks->fail, kKfFailVerify); atomicMin(&ks->fail_lev, fl); }
             return;
         }
         if (w >= ws.wgs) return;                                 // (the blocks that only pad the count to a multiple of 8)
         // (one workgroup per slab, all its levels: every workgroup of this grid costs dispatch time — 3072 of them, one per level and
         //  slab, cost 6 us)
-        for (int li = 0; li <= lend - ws.L0; ++li) vb |= kf_check_slab(ws, sig, w, li, lane);
-        if (__any(vb != 0) && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+        for (int li = 0; li <= lend - ws.L0; ++li) { vb |= kf_check_slab(ws, sig, w, li, lane); if (fl == 99 && __any(vb != 0)) fl = ws.L0 + li; }
+        if (fl != 99 && lane == 0) { atomicOr(&ks->fail, kKfFailVerify); atomicMin(&ks->fail_lev, fl); }
         return;
     }
     const int t = xcd_item(item, n_tiles);
@@ -1047,6 +1074,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
     unsigned long long wcur = lane < 2 * G2 ? tf[(size_t)t * 8 + lane] : 0ull;       // this level's flag words, lane j holds word j
     bool bad = false;            // wave-uniform findings
     int vbad = 0;                // per-lane findings
+    int fl = 99;                 // the first level at which either showed (KfSig::fail_lev)
     // the knots of the values in the registers (x_lo / x_hi: the samples next to the tile): the exact predicate, ITD.py:59 on x and -x
     auto knots_of = [&](double lo_v, double hi_v, unsigned long long (&E2)[G2], unsigned long long (&O2)[G2]) {
         double d0[G2], d1[G2];
@@ -1097,7 +1125,7 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
 #pragma unroll
         for (int q = 0; q < 2 * G2; ++q) kn += __popcll(wm.get(q));
         if (kn > CAP) { if (lane == 0) atomicOr(&ks->fail, kKfFailCapacity); return; }
-        if (kfst < 0 || kfst + kn + 2 > ws.wgs_max * kKcSlab) { if (lane == 0) atomicOr(&ks->fail, kKfFailVerify); return; }   // (never read beyond the pool)
+        if (kfst < 0 || kfst + kn + 2 > ws.wgs_max * kKcSlab) { if (lane == 0) { atomicOr(&ks->fail, kKfFailVerify); atomicMin(&ks->fail_lev, lev); } return; }   // (never read beyond the pool)
         // the next level's flag words (what the values computed below must reproduce)
         const unsigned long long wnext = (!last && lane < 2 * G2) ? tf[((size_t)(li + 1) * n_tiles + t) * 8 + lane] : 0ull;
         const KfEntry *tab = pool + kfst;
@@ -1108,7 +1136,9 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         wave_sync();
         double *row = rows_s + (int64_t)lev * (n + ITD_ROW_PAD);
         const __amdgpu_buffer_rsrc_t r_row = tile_rsrc32(row, rem, 8);
-        const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc32(bases_s ? bases_s + (int64_t)lev * n : row, (bases_s && !last) ? rem : 0, 8);
+        const __amdgpu_buffer_rsrc_t r_bas = tile_rsrc32(bases_s ? bases_s + (int64_t)lev * n : row, (bases_s && (!last || cont)) ? rem : 0, 8);
+        // (PART, no caller's baselines: the last fused level's baseline goes where the level launch behind expects its input)
+        const __amdgpu_buffer_rsrc_t r_nx = tile_rsrc32((PART && !BASES) ? ws.xnext + (int64_t)sig * ws.xnext_stride + si : row, (PART && !BASES && last && cont) ? rem : 0, 8);
         int gbase = 0;
         bool nonfin = false;
         if (ITD_KF_VERIFY & 2) {           // V1 for the two tiles that own a virtual knot (rare paths, kept out of the groups' loop)
@@ -1166,10 +1196,11 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
             }
             double re, ro;
             if (last && natural) { re = xe; ro = xo; }               // row c = baselines[c-1], ITD.py:404-416
-            else if (last) { re = (xe - be) + be; ro = (xo - bo) + bo; }   // "Out of time!": rotation + baseline, ITD.py:420
+            else if (last && !cont) { re = (xe - be) + be; ro = (xo - bo) + bo; }   // "Out of time!": rotation + baseline, ITD.py:420
             else { re = xe - be; ro = xo - bo; }                     // ITD.py:119
             tile_store2<true>(r_row, p * 8, re, ro);
             if constexpr (BASES) tile_store2<true>(r_bas, p * 8, be, bo);      // (without: not even a bounds-checked-away store is issued)
+            if constexpr (PART && !BASES) tile_store2<false>(r_nx, p * 8, be, bo);   // (an empty descriptor except at the last level of a capped call)
             nonfin = nonfin || nonfinite(be) || nonfinite(bo);
             xr[g][0] = be;
             xr[g][1] = bo;
@@ -1187,8 +1218,9 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
         x_lo = n_lo;
         x_hi = n_hi;
         wcur = wnext;
+        if (fl == 99 && (bad || __any(vbad != 0))) fl = lev;
     }
-    if ((bad || __any(vbad != 0)) && lane == 0) atomicOr(&ks->fail, kKfFailVerify);
+    if ((bad || __any(vbad != 0)) && lane == 0) { atomicOr(&ks->fail, kKfFailVerify); atomicMin(&ks->fail_lev, fl == 99 ? lend : fl); }
 }
 
 // The gate of the batch pipeline: ONE wavefront on the stream of the memory-bound launches.  The knot side of the next chunk has just become

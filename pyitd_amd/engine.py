@@ -47,6 +47,9 @@ class Engine:
         mode = os.environ.get("PYITD_FUSE_LEVEL")       # the first fused level (diagnostic sweeps)
         if mode:
             self.set_fuse_level(int(mode))
+        mode = os.environ.get("PYITD_FUSE_CAP")         # capped fused levels (a whole suite with the fused levels cut at this level)
+        if mode:
+            self.set_fuse_cap(int(mode))
         mode = os.environ.get("PYITD_FUSE_GROUP")       # chunks of a batch per knot side of the fused levels (sweeps)
         if mode:
             self.set_fuse_group(int(mode))
@@ -163,6 +166,16 @@ class Engine:
     def debug_kf_fault_signal(self, signal):
         """Tests only: the armed fault lands in signal `signal` of the batch (default 0)."""
         self._check(self._L.itd_debug_kf_fault_signal(self._h, int(signal)))
+
+    def set_fuse_cap(self, first_level_not_fused):
+        """Capped fused levels: 0 (default) = automatic (a refusal's failing level caps the next calls' fused levels, the rest runs level
+        by level), -1 = never, 4 .. max_iteration + 1 = always this cap."""
+        self._check(self._L.itd_set_fuse_cap(self._h, int(first_level_not_fused)))
+
+    @property
+    def last_fuse_cap(self):
+        """The cap of the last decomposition's fused levels as enqueued (0 = none)."""
+        return self._L.itd_get_last_fuse_cap(self._h)
 
     def set_fuse_level(self, first_fused_level):
         """The first fused level, 2 .. max_iteration, or 0 (default) = automatic: 2 where a launch sequence covers >= 2^22 samples, else 3."""

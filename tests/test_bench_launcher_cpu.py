@@ -62,3 +62,23 @@ def test_total_batch_is_strong_scaling_with_balanced_shards():
     assert d["config"]["signals_per_gpu"] == 4 and "7 (fixed: strong scaling)" in d["config"]["workload"]
     assert d["config"]["summary_allgather_ms"] is not None and len(d["config"]["per_rank_signals_rerun_per_step__whole_call_repeats__allgather_ms"]) == 2
     assert d["value"] > 0
+
+
+def test_eight_ranks_with_an_uneven_total_batch():
+    """The shape of the driver's SCALE run that no round has had hardware for: eight ranks (gloo on CPU, the engine stubbed), a fixed
+    batch that does not divide by eight (8195 = 8 x 1024 + 3): the first three ranks own 1025 signals, the rest 1024, every signal
+    appears once in the gathered table, in batch order, and the line carries one entry per rank."""
+    d = _run(["--gpus", "8", "--total-batch", "8195", "--log2n", "10"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["signals_in_gathered_table"] == 8195
+    assert d["config"]["table_signal_ids"] == list(range(8195))
+    assert d["config"]["signals_per_gpu"] == 1025
+    assert len(d["config"]["per_rank_ms_per_step"]) == 8
+    assert len(d["config"]["per_rank_signals_rerun_per_step__whole_call_repeats__allgather_ms"]) == 8
+    assert d["value"] > 0
+
+
+def test_eight_ranks_weak_scaling_form():
+    d = _run(["--gpus", "8", "--batch", "5", "--log2n", "10"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["signals_in_gathered_table"] == 40 and d["config"]["table_signal_ids"] == list(range(40))

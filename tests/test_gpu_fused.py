@@ -842,6 +842,94 @@ def test_batch_pipeline_equals_the_rotating_chunks(P, torch, oracle):
         eng.close()
 
 
+def _run_capped(P, torch, x, m, L0, cap, bases):
+    from pyitd_amd.engine import FUSE_ONLY
+    n = len(x)
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_ONLY)
+    eng.set_fuse_level(L0)
+    eng.set_fuse_cap(cap)
+    eng.set_fuse_min_samples(65536)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    bs = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda") if bases else None
+    torch.cuda.synchronize()
+    for _ in range(2):                # (twice: the state sets alternate, the second call starts from what the first one's launches left)
+        eng.decompose_dev(xd.data_ptr(), x.dtype, n, 1, n, m, rows.data_ptr(), bs.data_ptr() if bases else None, None)
+        took = (eng.last_fuse_level, eng.last_fuse_cap)
+        s = eng.summary(1)
+    out = {"rows": rows[: int(s["n_rows"][0])].cpu().numpy(), "bases": bs[: int(s["n_baselines"][0])].cpu().numpy() if bases else None,
+           "stop": ("natural", "timeout")[int(s["stop"][0])], "knots": [int(v) for v in s["knot_counts"][0] if v >= 0], "took": took}
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("name,make,m,L0,caps", [
+    ("sines 2^19 f32", lambda: sines_noise(1 << 19, seed=41), 7, 2, (4, 6, 8)),
+    ("sines 2^18 f64, 12 rows", lambda: sines_noise(1 << 18, seed=42, dtype=np.float64), 10, 3, (5, 9, 11)),
+    ("ragged length", lambda: sines_noise((1 << 18) + 1234, seed=43), 7, 3, (5, 7)),
+    ("natural stop behind the cap", lambda: sines_noise(1 << 17, seed=6), 20, 3, (5, 8)),
+    ("natural stop inside the capped fused levels", lambda: sines_noise(1 << 16, seed=44), 20, 2, (12, 16, 19)),
+    ("random walk f32", lambda: fuzz_signal(np.random.default_rng(8), 1, 300000).astype(np.float32), 9, 2, (4, 7)),
+])
+def test_capped_fused_levels_equal_the_oracle(P, torch, oracle, name, make, m, L0, caps):
+    """itd_set_fuse_cap: levels first_fused .. cap - 1 fused, the sample pass leaves the baseline behind level cap - 1, levels cap ..
+    max_iteration + 1 one launch each from a scan of it — rows, baselines, knot counts and the stop bit for bit the oracle's, whether
+    the signal stops behind the cap, inside the fused levels (the level launches then return at once) or not at all; with the caller's
+    baselines buffer and with the engine's rotating slots."""
+    from pyitd_amd import ITDError
+    x = make()
+    ref = oracle.itd(x, m)
+    delivered = 0
+    for cap in caps:
+        for bases in (True, False):
+            try:
+                got = _run_capped(P, torch, x, m, L0, cap, bases)
+            except ITDError:
+                continue                       # (deep levels may refuse — reported, as without a cap)
+            assert got["took"] == (L0, cap if L0 + 2 <= cap <= m + 1 else 0), (name, cap, got["took"])
+            _check(got, ref, "%s, cap %d, %s" % (name, cap, "baselines" if bases else "rows only"))
+            delivered += 1
+    assert delivered >= 2, name
+
+
+def test_a_workload_that_fails_at_one_level_keeps_the_levels_in_front_of_it_fused(P, torch, oracle):
+    """BASELINE configs[4]'s substitute: the reference's 8000-sample clip tiled — exactly periodic, its baseline collapses to a handful of
+    knots at one level, where every sample is a near tie: the fused levels refuse there, every time.  The first call is refused and
+    repeated level by level; it leaves the level behind (KfSig::fail_lev) and the calls after it run the levels in front of that one
+    fused and the rest level by level: delivered, bit for bit, no further repeat."""
+    from pyitd_amd.engine import FUSE_AUTO
+    radio = load_golden("radio8000_input")["x"]
+    n, m = 1 << 20, 9
+    x = np.resize(radio, n).astype(np.float32)
+    ref = oracle.itd_lean(x, m)
+    eng = P.Engine(n, 1, 0)
+    eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_min_samples(65536)
+    eng.set_fuse_level(0)
+    eng.set_fuse_cap(0)
+    xd = torch.from_numpy(x).cuda()
+    rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    forms = []
+    for call in range(6):
+        rows.fill_(float("nan"))
+        torch.cuda.synchronize()
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+        forms.append((eng.last_fuse_level, eng.last_fuse_cap))
+        s = eng.summary(1)
+        nr = int(s["n_rows"][0])
+        assert nr == ref["rows"].shape[0] and ("natural", "timeout")[int(s["stop"][0])] == ref["stop"]
+        assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "call %d" % call)
+        assert [int(v) for v in s["knot_counts"][0] if v >= 0][: len(ref["knot_counts"])] == ref["knot_counts"].tolist(), "call %d" % call
+    L0 = forms[0][0]
+    assert L0 >= 2 and forms[0][1] == 0, forms                      # the first call: every level fused — refused
+    cap = forms[1][1]
+    assert cap >= L0 + 2 and all(f == (L0, cap) for f in forms[1:]), forms
+    assert eng.fuse_repeats == 1, (eng.fuse_repeats, forms)
+    eng.close()
+
+
 def test_a_captured_fused_call_survives_a_workspace_change(P, torch, oracle):
     """A hipGraph that holds a fused call has the fused levels' workspace pointers baked into its launches.  When later calls of the
     same engine need a larger workspace (smaller ranges: itd_set_fuse_range, or the automatic halving after a capacity refusal) the
