@@ -1033,6 +1033,7 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
     def timed():
         # every step reads its summary: the few signals whose fused sparse levels refuse are re-run there, on their own, inside the
         # timed region
+        nonlocal steps
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -1051,8 +1052,23 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
         eng.set_fuse_mode(FUSE_OFF)
         dt = timed()
         s = eng.summary(batch)
-    alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
     lvl = 0 if refused else eng.last_fuse_level
+    # the same batch PIPELINED (itd_set_batch_pipeline(1): chunk k's sample pass on the engine's second stream beside chunk k + 1's knot side,
+    # behind a gate) — the form round 6 built to hide the knot side and measured slower than the rotating chunks (profiles/r06/experiments):
+    # in the line so that every box shows the comparison
+    pipe_ms = None
+    if not refused:
+        try:
+            eng.set_batch_pipeline(1)
+            eng.decompose_dev(x.data_ptr(), np.float32, n, batch, n, MAX_ITERATION, rows.data_ptr(), None, stream.cuda_stream)
+            eng.summary(batch)
+            steps_keep, steps = steps, 3
+            pipe_ms = round(timed() * 1e3, 3)
+            steps = steps_keep
+            eng.set_batch_pipeline(0)
+        except Exception:  # noqa: BLE001
+            pipe_ms = None
+    alg = algorithmic_bytes_per_sample(LEVELS) * batch * n / dt / 1e9
     own = own_bytes_per_sample(MAX_ITERATION + 2, lvl)
     out = {"workload": "batch of %d x 2^%d float32 signals (draw b mod 16, f*(1+b/8192)), %d levels, device resident" % (batch, log2n, LEVELS),
             "value": round(batch * n / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
@@ -1065,7 +1081,8 @@ def batch_leg(torch, dev, batch=1024, log2n=20, steps=5):
             "frac_of_peak_own_bytes": round(own * batch * n / dt / 1e9 / HBM_PEAK_GBPS, 4),
             "rows_per_signal": sorted(set(int(v) for v in s["n_rows"])),
             "fused_levels_refused_and_retimed_level_by_level": refused,
-            "signals_rerun_on_their_own_per_step": repaired, "summary_read_every_step": True, "order": "timed after the headline"}
+            "signals_rerun_on_their_own_per_step": repaired, "summary_read_every_step": True, "order": "timed after the headline",
+            "pipelined_form_ms_per_step": pipe_ms}
     eng.close()
     return out
 

@@ -224,6 +224,7 @@ def test_kernel_timing_api(P, torch, oracle):
     eng = P.Engine(n, 1, 0)
     eng.set_fuse_mode(FUSE_ONLY)
     eng.set_fuse_level(3)             # (whatever PYITD_FUSE_LEVEL says: the counts below are level 3's)
+    eng.set_fuse_cap(-1)              # (... and PYITD_FUSE_CAP: every level from 3 on fused)
     eng.set_timing(steps, stride=stride)
     for _ in range(steps):
         eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)

@@ -27,11 +27,13 @@ def oracle():
     return cpu_oracle
 
 
-def _run(P, torch, x, m, mode, L0=3, bases=True):
+def _run(P, torch, x, m, mode, L0=3, bases=True, cap=None):
     n = len(x)
     eng = P.Engine(n, 1, 0)
     eng.set_fuse_mode(mode)
     eng.set_fuse_level(L0)
+    if cap is not None:
+        eng.set_fuse_cap(cap)                # (a suite run under PYITD_FUSE_CAP caps every other engine's fused levels)
     eng.set_fuse_min_samples(65536)          # (the automatic mode fuses from 2 * 2^20 samples per launch sequence by default)
     xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     rows = torch.full((m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
@@ -559,6 +561,7 @@ def test_every_injected_fault_is_refused(P, torch, oracle):
         eng.set_fuse_range(tpw)
         eng.set_fuse_min_samples(65536)
         eng.set_fuse_mode(FUSE_ONLY)
+        eng.set_fuse_cap(-1)                                   # every level fused, whatever PYITD_FUSE_CAP says
 
         def run():
             rows.zero_()
@@ -645,6 +648,7 @@ def test_injected_faults_at_the_shipped_hand_over_level(P, torch, oracle):
         eng = P.Engine(n, 1, 0)
         eng.set_fuse_range(tpw)                                # 0 = automatic: 64 tiles
         eng.set_fuse_mode(FUSE_ONLY)
+        eng.set_fuse_cap(-1)
         tpw = tpw or 64
 
         def run():
@@ -718,6 +722,7 @@ def test_injected_faults_in_a_later_signal_of_a_batch(P, torch, oracle):
     n_tiles, tpw, L0 = n // 512, 64, 2
     eng = P.Engine(n, B, 0)
     eng.set_fuse_mode(FUSE_AUTO)
+    eng.set_fuse_cap(-1)
 
     def run():
         rows.zero_()
