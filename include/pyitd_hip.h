@@ -370,6 +370,18 @@ int itd_baseline_extract_cubic_f32(itd_engine *e, const float *x_dev, int64_t n,
 /* host form: extrema_host int64 [idx+1] or NULL (detect); extrema_out_host (optional, capacity n) receives detected knots */
 int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int64_t n, const int64_t *extrema_host,
                                         int64_t idx, double *baseline_host, int64_t *idx_out, int64_t *extrema_out_host);
+/* ABI revision 11: the common-baseline form of the same operator on COMPLEX (I/Q) data, itd_baseline_extract_iq, itd.cpp:58-154 (a
+ * non-compilable float32 fragment like the 1-D form below it: restated in float64 the way its Python twin restates the 1-D form; no
+ * upstream test or Python twin pins the I/Q form: "recipe unpinned").  iq: n complex samples, interleaved (re, im), 16-byte aligned.
+ *   knots      the samples at which BOTH components have an extremum under the file's 3-point predicate (itd.cpp:74-80), or the
+ *              caller's list (extrema_dev / extrema_host with idx as in itd_baseline_extract_cubic_f64: "retain the extrema and reuse
+ *              them ... along multiple channels", itd.cpp:40-44)
+ *   baseline   ONE real baseline [n]: the natural-cubic operator above on the components' mean (I + Q) / 2 (itd.cpp:96-108)
+ * Fewer than 2 knots leave the baseline buffer untouched (itd.cpp:85-87); *idx_host / *idx_out = the knot count. */
+int itd_baseline_extract_iq_f64(itd_engine *e, const double *iq_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
+                                double *baseline_dev, int64_t *idx_host, void *stream);
+int itd_baseline_extract_iq_host_f64(itd_engine *e, const double *iq_host, int64_t n, const int64_t *extrema_host, int64_t idx,
+                                     double *baseline_host, int64_t *idx_out, int64_t *extrema_out_host);
 /* find_extrema(signal), itd_fourier_decomposition.py:17-31: [0, the sign changes s[i] -> s[i+1], one extrapolated index],
  * zero padded to n entries like the reference's numpy.zeros array; *idx_out = the reference's returned idx. */
 int itd_find_extrema_host_f64(itd_engine *e, const double *s_host, int64_t n, int64_t *extrema_host, int64_t *idx_out);

@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import ITDError, build
 from .engine import Engine
 from .itd import (ITD, baseline_knot_estimation, detect_knots, detect_peaks, find_extrema, generate_sine_wave, instantaneous, isin, itd,
-                  itd_baseline_extract, itd_baseline_extract_cubic, itd_baseline_extract_fast, itd_batch, itd_levels,
+                  itd_baseline_extract, itd_baseline_extract_cubic, itd_baseline_extract_fast, itd_baseline_extract_iq, itd_batch, itd_levels,
                   itd_sine_wrapper, matlab_detect_peaks, release_engines)
 
 from .spline import (crossways_itd_baseline_extract, itd_baseline_extract_modified, itd_baseline_extract_rows,
@@ -19,4 +19,4 @@ from .spline import (crossways_itd_baseline_extract, itd_baseline_extract_modifi
 __all__ = ["itd_baseline_extract_modified", "itd_baseline_extract_spline", "itd_baseline_extract_rows", "mad",
            "crossways_itd_baseline_extract", "retrieve_statistical_image_component", "totalextract2d", "ITD", "ITDError", "Engine", "build", "itd", "itd_levels", "itd_batch", "itd_baseline_extract", "detect_peaks",
            "matlab_detect_peaks", "detect_knots", "baseline_knot_estimation", "isin", "find_extrema", "generate_sine_wave",
-           "itd_baseline_extract_fast", "itd_baseline_extract_cubic", "itd_sine_wrapper", "release_engines", "instantaneous"]
+           "itd_baseline_extract_fast", "itd_baseline_extract_cubic", "itd_baseline_extract_iq", "itd_sine_wrapper", "release_engines", "instantaneous"]

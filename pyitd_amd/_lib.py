@@ -47,6 +47,8 @@ ABI = {
     "itd_baseline_extract_cubic_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_baseline_extract_cubic_f32": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_baseline_extract_cubic_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
+    "itd_baseline_extract_iq_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
+    "itd_baseline_extract_iq_host_f64": (_INT, [_P, _P, _I64, _P, _I64, _P, _P, _P]),
     "itd_find_extrema_host_f64": (_INT, [_P, _P, _I64, _P, _P]),
     "itd_baseline_extract_spline_f64": (_INT, [_P, _P, _I64, _I32, _I64, _I32, _P, _I64, _P, _I64, _P, _P]),
     "itd_baseline_extract_spline_host_f64": (_INT, [_P, _P, _I64, _I32, _I32, _P, _P, _P]),

@@ -60,6 +60,64 @@ __global__ __launch_bounds__(kWave) void k_detect_fast(const double *__restrict_
     if (__any(nan_in) && lane == 0) state[sig].in_nan = 1;
 }
 
+// The common-baseline form of the cubic operator on complex (I/Q) data, itd.cpp:58-154: a knot is a sample at which BOTH components have
+// an extremum under the file's 3-point predicate (:74-80); the scalar series the spline runs on is the components' mean (:96-103: the
+// knot values are formed from (I + Q) / 2 at the knots).  One launch: the predicate on both components of the interleaved signal, the
+// tile's flag words / count / group sum (k_detect_fast's contract: k_compact_fast follows) and the mean series avg[n].
+// grid = (n_tiles, 1), 64 threads: lane l holds samples s + 64 g + l (one 16-byte load per sample: re, im)
+__global__ __launch_bounds__(kWave) void k_detect_fast_iq(const double *__restrict__ iq, int64_t n, int n_tiles, int32_t *__restrict__ counts,
+                                                          unsigned long long *__restrict__ fw, int32_t *__restrict__ gsum_out,
+                                                          SigState *__restrict__ state, double *__restrict__ avg)
+{
+    constexpr int TW = 512, G = TW / 64;
+    const int t = blockIdx.x, lane = lane_id();
+    const int64_t s = (int64_t)t * TW;
+    const double2 *z = reinterpret_cast<const double2 *>(iq);
+    double re[G], im[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t j = s + g * 64 + lane;
+        const double2 v = j < n ? z[j] : make_double2(0.0, 0.0);
+        re[g] = v.x; im[g] = v.y;
+        if (j < n) avg[j] = (v.x + v.y) / 2.0;                       // itd.cpp:101-103
+    }
+    const double2 zb = s >= 1 ? z[s - 1] : make_double2(0.0, 0.0), za = s + TW < n ? z[s + TW] : make_double2(0.0, 0.0);   // wave-uniform
+    bool nan_in = false;
+    int total = 0;
+    unsigned long long mine = 0ull;
+    auto flag = [&](const double (&x)[G], int g, double x_before, double x_after) {
+        const double x0 = x[g];
+        const double up = __shfl_up(x0, 1), dn = __shfl_down(x0, 1);
+        const double prev_last = g > 0 ? __shfl(x[g > 0 ? g - 1 : 0], 63) : x_before;
+        const double next_first = g + 1 < G ? __shfl(x[g + 1 < G ? g + 1 : g], 0) : x_after;
+        const double xm = lane > 0 ? up : prev_last;
+        const double xp = lane < 63 ? dn : next_first;
+        return ((xm < x0) && (x0 >= xp)) || ((xm > x0) && (x0 <= xp));                // itd.cpp:77-80
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t j = s + g * 64 + lane;
+        const bool fr = flag(re, g, zb.x, za.x), fi = flag(im, g, zb.y, za.y);
+        const bool f = fr && fi && j >= 1 && j <= n - 2;
+        nan_in = nan_in || (j < n && (re[g] != re[g] || im[g] != im[g]));
+        const unsigned long long mk = __ballot(f);
+        total += __popcll(mk);
+        if (lane == g) mine = mk;
+    }
+    if (lane < G) fw[(size_t)t * G + lane] = mine;
+    if (lane == 0) {
+        counts[t] = total;
+        if (total) atomicAdd(&gsum_out[(size_t)(t / kTilesPerGroup) * kGsumPitch], total);
+    }
+    if (__any(nan_in) && lane == 0) state[0].in_nan = 1;
+}
+// the mean series alone (the knots are the caller's: "retain the extrema and reuse them", itd.cpp:40-44)
+__global__ void k_iq_mean(const double *__restrict__ iq, int64_t n, double *__restrict__ avg)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { const double2 v = reinterpret_cast<const double2 *>(iq)[j]; avg[j] = (v.x + v.y) / 2.0; }
+}
+
 // grid = (n_tiles, batch), 64 threads: the tile's knots at their ranks (k_compact's contract)
 __global__ __launch_bounds__(kWave) void k_compact_fast(const unsigned long long *__restrict__ fw, const int32_t *__restrict__ counts,
                                                         const int32_t *__restrict__ gsum_in, int n_tiles, int64_t n,

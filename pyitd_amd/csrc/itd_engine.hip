@@ -287,6 +287,7 @@ struct itd_engine {
     double *d_sp2 = nullptr; size_t sp2_bytes = 0;        // 2-D consumers: three planes of scratch
     char *d_wpe = nullptr; size_t wpe_bytes = 0;          // weighted permutation entropy: the segments' sums
     void *d_io_x = nullptr; size_t io_x_bytes = 0;
+    void *d_iq_avg = nullptr; size_t iq_avg_bytes = 0;   // the I/Q form of the cubic operator: the components' mean series
     double *d_io_rows = nullptr; size_t io_rows_bytes = 0;
     double *d_io_bases = nullptr; size_t io_bases_bytes = 0;
     void *h_pin[2] = {nullptr, nullptr};   // host-form calls: pinned bounce buffers of the pipelined device -> host copy (copy_to_host)
@@ -1182,7 +1183,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_lists); (void)hipFree(e->d_counts); (void)hipFree(e->d_recs); (void)hipFree(e->d_total);
     (void)hipFree(e->d_kidx); (void)hipFree(e->d_pp); (void)hipFree(e->d_state); (void)hipFree(e->d_gsum);
     (void)hipFree(e->d_hcounts); (void)hipFree(e->d_hrecs); (void)hipFree(e->d_hgsum); (void)hipFree(e->d_hstate);
-    (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases);
+    (void)hipFree(e->d_io_x); (void)hipFree(e->d_io_rows); (void)hipFree(e->d_io_bases); (void)hipFree(e->d_iq_avg);
     (void)hipFree(e->d_cub); (void)hipFree(e->d_cub_e); (void)hipFree(e->d_dw); (void)hipFree(e->d_bw); (void)hipFree(e->d_kf); for (void *q : e->kf_retired) (void)hipFree(q); (void)hipFree(e->d_flag); (void)hipFree(e->d_need); (void)hipFree(e->d_valid_own);
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2); (void)hipFree(e->d_wpe);
     if (e->h_state) (void)hipHostFree(e->h_state);
@@ -2273,6 +2274,75 @@ int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int
     if (extrema_out_host && !extrema_host && got > 0) {
         int64_t *d_e64 = (int64_t *)(e->d_io_rows + n);
         k_widen_idx<<<(unsigned)((got + 255) / 256), 256, 0, st>>>(knots_dev, d_e64, got);
+        HIP_TRY(e, hipMemcpyAsync(extrema_out_host, d_e64, (size_t)got * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(e, hipStreamSynchronize(st));
+    return ITD_OK;
+}
+
+// The common-baseline form on complex (I/Q) data, itd.cpp:58-154 (itd_detect_fast.hpp: k_detect_fast_iq): knots where both
+// components have an extremum, the natural-cubic operator of itd_baseline_extract_cubic_* on the components' mean.
+int itd_baseline_extract_iq_f64(itd_engine *e, const double *iq_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
+                                double *baseline_dev, int64_t *idx_host, void *stream)
+{
+    if (!e || !iq_dev || !baseline_dev) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n || (reinterpret_cast<uintptr_t>(iq_dev) & 15)) return ITD_ERR_INVALID_ARG;
+    if (extrema_dev && (idx < 2 || idx > n - 1)) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+    int rc = grow(e, &e->d_iq_avg, &e->iq_avg_bytes, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    double *avg = (double *)e->d_iq_avg;
+    if (extrema_dev) {
+        k_iq_mean<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(iq_dev, n, avg);
+        return cubic_dev(e, avg, n, extrema_dev, idx, baseline_dev, idx_host, st);
+    }
+    const int n_tiles = (int)tiles_of(n);
+    k_init_state<<<(unsigned)std::min<int64_t>((3 * e->hgsum_third + 255) / 256 + 1, 2048), 256, 0, st>>>(e->d_hstate, 1, e->d_hgsum, 3 * e->hgsum_third, 0);
+    unsigned long long *fw = reinterpret_cast<unsigned long long *>(e->d_lists);
+    k_detect_fast_iq<<<n_tiles, kWave, 0, st>>>(iq_dev, n, n_tiles, e->d_hcounts, fw, e->d_hgsum, e->d_hstate, avg);
+    // the ordered list [lead slot, knots, e[idx] = 0 (itd.cpp's static array at first call)]
+    k_compact_fast<<<dim3(n_tiles, 1), kWave, 0, st>>>(fw, e->d_hcounts, e->d_hgsum, n_tiles, n, e->d_kidx, e->max_n + 2, e->d_total, e->d_hstate, 0,
+                                                       e->d_hcounts + e->max_tiles, 1);
+    int64_t m = 0;
+    rc = fetch_total(e, st, &m);
+    if (rc) return rc;
+    if (idx_host) *idx_host = m;
+    if (m < 2) return ITD_OK;                      // itd.cpp:85-87: the caller's buffer is left alone
+    return cubic_dev(e, avg, n, e->d_kidx + 1, m, baseline_dev, nullptr, st);
+}
+
+int itd_baseline_extract_iq_host_f64(itd_engine *e, const double *iq_host, int64_t n, const int64_t *extrema_host, int64_t idx,
+                                     double *baseline_host, int64_t *idx_out, int64_t *extrema_out_host)
+{
+    if (!e || !iq_host || !baseline_host) return ITD_ERR_INVALID_ARG;
+    if (n < 3 || n > e->max_n) return ITD_ERR_INVALID_ARG;
+    DevGuard g(e->device);
+    hipStream_t st = e->own_stream;
+    int rc = grow(e, &e->d_io_x, &e->io_x_bytes, (size_t)n * sizeof(double) * 2);
+    if (rc) return rc;
+    rc = grow(e, &e->d_io_rows, &e->io_rows_bytes, (size_t)n * sizeof(double) * 2);   // baseline | widened knots
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->d_io_x, iq_host, (size_t)n * sizeof(double) * 2, hipMemcpyHostToDevice, st));
+    const int32_t *ek = nullptr;
+    int64_t *d_e64 = (int64_t *)(e->d_io_rows + n);
+    if (extrema_host) {
+        if (idx < 2 || idx > n - 1) return ITD_ERR_INVALID_ARG;
+        for (int64_t k = 0; k <= idx; ++k)
+            if (extrema_host[k] < 0 || extrema_host[k] >= n) return ITD_ERR_INVALID_ARG;
+        rc = grow(e, &e->d_cub_e, &e->cub_e_bytes, (size_t)(idx + 1) * sizeof(int32_t));
+        if (rc) return rc;
+        HIP_TRY(e, hipMemcpyAsync(d_e64, extrema_host, (size_t)(idx + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        k_narrow_idx<<<(unsigned)((idx + 1 + 255) / 256), 256, 0, st>>>(d_e64, e->d_cub_e, idx + 1);
+        ek = e->d_cub_e;
+    }
+    int64_t got = extrema_host ? idx : 0;
+    rc = itd_baseline_extract_iq_f64(e, (const double *)e->d_io_x, n, ek, idx, e->d_io_rows, extrema_host ? nullptr : &got, st);
+    if (rc) return rc;
+    if (idx_out) *idx_out = got;
+    if (got >= 2) HIP_TRY(e, hipMemcpyAsync(baseline_host, e->d_io_rows, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (extrema_out_host && !extrema_host && got > 0) {
+        k_widen_idx<<<(unsigned)((got + 255) / 256), 256, 0, st>>>(e->d_kidx + 1, d_e64, got);
         HIP_TRY(e, hipMemcpyAsync(extrema_out_host, d_e64, (size_t)got * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(e, hipStreamSynchronize(st));

@@ -342,6 +342,25 @@ class Engine:
                                                                 ctypes.byref(got), None))
         return base, e, int(idx)
 
+    def iq_extract_host(self, z, extrema=None, idx=0):
+        """itd_baseline_extract_iq (itd.cpp:58-154): ONE real natural-cubic baseline for complex data — knots where both components
+        have an extremum (extrema=None) or the caller's, the operator on the components' mean.  Returns (baseline or None when fewer
+        than 2 knots, knots int64, idx)."""
+        z = np.ascontiguousarray(z, dtype=np.complex128)
+        n = z.shape[0]
+        iq = z.view(np.float64)                       # interleaved (re, im)
+        base = np.empty(n)
+        got = ctypes.c_int64(0)
+        if extrema is None:
+            kn = np.zeros(n, np.int64)
+            self._check(self._L.itd_baseline_extract_iq_host_f64(self._h, _np_ptr(iq), n, None, 0, _np_ptr(base), ctypes.byref(got), _np_ptr(kn)))
+            return (base if got.value >= 2 else None), kn, int(got.value)
+        e = np.ascontiguousarray(extrema, dtype=np.int64)
+        if e.shape[0] < idx + 1:
+            raise ValueError("extrema needs idx+1 entries")
+        self._check(self._L.itd_baseline_extract_iq_host_f64(self._h, _np_ptr(iq), n, _np_ptr(e), int(idx), _np_ptr(base), ctypes.byref(got), None))
+        return base, e, int(idx)
+
     # ---- batched single-level operators on device buffers (asynchronous; include/pyitd_hip.h: *_batch_f64) ---------------
     def extract_batch_dev(self, x_ptr, n, batch, x_stride, rot_ptr, rot_stride, base_ptr, base_stride, info_ptr=None, stream=None):
         """itd_baseline_extract (ITD.py:79-121) of every row; info int32[batch]: knot count, -1 - count if the row holds a NaN."""

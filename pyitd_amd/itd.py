@@ -335,6 +335,24 @@ def itd_baseline_extract_cubic(x, device=0, want_knots=False):
     return (out, kn[:idx].copy()) if want_knots else out
 
 
+def itd_baseline_extract_iq(data, extrema=None, idx=None, device=0, want_knots=False):
+    """itd.cpp:58-154 (`itd_baseline_extract_iq`) — the common baseline of complex (I/Q) data: knots where BOTH components have an
+    extremum under the file's 3-point predicate (:74-80) — or the caller's retained knots (`extrema`, `idx`: itd.cpp:40-44) —, then the
+    natural-cubic operator of itd_baseline_extract_fast on the components' mean (I + Q) / 2 (:96-108).  Returns the real baseline
+    float64[n] (the mean series itself, unchanged, when fewer than 2 knots exist: the file leaves the caller's buffer alone, :85-87);
+    with want_knots also (knots, idx)."""
+    z = numpy.asarray(data, dtype=numpy.complex128)
+    if z.ndim != 1 or len(z) < 3:
+        raise ValueError("itd_baseline_extract_iq needs a 1-D signal of at least 3 complex samples")
+    eng = _engine_for(len(z), device)
+    if extrema is None:
+        base, kn, got = eng.iq_extract_host(z)
+    else:
+        base, kn, got = eng.iq_extract_host(z, extrema, int(idx))
+    out = (z.real + z.imag) / 2.0 if base is None else base
+    return (out, kn[:got].copy(), got) if want_knots else out
+
+
 def itd_sine_wrapper(signal, sample_rate, device=0):
     """itd_fourier_decomposition.py:33-47 — peel frequency-governed bands: for each synthetic sine (descending
     frequencies) the sine's zero crossings are the knots of one cubic baseline extraction."""

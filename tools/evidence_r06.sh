@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round 6's evidence in two GPU sessions (tools/evidence.sh's steps, regrouped so that each call stays well inside gpurun's limit):
+# Round 6's evidence in three GPU sessions (tools/evidence.sh's steps, regrouped so that each call stays well inside gpurun's limit):
 #   bash tools/evidence_r06.sh core   the -m gpu log; bench.py in the driver's form (live PMC traffic), with 200 steps, under rocprofv3
 #                                     --kernel-trace --stats; the recorded traffic passes (profiles/traffic.json); a batch timeline
-#   bash tools/evidence_r06.sh wide   the suite in the fused levels' other modes; delivery rates by signal family; fuzz slices
+#   bash tools/evidence_r06.sh modes  the suite in the fused levels' other modes
+#   bash tools/evidence_r06.sh fuzz   delivery rates by signal family; fuzz slices (fused long signals from level 3 / 2, capped, default, batches, pipelined batches)
 # Output: gpurun_out/r06/ (copied into profiles/r06/ afterwards).
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/r06; mkdir -p $O
@@ -26,8 +27,10 @@ for f in ("bench_default_form", "bench_steps200", "bench_under_rocprof"):
     print(f, d["ms_per_step"], r["frac"], r["avg_launch_us"], r["level0_launch_us"], r["extract_launch_us"], r["knot_side_us"], r.get("traffic_live_attempt"))
 PY
   ;;
-wide)
+modes)
   bash tools/suite_modes.sh r06 || exit 1
+  ;;
+fuzz)
   timeout -k 10 900 python tools/kf_rates.py 12 11 > $O/kf_delivery_rates.txt 2>&1 || exit 1; tail -2 $O/kf_delivery_rates.txt
   FUZZ_MIN_N=65536 PYITD_FUSE_MIN=65536 timeout -k 10 600 python tools/fuzz_parity.py 3000 601 > $O/fuzz_3000_long_fused.txt 2>&1 || exit 1; tail -1 $O/fuzz_3000_long_fused.txt
   FUZZ_MIN_N=65536 PYITD_FUSE_MIN=65536 PYITD_FUSE_LEVEL=2 timeout -k 10 600 python tools/fuzz_parity.py 3000 602 > $O/fuzz_3000_long_fused_level2.txt 2>&1 || exit 1; tail -1 $O/fuzz_3000_long_fused_level2.txt
