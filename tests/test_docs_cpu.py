@@ -67,3 +67,18 @@ def test_no_profile_is_a_crashed_run():
                 if "Traceback (most recent call last)" in text or "undefined symbol" in text:
                     bad.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
     assert not bad, "crashed runs kept as evidence: " + ", ".join(bad)
+
+
+def test_design_quotes_the_last_bench_line_s_operator_figures():
+    """DESIGN.md section 5 quotes the SURVEY 8f operators' figures of the round's bench line: MEITD's milliseconds and the block-wise
+    microseconds must be the ones in profiles/r06/bench_default_form.json (round 5 shipped a 7.0 ms that every other place had at 2.7)."""
+    import json
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_default_form.json")))["f_rows"]
+    m = re.search(r"MEITD on the golden two-tone \+\s+noise signal ([0-9.]+) ms", text)
+    assert m, "DESIGN.md section 5 no longer quotes MEITD's time"
+    assert abs(float(m.group(1)) - line["meitd_two_tone_noise_3000"]["ms"]) <= 0.15 * line["meitd_two_tone_noise_3000"]["ms"]
+    m = re.search(r"block-wise ([0-9.]+) / ([0-9.]+) µs per 4096-sample block", text)
+    assert m, "DESIGN.md section 5 no longer quotes the block-wise operators' time"
+    assert abs(float(m.group(1)) - line["stream_cubic_block4096"]["us_per_block"]) <= 0.15 * line["stream_cubic_block4096"]["us_per_block"]
+    assert abs(float(m.group(2)) - line["stream_linear_block4096"]["us_per_block"]) <= 0.15 * line["stream_linear_block4096"]["us_per_block"]
