@@ -293,7 +293,9 @@ int itd_set_batch_streams(itd_engine *e, int32_t streams);
  * chunks rotate over the streams, each chunk's launches in order on its stream.  Measured on 512 x 2^20 samples, 8 levels: 12.8-13.0 ms
  * pipelined against 11.9-12.3 ms rotating — a resident knot side costs the memory-bound launches a quarter of the wave slots, more than
  * hiding it returns (profiles/r06/experiments/README.md); kept for devices / shapes where that balance differs.  Results do not depend
- * on it; a call that is being captured into a hipGraph always takes the rotating form. */
+ * on it; a call that is being captured into a hipGraph always takes the rotating form.  The gate also orders a sample pass behind its OWN
+ * knot side; one that gives up (50 ms: the device busy with somebody else's work) records it, the call is refused as a whole and repeated
+ * level by level — by itd_get_summary, or by the device-side repair (itd_set_device_repair) — and the engine's later batches rotate. */
 int itd_set_batch_pipeline(itd_engine *e, int32_t on);
 
 /* Per-level knot lists are not retained by a decomposition (each level's list is consumed by the next
@@ -377,7 +379,8 @@ int itd_baseline_extract_cubic_host_f64(itd_engine *e, const double *x_host, int
  *              caller's list (extrema_dev / extrema_host with idx as in itd_baseline_extract_cubic_f64: "retain the extrema and reuse
  *              them ... along multiple channels", itd.cpp:40-44)
  *   baseline   ONE real baseline [n]: the natural-cubic operator above on the components' mean (I + Q) / 2 (itd.cpp:96-108)
- * Fewer than 2 knots leave the baseline buffer untouched (itd.cpp:85-87); *idx_host / *idx_out = the knot count. */
+ * Fewer than 2 knots leave the baseline buffer untouched (itd.cpp:85-87); *idx_host / *idx_out = the knot count.  Synchronous (one host
+ * synchronisation for the knot count when the knots are detected, one at the end for the operator's validity). */
 int itd_baseline_extract_iq_f64(itd_engine *e, const double *iq_dev, int64_t n, const int32_t *extrema_dev, int64_t idx,
                                 double *baseline_dev, int64_t *idx_host, void *stream);
 int itd_baseline_extract_iq_host_f64(itd_engine *e, const double *iq_host, int64_t n, const int64_t *extrema_host, int64_t idx,

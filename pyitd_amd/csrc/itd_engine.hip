@@ -67,12 +67,14 @@ __global__ void k_init_state(SigState *st, int batch, int32_t *gsum, int64_t gsu
 // non-finite value) and a level-by-level run would repair it.  A NaN in the caller's signal is neither (the host repeats such a
 // call the way the reference runs it): valid = 0, need = 0.
 __global__ void k_verdict(SigState *__restrict__ state, int batch, const KfSig *__restrict__ kf, int L0, int nan_follow,
-                          int32_t *__restrict__ valid, int32_t *__restrict__ need)
+                          int32_t *__restrict__ valid, int32_t *__restrict__ need, const unsigned long long *__restrict__ pipe_gave_up = nullptr)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     SigState &st = state[b];
-    if (kf) {
+    // (a pipelined batch whose gate gave up — k_kf_gate — may have run a sample pass in front of its knot side: every signal is refused)
+    if (kf && pipe_gave_up && *pipe_gave_up) st.kf_fail = kKfFailWait;
+    else if (kf) {
         const KfSig &ks = kf[b];
         if (!ks.active) { if (ks.fail) st.kf_fail = ks.fail; }
         else {
@@ -247,6 +249,9 @@ struct itd_engine {
     int32_t fuse_cap = 0;                            // itd_set_fuse_cap: the first level NOT fused (0 = whatever the engine has learned)
     int32_t fuse_cap_auto = 0;                       // learned from a refusal's KfSig::fail_lev (0 = none)
     int32_t fuse_cap_calls = 0;                      // delivered calls under the learned cap: every 256th call tries all levels again
+    bool last_pipelined = false;                     // the last call was a pipelined batch (its gates' give-up word is read with its summary)
+    bool pipe_word_unread = false;                   // a pipelined batch has been enqueued since the give-up word was last read
+    unsigned long long *h_pipe = nullptr;            // pinned: that word on the host
     int last_kf_cap = 0, last_kf_cap_form = 0;       // the cap of the last call (as enqueued: itd_get_last_fuse_cap; 0 = all levels fused)
     bool kf_force_tickets = false;                   // a halo wait was given up on this engine (kKfFailWait): workgroup ids are tickets from then on
     bool fuse_level2_off = false;                    // automatic first fused level: a level-2 list has outgrown its workgroup, level 3 from then on
@@ -804,7 +809,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
             int rc = run_chunk(b0, nb, st, 3);
             if (rc) return rc;
             if (k >= 1) {
-                k_kf_gate<<<1, kWave, 0, q>>>(e->d_kf_started, e->kf_started_target, e->pipe_gate_timeout);
+                k_kf_gate<<<1, kWave, 0, q>>>(e->d_kf_started, e->kf_started_target, e->pipe_gate_timeout);      // (a gate that gives up says so: itd_get_summary)
                 rc = run_chunk(b0 - chunk, chunk, q, 4);
                 if (rc) return rc;
             }
@@ -861,6 +866,8 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     e->last_kf = kf;
     e->last_kf_level = L0;
     e->last_kf_cap = kf ? cap : 0;
+    e->last_pipelined = pipelined;
+    if (pipelined) e->pipe_word_unread = true;
     if (!repair_need) { e->last_kf_form = kf ? L0 : 0; e->last_kf_cap_form = kf ? cap : 0; }
     return ITD_OK;
 }
@@ -982,7 +989,8 @@ int enqueue_any(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int64_t x
     SigState *state_a = e->d_state + (size_t)e->cur_set * e->max_batch;
     int32_t *valid = e->valid_dev ? e->valid_dev : e->d_valid_own;
     const int follow = e->nan_input_mode == ITD_NAN_INPUT_FOLLOW ? 1 : 0;
-    k_verdict<<<vb, 64, 0, st>>>(state_a, batch, e->last_kf ? e->kf.sig : nullptr, e->last_kf_level, follow, valid, e->device_repair ? e->d_need : nullptr);
+    k_verdict<<<vb, 64, 0, st>>>(state_a, batch, e->last_kf ? e->kf.sig : nullptr, e->last_kf_level, follow, valid, e->device_repair ? e->d_need : nullptr,
+                                 (e->last_kf && e->last_pipelined) ? e->d_kf_started + 1 : nullptr);
     if (e->device_repair) {
         // the same call level by level (record-driven level 0: any knot spacing), guarded per signal by d_need: rows_dev is final
         // when the stream has drained, with no host synchronisation in between
@@ -1188,6 +1196,7 @@ void itd_engine_destroy(itd_engine *e)
     (void)hipFree(e->d_sp); (void)hipFree(e->d_sp2); (void)hipFree(e->d_wpe);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_kf) (void)hipHostFree(e->h_kf);
+    if (e->h_pipe) (void)hipHostFree(e->h_pipe);
     for (int k = 0; k < 2; ++k) if (e->h_pin[k]) (void)hipHostFree(e->h_pin[k]);
     if (e->h_small) (void)hipHostFree(e->h_small);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1416,8 +1425,23 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
         if (!e->h_kf) HIP_TRY(e, hipHostMalloc((void **)&e->h_kf, kKfSigHead * (size_t)e->max_batch));
         HIP_TRY(e, hipMemcpy2DAsync(e->h_kf, kKfSigHead, e->kf.sig, sizeof(KfSig), kKfSigHead, (size_t)B, hipMemcpyDeviceToHost, e->last_stream));
     }
+    const bool piped = e->pipe_word_unread;
+    if (piped) {
+        if (!e->h_pipe) HIP_TRY(e, hipHostMalloc((void **)&e->h_pipe, 8));
+        HIP_TRY(e, hipMemcpyAsync(e->h_pipe, e->d_kf_started + 1, 8, hipMemcpyDeviceToHost, e->last_stream));
+    }
     HIP_TRY(e, hipStreamSynchronize(e->last_stream));
     if (e->last_kf) kf_verdict(e, B);
+    e->pipe_word_unread = false;
+    if (piped && *e->h_pipe) {
+        // a gate of the pipelined batch gave up (k_kf_gate: the knot side it waited for did not start within its time-out — another
+        // process's work on the device): a sample pass may have run in front of its own knot side.  Every signal is refused (the whole
+        // call is repeated below) and this engine's batches rotate over the streams from now on.
+        // (behind a device-side repair the call has been re-run level by level already: k_verdict read the same word)
+        if (e->last_kf && e->last_pipelined) for (int b = 0; b < B; ++b) e->h_state[b].kf_fail |= kKfFailWait;
+        HIP_TRY(e, hipMemsetAsync(e->d_kf_started + 1, 0, 8, e->last_stream));
+        e->batch_pipeline = 0;
+    }
     if (e->last_device_repair) {
         // the call carried its own repair (itd_set_device_repair): nothing to repeat here; count what it re-ran and let the engine's
         // next calls start the way that would have delivered (workloads tend to be homogeneous) — as the host-side repeats do

@@ -1228,11 +1228,16 @@ void k_kf_apply(KfWs ws, const double *__restrict__ xl, int64_t xl_stride, int64
 // it has started (KfWs::started has reached `target`), so that the launch behind the gate — tens of thousands of one-wavefront
 // workgroups — cannot take the LDS and the wave slots the knot side's 65 KB workgroups need: side by side from then on, the
 // latency-bound launch hides behind the memory-bound ones (tools/anyorder_probe.hip: no gate 229 us, gate 192, the parts 62 + 2 x 87).
-// Gives up after `timeout` ticks of the 100 MHz clock (the launches then share the device as they can; results do not depend on it).
-__global__ __launch_bounds__(kWave) void k_kf_gate(const unsigned long long *started, unsigned long long target, long long timeout)
+// Gives up after `timeout` ticks of the 100 MHz clock — and says so in started[1]: the gate is also what orders a sample pass behind ITS
+// knot side (which ended before the awaited one could start), so a gate that gave up voids the call: the engine reads the word with
+// the call's summary (or k_verdict does, on the device) and repeats the call level by level.
+__global__ __launch_bounds__(kWave) void k_kf_gate(unsigned long long *started, unsigned long long target, long long timeout)
 {
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < timeout) __builtin_amdgcn_s_sleep(4);
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (wall_clock64() - t0 > timeout) { if (threadIdx.x == 0) __hip_atomic_store(started + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
 }
 
 // fault injection for the tests (itd_debug_kf_fault): ONE field of the workspace the sample pass is about to read is perturbed,

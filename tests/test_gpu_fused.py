@@ -937,6 +937,44 @@ def test_a_workload_that_fails_at_one_level_keeps_the_levels_in_front_of_it_fuse
     eng.close()
 
 
+def test_a_gate_that_gives_up_voids_the_pipelined_call(P, torch, oracle, monkeypatch):
+    """The pipelined batch's gate is also what orders a sample pass behind its own knot side; one that gives up (here: a time-out of zero,
+    PYITD_PIPE_GATE_US=0) says so, and the call is void: refused as a whole, repeated level by level — the oracle's rows —, and the engine's
+    later batches rotate over the streams again.  With the repair on the device (itd_set_device_repair) the same holds without the host."""
+    from pyitd_amd.engine import FUSE_AUTO
+    monkeypatch.setenv("PYITD_PIPE_GATE_US", "0")
+    n, m, B = 1 << 17, 6, 12
+    x = np.stack([sines_noise(n, seed=500 + b, fscale=1 + b / 64.0) for b in range(B)])
+    refs = [oracle.itd_lean(x[b], m) for b in range(B)]
+    xd = torch.from_numpy(x).cuda()
+    for device_repair in (False, True):
+        eng = P.Engine(n, B, 0)
+        eng.set_fuse_mode(FUSE_AUTO)
+        eng.set_fuse_min_samples(65536)
+        eng.set_batch_chunk(4)
+        eng.set_batch_pipeline(1)
+        valid = torch.zeros(B, dtype=torch.int32, device="cuda")
+        if device_repair:
+            eng.set_valid_flags(valid.data_ptr())
+            eng.set_device_repair(True)
+        rows = torch.full((B, m + 2, n), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for call in range(3):
+            rows.fill_(float("nan"))
+            torch.cuda.synchronize()
+            eng.decompose_dev(xd.data_ptr(), np.float32, n, B, n, m, rows.data_ptr(), None, None)
+            s = eng.summary(B)
+            for b in range(B):
+                nr = refs[b]["rows"].shape[0]
+                assert int(s["n_rows"][b]) == nr
+                assert_bits_equal(rows[b, :nr].cpu().numpy(), refs[b]["rows"], "call %d, signal %d, device repair %s" % (call, b, device_repair))
+        if device_repair:
+            assert eng.device_repairs >= B and bool((valid == 1).all())
+        else:
+            assert eng.fuse_repeats == 1          # the first call only: the engine left the pipelined form behind
+        eng.close()
+
+
 def test_a_captured_fused_call_survives_a_workspace_change(P, torch, oracle):
     """A hipGraph that holds a fused call has the fused levels' workspace pointers baked into its launches.  When later calls of the
     same engine need a larger workspace (smaller ranges: itd_set_fuse_range, or the automatic halving after a capacity refusal) the
