@@ -1267,9 +1267,21 @@ def measure_traffic_live(timeout_s=110):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", os.path.join(out, c), "--",
                    sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-extra", "--warm-ms", "0", "--steps", "3", "--warmup", "1"]
             env = dict(os.environ, TMPDIR="/tmp")
-            p = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            if p.returncode != 0:
-                return {"error": "rocprofv3 --pmc %s: exit code %d" % (c, p.returncode)}
+            # (a session of its own: a pass that outlives its time-out is killed with everything it started — no profiled child may
+            #  still hold the GPU when this process starts timing)
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+                return {"error": "the %s pass exceeded %d s" % (c, timeout_s)}
+            if rc != 0:
+                return {"error": "rocprofv3 --pmc %s: exit code %d" % (c, rc)}
             vals = {}
             for f in glob.glob(os.path.join(out, c, "*", "*counter_collection.csv")):
                 for r in csv.DictReader(open(f)):
@@ -1284,8 +1296,6 @@ def measure_traffic_live(timeout_s=110):
             if ks:
                 res[key] = 2.0 * acc["FETCH_SIZE"][ks[0]] * 1024.0 + acc["WRITE_SIZE"][ks[0]] * 1024.0
         return res
-    except subprocess.TimeoutExpired:
-        return {"error": "a PMC pass exceeded %d s" % timeout_s}
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)[:160]}
     finally:
