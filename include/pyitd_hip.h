@@ -219,8 +219,9 @@ int itd_set_fuse_min_samples(itd_engine *e, int64_t samples);
  * every sample a near tie there — keeps the fused form for the levels in front of that one: levels first_fused .. cap - 1 run fused
  * (the sample pass also stores the baseline behind level cap - 1), levels cap .. max_iteration + 1 one launch each from a scan of that
  * baseline.  first_level_not_fused = 0 (default): automatic — a whole-call refusal records the lowest level at which anything failed
- * (verification, non-finite knot data) and the engine's next calls are capped there instead of running level by level (every 256th
- * call tries all levels again); -1: never; 4 .. max_iteration + 1: always this cap (tests).  A cap leaves at least two fused levels or
+ * (verification, non-finite knot data) and the engine's next calls are capped there instead of running level by level (after 16
+ * delivered capped calls one call tries all levels again; a probe refused at the learned level doubles that span, up to 1024; a
+ * delivered probe drops the cap); -1: never; 4 .. max_iteration + 1: always this cap (tests).  A cap leaves at least two fused levels or
  * is ignored.  Results are bit-identical either way. */
 int itd_set_fuse_cap(itd_engine *e, int32_t first_level_not_fused);
 /* the cap of the last decomposition as it was enqueued (0: none — every level from the first fused one on ran fused, or no fused levels) */

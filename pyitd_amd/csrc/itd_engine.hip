@@ -248,7 +248,9 @@ struct itd_engine {
     // capped fused levels: a workload whose fused form fails at the same level every time keeps the fused form for the levels in front of it
     int32_t fuse_cap = 0;                            // itd_set_fuse_cap: the first level NOT fused (0 = whatever the engine has learned)
     int32_t fuse_cap_auto = 0;                       // learned from a refusal's KfSig::fail_lev (0 = none)
-    int32_t fuse_cap_calls = 0;                      // delivered calls under the learned cap: every 256th call tries all levels again
+    int32_t fuse_cap_calls = 0;                      // delivered calls under the learned cap since the last probe
+    int32_t fuse_cap_span = 16;                      // ... after this many the next call tries all levels again (a probe); doubles, up to 1024,
+                                                     // every time a probe is refused at the learned level again
     bool last_pipelined = false;                     // the last call was a pipelined batch (its gates' give-up word is read with its summary)
     bool pipe_word_unread = false;                   // a pipelined batch has been enqueued since the give-up word was last read
     unsigned long long *h_pipe = nullptr;            // pinned: that word on the host
@@ -529,7 +531,7 @@ int enqueue_decompose(itd_engine *e, const Tin *x, int64_t n, int32_t batch, int
     int cap = 0;
     if (kf) {
         cap = e->fuse_cap ? e->fuse_cap : e->fuse_cap_auto;                          // (fuse_cap -1 = never: falls out below)
-        if (cap > 0 && !e->fuse_cap && (e->fuse_cap_calls & 255) == 255) cap = 0;  // (a learned cap is probed now and then: workloads change)
+        if (cap > 0 && !e->fuse_cap && e->fuse_cap_calls >= e->fuse_cap_span) cap = 0;   // (a learned cap is probed now and then: workloads change)
         if (cap < L0 + 2 || cap > M + 1) cap = 0;                                    // (fewer than two fused levels are not worth a knot side; beyond the call's levels: no cap)
     }
     const int Mk = cap ? cap - 2 : M;               // the knot side's "max_iteration": its levels are L0 .. Mk + 1
@@ -1504,7 +1506,7 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
             e->fuse_off_span = 16; e->fuse_probe = false;
             if (!e->fuse_cap && e->fuse_cap_auto) {
                 if (e->last_kf_cap) ++e->fuse_cap_calls;
-                else if (e->last_m + 1 >= e->fuse_cap_auto) { e->fuse_cap_auto = 0; e->fuse_cap_calls = 0; }   // the probe without the cap was delivered: the workload has changed
+                else if (e->last_m + 1 >= e->fuse_cap_auto) { e->fuse_cap_auto = 0; e->fuse_cap_calls = 0; e->fuse_cap_span = 16; }   // the probe without the cap was delivered: the workload has changed
             }
         }
         if (nfail) {
@@ -1534,8 +1536,10 @@ int itd_get_summary(itd_engine *e, int32_t *n_rows, int32_t *n_baselines, int32_
                         if (e->h_state[b].kf_fail) fl = std::min<int>(fl, reinterpret_cast<const KfSig *>(e->h_kf + (size_t)b * kKfSigHead)->fail_lev);
                     const int L0 = e->last_kf_level;
                     if (fl >= L0 + 2 && fl <= e->last_m + 1 && (e->last_kf_cap == 0 || fl < e->last_kf_cap)) {
+                        // (a refused PROBE — the cap was known, this call tried without it —: the next probe comes later)
+                        e->fuse_cap_span = (e->fuse_cap_auto && !e->last_kf_cap) ? std::min(e->fuse_cap_span * 2, 1024) : 16;
                         e->fuse_cap_auto = fl; e->fuse_cap_calls = 0; capped_next = true;
-                    } else e->fuse_cap_auto = 0;
+                    } else { e->fuse_cap_auto = 0; e->fuse_cap_span = 16; }
                 }
                 if (!can_shrink && !capped_next) kf_levels_off(e);
                 const int rc = repeat(want_fused(e), false);
@@ -1721,6 +1725,7 @@ int itd_set_fuse_cap(itd_engine *e, int32_t first_level_not_fused)
     e->fuse_cap = first_level_not_fused;
     e->fuse_cap_auto = 0;
     e->fuse_cap_calls = 0;
+    e->fuse_cap_span = 16;
     return ITD_OK;
 }
 int itd_get_last_fuse_cap(const itd_engine *e) { return !e ? -1 : (e->ran && e->last_kf_form ? e->last_kf_cap_form : 0); }

@@ -934,6 +934,28 @@ def test_a_workload_that_fails_at_one_level_keeps_the_levels_in_front_of_it_fuse
     cap = forms[1][1]
     assert cap >= L0 + 2 and all(f == (L0, cap) for f in forms[1:]), forms
     assert eng.fuse_repeats == 1, (eng.fuse_repeats, forms)
+    # sixteen delivered capped calls, then one call probes without the cap: refused at the same level, repeated, the cap stays and the
+    # next probe is 32 calls away
+    for call in range(6, 40):
+        eng.decompose_dev(xd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+        forms.append((eng.last_fuse_level, eng.last_fuse_cap))
+        s = eng.summary(1)
+    assert [k for k, f in enumerate(forms) if f[1] == 0] == [0, 17], forms
+    assert eng.fuse_repeats == 2
+    nr = int(s["n_rows"][0])
+    assert_bits_equal(rows[:nr].cpu().numpy(), ref["rows"], "call 39")
+    # another workload on the same engine: the capped calls deliver it too, and the probe behind them drops the cap
+    y = sines_noise(n, seed=77)
+    ref_y = oracle.itd_lean(y, m)
+    yd = torch.from_numpy(y).cuda()
+    torch.cuda.synchronize()
+    seen = []
+    for call in range(40):
+        eng.decompose_dev(yd.data_ptr(), np.float32, n, 1, n, m, rows.data_ptr(), None, None)
+        seen.append(eng.last_fuse_cap)
+        s = eng.summary(1)
+    assert seen[0] == cap and seen[-1] == 0 and eng.fuse_repeats == 2, seen
+    assert_bits_equal(rows[: int(s["n_rows"][0])].cpu().numpy(), ref_y["rows"], "the other workload")
     eng.close()
 
 
