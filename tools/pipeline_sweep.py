@@ -1,7 +1,7 @@
 """The batch pipeline (itd_set_batch_pipeline) on BASELINE configs[2]'s recipe: batch x 2^20 samples, 8 levels, the summary read every
 step — pipelined against rotating chunks, by signals per chunk; the rows of both forms are compared bit for bit.
 usage (GPU box): python tools/pipeline_sweep.py [batch] [log2n] [chunks,comma,separated]
-(PYITD_PIPE_THIN = sample-pass workgroups in front of the gate, PYITD_PIPE_GATE_US = the gate's time-out: read by the library)"""
+(PYITD_PIPE_GATE_US = the gate's time-out in microseconds: read by the library at engine creation)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
